@@ -1,0 +1,160 @@
+/*
+ * qst.h -- C-ABI of libqst.so: the MI355X (gfx950) quadruplet fine-tuning hot path.
+ *
+ * This is the drop-in boundary. The reference is pure
+ * Python with no FFI of its own, so each entry point names the reference
+ * interface whose arithmetic it replaces. All pointers are DEVICE pointers
+ * unless the parameter name ends in _host; the library never allocates, frees
+ * or retains caller memory (handles own only small device tables that depend
+ * on the config). Every call enqueues on `stream` (a hipStream_t passed as
+ * void*) and returns without a host sync. Return value: 0 = OK, negative =
+ * qst_status (see qst_strerror). Nothing throws or aborts.
+ *
+ * Numeric contract: fp32 parameters, fp32 residual stream / LayerNorm /
+ * softmax / pooling / loss; GEMM and attention contractions take bf16 MFMA
+ * operands with fp32 accumulation. precision = QST_PREC_BF16X3 splits every
+ * fp32 operand into hi+lo bf16 and issues three MFMAs (fp32-class accuracy,
+ * the parity mode); QST_PREC_BF16 rounds operands once (the throughput mode).
+ */
+#ifndef QST_H
+#define QST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    QST_OK = 0,
+    QST_ERR_BAD_ARG = -1,      /* null pointer, non-positive size, bad enum           */
+    QST_ERR_UNSUPPORTED = -2,  /* dims the kernels are not built for (see qst_encoder_create) */
+    QST_ERR_WORKSPACE = -3,    /* workspace/saved arena smaller than qst_*_bytes() says */
+    QST_ERR_HIP = -4,          /* a HIP runtime call failed; qst_last_hip_error() has the code */
+    QST_ERR_NO_DEVICE = -5,
+    QST_ERR_COMM = -6          /* RCCL call failed */
+} qst_status;
+
+enum { QST_ARCH_BERT = 0, QST_ARCH_MPNET = 1 };
+enum { QST_PREC_BF16 = 0, QST_PREC_BF16X3 = 1 };
+enum { QST_REDUCE_NONE = 0, QST_REDUCE_SUM = 1, QST_REDUCE_MEAN = 2 };
+
+/* Encoder architecture. Mirrors HF BertConfig / MPNetConfig fields that the
+ * reference selects by model name (training/main.py:114,242). */
+typedef struct {
+    int32_t arch;              /* QST_ARCH_*                                           */
+    int32_t vocab_size;
+    int32_t hidden_size;       /* H; multiple of 64                                    */
+    int32_t num_layers;
+    int32_t num_heads;         /* H / num_heads must be 32 or 64                       */
+    int32_t intermediate_size; /* I; multiple of 64                                    */
+    int32_t max_position;
+    int32_t type_vocab_size;   /* 0 for MPNet                                          */
+    float   layer_norm_eps;
+    int32_t normalize;         /* ST Normalize module present                          */
+    int32_t rel_buckets;       /* MPNet relative_attention_num_buckets (32)            */
+    int32_t rel_max_distance;  /* MPNet (128)                                          */
+    int32_t pad_token_id;      /* MPNet position ids (1)                               */
+    int32_t precision;         /* QST_PREC_*                                           */
+} qst_config;
+
+typedef struct qst_encoder qst_encoder;
+
+const char* qst_strerror(int status);
+int  qst_last_hip_error(void);
+int  qst_version(void);
+
+/* ---- parameter arena layout (contract with config.build_layout on the Python side) ---- */
+/* Total elements of the flat fp32 arena (params, grads, exp_avg, exp_avg_sq all share it). */
+int64_t qst_arena_elems(const qst_config* cfg);
+/* Number of segments and per-segment description. name_out receives a static string. */
+int     qst_arena_num_segments(const qst_config* cfg);
+int     qst_arena_segment(const qst_config* cfg, int idx, const char** name_out, int64_t* offset_out,
+                          int64_t* numel_out, int32_t* decay_out, int32_t* gemm_out);
+/* Elements of the bf16 shadow arena: [W | W^T] copies of every GEMM weight. */
+int64_t qst_shadow_elems(const qst_config* cfg);
+
+/* ---- encoder handle ---- */
+int  qst_encoder_create(const qst_config* cfg, qst_encoder** out);
+void qst_encoder_destroy(qst_encoder* enc);
+
+/* Bytes of the activation arena `saved` for nseq sequences of length L.
+ * training != 0 also reserves what backward needs. */
+size_t qst_encoder_saved_bytes(const qst_encoder* enc, int nseq, int L, int training);
+/* Bytes of scratch for backward (gradient activations). */
+size_t qst_encoder_bwd_workspace_bytes(const qst_encoder* enc, int nseq, int L);
+
+/* Refresh the bf16 shadows (W and W^T of every GEMM weight) from the fp32 arena.
+ * Must be called after any parameter update and before forward/backward. */
+int qst_refresh_shadow(const qst_encoder* enc, const float* params, void* shadow_bf16, void* stream);
+
+/*
+ * Replaces SentenceTransformer.forward = Sequential(Transformer, Pooling(mean)[, Normalize])
+ * (sentence-transformers 2.2.2; call site /root/reference/models/quadruplet_sentence_transformer.py:42-60)
+ * over BertModel / MPNetModel.forward (transformers).
+ *   ids, mask, type_ids : int64 [nseq, L] (type_ids may be NULL = all zero); L multiple of 32, <= 512
+ *   params              : fp32 arena; shadow: bf16 arena from qst_refresh_shadow
+ *   out_emb             : fp32 [nseq, H]  ('sentence_embedding')
+ *   out_tok             : fp32 [nseq, L, H] token embeddings, or NULL
+ *   saved               : activation arena (qst_encoder_saved_bytes)
+ */
+int qst_encoder_forward(qst_encoder* enc, const int64_t* ids, const int64_t* mask, const int64_t* type_ids,
+                        int nseq, int L, const float* params, const void* shadow_bf16,
+                        float* out_emb, float* out_tok, void* saved, size_t saved_bytes, int training,
+                        void* stream);
+
+/*
+ * Backward of the call above (replaces autograd through the same modules;
+ * reference call site: `loss.backward()` inside SentenceTransformer.fit).
+ *   grad_emb   : fp32 [nseq, H]
+ *   grads      : fp32 arena; gradients are ACCUMULATED into it (zero it for a fresh step)
+ *   workspace  : qst_encoder_bwd_workspace_bytes
+ */
+int qst_encoder_backward(qst_encoder* enc, const int64_t* ids, const int64_t* mask, const int64_t* type_ids,
+                         int nseq, int L, const float* params, const void* shadow_bf16,
+                         const float* grad_emb, float* grads, void* saved, size_t saved_bytes,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Replaces gamma_quadruplet_loss (/root/reference/models/losses/losses.py:9-69) and its autograd:
+ * three triplet_margin_loss terms with pairwise_distance eps=1e-6 inside the norm.
+ *   xa,xp,xq,xn : fp32 [B, D] anchor / positive / partially-positive / negative (row stride = D)
+ *   out_loss    : fp32 [B] (reduction none) or [1]
+ *   grad_*      : fp32 [B, D] d(loss)/dx, or all NULL for forward only. For reduction none the
+ *                 upstream gradient is grad_out [B] (NULL = ones); for sum/mean grad_out is [1] or NULL.
+ *   scratch     : fp32 [B] used for deterministic two-stage reduction when reduction != none
+ */
+int qst_quadruplet_loss(const float* xa, const float* xp, const float* xq, const float* xn,
+                        int B, int D, float gamma, float margin_pos_neg, float margin_pos_part,
+                        float margin_part_neg, float p, int swap, int reduction,
+                        float* out_loss, const float* grad_out,
+                        float* grad_a, float* grad_p, float* grad_q, float* grad_n,
+                        float* scratch, void* stream);
+
+/*
+ * Replaces torch.nn.utils.clip_grad_norm_(params, max_grad_norm) + torch.optim.AdamW.step()
+ * with ST fit()'s two parameter groups (/root/reference/training/main.py:128-148).
+ *   n            : arena elements; decay is applied per segment as the layout says
+ *   grad_scale   : multiplies every gradient first (1/world_size after an all-reduce sum)
+ *   max_grad_norm: <= 0 disables clipping. norm_out (fp32 [1], device) receives the pre-clip global L2 norm.
+ *   step         : 1-based optimiser step for bias correction
+ *   scratch      : fp32 [1024] partial sums
+ */
+int qst_clip_adamw_step(const qst_encoder* enc, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                        float lr, float beta1, float beta2, float eps, float weight_decay,
+                        float max_grad_norm, float grad_scale, int64_t step,
+                        float* norm_out, float* scratch, void* stream);
+
+/* ---- data parallelism: RCCL over xGMI (no reference counterpart) ---- */
+typedef struct qst_comm qst_comm;
+int  qst_comm_unique_id(void* id_out_host_128);                 /* 128-byte ncclUniqueId */
+int  qst_comm_init(int rank, int world, const void* id_host_128, qst_comm** out);
+void qst_comm_destroy(qst_comm* c);
+/* In-place sum all-reduce of `count` fp32 elements on `stream`. */
+int  qst_allreduce_sum_f32(qst_comm* c, float* buf, int64_t count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QST_H */

@@ -1,0 +1,179 @@
+"""TEST INFRASTRUCTURE ONLY -- fp32 torch restatement of the hot path (CPU oracle).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this file. The product path (quadruplet-sentence-transformer_amd/) never does.
+
+What it restates, op for op, with plain torch primitives (no nn.Module, no
+transformers import), so autograd gives the backward oracle as well:
+
+  * BertModel.forward  (transformers 4.30.2 per requirements.txt:9; local copy
+    transformers 5.15.0 modeling_bert.py:53-108 embeddings, :111-136 eager
+    attention, :282-293 / :325-351 output blocks, :354-416 layer)
+  * MPNetModel.forward (modeling_mpnet.py:58-95 embeddings, :115-174 attention,
+    :312-348 relative bias, :873-881 position ids)
+  * sentence-transformers 2.2.2 Pooling(mean) + Normalize head (third-party, not
+    under /root/reference; call site models/quadruplet_sentence_transformer.py:42-60;
+    arithmetic in SURVEY.md 8a row a4)
+  * gamma_quadruplet_loss (/root/reference/models/losses/losses.py:9-69) on top of
+    torch's triplet_margin_loss / pairwise_distance semantics (eps added to every
+    component of the difference)
+
+Pinned by tests/golden/*.npz, which oracle/make_golden.py generates from the real
+reference loss module and HF BertModel/MPNetModel (tests/test_oracle_golden.py).
+
+`bf16_operands=True` rounds every GEMM operand (activations, weights, Q/K/V, P)
+to bf16 and keeps fp32 accumulation -- the arithmetic the HIP kernels do -- so
+kernel bugs can be told apart from bf16 rounding.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+
+def _r(x: torch.Tensor, on: bool) -> torch.Tensor:
+    """Round-trip through bf16 with a straight-through gradient."""
+    if not on:
+        return x
+    return x + (x.detach().to(torch.bfloat16).to(torch.float32) - x.detach())
+
+
+def _linear(x, w, b, bf16):
+    return F.linear(_r(x, bf16), _r(w, bf16), b)
+
+
+def mpnet_position_ids(ids: torch.Tensor, pad: int = 1) -> torch.Tensor:
+    m = ids.ne(pad).int()
+    return (torch.cumsum(m, dim=1).type_as(m) * m).long() + pad
+
+
+def mpnet_bucket_table(L: int, num_buckets: int = 32, max_distance: int = 128) -> torch.Tensor:
+    """[L, L] int64 bucket of (j - i); modeling_mpnet.py:329-348."""
+    ctx = torch.arange(L)[:, None]
+    mem = torch.arange(L)[None, :]
+    n = -(mem - ctx)
+    nb = num_buckets // 2
+    ret = (n < 0).long() * nb
+    n = n.abs()
+    max_exact = nb // 2
+    is_small = n < max_exact
+    large = max_exact + (torch.log(n.float() / max_exact) / math.log(max_distance / max_exact)
+                         * (nb - max_exact)).long()
+    large = torch.min(large, torch.full_like(large, nb - 1))
+    return ret + torch.where(is_small, n, large)
+
+
+def encoder_forward(P: Dict[str, torch.Tensor], cfg, ids: torch.Tensor, mask: torch.Tensor,
+                    type_ids: Optional[torch.Tensor] = None, bf16_operands: bool = False,
+                    collect: Optional[list] = None) -> torch.Tensor:
+    """Token embeddings [n, L, H]. P is keyed by the build's segment names (config.build_layout)."""
+    n, L = ids.shape
+    H, A = cfg.hidden_size, cfg.num_heads
+    d = H // A
+    bf = bf16_operands
+    if cfg.arch == 0:
+        x = P["word_emb"][ids]
+        if cfg.type_vocab_size > 0:
+            tt = type_ids if type_ids is not None else torch.zeros_like(ids)
+            x = x + P["type_emb"][tt]                      # HF order: (word + type) + position
+        x = x + P["pos_emb"][torch.arange(L)][None]
+        rel = None
+    else:
+        x = P["word_emb"][ids] + P["pos_emb"][mpnet_position_ids(ids, cfg.pad_token_id)]
+        bucket = mpnet_bucket_table(L, cfg.rel_buckets, cfg.rel_max_distance)
+        rel = P["rel_bias"][bucket].permute(2, 0, 1)[None]          # [1, A, L, L]
+    x = F.layer_norm(x, (H,), P["emb_ln_g"], P["emb_ln_b"], cfg.layer_norm_eps)
+    if collect is not None:
+        collect.append(x)
+    neg = torch.finfo(torch.float32).min
+    add_mask = (1.0 - mask[:, None, None, :].to(torch.float32)) * neg   # modeling_bert.py:688-708
+    for l in range(cfg.num_layers):
+        p = f"layer.{l}."
+        qkv = _linear(x, P[p + "w_qkv"], P[p + "b_qkv"], bf)
+        q, k, v = [t.view(n, L, A, d).transpose(1, 2) for t in qkv.split(H, dim=-1)]
+        s = torch.matmul(_r(q, bf), _r(k, bf).transpose(-1, -2)) / math.sqrt(d)
+        if rel is not None:
+            s = s + rel
+        s = s + add_mask
+        pr = torch.softmax(s, dim=-1)
+        ctx = torch.matmul(_r(pr, bf), _r(v, bf)).transpose(1, 2).reshape(n, L, H)
+        a = _linear(ctx, P[p + "w_o"], P[p + "b_o"], bf)
+        x = F.layer_norm(a + x, (H,), P[p + "ln1_g"], P[p + "ln1_b"], cfg.layer_norm_eps)
+        h = F.gelu(_linear(x, P[p + "w_1"], P[p + "b_1"], bf))          # erf GELU
+        o = _linear(h, P[p + "w_2"], P[p + "b_2"], bf)
+        x = F.layer_norm(o + x, (H,), P[p + "ln2_g"], P[p + "ln2_b"], cfg.layer_norm_eps)
+        if collect is not None:
+            collect.append(x)
+    return x
+
+
+def st_head(tok: torch.Tensor, mask: torch.Tensor, normalize: bool) -> torch.Tensor:
+    """ST Pooling(mean) [+ Normalize]: sum(tok*mask)/clamp(sum mask, 1e-9); F.normalize eps 1e-12."""
+    m = mask[:, :, None].to(tok.dtype)
+    e = (tok * m).sum(1) / m.sum(1).clamp(min=1e-9)
+    if normalize:
+        e = e / e.norm(p=2, dim=1, keepdim=True).clamp_min(1e-12)
+    return e
+
+
+def sentence_embeddings(P, cfg, ids, mask, type_ids=None, bf16_operands=False):
+    return st_head(encoder_forward(P, cfg, ids, mask, type_ids, bf16_operands), mask, cfg.normalize)
+
+
+def _pdist(x1, x2, p, eps=1e-6):
+    # torch.nn.functional.pairwise_distance: ||x1 - x2 + eps||_p over the last dim
+    return torch.linalg.vector_norm(x1 - x2 + eps, ord=p, dim=-1)
+
+
+def _tml(a, pos, neg, margin, p, swap):
+    dp = _pdist(a, pos, p)
+    dn = _pdist(a, neg, p)
+    if swap:
+        dn = torch.minimum(dn, _pdist(pos, neg, p))
+    return torch.clamp_min(margin + dp - dn, 0.0)
+
+
+def gamma_quadruplet_loss_ref(xa, xp, xq, xn, gamma=0.6, margin_pos_neg=1.0, margin_pos_part=0.5,
+                              margin_part_neg=0.5, p=2.0, swap=False, reduction="mean"):
+    """Restatement of /root/reference/models/losses/losses.py:35-69 (same term order)."""
+    a = _tml(xa, xp, xn, margin_pos_neg, p, swap)       # :35-43
+    b = _tml(xa, xq, xn, margin_part_neg, p, swap)      # :44-52
+    c = _tml(xa, xp, xq, margin_pos_part, p, swap)      # :53-61
+    if reduction == "none":
+        return a + gamma * b + (1 - gamma) * c
+    if reduction == "sum":
+        return a.sum() + (gamma * b).sum() + ((1 - gamma) * c).sum()
+    return a.mean() + (gamma * b).mean() + ((1 - gamma) * c).mean()
+
+
+def arena_to_dict(arena, cfg, requires_grad: bool = False) -> Dict[str, torch.Tensor]:
+    """Split a flat fp32 arena (numpy or torch) into named leaf tensors."""
+    import importlib
+    qst = importlib.import_module("quadruplet_sentence_transformer_amd.config")
+    segs, _ = qst.build_layout(cfg)
+    t = torch.as_tensor(arena, dtype=torch.float32)
+    out = {}
+    for s in segs:
+        v = t[s.offset:s.offset + s.numel].clone().view(*s.shape)
+        v.requires_grad_(requires_grad)
+        out[s.name] = v
+    return out
+
+
+def quadruplet_step(P, cfg, ids4, mask4, types4=None, loss_kw=None, bf16_operands=False):
+    """Forward of one quadruplet batch: ids4 [4,B,L] -> (loss, emb [4,B,H]).
+
+    Column order = reference/positive/part_positive/negative
+    (/root/reference/models/quadruplet_sentence_transformer.py:24-60).
+    """
+    loss_kw = loss_kw or {}
+    four, B, L = ids4.shape
+    ids = ids4.reshape(4 * B, L)
+    mask = mask4.reshape(4 * B, L)
+    tt = types4.reshape(4 * B, L) if types4 is not None else None
+    emb = sentence_embeddings(P, cfg, ids, mask, tt, bf16_operands).view(4, B, -1)
+    loss = gamma_quadruplet_loss_ref(emb[0], emb[1], emb[2], emb[3], **loss_kw)
+    return loss, emb

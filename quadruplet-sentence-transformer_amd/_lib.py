@@ -1,0 +1,119 @@
+"""ctypes binding of libqst.so (include/qst.h, include/qst_kernels.h).
+
+There is no fallback: if the shared library is missing the import of anything
+numeric fails with an explicit error (build it with `python -c "import
+__graft_entry__ as g; g.build()"` or `make -C quadruplet-sentence-transformer_amd/csrc`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqst.so")
+
+c_i64p = C.POINTER(C.c_int64)
+c_i32p = C.POINTER(C.c_int32)
+c_f32p = C.POINTER(C.c_float)
+vp = C.c_void_p
+
+
+class QstError(RuntimeError):
+    pass
+
+
+class QstConfig(C.Structure):
+    _fields_ = [("arch", C.c_int32), ("vocab_size", C.c_int32), ("hidden_size", C.c_int32),
+                ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("intermediate_size", C.c_int32),
+                ("max_position", C.c_int32), ("type_vocab_size", C.c_int32), ("layer_norm_eps", C.c_float),
+                ("normalize", C.c_int32), ("rel_buckets", C.c_int32), ("rel_max_distance", C.c_int32),
+                ("pad_token_id", C.c_int32), ("precision", C.c_int32)]
+
+
+class QstGemmArgs(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("C2", vp), ("aux", vp), ("bias", vp), ("resid", vp),
+                ("colsum", vp), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32),
+                ("ldb", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32), ("splits", C.c_int32)]
+
+
+# name -> (restype, argtypes). Every symbol the two public headers declare.
+SIGNATURES = {
+    "qst_strerror": (C.c_char_p, [C.c_int]),
+    "qst_last_hip_error": (C.c_int, []),
+    "qst_version": (C.c_int, []),
+    "qst_arena_elems": (C.c_int64, [C.POINTER(QstConfig)]),
+    "qst_arena_num_segments": (C.c_int, [C.POINTER(QstConfig)]),
+    "qst_arena_segment": (C.c_int, [C.POINTER(QstConfig), C.c_int, C.POINTER(C.c_char_p), c_i64p, c_i64p, c_i32p, c_i32p]),
+    "qst_shadow_elems": (C.c_int64, [C.POINTER(QstConfig)]),
+    "qst_encoder_create": (C.c_int, [C.POINTER(QstConfig), C.POINTER(vp)]),
+    "qst_encoder_destroy": (None, [vp]),
+    "qst_encoder_saved_bytes": (C.c_size_t, [vp, C.c_int, C.c_int, C.c_int]),
+    "qst_encoder_bwd_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int]),
+    "qst_refresh_shadow": (C.c_int, [vp, vp, vp, vp]),
+    "qst_encoder_forward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_size_t, C.c_int, vp]),
+    "qst_encoder_backward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp]),
+    "qst_quadruplet_loss": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                      C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "qst_clip_adamw_step": (C.c_int, [vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                      C.c_float, C.c_float, C.c_int64, vp, vp, vp]),
+    # kernel level (include/qst_kernels.h)
+    "qst_gemm_nt": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int, vp]),
+    "qst_gemm_tn": (C.c_int, [C.POINTER(QstGemmArgs), vp]),
+    "qst_embed_ln_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+    "qst_ln_fwd": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+    "qst_ln_bwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+    "qst_embed_bwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "qst_position_ids": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "qst_pool_norm_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "qst_pool_norm_bwd": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "qst_attention_fwd": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "qst_attention_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "qst_rel_bucket_host": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "qst_rel_bias_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
+    "qst_rel_bias_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "qst_shadow_matrix": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libqst.so and bind every declared symbol; raises QstError if the extension is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QstError(f"HIP extension not built: {LIB_PATH} is missing (no CPU fallback exists). "
+                       f"Run `make -C {os.path.join(_HERE, 'csrc')}` or __graft_entry__.build().")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        lib = load()
+        msg = lib.qst_strerror(status).decode()
+        extra = f" (hip error {lib.qst_last_hip_error()})" if status == -4 else ""
+        raise QstError(f"{what or 'libqst'}: {msg}{extra}")
+
+
+def make_config(cfg, precision: int = 0) -> QstConfig:
+    return QstConfig(cfg.arch, cfg.vocab_size, cfg.hidden_size, cfg.num_layers, cfg.num_heads,
+                     cfg.intermediate_size, cfg.max_position, cfg.type_vocab_size, cfg.layer_norm_eps,
+                     int(cfg.normalize), cfg.rel_buckets, cfg.rel_max_distance, cfg.pad_token_id, precision)
+
+
+def ptr(t) -> Optional[int]:
+    """data_ptr of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream_ptr() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,447 @@
+// attention.hip -- masked softmax self-attention forward and backward, LDS-staged, bf16 MFMA 32x32x16.
+//
+// Replaces BertSelfAttention eager path (modeling_bert.py:111-136: softmax(QK^T/sqrt(d) + mask) V) and
+// MPNetSelfAttention (modeling_mpnet.py:149-158: + position_bias before the mask) and their autograd.
+// Head dims 32 (MiniLM) and 64 (mpnet/bert-base); L multiple of 32, <= 512.
+//
+// Orientation (cdna guide section 3 "accumulator tile as the next MFMA's operand"):
+//  fwd / dQ : S^T = K.Q^T  -> accumulator rows = keys (registers), column = query (lane): softmax statistics
+//             are per lane; P^T feeds the next MFMA as the B operand with no lane movement:
+//             O^T = V^T.P^T and dQ^T = K^T.dS^T, the A operand (V^T / K^T) by ds_read_b64_tr_b16.
+//  dK/dV    : S = Q.K^T    -> rows = queries (registers), column = key (lane); dV^T = dO^T.P, dK^T = Q^T.dS.
+// One workgroup = 4 waves = 128 queries (fwd, dQ) or 128 keys (dK/dV) of one (sequence, head); the other
+// side is streamed through LDS in chunks of 128 rows.
+#include "qst_common.h"
+#include "qst_kernels.h"
+
+namespace {
+
+constexpr float kMaskMin = -3.4028234663852886e38f;   // torch.finfo(float32).min, HF's additive mask value
+
+template <int D> __device__ __forceinline__ uint32_t rr_off(int row, int chunk) {   // image for ds_read_b128 row reads
+    if (D == 32) return (uint32_t)(row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4));
+    return (uint32_t)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+}
+template <int D> __device__ __forceinline__ uint32_t tr_off(int row, int byte) {     // image for transposed reads
+    if (D == 32) return (uint32_t)(row * 64 + byte);
+    return (uint32_t)(row * 128 + (byte ^ (((row >> 1) & 1) << 6)));
+}
+__device__ __forceinline__ bf16x4 lds_tr(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
+}
+// A-operand fragment (32 rows = dd block `ddb`, k = 16 rows of the image starting at `row0`), k order matching an
+// accumulator-sourced B operand: element e of lane-half h <-> image row row0 + 8*(e>>2) + 4h + (e&3)
+template <int D> __device__ __forceinline__ bf16x8 tr_frag(const char* img, int row0, int ddb, int lane) {
+    const int li = lane & 15, q = li >> 2, p = li & 3, gsel = (lane >> 4) & 1, h = lane >> 5;
+    const int byte = ddb * 64 + gsel * 32 + 8 * p;
+    const bf16x4 a = lds_tr(img + tr_off<D>(row0 + 4 * h + q, byte));
+    const bf16x4 b = lds_tr(img + tr_off<D>(row0 + 8 + 4 * h + q, byte));
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[e] = a[e]; f[4 + e] = b[e]; }
+    return f;
+}
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& acc, int s) {
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (bf16)acc[8 * s + e];
+    return f;
+}
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// stage `rows` x D bf16 (global row stride ld elements) into an LDS image
+template <int D, bool TR>
+__device__ __forceinline__ void stage(char* img, const bf16* g, int ld, int rows, int tid) {
+    constexpr int CPR = D / 8;
+    for (int idx = tid; idx < rows * CPR; idx += 256) {
+        const int row = idx / CPR, c = idx % CPR;
+        const u32x4 v = *(const u32x4*)(g + (size_t)row * ld + c * 8);
+        const uint32_t off = TR ? tr_off<D>(row, c * 16) : rr_off<D>(row, c);
+        *(u32x4*)(img + off) = v;
+    }
+}
+
+struct AttnArgs {
+    const bf16* qkv; const bf16* ctx; const bf16* dctx; const float* lse_in; const int64_t* mask;
+    const float* rel; bf16* out; bf16* dqkv; float* lse_out; float* drel;
+    int nseq, L, A, H; float scale;
+};
+
+// ------------------------------------------------------------------ forward
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = D / 16, DB = D / 32, IMG = 128 * D * 2;
+    char* kimg = smem;                  // row-read image of the K chunk
+    char* vimg = smem + IMG;            // transposed-read image of the V chunk
+    float* madd = (float*)(smem + 2 * IMG);   // additive key mask for the whole sequence [L]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, fr = lane & 31;
+    const int nqb = (a.L + 127) / 128;
+    const int qb = blockIdx.x % nqb, head = (blockIdx.x / nqb) % a.A, seq = blockIdx.x / (nqb * a.A);
+    const int ld = 3 * a.H;
+    const bf16* base = a.qkv + (size_t)seq * a.L * ld + head * D;
+    const int i0 = qb * 128 + wave * 32;
+    const bool active = i0 < a.L;
+    const int qi = i0 + fr;
+
+    for (int t = tid; t < a.L; t += 256) madd[t] = a.mask[(size_t)seq * a.L + t] ? 0.f : kMaskMin;
+
+    bf16x8 qf[KS];
+    if (active) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) qf[s] = *(const bf16x8*)(base + (size_t)qi * ld + 16 * s + 8 * h);
+    }
+    f32x16 o[DB];
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    const int nchunk = (a.L + 127) / 128;
+    for (int c = 0; c < nchunk; ++c) {
+        const int rows = min(128, a.L - c * 128);
+        __syncthreads();
+        stage<D, false>(kimg, base + (size_t)c * 128 * ld + a.H, ld, rows, tid);
+        stage<D, true>(vimg, base + (size_t)c * 128 * ld + 2 * a.H, ld, rows, tid);
+        __syncthreads();
+        if (!active) continue;
+        for (int jt = 0; jt < rows / 32; ++jt) {
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(kimg + rr_off<D>(jt * 32 + fr, 2 * ks + h));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+            }
+            const int j0 = c * 128 + jt * 32;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = j0 + acc_row(r, h);
+                float v = s[r] * a.scale;
+                if (a.rel) v += a.rel[((size_t)head * a.L + qi) * a.L + j];
+                v += madd[j];
+                s[r] = v;
+                mx = fmaxf(mx, v);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m, mx);
+            const float alpha = __expf(m - mn);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - mn); ps += s[r]; }
+            ps += __shfl_xor(ps, 32, 64);
+            l = l * alpha + ps;
+            m = mn;
+#pragma unroll
+            for (int b = 0; b < DB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 pf = acc_frag(s, ks);
+#pragma unroll
+                for (int b = 0; b < DB; ++b) {
+                    const bf16x8 vf = tr_frag<D>(vimg, jt * 32 + 16 * ks, b, lane);
+                    o[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[b], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!active) return;
+    const float inv = 1.0f / l;
+    bf16* orow = a.out + ((size_t)seq * a.L + qi) * a.H + head * D;
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32x2 pk;
+            pk[0] = pack_bf16x2(o[b][4 * g] * inv, o[b][4 * g + 1] * inv);
+            pk[1] = pack_bf16x2(o[b][4 * g + 2] * inv, o[b][4 * g + 3] * inv);
+            *(u32x2*)(orow + b * 32 + 8 * g + 4 * h) = pk;
+        }
+    if (h == 0 && a.lse_out) a.lse_out[((size_t)seq * a.A + head) * a.L + qi] = m + __logf(l);
+}
+
+// ------------------------------------------------------------------ backward: dQ
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = D / 16, DB = D / 32, IMG = 128 * D * 2;
+    char* kimg = smem;                  // K rows (S^T = K.Q^T)
+    char* ktr = smem + IMG;             // K transposed reads (dQ^T = K^T.dS^T)
+    char* vimg = smem + 2 * IMG;        // V rows (dP^T = V.dO^T)
+    float* madd = (float*)(smem + 3 * IMG);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, fr = lane & 31;
+    const int nqb = (a.L + 127) / 128;
+    const int qb = blockIdx.x % nqb, head = (blockIdx.x / nqb) % a.A, seq = blockIdx.x / (nqb * a.A);
+    const int ld = 3 * a.H;
+    const bf16* base = a.qkv + (size_t)seq * a.L * ld + head * D;
+    const int i0 = qb * 128 + wave * 32;
+    const bool active = i0 < a.L;
+    const int qi = i0 + fr;
+
+    for (int t = tid; t < a.L; t += 256) madd[t] = a.mask[(size_t)seq * a.L + t] ? 0.f : kMaskMin;
+
+    bf16x8 qf[KS], dof[KS];
+    float lse = 0.f, delta = 0.f;
+    if (active) {
+        const bf16* orow = a.ctx + ((size_t)seq * a.L + qi) * a.H + head * D;
+        const bf16* drow = a.dctx + ((size_t)seq * a.L + qi) * a.H + head * D;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            qf[s] = *(const bf16x8*)(base + (size_t)qi * ld + 16 * s + 8 * h);
+            dof[s] = *(const bf16x8*)(drow + 16 * s + 8 * h);
+            const bf16x8 of = *(const bf16x8*)(orow + 16 * s + 8 * h);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) delta += (float)dof[s][e] * (float)of[e];
+        }
+        delta += __shfl_xor(delta, 32, 64);
+        lse = a.lse_in[((size_t)seq * a.A + head) * a.L + qi];
+    }
+    f32x16 dq[DB];
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[b][r] = 0.f;
+
+    const int nchunk = (a.L + 127) / 128;
+    for (int c = 0; c < nchunk; ++c) {
+        const int rows = min(128, a.L - c * 128);
+        __syncthreads();
+        stage<D, false>(kimg, base + (size_t)c * 128 * ld + a.H, ld, rows, tid);
+        stage<D, true>(ktr, base + (size_t)c * 128 * ld + a.H, ld, rows, tid);
+        stage<D, false>(vimg, base + (size_t)c * 128 * ld + 2 * a.H, ld, rows, tid);
+        __syncthreads();
+        if (!active) continue;
+        for (int jt = 0; jt < rows / 32; ++jt) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(kimg + rr_off<D>(jt * 32 + fr, 2 * ks + h));
+                const bf16x8 vf = *(const bf16x8*)(vimg + rr_off<D>(jt * 32 + fr, 2 * ks + h));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);
+            }
+            const int j0 = c * 128 + jt * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = j0 + acc_row(r, h);
+                float v = s[r] * a.scale;
+                if (a.rel) v += a.rel[((size_t)head * a.L + qi) * a.L + j];
+                v += madd[j];
+                const float p = __expf(v - lse);
+                s[r] = p * (dp[r] - delta) * a.scale;          // dS^T * scale
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 df = acc_frag(s, ks);
+#pragma unroll
+                for (int b = 0; b < DB; ++b) {
+                    const bf16x8 kt = tr_frag<D>(ktr, jt * 32 + 16 * ks, b, lane);
+                    dq[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, df, dq[b], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!active) return;
+    bf16* orow = a.dqkv + ((size_t)seq * a.L + qi) * ld + head * D;
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32x2 pk;
+            pk[0] = pack_bf16x2(dq[b][4 * g], dq[b][4 * g + 1]);
+            pk[1] = pack_bf16x2(dq[b][4 * g + 2], dq[b][4 * g + 3]);
+            *(u32x2*)(orow + b * 32 + 8 * g + 4 * h) = pk;
+        }
+}
+
+// ------------------------------------------------------------------ backward: dK, dV
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = D / 16, DB = D / 32, IMG = 128 * D * 2;
+    char* qimg = smem;                  // Q rows   (S = Q.K^T)
+    char* qtr = smem + IMG;             // Q^T      (dK^T = Q^T.dS)
+    char* dimg = smem + 2 * IMG;        // dO rows  (dP = dO.V^T)
+    char* dtr = smem + 3 * IMG;         // dO^T     (dV^T = dO^T.P)
+    float* lse_s = (float*)(smem + 4 * IMG);   // [128]
+    float* del_s = lse_s + 128;                // [128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, fr = lane & 31;
+    const int nkb = (a.L + 127) / 128;
+    const int kb = blockIdx.x % nkb, head = (blockIdx.x / nkb) % a.A, seq = blockIdx.x / (nkb * a.A);
+    const int ld = 3 * a.H;
+    const bf16* base = a.qkv + (size_t)seq * a.L * ld + head * D;
+    const bf16* cbase = a.ctx + (size_t)seq * a.L * a.H + head * D;
+    const bf16* dbase = a.dctx + (size_t)seq * a.L * a.H + head * D;
+    const int j0 = kb * 128 + wave * 32;
+    const bool active = j0 < a.L;
+    const int kj = j0 + fr;
+
+    bf16x8 kf[KS], vf[KS];
+    float madd = 0.f;
+    if (active) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            kf[s] = *(const bf16x8*)(base + (size_t)kj * ld + a.H + 16 * s + 8 * h);
+            vf[s] = *(const bf16x8*)(base + (size_t)kj * ld + 2 * a.H + 16 * s + 8 * h);
+        }
+        madd = a.mask[(size_t)seq * a.L + kj] ? 0.f : kMaskMin;
+    }
+    f32x16 dk[DB], dv[DB];
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[b][r] = 0.f; dv[b][r] = 0.f; }
+
+    const int nchunk = (a.L + 127) / 128;
+    for (int c = 0; c < nchunk; ++c) {
+        const int rows = min(128, a.L - c * 128);
+        __syncthreads();
+        stage<D, false>(qimg, base + (size_t)c * 128 * ld, ld, rows, tid);
+        stage<D, true>(qtr, base + (size_t)c * 128 * ld, ld, rows, tid);
+        stage<D, false>(dimg, dbase + (size_t)c * 128 * a.H, a.H, rows, tid);
+        stage<D, true>(dtr, dbase + (size_t)c * 128 * a.H, a.H, rows, tid);
+        {   // delta_i = sum_dd dO[i][dd] * O[i][dd]; two threads per row
+            const int row = tid >> 1, half = tid & 1;
+            float dsum = 0.f;
+            if (row < rows) {
+                const bf16* orow = cbase + (size_t)(c * 128 + row) * a.H + half * (D / 2);
+                const bf16* drow = dbase + (size_t)(c * 128 + row) * a.H + half * (D / 2);
+#pragma unroll
+                for (int e = 0; e < D / 2; e += 8) {
+                    const bf16x8 ov = *(const bf16x8*)(orow + e), dvv = *(const bf16x8*)(drow + e);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) dsum += (float)ov[t] * (float)dvv[t];
+                }
+            }
+            dsum += __shfl_xor(dsum, 1, 64);
+            if (row < rows && half == 0) {
+                del_s[row] = dsum;
+                lse_s[row] = a.lse_in[((size_t)seq * a.A + head) * a.L + c * 128 + row];
+            }
+        }
+        __syncthreads();
+        if (!active) continue;
+        for (int it = 0; it < rows / 32; ++it) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 qf = *(const bf16x8*)(qimg + rr_off<D>(it * 32 + fr, 2 * ks + h));
+                const bf16x8 df = *(const bf16x8*)(dimg + rr_off<D>(it * 32 + fr, 2 * ks + h));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], s, 0, 0, 0);      // rows i, col j
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], dp, 0, 0, 0);
+            }
+            const int i0 = c * 128 + it * 32;
+            f32x16 p;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int il = it * 32 + acc_row(r, h);
+                const int i = i0 + acc_row(r, h);
+                float v = s[r] * a.scale;
+                if (a.rel) v += a.rel[((size_t)head * a.L + i) * a.L + kj];
+                v += madd;
+                const float pr = __expf(v - lse_s[il]);
+                const float dsr = pr * (dp[r] - del_s[il]);                // dS (unscaled) = d(score)
+                if (a.drel) atomicAdd(a.drel + ((size_t)head * a.L + i) * a.L + kj, dsr);
+                p[r] = pr;
+                s[r] = dsr * a.scale;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 pf = acc_frag(p, ks), sf = acc_frag(s, ks);
+#pragma unroll
+                for (int b = 0; b < DB; ++b) {
+                    const bf16x8 dt = tr_frag<D>(dtr, it * 32 + 16 * ks, b, lane);
+                    const bf16x8 qt = tr_frag<D>(qtr, it * 32 + 16 * ks, b, lane);
+                    dv[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt, pf, dv[b], 0, 0, 0);
+                    dk[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, sf, dk[b], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!active) return;
+    bf16* krow = a.dqkv + ((size_t)seq * a.L + kj) * ld + a.H + head * D;
+    bf16* vrow = krow + a.H;
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32x2 pk;
+            pk[0] = pack_bf16x2(dk[b][4 * g], dk[b][4 * g + 1]);
+            pk[1] = pack_bf16x2(dk[b][4 * g + 2], dk[b][4 * g + 3]);
+            *(u32x2*)(krow + b * 32 + 8 * g + 4 * h) = pk;
+            pk[0] = pack_bf16x2(dv[b][4 * g], dv[b][4 * g + 1]);
+            pk[1] = pack_bf16x2(dv[b][4 * g + 2], dv[b][4 * g + 3]);
+            *(u32x2*)(vrow + b * 32 + 8 * g + 4 * h) = pk;
+        }
+}
+
+template <typename K>
+int set_lds(K kern, size_t bytes) {
+    QST_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return QST_OK;
+}
+
+}  // namespace
+
+static int check_attn(int nseq, int L, int A, int d) {
+    if (nseq <= 0 || L <= 0 || A <= 0) return QST_ERR_BAD_ARG;
+    if ((d != 32 && d != 64) || (L % 32) != 0 || L > 512) return QST_ERR_UNSUPPORTED;
+    return QST_OK;
+}
+
+extern "C" int qst_attention_fwd(const void* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A,
+                                 int d, void* ctx, float* lse, void* stream) {
+    if (!qkv || !mask || !ctx) return QST_ERR_BAD_ARG;
+    int rc = check_attn(nseq, L, A, d);
+    if (rc) return rc;
+    AttnArgs a{};
+    a.qkv = (const bf16*)qkv; a.mask = mask; a.rel = rel_bias; a.out = (bf16*)ctx; a.lse_out = lse;
+    a.nseq = nseq; a.L = L; a.A = A; a.H = A * d; a.scale = 1.0f / sqrtf((float)d);
+    const int grid = nseq * A * ((L + 127) / 128);
+    const size_t lds = (size_t)2 * 128 * d * 2 + (size_t)L * 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (d == 32) { if ((rc = set_lds(attn_fwd_kernel<32>, lds))) return rc; attn_fwd_kernel<32><<<grid, 256, lds, st>>>(a); }
+    else         { if ((rc = set_lds(attn_fwd_kernel<64>, lds))) return rc; attn_fwd_kernel<64><<<grid, 256, lds, st>>>(a); }
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+extern "C" int qst_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse,
+                                 const int64_t* mask, const float* rel_bias, int nseq, int L, int A, int d,
+                                 void* dqkv, float* drel, void* stream) {
+    if (!qkv || !ctx || !dctx || !lse || !mask || !dqkv) return QST_ERR_BAD_ARG;
+    int rc = check_attn(nseq, L, A, d);
+    if (rc) return rc;
+    AttnArgs a{};
+    a.qkv = (const bf16*)qkv; a.ctx = (const bf16*)ctx; a.dctx = (const bf16*)dctx; a.lse_in = lse; a.mask = mask;
+    a.rel = rel_bias; a.dqkv = (bf16*)dqkv; a.drel = drel;
+    a.nseq = nseq; a.L = L; a.A = A; a.H = A * d; a.scale = 1.0f / sqrtf((float)d);
+    const int grid = nseq * A * ((L + 127) / 128);
+    const size_t lds_q = (size_t)3 * 128 * d * 2 + (size_t)L * 4;
+    const size_t lds_kv = (size_t)4 * 128 * d * 2 + 256 * 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (d == 32) {
+        if ((rc = set_lds(attn_bwd_dq_kernel<32>, lds_q))) return rc;
+        attn_bwd_dq_kernel<32><<<grid, 256, lds_q, st>>>(a);
+        QST_LAUNCH_CHECK();
+        if ((rc = set_lds(attn_bwd_dkv_kernel<32>, lds_kv))) return rc;
+        attn_bwd_dkv_kernel<32><<<grid, 256, lds_kv, st>>>(a);
+    } else {
+        if ((rc = set_lds(attn_bwd_dq_kernel<64>, lds_q))) return rc;
+        attn_bwd_dq_kernel<64><<<grid, 256, lds_q, st>>>(a);
+        QST_LAUNCH_CHECK();
+        if ((rc = set_lds(attn_bwd_dkv_kernel<64>, lds_kv))) return rc;
+        attn_bwd_dkv_kernel<64><<<grid, 256, lds_kv, st>>>(a);
+    }
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}

@@ -1,0 +1,101 @@
+// optim.hip -- global-norm gradient clipping + AdamW over the flat parameter arena (HBM-bound, 28 B/param).
+//
+// Replaces torch.nn.utils.clip_grad_norm_(loss_model.parameters(), max_grad_norm) followed by
+// torch.optim.AdamW(lr, betas=(0.9,0.999), eps=1e-8, weight_decay on all but bias/LayerNorm).step()
+// and optimizer.zero_grad() as SentenceTransformer.fit runs them (sentence-transformers 2.2.2;
+// reference call site /root/reference/training/main.py:128-148).
+// The clip coefficient is computed on the device from the reduced norm: no host sync in the step.
+#include "qst_common.h"
+#include "qst_kernels.h"
+
+namespace {
+
+constexpr int kNormBlocks = 1024;
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, int64_t n4, float* partial) {
+    float s = 0.f;
+    const f32x4* g4 = (const f32x4*)g;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = g4[i];
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    __shared__ float red[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(1024) void norm_finish_kernel(const float* partial, int n, float grad_scale, float* norm_out) {
+    __shared__ float red[16];
+    float s = threadIdx.x < n ? partial[threadIdx.x] : 0.f;
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float v = threadIdx.x < 16 ? red[threadIdx.x] : 0.f;
+        v = wave_sum(v);
+        if (threadIdx.x == 0) norm_out[0] = sqrtf(v) * fabsf(grad_scale);
+    }
+}
+
+struct AdamArgs {
+    float* p; float* g; float* m; float* v;
+    const uint8_t* chunk_decay;     // one flag per 256-element chunk of the arena
+    const float* norm;              // device scalar (pre-clip global norm), or null
+    int64_t n4;
+    float lr, beta1, beta2, eps, wd, max_norm, grad_scale, bc1, bc2_sqrt;
+};
+
+__global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
+    float coef = a.grad_scale;
+    if (a.norm && a.max_norm > 0.f) {
+        const float c = a.max_norm / (a.norm[0] + 1e-6f);      // clip_grad_norm_: clamp(max_norm/(norm+1e-6), max=1)
+        coef *= fminf(c, 1.0f);
+    }
+    const float step = a.lr / a.bc1;
+    f32x4* p4 = (f32x4*)a.p; f32x4* g4 = (f32x4*)a.g; f32x4* m4 = (f32x4*)a.m; f32x4* v4 = (f32x4*)a.v;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (int64_t)gridDim.x * 256) {
+        const float decay = a.chunk_decay[i >> 6] ? (1.0f - a.lr * a.wd) : 1.0f;   // 64 float4 per 256-element chunk
+        f32x4 p = p4[i], g = g4[i], m = m4[i], v = v4[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gg = g[k] * coef;
+            p[k] *= decay;
+            m[k] = m[k] + (1.0f - a.beta1) * (gg - m[k]);                // exp_avg.lerp_(grad, 1-beta1)
+            v[k] = a.beta2 * v[k] + (1.0f - a.beta2) * gg * gg;
+            const float denom = sqrtf(v[k]) / a.bc2_sqrt + a.eps;
+            p[k] -= step * (m[k] / denom);
+            g[k] = 0.f;                                                  // optimizer.zero_grad()
+        }
+        p4[i] = p; m4[i] = m; v4[i] = v; g4[i] = g;
+    }
+}
+
+}  // namespace
+
+extern "C" int qst_adamw_launch(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                                const uint8_t* chunk_decay, int64_t n, float lr, float beta1, float beta2, float eps,
+                                float weight_decay, float max_grad_norm, float grad_scale, int64_t step,
+                                float* norm_out, float* scratch, hipStream_t st) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !chunk_decay || n <= 0 || (n & 255) || step < 1)
+        return QST_ERR_BAD_ARG;
+    if (max_grad_norm > 0.f || norm_out) {
+        if (!norm_out || !scratch) return QST_ERR_BAD_ARG;
+        sumsq_kernel<<<kNormBlocks, 256, 0, st>>>(grads, n / 4, scratch);
+        QST_LAUNCH_CHECK();
+        norm_finish_kernel<<<1, 1024, 0, st>>>(scratch, kNormBlocks, grad_scale, norm_out);
+        QST_LAUNCH_CHECK();
+    }
+    AdamArgs a;
+    a.p = params; a.g = grads; a.m = exp_avg; a.v = exp_avg_sq; a.chunk_decay = chunk_decay;
+    a.norm = (max_grad_norm > 0.f) ? norm_out : nullptr;
+    a.n4 = n / 4;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.max_norm = max_grad_norm;
+    a.grad_scale = grad_scale;
+    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    adamw_kernel<<<2048, 256, 0, st>>>(a);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}

@@ -1,0 +1,419 @@
+// qst_api.hip -- C-ABI entry points of libqst.so: arena layout, encoder handle, forward/backward
+// orchestration (which kernels run, in which order, on which buffers). See include/qst.h.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "qst_common.h"
+#include "qst_kernels.h"
+
+extern "C" int qst_adamw_launch(float*, float*, float*, float*, const uint8_t*, int64_t, float, float, float, float,
+                                float, float, float, int64_t, float*, float*, hipStream_t);
+
+static thread_local int g_last_hip_error = 0;
+extern "C" int qst_set_hip_error(int code) { g_last_hip_error = code; return code; }
+extern "C" int qst_last_hip_error(void) { return g_last_hip_error; }
+extern "C" int qst_version(void) { return 100; }
+
+extern "C" const char* qst_strerror(int s) {
+    switch (s) {
+        case QST_OK: return "ok";
+        case QST_ERR_BAD_ARG: return "bad argument (null pointer, non-positive size or bad enum)";
+        case QST_ERR_UNSUPPORTED: return "unsupported dimensions for the gfx950 kernels";
+        case QST_ERR_WORKSPACE: return "workspace or saved-activation arena too small";
+        case QST_ERR_HIP: return "HIP runtime error (see qst_last_hip_error)";
+        case QST_ERR_NO_DEVICE: return "no HIP device";
+        case QST_ERR_COMM: return "collective communication error";
+        default: return "unknown qst status";
+    }
+}
+
+// ------------------------------------------------------------------ layout
+namespace {
+
+constexpr int64_t kAlign = 256;
+
+struct Seg {
+    std::string name;
+    int64_t off, numel;
+    int rows, cols;     // 2-D view (cols = 1 rows = numel for vectors)
+    int decay, gemm;
+    int64_t shadow_off; // bf16 shadow arena offset of W (W^T follows at shadow_off + align(numel)); -1 if none
+};
+
+struct Layout {
+    std::vector<Seg> segs;
+    int64_t total = 0, shadow_total = 0;
+    // indices
+    int word = -1, pos = -1, type = -1, eg = -1, eb = -1, rel = -1;
+    std::vector<int> layer0;   // index of w_qkv per layer; following 11 entries are fixed order
+};
+
+bool cfg_ok(const qst_config* c) {
+    if (!c) return false;
+    if (c->arch != QST_ARCH_BERT && c->arch != QST_ARCH_MPNET) return false;
+    if (c->hidden_size <= 0 || c->num_layers <= 0 || c->num_heads <= 0 || c->intermediate_size <= 0) return false;
+    if (c->vocab_size <= 0 || c->max_position <= 0 || c->type_vocab_size < 0) return false;
+    return true;
+}
+
+Layout build_layout(const qst_config* c) {
+    Layout L;
+    const int H = c->hidden_size, I = c->intermediate_size;
+    int64_t off = 0, soff = 0;
+    auto add = [&](const std::string& nm, int rows, int cols, int decay, int gemm) {
+        Seg s;
+        s.name = nm; s.off = off; s.rows = rows; s.cols = cols; s.numel = (int64_t)rows * cols;
+        s.decay = decay; s.gemm = gemm; s.shadow_off = -1;
+        if (gemm) { s.shadow_off = soff; soff += 2 * qst_align_up(s.numel, kAlign); }
+        off = qst_align_up(off + s.numel, kAlign);
+        L.segs.push_back(s);
+        return (int)L.segs.size() - 1;
+    };
+    L.word = add("word_emb", c->vocab_size, H, 1, 0);
+    L.pos = add("pos_emb", c->max_position, H, 1, 0);
+    if (c->type_vocab_size > 0) L.type = add("type_emb", c->type_vocab_size, H, 1, 0);
+    L.eg = add("emb_ln_g", H, 1, 0, 0);
+    L.eb = add("emb_ln_b", H, 1, 0, 0);
+    if (c->arch == QST_ARCH_MPNET) L.rel = add("rel_bias", c->rel_buckets, c->num_heads, 1, 0);
+    for (int l = 0; l < c->num_layers; ++l) {
+        const std::string p = "layer." + std::to_string(l) + ".";
+        L.layer0.push_back(add(p + "w_qkv", 3 * H, H, 1, 1));
+        add(p + "b_qkv", 3 * H, 1, 0, 0);
+        add(p + "w_o", H, H, 1, 1);
+        add(p + "b_o", H, 1, 0, 0);
+        add(p + "ln1_g", H, 1, 0, 0);
+        add(p + "ln1_b", H, 1, 0, 0);
+        add(p + "w_1", I, H, 1, 1);
+        add(p + "b_1", I, 1, 0, 0);
+        add(p + "w_2", H, I, 1, 1);
+        add(p + "b_2", H, 1, 0, 0);
+        add(p + "ln2_g", H, 1, 0, 0);
+        add(p + "ln2_b", H, 1, 0, 0);
+    }
+    L.total = off;
+    L.shadow_total = soff;
+    return L;
+}
+enum { W_QKV = 0, B_QKV, W_O, B_O, LN1_G, LN1_B, W_1, B_1, W_2, B_2, LN2_G, LN2_B };
+
+}  // namespace
+
+struct qst_encoder {
+    qst_config cfg;
+    Layout lay;
+    uint8_t* chunk_decay = nullptr;   // device: decay flag per 256-element chunk
+    int32_t* rel_lut = nullptr;       // device: MPNet bucket of (j - i), index (j - i) + 511
+};
+
+extern "C" int64_t qst_arena_elems(const qst_config* cfg) { return cfg_ok(cfg) ? build_layout(cfg).total : QST_ERR_BAD_ARG; }
+extern "C" int64_t qst_shadow_elems(const qst_config* cfg) { return cfg_ok(cfg) ? build_layout(cfg).shadow_total : QST_ERR_BAD_ARG; }
+extern "C" int qst_arena_num_segments(const qst_config* cfg) { return cfg_ok(cfg) ? (int)build_layout(cfg).segs.size() : QST_ERR_BAD_ARG; }
+extern "C" int qst_arena_segment(const qst_config* cfg, int idx, const char** name_out, int64_t* offset_out,
+                                 int64_t* numel_out, int32_t* decay_out, int32_t* gemm_out) {
+    if (!cfg_ok(cfg)) return QST_ERR_BAD_ARG;
+    static thread_local Layout L;      // keeps name storage alive for the caller
+    L = build_layout(cfg);
+    if (idx < 0 || idx >= (int)L.segs.size()) return QST_ERR_BAD_ARG;
+    const Seg& s = L.segs[idx];
+    if (name_out) *name_out = s.name.c_str();
+    if (offset_out) *offset_out = s.off;
+    if (numel_out) *numel_out = s.numel;
+    if (decay_out) *decay_out = s.decay;
+    if (gemm_out) *gemm_out = s.gemm;
+    return QST_OK;
+}
+
+// MPNet relative_position_bucket (modeling_mpnet.py:329-348) evaluated on the host in the same float32
+// steps torch takes: log(n.float()/max_exact) / math.log(max_distance/max_exact) * (nb - max_exact) -> trunc.
+extern "C" int qst_rel_bucket_host(int rel /* j - i */, int num_buckets, int max_distance) {
+    int n = -rel;
+    const int nb = num_buckets / 2;
+    int ret = (n < 0) ? nb : 0;
+    n = n < 0 ? -n : n;
+    const int max_exact = nb / 2;
+    if (n < max_exact) return ret + n;
+    const float ratio = (float)n / (float)max_exact;
+    const float denom = (float)log((double)max_distance / (double)max_exact);
+    float v = logf(ratio) / denom;
+    v = v * (float)(nb - max_exact);
+    int large = max_exact + (int)v;
+    if (large > nb - 1) large = nb - 1;
+    return ret + large;
+}
+
+extern "C" int qst_encoder_create(const qst_config* cfg, qst_encoder** out) {
+    if (!cfg_ok(cfg) || !out) return QST_ERR_BAD_ARG;
+    const int d = cfg->hidden_size / cfg->num_heads;
+    if (cfg->hidden_size % cfg->num_heads != 0 || (d != 32 && d != 64)) return QST_ERR_UNSUPPORTED;
+    if (cfg->hidden_size % 64 != 0 || cfg->intermediate_size % 64 != 0 || cfg->hidden_size > 1024) return QST_ERR_UNSUPPORTED;
+    if (cfg->type_vocab_size > 2) return QST_ERR_UNSUPPORTED;
+    if (cfg->precision != QST_PREC_BF16) return QST_ERR_UNSUPPORTED;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return QST_ERR_NO_DEVICE;
+    qst_encoder* e = new qst_encoder();
+    e->cfg = *cfg;
+    e->lay = build_layout(cfg);
+    const int64_t nchunks = e->lay.total / kAlign;
+    std::vector<uint8_t> flags((size_t)nchunks, 0);
+    for (const Seg& s : e->lay.segs)
+        if (s.decay)
+            for (int64_t ch = s.off / kAlign; ch < qst_align_up(s.off + s.numel, kAlign) / kAlign; ++ch) flags[(size_t)ch] = 1;
+    if (hipMalloc((void**)&e->chunk_decay, (size_t)nchunks) != hipSuccess) { delete e; return QST_ERR_HIP; }
+    if (hipMemcpy(e->chunk_decay, flags.data(), (size_t)nchunks, hipMemcpyHostToDevice) != hipSuccess) {
+        hipFree(e->chunk_decay); delete e; return QST_ERR_HIP;
+    }
+    if (cfg->arch == QST_ARCH_MPNET) {
+        std::vector<int32_t> lut(1023);
+        for (int r = -511; r <= 511; ++r) lut[(size_t)(r + 511)] = qst_rel_bucket_host(r, cfg->rel_buckets, cfg->rel_max_distance);
+        if (hipMalloc((void**)&e->rel_lut, 1023 * sizeof(int32_t)) != hipSuccess ||
+            hipMemcpy(e->rel_lut, lut.data(), 1023 * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            hipFree(e->chunk_decay); if (e->rel_lut) hipFree(e->rel_lut); delete e; return QST_ERR_HIP;
+        }
+    }
+    *out = e;
+    return QST_OK;
+}
+
+extern "C" void qst_encoder_destroy(qst_encoder* e) {
+    if (!e) return;
+    if (e->chunk_decay) hipFree(e->chunk_decay);
+    if (e->rel_lut) hipFree(e->rel_lut);
+    delete e;
+}
+
+// ------------------------------------------------------------------ activation arena
+namespace {
+
+struct LayerAct {
+    size_t qkv, lse, ctx, y1, y1b, xh1, rs1, u, hact, x, xb, xh2, rs2;   // x/xb/xh2/rs2 = layer OUTPUT
+};
+struct ActPlan {
+    size_t pos_ids, x0, x0b, xh0, rs0, s_scratch, pooled, rel;
+    std::vector<LayerAct> layers;
+    size_t total;
+};
+
+ActPlan plan_acts(const qst_config& c, int nseq, int L, bool training) {
+    ActPlan p;
+    const size_t M = (size_t)nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    p.pos_ids = take(M * 4);
+    p.x0 = take(M * H * 4); p.x0b = take(M * H * 2); p.xh0 = take(M * H * 2); p.rs0 = take(M * 4);
+    p.s_scratch = take(M * H * 4);
+    p.pooled = take((size_t)nseq * H * 4);
+    p.rel = (c.arch == QST_ARCH_MPNET) ? take(A * (size_t)L * L * 4) : 0;
+    p.layers.resize(c.num_layers);
+    for (int l = 0; l < c.num_layers; ++l) {
+        LayerAct& a = p.layers[l];
+        if (training || l < 2) {
+            a.qkv = take(M * 3 * H * 2); a.lse = take((size_t)nseq * A * L * 4); a.ctx = take(M * H * 2);
+            a.y1 = take(M * H * 4); a.y1b = take(M * H * 2); a.xh1 = take(M * H * 2); a.rs1 = take(M * 4);
+            a.u = take(M * I * 2); a.hact = take(M * I * 2);
+            a.x = take(M * H * 4); a.xb = take(M * H * 2); a.xh2 = take(M * H * 2); a.rs2 = take(M * 4);
+        } else {
+            a = p.layers[l - 2];      // inference: ping-pong two layer slots (a layer reads the previous slot's x)
+        }
+    }
+    p.total = off;
+    return p;
+}
+
+struct BwdPlan { size_t dxa, dxb, ds, dsb, du, dctx, dqkv, drel, total; };
+BwdPlan plan_bwd(const qst_config& c, int nseq, int L) {
+    BwdPlan p;
+    const size_t M = (size_t)nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    p.dxa = take(M * H * 4); p.dxb = take(M * H * 4); p.ds = take(M * H * 4); p.dsb = take(M * H * 2);
+    p.du = take(M * I * 2); p.dctx = take(M * H * 2); p.dqkv = take(M * 3 * H * 2);
+    p.drel = (c.arch == QST_ARCH_MPNET) ? take(A * (size_t)L * L * 4) : 0;
+    p.total = off;
+    return p;
+}
+
+int shape_ok(const qst_encoder* e, int nseq, int L) {
+    if (!e || nseq <= 0 || L <= 0) return QST_ERR_BAD_ARG;
+    if (L % 32 != 0 || L > 512) return QST_ERR_UNSUPPORTED;
+    if ((int64_t)nseq * L * e->cfg.intermediate_size * 2 >= ((int64_t)1 << 32)) return QST_ERR_UNSUPPORTED;  // 32-bit buffer offsets
+    if (e->cfg.arch == QST_ARCH_BERT && L > e->cfg.max_position) return QST_ERR_UNSUPPORTED;
+    if (e->cfg.arch == QST_ARCH_MPNET && L + e->cfg.pad_token_id + 1 > e->cfg.max_position) return QST_ERR_UNSUPPORTED;
+    return QST_OK;
+}
+
+int nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* C2, const void* aux, const float* bias,
+       const float* resid, int ldr, int M, int N, int K, int epi, hipStream_t st) {
+    QstGemmArgs g{};
+    g.A = A; g.B = B; g.C = C; g.C2 = C2; g.aux = aux; g.bias = bias; g.resid = resid;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
+    return qst_gemm_nt(&g, epi, st);
+}
+int tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, float* colsum, int M, int N, int K,
+       hipStream_t st) {
+    QstGemmArgs g{};
+    g.A = A; g.B = B; g.C = C; g.colsum = colsum; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.splits = 0;
+    return qst_gemm_tn(&g, st);
+}
+
+#define QST_TRY(expr) do { int _rc = (expr); if (_rc != QST_OK) return _rc; } while (0)
+
+}  // namespace
+
+extern "C" size_t qst_encoder_saved_bytes(const qst_encoder* e, int nseq, int L, int training) {
+    if (shape_ok(e, nseq, L) != QST_OK) return 0;
+    return plan_acts(e->cfg, nseq, L, training != 0).total;
+}
+extern "C" size_t qst_encoder_bwd_workspace_bytes(const qst_encoder* e, int nseq, int L) {
+    if (shape_ok(e, nseq, L) != QST_OK) return 0;
+    return plan_bwd(e->cfg, nseq, L).total;
+}
+
+extern "C" int qst_refresh_shadow(const qst_encoder* e, const float* params, void* shadow, void* stream) {
+    if (!e || !params || !shadow) return QST_ERR_BAD_ARG;
+    bf16* sh = (bf16*)shadow;
+    for (const Seg& s : e->lay.segs) {
+        if (!s.gemm) continue;
+        QST_TRY(qst_shadow_matrix(params + s.off, s.rows, s.cols, sh + s.shadow_off,
+                                  sh + s.shadow_off + qst_align_up(s.numel, kAlign), stream));
+    }
+    return QST_OK;
+}
+
+extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int64_t* mask, const int64_t* type_ids,
+                                   int nseq, int L, const float* params, const void* shadow, float* out_emb,
+                                   float* out_tok, void* saved, size_t saved_bytes, int training, void* stream) {
+    if (!e || !ids || !mask || !params || !shadow || !out_emb || !saved) return QST_ERR_BAD_ARG;
+    QST_TRY(shape_ok(e, nseq, L));
+    const qst_config& c = e->cfg;
+    const ActPlan p = plan_acts(c, nseq, L, training != 0);
+    if (saved_bytes < p.total) return QST_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* sv = (char*)saved;
+    const bf16* sh = (const bf16*)shadow;
+    const int M = nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads, d = H / A;
+    const Layout& lay = e->lay;
+    auto P = [&](int seg) { return params + lay.segs[seg].off; };
+    auto W = [&](int seg) { return sh + lay.segs[seg].shadow_off; };
+
+    int32_t* pos_ids = (int32_t*)(sv + p.pos_ids);
+    QST_TRY(qst_position_ids(ids, nseq, L, c.arch, c.pad_token_id, pos_ids, st));
+    QST_TRY(qst_embed_ln_fwd(ids, type_ids, pos_ids, P(lay.word), P(lay.pos), lay.type >= 0 ? P(lay.type) : nullptr,
+                             P(lay.eg), P(lay.eb), c.layer_norm_eps, M, H, (float*)(sv + p.x0), sv + p.x0b,
+                             sv + p.xh0, (float*)(sv + p.rs0), st));
+    const float* rel = nullptr;
+    if (c.arch == QST_ARCH_MPNET) {
+        QST_TRY(qst_rel_bias_fwd(P(lay.rel), e->rel_lut, A, L, (float*)(sv + p.rel), st));
+        rel = (const float*)(sv + p.rel);
+    }
+    const float* x = (const float*)(sv + p.x0);
+    const void* xb = sv + p.x0b;
+    float* s = (float*)(sv + p.s_scratch);
+    for (int l = 0; l < c.num_layers; ++l) {
+        const LayerAct& a = p.layers[l];
+        const int b = lay.layer0[l];
+        QST_TRY(nt(xb, H, W(b + W_QKV), H, sv + a.qkv, 3 * H, nullptr, nullptr, P(b + B_QKV), nullptr, 0, M, 3 * H, H,
+                   QST_EPI_BF16, st));
+        QST_TRY(qst_attention_fwd(sv + a.qkv, mask, rel, nseq, L, A, d, sv + a.ctx, (float*)(sv + a.lse), st));
+        QST_TRY(nt(sv + a.ctx, H, W(b + W_O), H, s, H, nullptr, nullptr, P(b + B_O), x, H, M, H, H, QST_EPI_F32_RESID, st));
+        QST_TRY(qst_ln_fwd(s, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, (float*)(sv + a.y1), sv + a.y1b,
+                           sv + a.xh1, (float*)(sv + a.rs1), st));
+        QST_TRY(nt(sv + a.y1b, H, W(b + W_1), H, sv + a.u, I, sv + a.hact, nullptr, P(b + B_1), nullptr, 0, M, I, H,
+                   QST_EPI_GELU, st));
+        QST_TRY(nt(sv + a.hact, I, W(b + W_2), I, s, H, nullptr, nullptr, P(b + B_2), (const float*)(sv + a.y1), H, M, H,
+                   I, QST_EPI_F32_RESID, st));
+        QST_TRY(qst_ln_fwd(s, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, M, H, (float*)(sv + a.x), sv + a.xb,
+                           sv + a.xh2, (float*)(sv + a.rs2), st));
+        x = (const float*)(sv + a.x);
+        xb = sv + a.xb;
+    }
+    QST_TRY(qst_pool_norm_fwd(x, mask, nseq, L, H, c.normalize, out_emb, (float*)(sv + p.pooled), st));
+    if (out_tok) QST_HIP_CHECK(hipMemcpyAsync(out_tok, x, (size_t)M * H * 4, hipMemcpyDeviceToDevice, st));
+    return QST_OK;
+}
+
+extern "C" int qst_encoder_backward(qst_encoder* e, const int64_t* ids, const int64_t* mask, const int64_t* type_ids,
+                                    int nseq, int L, const float* params, const void* shadow, const float* grad_emb,
+                                    float* grads, void* saved, size_t saved_bytes, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    if (!e || !ids || !mask || !params || !shadow || !grad_emb || !grads || !saved || !workspace) return QST_ERR_BAD_ARG;
+    QST_TRY(shape_ok(e, nseq, L));
+    const qst_config& c = e->cfg;
+    const ActPlan p = plan_acts(c, nseq, L, true);
+    const BwdPlan w = plan_bwd(c, nseq, L);
+    if (saved_bytes < p.total || workspace_bytes < w.total) return QST_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* sv = (char*)saved;
+    char* ws = (char*)workspace;
+    const bf16* sh = (const bf16*)shadow;
+    const int M = nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads, d = H / A;
+    const Layout& lay = e->lay;
+    auto P = [&](int seg) { return params + lay.segs[seg].off; };
+    auto G = [&](int seg) { return grads + lay.segs[seg].off; };
+    auto WT = [&](int seg) { return sh + lay.segs[seg].shadow_off + qst_align_up(lay.segs[seg].numel, kAlign); };
+
+    float* dxa = (float*)(ws + w.dxa);
+    float* dxb = (float*)(ws + w.dxb);
+    float* ds = (float*)(ws + w.ds);
+    void* dsb = ws + w.dsb;
+    void* du = ws + w.du;
+    void* dctx = ws + w.dctx;
+    void* dqkv = ws + w.dqkv;
+    float* drel = nullptr;
+    const float* rel = nullptr;
+    if (c.arch == QST_ARCH_MPNET) {
+        drel = (float*)(ws + w.drel);
+        rel = (const float*)(sv + p.rel);
+        QST_HIP_CHECK(hipMemsetAsync(drel, 0, (size_t)A * L * L * 4, st));
+    }
+    const LayerAct& top = p.layers[c.num_layers - 1];
+    (void)top;
+    QST_TRY(qst_pool_norm_bwd(grad_emb, (const float*)(sv + p.pooled), mask, nseq, L, H, c.normalize, dxa, st));
+    for (int l = c.num_layers - 1; l >= 0; --l) {
+        const LayerAct& a = p.layers[l];
+        const int b = lay.layer0[l];
+        const void* xin_b = (l == 0) ? (const void*)(sv + p.x0b) : (const void*)(sv + p.layers[l - 1].xb);
+        // LN2
+        QST_TRY(qst_ln_bwd(dxa, sv + a.xh2, (const float*)(sv + a.rs2), P(b + LN2_G), M, H, ds, dsb, G(b + LN2_G),
+                           G(b + LN2_B), st));
+        // FFN2: wgrad [H, I] (+ bias), dgrad through GELU
+        QST_TRY(tn(dsb, H, sv + a.hact, I, G(b + W_2), I, G(b + B_2), M, H, I, st));
+        QST_TRY(nt(dsb, H, WT(b + W_2), H, du, I, nullptr, sv + a.u, nullptr, nullptr, 0, M, I, H, QST_EPI_GELU_BWD, st));
+        // FFN1
+        QST_TRY(tn(du, I, sv + a.y1b, H, G(b + W_1), H, G(b + B_1), M, I, H, st));
+        QST_TRY(nt(du, I, WT(b + W_1), I, dxb, H, nullptr, nullptr, nullptr, ds, H, M, H, I, QST_EPI_F32_RESID, st));
+        // LN1
+        QST_TRY(qst_ln_bwd(dxb, sv + a.xh1, (const float*)(sv + a.rs1), P(b + LN1_G), M, H, ds, dsb, G(b + LN1_G),
+                           G(b + LN1_B), st));
+        // attention output projection
+        QST_TRY(tn(dsb, H, sv + a.ctx, H, G(b + W_O), H, G(b + B_O), M, H, H, st));
+        QST_TRY(nt(dsb, H, WT(b + W_O), H, dctx, H, nullptr, nullptr, nullptr, nullptr, 0, M, H, H, QST_EPI_BF16, st));
+        // attention core
+        QST_TRY(qst_attention_bwd(sv + a.qkv, sv + a.ctx, dctx, (const float*)(sv + a.lse), mask, rel, nseq, L, A, d,
+                                  dqkv, drel, st));
+        // QKV projection
+        QST_TRY(tn(dqkv, 3 * H, xin_b, H, G(b + W_QKV), H, G(b + B_QKV), M, 3 * H, H, st));
+        QST_TRY(nt(dqkv, 3 * H, WT(b + W_QKV), 3 * H, dxa, H, nullptr, nullptr, nullptr, ds, H, M, H, 3 * H,
+                   QST_EPI_F32_RESID, st));
+    }
+    // embeddings
+    QST_TRY(qst_ln_bwd(dxa, sv + p.xh0, (const float*)(sv + p.rs0), P(lay.eg), M, H, ds, nullptr, G(lay.eg), G(lay.eb), st));
+    QST_TRY(qst_embed_bwd(ds, ids, type_ids, (const int32_t*)(sv + p.pos_ids), nseq, L, H, c.type_vocab_size,
+                          G(lay.word), G(lay.pos), lay.type >= 0 ? G(lay.type) : nullptr, st));
+    if (c.arch == QST_ARCH_MPNET) {
+        QST_TRY(qst_rel_bias_bwd(drel, e->rel_lut, c.rel_buckets, A, L, G(lay.rel), st));
+    }
+    return QST_OK;
+}
+
+extern "C" int qst_clip_adamw_step(const qst_encoder* e, float* params, float* grads, float* exp_avg,
+                                   float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
+                                   float weight_decay, float max_grad_norm, float grad_scale, int64_t step,
+                                   float* norm_out, float* scratch, void* stream) {
+    if (!e) return QST_ERR_BAD_ARG;
+    return qst_adamw_launch(params, grads, exp_avg, exp_avg_sq, e->chunk_decay, e->lay.total, lr, beta1, beta2, eps,
+                            weight_decay, max_grad_norm, grad_scale, step, norm_out, scratch, (hipStream_t)stream);
+}

@@ -1,0 +1,73 @@
+// qst_common.h -- shared device helpers for the gfx950 kernels (wave64, MFMA, buffer loads).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/qst.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define QST_WAVE 64
+
+extern "C" int qst_set_hip_error(int code);
+
+#define QST_HIP_CHECK(expr)                                 \
+    do {                                                    \
+        hipError_t _e = (expr);                             \
+        if (_e != hipSuccess) {                             \
+            qst_set_hip_error((int)_e);                     \
+            return QST_ERR_HIP;                             \
+        }                                                   \
+    } while (0)
+
+#define QST_LAUNCH_CHECK() QST_HIP_CHECK(hipGetLastError())
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+__device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
+
+// 16-byte buffer load with hardware range check: bytes past `num_bytes` read as zero.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t num_bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)num_bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+}
+__device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)byte_off, 0, 0);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    bf16x2 v;
+    v[0] = (bf16)lo;
+    v[1] = (bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bf16lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf16hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
+
+// erf GELU (HF "gelu", modeling_bert.py:325-337 via ACT2FN) and its derivative
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+static inline int64_t qst_align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }

@@ -1,0 +1,82 @@
+// qst_kernels.h -- kernel-level C entry points of libqst.so (internal building blocks of
+// qst_encoder_forward/backward; exported so tests can check each kernel against the oracle).
+// Public mirror: include/qst_kernels.h includes this file.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    QST_EPI_BF16 = 0,            // C(bf16) = acc + bias
+    QST_EPI_F32_RESID = 1,       // C(f32)  = acc + bias + resid
+    QST_EPI_GELU = 2,            // C(bf16) = u = acc + bias ; C2(bf16) = gelu(u)
+    QST_EPI_GELU_BWD = 3,        // C(bf16) = (acc) * gelu'(aux)
+    QST_EPI_F32_RESID_BF16 = 4   // C(f32) = acc + bias + resid ; C2(bf16) = same
+};
+
+typedef struct {
+    const void* A;        // bf16
+    const void* B;        // bf16
+    void* C;
+    void* C2;
+    const void* aux;      // bf16, same shape/ld as C (GELU_BWD)
+    const float* bias;    // [N] or NULL
+    const float* resid;   // f32 [M, ldr] or NULL
+    float* colsum;        // tn only: f32 [N] += column sums of A (bias gradient), or NULL
+    int32_t M, N, K;
+    int32_t lda, ldb, ldc, ldr;
+    int32_t splits;       // tn only: reduction splits over M (0 = auto)
+} QstGemmArgs;
+
+/* C[M,N] = A[M,K] . B[N,K]^T with epilogue `epi`. K % 64 == 0, lda/ldb % 8 == 0. */
+int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream);
+/* C[N,K] (f32, atomically accumulated) += A[M,N]^T . B[M,K]; colsum[N] += sum_m A[m,:]. */
+int qst_gemm_tn(const QstGemmArgs* a, void* stream);
+
+/* Embedding gather + LayerNorm (BertEmbeddings / MPNetEmbeddings forward).
+ * pos_ids: int32 [M] position row per token. type_emb may be NULL. Outputs: y f32, y bf16, xhat bf16, rstd f32. */
+int qst_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
+                     const float* word_emb, const float* pos_emb, const float* type_emb,
+                     const float* gamma, const float* beta, float eps, int M, int H,
+                     float* y, void* y_bf16, void* xhat_bf16, float* rstd, void* stream);
+/* LayerNorm over rows of s f32 [M,H]. */
+int qst_ln_fwd(const float* s, const float* gamma, const float* beta, float eps, int M, int H,
+               float* y, void* y_bf16, void* xhat_bf16, float* rstd, void* stream);
+/* LayerNorm backward: ds = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)); dgamma += sum dy*xhat; dbeta += sum dy. */
+int qst_ln_bwd(const float* dy, const void* xhat_bf16, const float* rstd, const float* gamma, int M, int H,
+               float* ds, void* ds_bf16, float* dgamma, float* dbeta, void* stream);
+/* Embedding backward: scatter ds rows into word/pos/type gradient tables. */
+int qst_embed_bwd(const float* ds, const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
+                  int nseq, int L, int H, int num_types, float* dword, float* dpos, float* dtype_, void* stream);
+/* MPNet position ids (cumsum of non-pad) or BERT arange -> int32 [nseq*L]. */
+int qst_position_ids(const int64_t* ids, int nseq, int L, int arch, int pad_id, int32_t* pos_ids, void* stream);
+
+/* ST Pooling(mean) + optional Normalize. tok f32 [nseq,L,H]; pooled f32 [nseq,H] (pre-normalize, saved). */
+int qst_pool_norm_fwd(const float* tok, const int64_t* mask, int nseq, int L, int H, int normalize,
+                      float* emb, float* pooled, void* stream);
+int qst_pool_norm_bwd(const float* demb, const float* pooled, const int64_t* mask, int nseq, int L, int H,
+                      int normalize, float* dtok, void* stream);
+
+/* Self-attention forward: qkv bf16 [nseq*L, 3H] token-major (q | k | v, heads concatenated),
+ * mask int64 [nseq, L], rel_bias f32 [A, L, L] or NULL -> ctx bf16 [nseq*L, H], lse f32 [nseq, A, L]. */
+int qst_attention_fwd(const void* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A, int d,
+                      void* ctx, float* lse, void* stream);
+/* Backward: dctx bf16 [nseq*L, H] -> dqkv bf16 [nseq*L, 3H]; drel f32 [A, L, L] += (or NULL). */
+int qst_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, const int64_t* mask,
+                      const float* rel_bias, int nseq, int L, int A, int d, void* dqkv, float* drel, void* stream);
+
+/* MPNet relative position bias: rel_bias[a, i, j] = table[lut[(j - i) + 511]][a]; lut = int32 [1023] device
+ * table of qst_rel_bucket_host(j - i). Backward accumulates drel [A, L, L] into dtable [buckets, A]. */
+int qst_rel_bucket_host(int rel, int num_buckets, int max_distance);
+int qst_rel_bias_fwd(const float* table, const int32_t* lut, int A, int L, float* rel_bias, void* stream);
+int qst_rel_bias_bwd(const float* drel, const int32_t* lut, int buckets, int A, int L, float* dtable, void* stream);
+
+/* bf16 shadow: dst[i] = bf16(src[i]) and dstT = transpose for a [rows, cols] matrix. */
+int qst_shadow_matrix(const float* src, int rows, int cols, void* dst_bf16, void* dstT_bf16, void* stream);
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,484 @@
+// rowops.hip -- HBM-bound row kernels: embedding gather + LayerNorm, LayerNorm fwd/bwd,
+// embedding backward, mean-pool + L2-normalise head fwd/bwd, MPNet position ids / relative bias,
+// bf16 shadow refresh.
+//
+// Replaces BertEmbeddings.forward (modeling_bert.py:53-108), nn.LayerNorm in BertSelfOutput/BertOutput
+// (:282-293, :340-351), ST Pooling(mean)+Normalize and their autograd.
+// One wave64 per token row; a lane owns float2 columns lane, lane+64, ... so row statistics are one
+// wave reduction and all global accesses are coalesced 8-byte-per-lane.
+#include "qst_common.h"
+#include "qst_kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+template <int VPL>
+__device__ __forceinline__ void ln_row_finish(const f32x2 (&v)[VPL], int lane, int H, int row,
+                                              const float* gamma, const float* beta, float eps,
+                                              float* y, bf16* yb, bf16* xh, float* rstd_out) {
+    const int nv = H >> 1;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+        if (lane + 64 * i < nv) s += v[i][0] + v[i][1];
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+        if (lane + 64 * i < nv) {
+            const float a = v[i][0] - mean, b = v[i][1] - mean;
+            q += a * a + b * b;
+        }
+    const float var = wave_sum(q) / (float)H;       // biased variance, as nn.LayerNorm
+    const float rstd = rsqrtf(var + eps);
+    if (lane == 0 && rstd_out) rstd_out[row] = rstd;
+    const size_t base = (size_t)row * H;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float h0 = (v[i][0] - mean) * rstd, h1 = (v[i][1] - mean) * rstd;
+            const f32x2 g = *(const f32x2*)(gamma + 2 * c), b = *(const f32x2*)(beta + 2 * c);
+            f32x2 o;
+            o[0] = h0 * g[0] + b[0];
+            o[1] = h1 * g[1] + b[1];
+            *(f32x2*)(y + base + 2 * c) = o;
+            if (yb) *(uint32_t*)(yb + base + 2 * c) = pack_bf16x2(o[0], o[1]);
+            if (xh) *(uint32_t*)(xh + base + 2 * c) = pack_bf16x2(h0, h1);
+        }
+    }
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, const int64_t* type_ids,
+                                                           const int32_t* pos_ids, const float* word,
+                                                           const float* pos, const float* type,
+                                                           const float* gamma, const float* beta, float eps,
+                                                           int M, int H, float* y, bf16* yb, bf16* xh, float* rstd) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = H >> 1;
+    const size_t wrow = (size_t)ids[row] * H, prow = (size_t)pos_ids[row] * H;
+    const size_t trow = (size_t)(type_ids ? type_ids[row] : 0) * H;
+    f32x2 v[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            f32x2 w = *(const f32x2*)(word + wrow + 2 * c);
+            if (type) {                                   // HF order: (word + type) + position
+                const f32x2 t = *(const f32x2*)(type + trow + 2 * c);
+                w[0] += t[0]; w[1] += t[1];
+            }
+            const f32x2 p = *(const f32x2*)(pos + prow + 2 * c);
+            v[i][0] = w[0] + p[0];
+            v[i][1] = w[1] + p[1];
+        } else { v[i][0] = 0.f; v[i][1] = 0.f; }
+    }
+    ln_row_finish<VPL>(v, lane, H, row, gamma, beta, eps, y, yb, xh, rstd);
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* s, const float* gamma, const float* beta, float eps,
+                                                     int M, int H, float* y, bf16* yb, bf16* xh, float* rstd) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = H >> 1;
+    f32x2 v[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) v[i] = *(const f32x2*)(s + (size_t)row * H + 2 * c);
+        else { v[i][0] = 0.f; v[i][1] = 0.f; }
+    }
+    ln_row_finish<VPL>(v, lane, H, row, gamma, beta, eps, y, yb, xh, rstd);
+}
+
+// LayerNorm backward. Each wave walks ROWS_PER_WAVE rows, keeps dgamma/dbeta partials for its columns in
+// registers, and the block adds them to global once (one atomic per column per block).
+constexpr int LN_BWD_ROWS_PER_WAVE = 32;
+
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const bf16* xh, const float* rstd,
+                                                     const float* gamma, int M, int H, float* ds, bf16* dsb,
+                                                     float* dgamma, float* dbeta) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [4 waves][2][H] floats
+    float* sh = (float*)smem;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = H >> 1;
+    f32x2 g[VPL], ag[VPL], ab[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = lane + 64 * i;
+        g[i][0] = g[i][1] = 0.f;
+        if (c < nv) g[i] = *(const f32x2*)(gamma + 2 * c);
+        ag[i][0] = ag[i][1] = ab[i][0] = ab[i][1] = 0.f;
+    }
+    const int row0 = (blockIdx.x * 4 + wave) * LN_BWD_ROWS_PER_WAVE;
+    for (int rr = 0; rr < LN_BWD_ROWS_PER_WAVE; ++rr) {
+        const int row = row0 + rr;
+        if (row >= M) break;
+        const size_t base = (size_t)row * H;
+        f32x2 d[VPL], x[VPL];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lane + 64 * i;
+            d[i][0] = d[i][1] = x[i][0] = x[i][1] = 0.f;
+            if (c < nv) {
+                d[i] = *(const f32x2*)(dy + base + 2 * c);
+                const uint32_t u = *(const uint32_t*)(xh + base + 2 * c);
+                x[i][0] = bf16lo(u); x[i][1] = bf16hi(u);
+                ag[i][0] += d[i][0] * x[i][0]; ag[i][1] += d[i][1] * x[i][1];
+                ab[i][0] += d[i][0];           ab[i][1] += d[i][1];
+                d[i][0] *= g[i][0]; d[i][1] *= g[i][1];          // dxhat
+                s1 += d[i][0] + d[i][1];
+                s2 += d[i][0] * x[i][0] + d[i][1] * x[i][1];
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
+        const float rs = rstd[row];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                f32x2 o;
+                o[0] = rs * (d[i][0] - m1 - x[i][0] * m2);
+                o[1] = rs * (d[i][1] - m1 - x[i][1] * m2);
+                *(f32x2*)(ds + base + 2 * c) = o;
+                if (dsb) *(uint32_t*)(dsb + base + 2 * c) = pack_bf16x2(o[0], o[1]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            *(f32x2*)(sh + (wave * 2 + 0) * H + 2 * c) = ag[i];
+            *(f32x2*)(sh + (wave * 2 + 1) * H + 2 * c) = ab[i];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { a += sh[(w * 2 + 0) * H + c]; b += sh[(w * 2 + 1) * H + c]; }
+        atomicAdd(dgamma + c, a);
+        atomicAdd(dbeta + c, b);
+    }
+}
+
+// Embedding backward.
+//  word: row scatter with float atomics (rows are spread over the vocabulary; low contention)
+//  type: every token hits one of <= 2 rows -> per-block register partials, one atomic per column per block
+__global__ __launch_bounds__(256) void embed_bwd_word_type_kernel(const float* ds, const int64_t* ids,
+                                                                  const int64_t* type_ids, int M, int H, int num_types,
+                                                                  float* dword, float* dtype_) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 types][H] floats
+    float* sh = (float*)smem;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = threadIdx.x; c < 2 * H; c += 256) sh[c] = 0.f;
+    __syncthreads();
+    const int rows_per_wave = 16;
+    const int row0 = (blockIdx.x * 4 + wave) * rows_per_wave;
+    for (int rr = 0; rr < rows_per_wave; ++rr) {
+        const int row = row0 + rr;
+        if (row >= M) break;
+        const size_t base = (size_t)row * H;
+        const size_t wrow = (size_t)ids[row] * H;
+        const int t = (num_types > 0 && type_ids) ? (int)type_ids[row] : 0;
+        for (int c = lane; c < H; c += 64) {
+            const float v = ds[base + c];
+            atomicAdd(dword + wrow + c, v);
+            if (num_types > 0) atomicAdd(sh + (t & 1) * H + c, v);     // LDS atomic
+        }
+    }
+    __syncthreads();
+    if (num_types > 0)
+        for (int c = threadIdx.x; c < min(num_types, 2) * H; c += 256) {
+            const float v = sh[c];
+            if (v != 0.f) atomicAdd(dtype_ + c, v);
+        }
+}
+//  position: block per (t, column chunk); sum over sequences whose position id equals the block's
+//  first one in registers, atomics only for the irregular rest
+__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const float* ds, const int32_t* pos_ids, int nseq, int L,
+                                                            int H, float* dpos) {
+    const int t = blockIdx.x;
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= H) return;
+    const int p0 = pos_ids[t];
+    float acc = 0.f;
+    for (int s = 0; s < nseq; ++s) {
+        const int row = s * L + t;
+        const int p = pos_ids[row];
+        const float v = ds[(size_t)row * H + c];
+        if (p == p0) acc += v;
+        else if (v != 0.f) atomicAdd(dpos + (size_t)p * H + c, v);
+    }
+    atomicAdd(dpos + (size_t)p0 * H + c, acc);
+}
+
+__global__ void position_ids_kernel(const int64_t* ids, int nseq, int L, int arch, int pad_id, int32_t* pos) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseq) return;
+    if (arch == QST_ARCH_BERT) {
+        for (int t = 0; t < L; ++t) pos[s * L + t] = t;
+    } else {
+        int cum = 0;                                   // modeling_mpnet.py:873-881
+        for (int t = 0; t < L; ++t) {
+            const int m = ids[(size_t)s * L + t] != pad_id;
+            cum += m;
+            pos[s * L + t] = cum * m + pad_id;
+        }
+    }
+}
+
+// mean pool + normalise: block per sequence, thread per column (loops when H > 256)
+__global__ __launch_bounds__(256) void pool_norm_fwd_kernel(const float* tok, const int64_t* mask, int L, int H,
+                                                            int normalize, float* emb, float* pooled) {
+    __shared__ float red[4];
+    __shared__ float msk[512];
+    const int s = blockIdx.x;
+    float cnt = 0.f;
+    for (int t = threadIdx.x; t < L; t += 256) msk[t] = (float)mask[(size_t)s * L + t];
+    __syncthreads();
+    for (int t = 0; t < L; ++t) cnt += msk[t];
+    const float inv = 1.0f / fmaxf(cnt, 1e-9f);
+    float sq = 0.f;
+    float e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        e[k] = 0.f;
+        if (c < H) {
+            float a = 0.f;
+            for (int t = 0; t < L; ++t) a += tok[((size_t)s * L + t) * H + c] * msk[t];
+            e[k] = a * inv;
+            sq += e[k] * e[k];
+            if (pooled) pooled[(size_t)s * H + c] = e[k];
+        }
+    }
+    sq = wave_sum(sq);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    const float sc = normalize ? 1.0f / fmaxf(nrm, 1e-12f) : 1.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        if (c < H) emb[(size_t)s * H + c] = e[k] * sc;
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_norm_bwd_kernel(const float* demb, const float* pooled, const int64_t* mask,
+                                                            int L, int H, int normalize, float* dtok) {
+    __shared__ float red[8];
+    __shared__ float msk[512];
+    const int s = blockIdx.x;
+    for (int t = threadIdx.x; t < L; t += 256) msk[t] = (float)mask[(size_t)s * L + t];
+    __syncthreads();
+    float cnt = 0.f;
+    for (int t = 0; t < L; ++t) cnt += msk[t];
+    const float inv = 1.0f / fmaxf(cnt, 1e-9f);
+    float e[4], g[4];
+    float sq = 0.f, dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        e[k] = g[k] = 0.f;
+        if (c < H) {
+            e[k] = pooled[(size_t)s * H + c];
+            g[k] = demb[(size_t)s * H + c];
+            sq += e[k] * e[k];
+            dot += e[k] * g[k];
+        }
+    }
+    sq = wave_sum(sq); dot = wave_sum(dot);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = sq; red[4 + (threadIdx.x >> 6)] = dot; }
+    __syncthreads();
+    sq = red[0] + red[1] + red[2] + red[3];
+    dot = red[4] + red[5] + red[6] + red[7];
+    const float nrm = sqrtf(sq);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        if (c < H) {
+            float dp = g[k];
+            if (normalize) {
+                // y = e / max(n, eps): dy/de = (I - e e^T / n^2) / n for n > eps, I/eps otherwise
+                if (nrm > 1e-12f) dp = (g[k] - e[k] * dot / sq) / nrm;
+                else dp = g[k] / 1e-12f;
+            }
+            dp *= inv;
+            for (int t = 0; t < L; ++t) dtok[((size_t)s * L + t) * H + c] = dp * msk[t];
+        }
+    }
+}
+
+// MPNet relative position bias (modeling_mpnet.py:312-348): rel[a,i,j] = table[bucket(j-i)][a]. The bucket of each
+// offset comes from a host-built LUT (qst_rel_bucket_host) so the float32 log matches torch's on the boundaries.
+__global__ void rel_bias_fwd_kernel(const float* table, const int32_t* lut, int A, int L, float* out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= A * L * L) return;
+    const int j = idx % L, i = (idx / L) % L, a = idx / (L * L);
+    out[idx] = table[lut[j - i + 511] * A + a];
+}
+__global__ void rel_bias_bwd_kernel(const float* drel, const int32_t* lut, int buckets, int A, int L, float* dtable) {
+    // block per (bucket, head): sum drel over the (i, j) that fall in the bucket (deterministic)
+    const int b = blockIdx.x % buckets, a = blockIdx.x / buckets;
+    float acc = 0.f;
+    for (int idx = threadIdx.x; idx < L * L; idx += blockDim.x) {
+        const int j = idx % L, i = idx / L;
+        if (lut[j - i + 511] == b) acc += drel[(size_t)a * L * L + idx];
+    }
+    __shared__ float red[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) dtable[b * A + a] += red[0] + red[1] + red[2] + red[3];
+}
+
+// bf16 shadow of a [rows, cols] fp32 matrix and its transpose, via a 32x32 LDS tile
+__global__ __launch_bounds__(256) void shadow_kernel(const float* src, int rows, int cols, bf16* dst, bf16* dstT) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        float v = 0.f;
+        if (r < rows && c < cols) {
+            v = src[(size_t)r * cols + c];
+            if (dst) dst[(size_t)r * cols + c] = f2bf(v);
+        }
+        tile[ty + 8 * k][tx] = v;
+    }
+    __syncthreads();
+    if (dstT)
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + ty + 8 * k, r = r0 + tx;
+            if (r < rows && c < cols) dstT[(size_t)c * rows + r] = f2bf(tile[tx][ty + 8 * k]);
+        }
+}
+
+#define QST_VPL_DISPATCH(H, CALL)                           \
+    do {                                                    \
+        const int _vpl = ((H) / 2 + 63) / 64;               \
+        switch (_vpl) {                                     \
+            case 1: { constexpr int VPL = 1; CALL; } break; \
+            case 2: { constexpr int VPL = 2; CALL; } break; \
+            case 3: { constexpr int VPL = 3; CALL; } break; \
+            case 4: { constexpr int VPL = 4; CALL; } break; \
+            case 5: case 6: { constexpr int VPL = 6; CALL; } break; \
+            case 7: case 8: { constexpr int VPL = 8; CALL; } break; \
+            default: return QST_ERR_UNSUPPORTED;            \
+        }                                                   \
+    } while (0)
+
+}  // namespace
+
+extern "C" int qst_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
+                                const float* word_emb, const float* pos_emb, const float* type_emb,
+                                const float* gamma, const float* beta, float eps, int M, int H,
+                                float* y, void* y_bf16, void* xhat_bf16, float* rstd, void* stream) {
+    if (!ids || !pos_ids || !word_emb || !pos_emb || !gamma || !beta || !y || M <= 0 || H <= 0 || (H & 1))
+        return QST_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    QST_VPL_DISPATCH(H, (embed_ln_fwd_kernel<VPL><<<(M + 3) / 4, 256, 0, st>>>(
+                            ids, type_ids, pos_ids, word_emb, pos_emb, type_emb, gamma, beta, eps, M, H, y,
+                            (bf16*)y_bf16, (bf16*)xhat_bf16, rstd)));
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+extern "C" int qst_ln_fwd(const float* s, const float* gamma, const float* beta, float eps, int M, int H,
+                          float* y, void* y_bf16, void* xhat_bf16, float* rstd, void* stream) {
+    if (!s || !gamma || !beta || !y || M <= 0 || H <= 0 || (H & 1)) return QST_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    QST_VPL_DISPATCH(H, (ln_fwd_kernel<VPL><<<(M + 3) / 4, 256, 0, st>>>(s, gamma, beta, eps, M, H, y, (bf16*)y_bf16,
+                                                                         (bf16*)xhat_bf16, rstd)));
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+extern "C" int qst_ln_bwd(const float* dy, const void* xhat_bf16, const float* rstd, const float* gamma, int M, int H,
+                          float* ds, void* ds_bf16, float* dgamma, float* dbeta, void* stream) {
+    if (!dy || !xhat_bf16 || !rstd || !gamma || !ds || !dgamma || !dbeta || M <= 0 || H <= 0 || (H & 1))
+        return QST_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int rows_per_block = 4 * LN_BWD_ROWS_PER_WAVE;
+    const int grid = (M + rows_per_block - 1) / rows_per_block;
+    const size_t lds = (size_t)8 * H * sizeof(float);
+    QST_VPL_DISPATCH(H, (ln_bwd_kernel<VPL><<<grid, 256, lds, st>>>(dy, (const bf16*)xhat_bf16, rstd, gamma, M, H, ds,
+                                                                   (bf16*)ds_bf16, dgamma, dbeta)));
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+extern "C" int qst_embed_bwd(const float* ds, const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
+                             int nseq, int L, int H, int num_types, float* dword, float* dpos, float* dtype_,
+                             void* stream) {
+    if (!ds || !ids || !pos_ids || !dword || !dpos || nseq <= 0 || L <= 0 || H <= 0) return QST_ERR_BAD_ARG;
+    if (num_types > 2) return QST_ERR_UNSUPPORTED;
+    if (num_types > 0 && !dtype_) return QST_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int M = nseq * L;
+    embed_bwd_word_type_kernel<<<(M + 63) / 64, 256, (size_t)2 * H * sizeof(float), st>>>(ds, ids, type_ids, M, H,
+                                                                                           num_types, dword, dtype_);
+    QST_LAUNCH_CHECK();
+    embed_bwd_pos_kernel<<<dim3(L, (H + 255) / 256), 256, 0, st>>>(ds, pos_ids, nseq, L, H, dpos);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+extern "C" int qst_position_ids(const int64_t* ids, int nseq, int L, int arch, int pad_id, int32_t* pos_ids,
+                                void* stream) {
+    if (!ids || !pos_ids || nseq <= 0 || L <= 0) return QST_ERR_BAD_ARG;
+    position_ids_kernel<<<(nseq + 63) / 64, 64, 0, (hipStream_t)stream>>>(ids, nseq, L, arch, pad_id, pos_ids);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+extern "C" int qst_pool_norm_fwd(const float* tok, const int64_t* mask, int nseq, int L, int H, int normalize,
+                                 float* emb, float* pooled, void* stream) {
+    if (!tok || !mask || !emb || nseq <= 0 || L <= 0 || H <= 0) return QST_ERR_BAD_ARG;
+    if (L > 512 || H > 1024) return QST_ERR_UNSUPPORTED;
+    pool_norm_fwd_kernel<<<nseq, 256, 0, (hipStream_t)stream>>>(tok, mask, L, H, normalize, emb, pooled);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+extern "C" int qst_pool_norm_bwd(const float* demb, const float* pooled, const int64_t* mask, int nseq, int L, int H,
+                                 int normalize, float* dtok, void* stream) {
+    if (!demb || !pooled || !mask || !dtok || nseq <= 0 || L <= 0 || H <= 0) return QST_ERR_BAD_ARG;
+    if (L > 512 || H > 1024) return QST_ERR_UNSUPPORTED;
+    pool_norm_bwd_kernel<<<nseq, 256, 0, (hipStream_t)stream>>>(demb, pooled, mask, L, H, normalize, dtok);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+extern "C" int qst_rel_bias_fwd(const float* table, const int32_t* lut, int A, int L, float* rel_bias, void* stream) {
+    if (!table || !lut || !rel_bias || A <= 0 || L <= 0 || L > 512) return QST_ERR_BAD_ARG;
+    const int n = A * L * L;
+    rel_bias_fwd_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(table, lut, A, L, rel_bias);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+extern "C" int qst_rel_bias_bwd(const float* drel, const int32_t* lut, int buckets, int A, int L, float* dtable,
+                                void* stream) {
+    if (!drel || !lut || !dtable || A <= 0 || L <= 0 || L > 512 || buckets <= 0) return QST_ERR_BAD_ARG;
+    rel_bias_bwd_kernel<<<buckets * A, 256, 0, (hipStream_t)stream>>>(drel, lut, buckets, A, L, dtable);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+extern "C" int qst_shadow_matrix(const float* src, int rows, int cols, void* dst_bf16, void* dstT_bf16, void* stream) {
+    if (!src || rows <= 0 || cols <= 0) return QST_ERR_BAD_ARG;
+    shadow_kernel<<<dim3((cols + 31) / 32, (rows + 31) / 32), 256, 0, (hipStream_t)stream>>>(
+        src, rows, cols, (bf16*)dst_bf16, (bf16*)dstT_bf16);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}

@@ -1,0 +1,178 @@
+"""HipEncoder: torch tensors as storage, libqst.so as the only executor.
+
+Owns the flat fp32 parameter / gradient / Adam-moment arenas and the bf16
+operand shadow on one GPU and drives the C-ABI (include/qst.h). No
+torch.nn.Module executes anything here; torch is used for device memory and
+streams only (ownership rule).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import EncoderConfig, build_layout, hf_param_views
+
+
+def _round_up(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+class HipEncoder:
+    def __init__(self, cfg: EncoderConfig, device: Optional[torch.device] = None, precision: int = 0):
+        self.cfg = cfg
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.QstError("HipEncoder needs a HIP device; there is no CPU fallback")
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        torch.cuda.set_device(self.device)
+        self.ccfg = _lib.make_config(cfg, precision)
+        self.segments, self.total = build_layout(cfg)
+        n = self.lib.qst_arena_elems(self.ccfg)
+        if n != self.total:
+            raise _lib.QstError(f"arena layout mismatch: python {self.total} vs libqst {n}")
+        h = _lib.vp()
+        _lib.check(self.lib.qst_encoder_create(self.ccfg, h), "qst_encoder_create")
+        self.handle = h
+        self.params = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        self.grads: Optional[torch.Tensor] = None
+        self.exp_avg: Optional[torch.Tensor] = None
+        self.exp_avg_sq: Optional[torch.Tensor] = None
+        self.shadow = torch.zeros(self.lib.qst_shadow_elems(self.ccfg), dtype=torch.bfloat16, device=self.device)
+        self.shadow_stale = True
+        self._saved: Optional[torch.Tensor] = None
+        self._ws: Optional[torch.Tensor] = None
+        self._scratch = torch.zeros(2048, dtype=torch.float32, device=self.device)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.opt_step = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.qst_encoder_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ parameters
+    def load_arena(self, arena) -> None:
+        t = torch.as_tensor(np.asarray(arena), dtype=torch.float32) if not torch.is_tensor(arena) else arena
+        if t.numel() != self.total:
+            raise ValueError(f"arena has {t.numel()} elements, expected {self.total}")
+        self.params.copy_(t.to(self.device))
+        self.shadow_stale = True
+
+    def named_views(self) -> Dict[str, torch.Tensor]:
+        """HF-named views into the parameter arena (no copies)."""
+        seg = {s.name: s for s in self.segments}
+        out = {}
+        for name, sname, off, shape in hf_param_views(self.cfg):
+            s = seg[sname]
+            n = int(np.prod(shape))
+            out[name] = self.params[s.offset + off: s.offset + off + n].view(*shape)
+        return out
+
+    def grad_views(self) -> Dict[str, torch.Tensor]:
+        self.ensure_train_state()
+        seg = {s.name: s for s in self.segments}
+        out = {}
+        for name, sname, off, shape in hf_param_views(self.cfg):
+            s = seg[sname]
+            n = int(np.prod(shape))
+            out[name] = self.grads[s.offset + off: s.offset + off + n].view(*shape)
+        return out
+
+    def ensure_train_state(self) -> None:
+        if self.grads is None:
+            self.grads = torch.zeros_like(self.params)
+        if self.exp_avg is None:
+            self.exp_avg = torch.zeros_like(self.params)
+            self.exp_avg_sq = torch.zeros_like(self.params)
+
+    def refresh_shadow(self) -> None:
+        _lib.check(self.lib.qst_refresh_shadow(self.handle, self.params.data_ptr(), self.shadow.data_ptr(),
+                                               _lib.current_stream_ptr()), "qst_refresh_shadow")
+        self.shadow_stale = False
+
+    # ------------------------------------------------------------------ shapes
+    @staticmethod
+    def pad_inputs(ids: torch.Tensor, mask: torch.Tensor, type_ids: Optional[torch.Tensor], pad_id: int
+                   ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor], int]:
+        """Pad L up to a multiple of 32 with masked positions (outputs do not depend on padded content)."""
+        n, L = ids.shape
+        Lp = _round_up(L, 32)
+        if Lp != L:
+            ids = torch.nn.functional.pad(ids, (0, Lp - L), value=pad_id)
+            mask = torch.nn.functional.pad(mask, (0, Lp - L), value=0)
+            if type_ids is not None:
+                type_ids = torch.nn.functional.pad(type_ids, (0, Lp - L), value=0)
+        return ids.contiguous(), mask.contiguous(), None if type_ids is None else type_ids.contiguous(), L
+
+    def _arena(self, attr: str, nbytes: int) -> torch.Tensor:
+        buf = getattr(self, attr)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            setattr(self, attr, buf)
+        return buf
+
+    # ------------------------------------------------------------------ forward / backward
+    def forward(self, ids: torch.Tensor, mask: torch.Tensor, type_ids: Optional[torch.Tensor] = None,
+                training: bool = False, want_tokens: bool = False, saved: Optional[torch.Tensor] = None):
+        """ids/mask int64 [n, L] on this device, L % 32 == 0. Returns (emb [n,H], tok [n,L,H] or None, saved)."""
+        assert ids.dtype == torch.int64 and mask.dtype == torch.int64 and ids.is_cuda and ids.is_contiguous()
+        n, L = ids.shape
+        if self.shadow_stale:
+            self.refresh_shadow()
+        nbytes = self.lib.qst_encoder_saved_bytes(self.handle, n, L, int(training))
+        if nbytes == 0:
+            raise _lib.QstError(f"unsupported shape nseq={n} L={L} for this encoder (L % 32 == 0, L <= 512)")
+        if saved is None:
+            saved = self._arena("_saved", nbytes)
+        emb = torch.empty(n, self.cfg.hidden_size, dtype=torch.float32, device=self.device)
+        tok = torch.empty(n, L, self.cfg.hidden_size, dtype=torch.float32, device=self.device) if want_tokens else None
+        _lib.check(self.lib.qst_encoder_forward(
+            self.handle, ids.data_ptr(), mask.data_ptr(), _lib.ptr(type_ids), n, L, self.params.data_ptr(),
+            self.shadow.data_ptr(), emb.data_ptr(), _lib.ptr(tok), saved.data_ptr(), saved.numel(), int(training),
+            _lib.current_stream_ptr()), "qst_encoder_forward")
+        return emb, tok, saved
+
+    def backward(self, ids, mask, type_ids, grad_emb: torch.Tensor, saved: torch.Tensor) -> None:
+        """Accumulate d(loss)/d(params) into self.grads given d(loss)/d(emb)."""
+        self.ensure_train_state()
+        n, L = ids.shape
+        ws = self._arena("_ws", self.lib.qst_encoder_bwd_workspace_bytes(self.handle, n, L))
+        grad_emb = grad_emb.contiguous()
+        _lib.check(self.lib.qst_encoder_backward(
+            self.handle, ids.data_ptr(), mask.data_ptr(), _lib.ptr(type_ids), n, L, self.params.data_ptr(),
+            self.shadow.data_ptr(), grad_emb.data_ptr(), self.grads.data_ptr(), saved.data_ptr(), saved.numel(),
+            ws.data_ptr(), ws.numel(), _lib.current_stream_ptr()), "qst_encoder_backward")
+
+    def adamw_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
+                   max_grad_norm: float = 1.0, grad_scale: float = 1.0) -> None:
+        """clip_grad_norm_ + AdamW + zero_grad in one pass over the arena; the norm stays on the device."""
+        self.ensure_train_state()
+        self.opt_step += 1
+        _lib.check(self.lib.qst_clip_adamw_step(
+            self.handle, self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
+            self.exp_avg_sq.data_ptr(), lr, betas[0], betas[1], eps, weight_decay, max_grad_norm, grad_scale,
+            self.opt_step, self.grad_norm.data_ptr(), self._scratch.data_ptr(), _lib.current_stream_ptr()),
+            "qst_clip_adamw_step")
+        self.shadow_stale = True
+
+
+def quadruplet_loss_raw(xa, xp, xq, xn, gamma, m_pn, m_pq, m_qn, p, swap, reduction: int,
+                        grad_out: Optional[torch.Tensor] = None, want_grads: bool = False):
+    """Direct call of qst_quadruplet_loss on contiguous fp32 CUDA tensors [B, D]."""
+    lib = _lib.load()
+    B, D = xa.shape
+    dev = xa.device
+    out = torch.empty(B if reduction == 0 else 1, dtype=torch.float32, device=dev)
+    scratch = torch.empty(B, dtype=torch.float32, device=dev)
+    grads = [torch.empty_like(xa) for _ in range(4)] if want_grads else [None] * 4
+    _lib.check(lib.qst_quadruplet_loss(
+        xa.data_ptr(), xp.data_ptr(), xq.data_ptr(), xn.data_ptr(), B, D, gamma, m_pn, m_pq, m_qn, p, int(swap),
+        reduction, out.data_ptr(), _lib.ptr(grad_out), *[_lib.ptr(g) for g in grads], scratch.data_ptr(),
+        _lib.current_stream_ptr()), "qst_quadruplet_loss")
+    return out, grads

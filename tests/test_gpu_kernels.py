@@ -1,0 +1,261 @@
+"""GPU parity of every HIP kernel (through the C-ABI) against the CPU oracle / plain torch fp32.
+
+Tolerances: kernels that round operands to bf16 are compared with a reference fed the SAME
+bf16-rounded operands (fp32 accumulate), so only accumulation order differs: rtol 2e-3 on
+bf16 outputs (one bf16 ulp = 2^-8 relative), 1e-4 on fp32 outputs.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import quadruplet_sentence_transformer_amd as qst  # noqa: E402
+from quadruplet_sentence_transformer_amd import _lib  # noqa: E402
+from quadruplet_sentence_transformer_amd.encoder import quadruplet_loss_raw  # noqa: E402
+from oracle import torch_ref as R  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return _lib.load()
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def stream():
+    return _lib.current_stream_ptr()
+
+
+def bfr(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+# ------------------------------------------------------------------ loss
+@pytest.mark.parametrize("B,D", [(1, 10), (5, 10), (8, 384), (64, 384), (32, 768), (7, 33), (3, 2052)])
+@pytest.mark.parametrize("p", [2.0, 1.0, 3.0])
+@pytest.mark.parametrize("swap", [False, True])
+def test_loss_matches_oracle(lib, B, D, p, swap):
+    g = torch.Generator().manual_seed(B * 1000 + D)
+    x = [torch.randn(B, D, generator=g) for _ in range(4)]
+    if D == 384:
+        x = [t / t.norm(dim=1, keepdim=True) for t in x]
+    kw = dict(gamma=0.6, margin_pos_neg=1.0, margin_pos_part=0.5, margin_part_neg=0.5, p=p, swap=swap)
+    for red_name, red in (("none", 0), ("sum", 1), ("mean", 2)):
+        xs = [t.clone().requires_grad_(True) for t in x]
+        ref = R.gamma_quadruplet_loss_ref(*xs, reduction=red_name, **kw)
+        w = torch.linspace(0.5, 1.5, B) if red == 0 else torch.tensor([1.7])
+        (ref * w).sum().backward()
+        out, grads = quadruplet_loss_raw(*[dev(t) for t in x], 0.6, 1.0, 0.5, 0.5, p, swap, red,
+                                         grad_out=dev(w), want_grads=True)
+        torch.testing.assert_close(out.cpu().view(ref.shape), ref.detach(), rtol=1e-5, atol=1e-5)
+        for gi, xi in zip(grads, xs):
+            torch.testing.assert_close(gi.cpu(), xi.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_loss_edge_cases(lib):
+    B, D = 6, 64
+    a = torch.randn(B, D)
+    # all hinges inactive: positives at the anchor, negatives far away -> zero loss, zero grads
+    far = a + 100.0
+    out, grads = quadruplet_loss_raw(dev(a), dev(a + 1e-3), dev(a + 2e-3), dev(far), 0.6, 1.0, 0.5, 0.5, 2.0, False, 2,
+                                     want_grads=True)
+    # c = max(0.5 + d(a,p) - d(a,q), 0) is active here; use explicit reference
+    xs = [t.clone().requires_grad_(True) for t in (a, a + 1e-3, a + 2e-3, far)]
+    ref = R.gamma_quadruplet_loss_ref(*xs)
+    ref.backward()
+    torch.testing.assert_close(out.cpu()[0], ref.detach(), rtol=1e-5, atol=1e-6)
+    for gi, xi in zip(grads, xs):
+        torch.testing.assert_close(gi.cpu(), xi.grad, rtol=1e-4, atol=1e-7)
+    # anchor == positive: distance is ||1e-6 * 1||
+    out, _ = quadruplet_loss_raw(dev(a), dev(a), dev(a), dev(a), 0.6, 1.0, 0.5, 0.5, 2.0, False, 0)
+    ref = R.gamma_quadruplet_loss_ref(a, a, a, a, reduction="none")
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-6, atol=1e-6)
+
+
+def test_loss_bad_args(lib):
+    x = torch.zeros(4, 8, device="cuda")
+    s = torch.zeros(4, device="cuda")
+    o = torch.zeros(4, device="cuda")
+    rc = lib.qst_quadruplet_loss(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 4, 8, 1.5, 1.0, 0.5, 0.5, 2.0,
+                                 0, 2, o.data_ptr(), None, None, None, None, None, s.data_ptr(), stream())
+    assert rc == -1
+
+
+# ------------------------------------------------------------------ GEMM
+def gemm_args(**kw):
+    g = _lib.QstGemmArgs()
+    for k, v in kw.items():
+        setattr(g, k, v.data_ptr() if torch.is_tensor(v) else v)
+    return g
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 384), (200, 192, 128), (1000, 1152, 384), (64, 64, 64),
+                                   (4096, 384, 1536)])
+def test_gemm_nt_epilogues(lib, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = bfr(torch.randn(M, K, generator=g))
+    B = bfr(torch.randn(N, K, generator=g) * 0.05)
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    ref = A @ B.t() + bias
+    Ad, Bd = dev(A.to(torch.bfloat16)), dev(B.to(torch.bfloat16))
+    # EPI_BF16
+    Cb = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=Cb, bias=dev(bias), M=M, N=N, K=K, lda=K, ldb=K, ldc=N), 0, stream()))
+    torch.testing.assert_close(Cb.float().cpu(), ref, rtol=8e-3, atol=2e-2)
+    # EPI_F32_RESID
+    Cf = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=Cf, bias=dev(bias), resid=dev(resid), M=M, N=N, K=K, lda=K, ldb=K,
+                                         ldc=N, ldr=N), 1, stream()))
+    torch.testing.assert_close(Cf.cpu(), ref + resid, rtol=1e-4, atol=1e-3)
+    # EPI_GELU
+    C2 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=Cb, C2=C2, bias=dev(bias), M=M, N=N, K=K, lda=K, ldb=K, ldc=N), 2, stream()))
+    torch.testing.assert_close(Cb.float().cpu(), ref, rtol=8e-3, atol=2e-2)
+    torch.testing.assert_close(C2.float().cpu(), torch.nn.functional.gelu(ref), rtol=8e-3, atol=2e-2)
+    # EPI_GELU_BWD: C = acc * gelu'(aux)
+    u = bfr(torch.randn(M, N, generator=g))
+    ur = u.clone().requires_grad_(True)
+    torch.nn.functional.gelu(ur).sum().backward()
+    _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=Cb, aux=dev(u.to(torch.bfloat16)), M=M, N=N, K=K, lda=K, ldb=K, ldc=N), 3, stream()))
+    torch.testing.assert_close(Cb.float().cpu(), (A @ B.t()) * ur.grad, rtol=8e-3, atol=2e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (512, 384, 384), (1000, 1152, 384), (300, 64, 256), (4096, 384, 1536),
+                                   (96, 192, 64)])
+def test_gemm_tn_wgrad(lib, M, N, K):
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    A = bfr(torch.randn(M, N, generator=g))      # dY
+    B = bfr(torch.randn(M, K, generator=g))      # X
+    ref = A.t() @ B
+    C = torch.zeros(N, K, dtype=torch.float32, device="cuda")
+    cs = torch.zeros(N, dtype=torch.float32, device="cuda")
+    _lib.check(lib.qst_gemm_tn(gemm_args(A=dev(A.to(torch.bfloat16)), B=dev(B.to(torch.bfloat16)), C=C, colsum=cs, M=M, N=N,
+                                         K=K, lda=N, ldb=K, ldc=K, splits=0), stream()))
+    scale = math.sqrt(M)
+    torch.testing.assert_close(C.cpu(), ref, rtol=1e-3, atol=1e-3 * scale)
+    torch.testing.assert_close(cs.cpu(), A.sum(0), rtol=1e-3, atol=1e-3 * scale)
+    # accumulation semantics: a second call doubles the result
+    _lib.check(lib.qst_gemm_tn(gemm_args(A=dev(A.to(torch.bfloat16)), B=dev(B.to(torch.bfloat16)), C=C, colsum=cs, M=M, N=N,
+                                         K=K, lda=N, ldb=K, ldc=K, splits=3), stream()))
+    torch.testing.assert_close(C.cpu(), 2 * ref, rtol=1e-3, atol=2e-3 * scale)
+
+
+# ------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("M,H", [(37, 64), (128, 128), (300, 384), (129, 768), (5, 1024)])
+def test_layernorm_fwd_bwd(lib, M, H):
+    g = torch.Generator().manual_seed(M + H)
+    s = torch.randn(M, H, generator=g) * 2 + 0.3
+    gamma = 1 + 0.1 * torch.randn(H, generator=g)
+    beta = 0.1 * torch.randn(H, generator=g)
+    dy = torch.randn(M, H, generator=g)
+    sr = s.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yref = torch.nn.functional.layer_norm(sr, (H,), gr, br, 1e-12)
+    (yref * dy).sum().backward()
+    y = torch.empty(M, H, device="cuda")
+    yb = torch.empty(M, H, dtype=torch.bfloat16, device="cuda")
+    xh = torch.empty(M, H, dtype=torch.bfloat16, device="cuda")
+    rs = torch.empty(M, device="cuda")
+    _lib.check(lib.qst_ln_fwd(dev(s).data_ptr(), dev(gamma).data_ptr(), dev(beta).data_ptr(), 1e-12, M, H, y.data_ptr(),
+                              yb.data_ptr(), xh.data_ptr(), rs.data_ptr(), stream()))
+    torch.testing.assert_close(y.cpu(), yref.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(yb.float().cpu(), yref.detach(), rtol=8e-3, atol=1e-2)
+    ds = torch.empty(M, H, device="cuda")
+    dsb = torch.empty(M, H, dtype=torch.bfloat16, device="cuda")
+    dg = torch.zeros(H, device="cuda")
+    db = torch.zeros(H, device="cuda")
+    _lib.check(lib.qst_ln_bwd(dev(dy).data_ptr(), xh.data_ptr(), rs.data_ptr(), dev(gamma).data_ptr(), M, H, ds.data_ptr(),
+                              dsb.data_ptr(), dg.data_ptr(), db.data_ptr(), stream()))
+    # xhat is stored in bf16 -> 2^-9 relative perturbation of the xhat terms
+    torch.testing.assert_close(ds.cpu(), sr.grad, rtol=2e-2, atol=2e-2 * sr.grad.abs().max().item())
+    torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-4, atol=1e-4 * math.sqrt(M))
+    torch.testing.assert_close(dg.cpu(), gr.grad, rtol=1e-2, atol=1e-2 * math.sqrt(M))
+
+
+# ------------------------------------------------------------------ attention
+def attn_ref(qkv, mask, rel, n, L, A, d):
+    H = A * d
+    q, k, v = [t.view(n, L, A, d).transpose(1, 2) for t in qkv.view(n, L, 3 * H).split(H, dim=-1)]
+    s = q @ k.transpose(-1, -2) / math.sqrt(d)
+    if rel is not None:
+        s = s + rel[None]
+    s = s + (1.0 - mask[:, None, None, :].float()) * torch.finfo(torch.float32).min
+    p = torch.softmax(s, -1)
+    return (p @ v).transpose(1, 2).reshape(n * L, H)
+
+
+@pytest.mark.parametrize("n,L,A,d,use_rel", [(2, 32, 2, 32, False), (3, 128, 12, 32, False), (2, 160, 2, 64, True),
+                                              (2, 256, 3, 64, False), (1, 384, 2, 64, True), (2, 64, 2, 32, True)])
+def test_attention_fwd_bwd(lib, n, L, A, d, use_rel):
+    H = A * d
+    g = torch.Generator().manual_seed(n * L + A + d)
+    qkv = bfr(torch.randn(n * L, 3 * H, generator=g))
+    lens = torch.randint(max(1, L // 8), L + 1, (n,), generator=g)
+    lens[0] = L
+    mask = (torch.arange(L)[None, :] < lens[:, None]).long()
+    rel = (0.5 * torch.randn(A, L, L, generator=g)) if use_rel else None
+    dctx = bfr(torch.randn(n * L, H, generator=g))
+    qr = qkv.clone().requires_grad_(True)
+    relr = rel.clone().requires_grad_(True) if use_rel else None
+    ref = attn_ref(qr, mask, relr, n, L, A, d)
+    (ref * dctx).sum().backward()
+
+    qd = dev(qkv.to(torch.bfloat16))
+    md = dev(mask)
+    reld = dev(rel) if use_rel else None
+    ctx = torch.empty(n * L, H, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(n, A, L, device="cuda")
+    _lib.check(lib.qst_attention_fwd(qd.data_ptr(), md.data_ptr(), _lib.ptr(reld), n, L, A, d, ctx.data_ptr(), lse.data_ptr(), stream()))
+    torch.testing.assert_close(ctx.float().cpu(), ref.detach(), rtol=2e-2, atol=2e-2)
+
+    dq = torch.empty(n * L, 3 * H, dtype=torch.bfloat16, device="cuda")
+    drel = torch.zeros(A, L, L, device="cuda") if use_rel else None
+    _lib.check(lib.qst_attention_bwd(qd.data_ptr(), ctx.data_ptr(), dev(dctx.to(torch.bfloat16)).data_ptr(), lse.data_ptr(),
+                                     md.data_ptr(), _lib.ptr(reld), n, L, A, d, dq.data_ptr(), _lib.ptr(drel), stream()))
+    gref = qr.grad
+    err = (dq.float().cpu() - gref).abs().max().item()
+    assert err <= 3e-2 * max(1.0, gref.abs().max().item()), f"dqkv max err {err}"
+    rel_l2 = ((dq.float().cpu() - gref).norm() / gref.norm()).item()
+    assert rel_l2 < 1e-2, f"dqkv relative L2 error {rel_l2}"
+    if use_rel:
+        rel_l2 = ((drel.cpu() - relr.grad).norm() / relr.grad.norm()).item()
+        assert rel_l2 < 1e-2, f"drel relative L2 error {rel_l2}"
+
+
+# ------------------------------------------------------------------ AdamW
+def test_clip_adamw_matches_torch(lib):
+    from quadruplet_sentence_transformer_amd.encoder import HipEncoder
+    from quadruplet_sentence_transformer_amd.config import PRESETS
+    from quadruplet_sentence_transformer_amd.synthetic import synthetic_params
+    cfg = PRESETS["tiny-bert"]
+    enc = HipEncoder(cfg)
+    arena = synthetic_params(cfg, seed=3, std=0.05, bias_std=0.02, ln_jitter=0.05)
+    enc.load_arena(arena)
+    enc.ensure_train_state()
+    # torch reference with ST's two parameter groups
+    views = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in enc.named_views().items()}
+    no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
+    groups = [{"params": [p for n, p in views.items() if not any(nd in n for nd in no_decay)], "weight_decay": 0.01},
+              {"params": [p for n, p in views.items() if any(nd in n for nd in no_decay)], "weight_decay": 0.0}]
+    opt = torch.optim.AdamW(groups, lr=1e-2)
+    gen = torch.Generator().manual_seed(0)
+    for step in range(3):
+        gv = enc.grad_views()
+        for n_, p in views.items():
+            gr = torch.randn(p.shape, generator=gen) * (3.0 if step == 0 else 0.01)
+            p.grad = gr.clone()
+            gv[n_].copy_(gr)
+        total = torch.nn.utils.clip_grad_norm_(list(views.values()), 1.0)
+        opt.step()
+        enc.adamw_step(lr=1e-2, weight_decay=0.01, max_grad_norm=1.0)
+        torch.testing.assert_close(enc.grad_norm.cpu()[0], total, rtol=1e-4, atol=1e-6)
+        for n_, p in views.items():
+            torch.testing.assert_close(enc.named_views()[n_].cpu(), p.detach(), rtol=1e-5, atol=1e-6)
+        assert float(enc.grads.abs().max()) == 0.0   # zero_grad fused
