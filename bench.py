@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Headline benchmark: quadruplets/sec of one full fine-tuning step (forward + quadruplet loss +
+backward + clip + AdamW) on synthetic all-MiniLM-L6-v2-shaped batches, seq_len=128, 64 quadruplets
+per GPU (BASELINE.json configs[1]; configs[3] when launched with N > 1 ranks).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement): value = whole-job quadruplets/s with the
+inputs resident in HBM; `roofline` = the dominant kernel's achieved TFLOP/s (its algorithmic FLOPs per
+launch / its average launch duration measured here with HIP events) against the dense bf16 MFMA peak;
+`cpu_baseline` = the CPU oracle (oracle/torch_ref.py) timed on this box's host cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md chip table)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--model", default="all-MiniLM-L6-v2")
+    ap.add_argument("--batch", type=int, default=64, help="quadruplets per GPU")
+    ap.add_argument("--seq-len", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--kernel-reps", type=int, default=20)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, arena, seq_len, budget_s=20.0):
+    """Time the CPU oracle (fp32 torch restatement of the reference path) on a bounded sample of the same
+    workload: full training-shaped step = forward + loss + autograd backward, B=4 quadruplets per step."""
+    import torch
+    from oracle import torch_ref as R
+    from quadruplet_sentence_transformer_amd.synthetic import synthetic_quadruplets
+    B = 4
+    P = R.arena_to_dict(arena, cfg, requires_grad=True)
+    kw = dict(gamma=0.6, margin_pos_neg=1.0, margin_pos_part=0.5, margin_part_neg=0.5)
+    n_done, t_total = 0, 0.0
+    step = 0
+    while True:
+        ids, mask, types = synthetic_quadruplets(cfg, B, seq_len, seed=14, step=1000 + step)
+        ids, mask, types = torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(types)
+        t0 = time.perf_counter()
+        loss, _ = R.quadruplet_step(P, cfg, ids, mask, types, kw)
+        loss.backward()
+        dt = time.perf_counter() - t0
+        for v in P.values():
+            v.grad = None
+        if step > 0:                    # first step pays allocator / thread-pool start-up
+            n_done += B
+            t_total += dt
+        step += 1
+        if (t_total > budget_s) or step >= 12:
+            break
+    return {"value": round(n_done / t_total, 3), "unit": "quadruplets/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{n_done} quadruplets ({step - 1} steps of B={B}, seq_len={seq_len}) fwd+loss+bwd, fp32 torch CPU "
+                      f"oracle (oracle/torch_ref.py), {t_total:.1f} s"}
+
+
+def time_dominant_kernel(trainer, n, L, reps):
+    """Average launch duration of the dominant kernel (FFN-1 forward GEMM, gemm_nt_kernel<QST_EPI_GELU>:
+    [M,H] x [I,H]^T with bias+GELU epilogue) at the step's shapes, HIP events on the launch stream."""
+    import torch
+    from quadruplet_sentence_transformer_amd import _lib
+    cfg = trainer.cfg
+    M, H, I = n * L, cfg.hidden_size, cfg.intermediate_size
+    dev = trainer.enc.device
+    A = (torch.randn(M, H, device=dev) * 1.0).to(torch.bfloat16)
+    W = (torch.randn(I, H, device=dev) * 0.02).to(torch.bfloat16)
+    bias = torch.zeros(I, device=dev)
+    U = torch.empty(M, I, dtype=torch.bfloat16, device=dev)
+    Hh = torch.empty(M, I, dtype=torch.bfloat16, device=dev)
+    g = _lib.QstGemmArgs()
+    g.A, g.B, g.C, g.C2, g.bias = A.data_ptr(), W.data_ptr(), U.data_ptr(), Hh.data_ptr(), bias.data_ptr()
+    g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, I, H, H, H, I
+    lib = trainer.enc.lib
+    st = _lib.current_stream_ptr()
+    for _ in range(3):
+        _lib.check(lib.qst_gemm_nt(g, 2, st))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        _lib.check(lib.qst_gemm_nt(g, 2, st))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * M * I * H
+    return {"kernel": "gemm_nt_kernel<2> (FFN1 fwd, bias+GELU epilogue)", "ms": ms, "flops_per_launch": flops,
+            "shape": [M, I, H]}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from quadruplet_sentence_transformer_amd.config import PRESETS, forward_flops_per_sequence
+    from quadruplet_sentence_transformer_amd.synthetic import synthetic_params, synthetic_quadruplets
+    from quadruplet_sentence_transformer_amd.trainer import QuadrupletTrainer
+
+    cfg = PRESETS[args.model]
+    B, L = args.batch, args.seq_len
+    arena = synthetic_params(cfg, seed=14)          # same replica on every rank
+    trainer = QuadrupletTrainer(cfg, arena=arena, device=f"cuda:{local_rank}", lr=2e-5, weight_decay=0.01,
+                                max_grad_norm=1.0, warmup_steps=10000, total_steps=1000000,
+                                process_group=None, world_size=world, overlap=not args.no_overlap)
+    # a few distinct synthetic batches, resident in HBM before the timed region (rank-offset streams)
+    nb = 4
+    batches = []
+    for i in range(nb):
+        ids, mask, types = synthetic_quadruplets(cfg, B, L, seed=14, step=i, rank=rank)
+        batches.append(tuple(torch.from_numpy(x).cuda() for x in (ids, mask, types)))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for i in range(args.warmup):
+        loss = trainer.step(*batches[i % nb])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = trainer.step(*batches[i % nb])
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+    final_loss = float(loss.item())
+
+    out = None
+    if rank == 0:
+        fwd_flops_q = 4.0 * forward_flops_per_sequence(cfg, L)
+        train_flops_q = 3.0 * fwd_flops_q
+        step_tflops = value * train_flops_q / 1e12
+        dk = time_dominant_kernel(trainer, 4 * B, L, args.kernel_reps)
+        achieved = dk["flops_per_launch"] / (dk["ms"] * 1e-3) / 1e12
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get("gemm_nt_kernel<2>_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "quadruplets/sec (seq_len=128, all-MiniLM-L6) training step", "value": round(value, 1),
+            "unit": "quadruplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.model} dims (random-init), {B} quadruplets/GPU x {world} GPU, seq_len={L}, "
+                                   "fwd + gamma-quadruplet loss + bwd + clip + AdamW (BASELINE.json configs[1]"
+                                   + ("/[3]" if world > 1 else "") + ")",
+                       "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}",
+                       "precision": "bf16 MFMA operands, fp32 accumulate/residual/LN/softmax/loss/optimizer"},
+            "loss": round(final_loss, 6),
+            "step_tflops": round(step_tflops, 2),
+            "step_mfma_frac": round(step_tflops / (PEAK_BF16_TFLOPS * world), 4),
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "kernel": dk["kernel"], "avg_launch_ms": round(dk["ms"], 5), "shape_MNK": dk["shape"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, arena, L)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -32,8 +32,7 @@ typedef enum {
     QST_ERR_UNSUPPORTED = -2,  /* dims the kernels are not built for (see qst_encoder_create) */
     QST_ERR_WORKSPACE = -3,    /* workspace/saved arena smaller than qst_*_bytes() says */
     QST_ERR_HIP = -4,          /* a HIP runtime call failed; qst_last_hip_error() has the code */
-    QST_ERR_NO_DEVICE = -5,
-    QST_ERR_COMM = -6          /* RCCL call failed */
+    QST_ERR_NO_DEVICE = -5
 } qst_status;
 
 enum { QST_ARCH_BERT = 0, QST_ARCH_MPNET = 1 };
@@ -116,6 +115,16 @@ int qst_encoder_backward(qst_encoder* enc, const int64_t* ids, const int64_t* ma
                          const float* grad_emb, float* grads, void* saved, size_t saved_bytes,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* Same backward pass in stages (head -> layers [layer_lo, layer_hi) top-down -> embeddings) so the caller can start
+ * the RCCL all-reduce of a finished layer's gradients while lower layers are still running.
+ * Calls must cover head first, then contiguous descending layer ranges, then embeddings, on one stream.
+ * Per-layer gradient ranges of the arena: qst_arena_segment(). */
+int qst_encoder_backward_partial(qst_encoder* enc, const int64_t* ids, const int64_t* mask, const int64_t* type_ids,
+                                 int nseq, int L, const float* params, const void* shadow_bf16,
+                                 const float* grad_emb, float* grads, void* saved, size_t saved_bytes,
+                                 void* workspace, size_t workspace_bytes,
+                                 int do_head, int layer_hi, int layer_lo, int do_embed, void* stream);
+
 /*
  * Replaces gamma_quadruplet_loss (/root/reference/models/losses/losses.py:9-69) and its autograd:
  * three triplet_margin_loss terms with pairwise_distance eps=1e-6 inside the norm.
@@ -146,13 +155,9 @@ int qst_clip_adamw_step(const qst_encoder* enc, float* params, float* grads, flo
                         float max_grad_norm, float grad_scale, int64_t step,
                         float* norm_out, float* scratch, void* stream);
 
-/* ---- data parallelism: RCCL over xGMI (no reference counterpart) ---- */
-typedef struct qst_comm qst_comm;
-int  qst_comm_unique_id(void* id_out_host_128);                 /* 128-byte ncclUniqueId */
-int  qst_comm_init(int rank, int world, const void* id_host_128, qst_comm** out);
-void qst_comm_destroy(qst_comm* c);
-/* In-place sum all-reduce of `count` fp32 elements on `stream`. */
-int  qst_allreduce_sum_f32(qst_comm* c, float* buf, int64_t count, void* stream);
+/* Data parallelism has no entry point here: the gradient arena is one contiguous fp32 buffer, and
+ * the host side all-reduces slices of it with torch.distributed (backend "nccl" = RCCL over xGMI) on a side stream,
+ * between qst_encoder_backward_partial stages; qst_clip_adamw_step's grad_scale applies the 1/world_size. */
 
 #ifdef __cplusplus
 }

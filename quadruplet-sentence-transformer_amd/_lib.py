@@ -53,6 +53,8 @@ SIGNATURES = {
     "qst_refresh_shadow": (C.c_int, [vp, vp, vp, vp]),
     "qst_encoder_forward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_size_t, C.c_int, vp]),
     "qst_encoder_backward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp]),
+    "qst_encoder_backward_partial": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t,
+                                               C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "qst_quadruplet_loss": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                       C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "qst_clip_adamw_step": (C.c_int, [vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,

@@ -25,7 +25,6 @@ extern "C" const char* qst_strerror(int s) {
         case QST_ERR_WORKSPACE: return "workspace or saved-activation arena too small";
         case QST_ERR_HIP: return "HIP runtime error (see qst_last_hip_error)";
         case QST_ERR_NO_DEVICE: return "no HIP device";
-        case QST_ERR_COMM: return "collective communication error";
         default: return "unknown qst status";
     }
 }
@@ -335,11 +334,17 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     return QST_OK;
 }
 
-extern "C" int qst_encoder_backward(qst_encoder* e, const int64_t* ids, const int64_t* mask, const int64_t* type_ids,
-                                    int nseq, int L, const float* params, const void* shadow, const float* grad_emb,
-                                    float* grads, void* saved, size_t saved_bytes, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
-    if (!e || !ids || !mask || !params || !shadow || !grad_emb || !grads || !saved || !workspace) return QST_ERR_BAD_ARG;
+// Stages of one backward pass, top to bottom: head (pool/normalise), layers N-1..0, embeddings. A caller may run
+// them in several calls (layer_hi > layer_lo) to launch the gradient all-reduce of finished layers in between;
+// the running d(loss)/d(x) lives in the workspace between calls.
+extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, const int64_t* mask,
+                                            const int64_t* type_ids, int nseq, int L, const float* params,
+                                            const void* shadow, const float* grad_emb, float* grads, void* saved,
+                                            size_t saved_bytes, void* workspace, size_t workspace_bytes,
+                                            int do_head, int layer_hi, int layer_lo, int do_embed, void* stream) {
+    if (!e || !ids || !mask || !params || !shadow || !grads || !saved || !workspace) return QST_ERR_BAD_ARG;
+    if (do_head && !grad_emb) return QST_ERR_BAD_ARG;
+    if (layer_lo < 0 || layer_hi > e->cfg.num_layers || layer_lo > layer_hi) return QST_ERR_BAD_ARG;
     QST_TRY(shape_ok(e, nseq, L));
     const qst_config& c = e->cfg;
     const ActPlan p = plan_acts(c, nseq, L, true);
@@ -367,12 +372,11 @@ extern "C" int qst_encoder_backward(qst_encoder* e, const int64_t* ids, const in
     if (c.arch == QST_ARCH_MPNET) {
         drel = (float*)(ws + w.drel);
         rel = (const float*)(sv + p.rel);
-        QST_HIP_CHECK(hipMemsetAsync(drel, 0, (size_t)A * L * L * 4, st));
+        if (do_head) QST_HIP_CHECK(hipMemsetAsync(drel, 0, (size_t)A * L * L * 4, st));
     }
-    const LayerAct& top = p.layers[c.num_layers - 1];
-    (void)top;
-    QST_TRY(qst_pool_norm_bwd(grad_emb, (const float*)(sv + p.pooled), mask, nseq, L, H, c.normalize, dxa, st));
-    for (int l = c.num_layers - 1; l >= 0; --l) {
+    if (do_head)
+        QST_TRY(qst_pool_norm_bwd(grad_emb, (const float*)(sv + p.pooled), mask, nseq, L, H, c.normalize, dxa, st));
+    for (int l = layer_hi - 1; l >= layer_lo; --l) {
         const LayerAct& a = p.layers[l];
         const int b = lay.layer0[l];
         const void* xin_b = (l == 0) ? (const void*)(sv + p.x0b) : (const void*)(sv + p.layers[l - 1].xb);
@@ -399,6 +403,7 @@ extern "C" int qst_encoder_backward(qst_encoder* e, const int64_t* ids, const in
         QST_TRY(nt(dqkv, 3 * H, WT(b + W_QKV), 3 * H, dxa, H, nullptr, nullptr, nullptr, ds, H, M, H, 3 * H,
                    QST_EPI_F32_RESID, st));
     }
+    if (!do_embed) return QST_OK;
     // embeddings
     QST_TRY(qst_ln_bwd(dxa, sv + p.xh0, (const float*)(sv + p.rs0), P(lay.eg), M, H, ds, nullptr, G(lay.eg), G(lay.eb), st));
     QST_TRY(qst_embed_bwd(ds, ids, type_ids, (const int32_t*)(sv + p.pos_ids), nseq, L, H, c.type_vocab_size,
@@ -407,6 +412,15 @@ extern "C" int qst_encoder_backward(qst_encoder* e, const int64_t* ids, const in
         QST_TRY(qst_rel_bias_bwd(drel, e->rel_lut, c.rel_buckets, A, L, G(lay.rel), st));
     }
     return QST_OK;
+}
+
+extern "C" int qst_encoder_backward(qst_encoder* e, const int64_t* ids, const int64_t* mask, const int64_t* type_ids,
+                                    int nseq, int L, const float* params, const void* shadow, const float* grad_emb,
+                                    float* grads, void* saved, size_t saved_bytes, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    if (!e) return QST_ERR_BAD_ARG;
+    return qst_encoder_backward_partial(e, ids, mask, type_ids, nseq, L, params, shadow, grad_emb, grads, saved,
+                                        saved_bytes, workspace, workspace_bytes, 1, e->cfg.num_layers, 0, 1, stream);
 }
 
 extern "C" int qst_clip_adamw_step(const qst_encoder* e, float* params, float* grads, float* exp_avg,
