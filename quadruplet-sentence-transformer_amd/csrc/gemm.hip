@@ -31,7 +31,7 @@ __device__ __forceinline__ uint32_t nt_off(int row, int chunk) {
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(QstGemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (16K A + 16K B)
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (16K A + 16K B); reused by the epilogue (4 x 17K)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
@@ -103,42 +103,63 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(QstGemmArgs g) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // D rows = n, col = m
         }
         if (kt + 1 < nk) lstore(cur ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds column n (lane&31), rows (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // ---- epilogue. The MFMA operands were swapped (D rows = n in registers, D column = m on the lane), so each
+    // lane holds 4 consecutive n per register group: stage the wave's 64x64 fp32 sub-tile through LDS as [m][n]
+    // (row stride 68 floats: conflict-free ds_write_b128) and read it back row-wise, so bias / residual / GELU
+    // and the global stores all run on 16-byte row-contiguous vectors (16 lanes = one 256-byte row segment).
+    float* stg = (float*)smem + wave * (64 * 68);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + fr;
-        if (n >= g.N) continue;
-        const float bias = g.bias ? g.bias[n] : 0.f;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (m >= g.M) continue;
-                float v = acc[i][j][r] + bias;
-                const size_t o = (size_t)m * g.ldc + n;
-                if (EPI == QST_EPI_BF16) {
-                    ((bf16*)g.C)[o] = f2bf(v);
-                } else if (EPI == QST_EPI_F32_RESID) {
-                    if (g.resid) v += g.resid[(size_t)m * g.ldr + n];
-                    ((float*)g.C)[o] = v;
-                } else if (EPI == QST_EPI_GELU) {
-                    ((bf16*)g.C)[o] = f2bf(v);                       // u (pre-activation), saved for backward
-                    ((bf16*)g.C2)[o] = f2bf(gelu_erf(v));             // h
-                } else if (EPI == QST_EPI_GELU_BWD) {
-                    const float u = bf2f(((const bf16*)g.aux)[o]);
-                    ((bf16*)g.C)[o] = f2bf(v * gelu_erf_grad(u));
-                } else if (EPI == QST_EPI_F32_RESID_BF16) {
-                    if (g.resid) v += g.resid[(size_t)m * g.ldr + n];
-                    ((float*)g.C)[o] = v;
-                    ((bf16*)g.C2)[o] = f2bf(v);
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g4 + e];
+                *(f32x4*)(stg + (i * 32 + fr) * 68 + j * 32 + 8 * g4 + 4 * fh) = v;
+            }
+    // same wave reads what it wrote: no workgroup barrier needed (the K loop ended with one)
+    const int c4 = lane & 15, rsub = lane >> 4;
+    const int n = n0 + wn * 64 + c4 * 4;
+    if (n < g.N) {
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) bias = *(const f32x4*)(g.bias + n);
+#pragma unroll 4
+        for (int t = 0; t < 16; ++t) {
+            const int row = t * 4 + rsub;
+            const int m = m0 + wm * 64 + row;
+            if (m >= g.M) continue;
+            f32x4 v = *(const f32x4*)(stg + row * 68 + c4 * 4);
+            v += bias;
+            const size_t o = (size_t)m * g.ldc + n;
+            if (EPI == QST_EPI_BF16) {
+                u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
+                *(u32x2*)((bf16*)g.C + o) = pk;
+            } else if (EPI == QST_EPI_F32_RESID || EPI == QST_EPI_F32_RESID_BF16) {
+                if (g.resid) v += *(const f32x4*)(g.resid + (size_t)m * g.ldr + n);
+                *(f32x4*)((float*)g.C + o) = v;
+                if (EPI == QST_EPI_F32_RESID_BF16) {
+                    u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
+                    *(u32x2*)((bf16*)g.C2 + o) = pk;
                 }
+            } else if (EPI == QST_EPI_GELU) {
+                u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
+                *(u32x2*)((bf16*)g.C + o) = pk;                                   // u (pre-activation), saved for backward
+                pk[0] = pack_bf16x2(gelu_erf(v[0]), gelu_erf(v[1])); pk[1] = pack_bf16x2(gelu_erf(v[2]), gelu_erf(v[3]));
+                *(u32x2*)((bf16*)g.C2 + o) = pk;                                  // h
+            } else if (EPI == QST_EPI_GELU_BWD) {
+                const u32x2 ua = *(const u32x2*)((const bf16*)g.aux + o);
+                u32x2 pk;
+                pk[0] = pack_bf16x2(v[0] * gelu_erf_grad(bf16lo(ua[0])), v[1] * gelu_erf_grad(bf16hi(ua[0])));
+                pk[1] = pack_bf16x2(v[2] * gelu_erf_grad(bf16lo(ua[1])), v[3] * gelu_erf_grad(bf16hi(ua[1])));
+                *(u32x2*)((bf16*)g.C + o) = pk;
             }
         }
     }
@@ -293,11 +314,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(QstGemmArgs g) {
 
 extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
     if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
-    if (a->K % BK != 0 || a->lda % 8 != 0 || a->ldb % 8 != 0) return QST_ERR_UNSUPPORTED;
+    if (a->K % BK != 0 || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->N % 4 != 0 || a->ldc % 4 != 0) return QST_ERR_UNSUPPORTED;
     const int ntm = (a->M + BM - 1) / BM, ntn = (a->N + BN - 1) / BN;
     dim3 grid(ntm * ntn), block(256);
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = 65536;
+    const size_t lds = 4 * 64 * 68 * sizeof(float);   // 69632: epilogue staging is the larger user
 #define QST_NT_CASE(E)                                                                                  \
     case E: {                                                                                           \
         static bool attr_set = false;                                                                   \

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* s, const float
 
 // LayerNorm backward. Each wave walks ROWS_PER_WAVE rows, keeps dgamma/dbeta partials for its columns in
 // registers, and the block adds them to global once (one atomic per column per block).
-constexpr int LN_BWD_ROWS_PER_WAVE = 32;
+constexpr int LN_BWD_ROWS_PER_WAVE = 8;
 
 template <int VPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const bf16* xh, const float* rstd,

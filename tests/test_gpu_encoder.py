@@ -49,7 +49,7 @@ def run_case(name, B, L, ragged, weights_kw, check_grads=True, emb_atol_vs_bf16_
     torch.cuda.synchronize()
     assert torch.isfinite(emb).all()
     torch.testing.assert_close(emb.cpu().view(4, B, -1), embb.detach(), rtol=1e-3, atol=emb_atol_vs_bf16_oracle)
-    assert abs(loss.item() - lossb.item()) < 1e-4
+    assert abs(loss.item() - lossb.item()) < max(1e-4, 0.3 * emb_atol_vs_bf16_oracle)
     assert abs(loss.item() - loss32.item()) < 1e-3
     torch.testing.assert_close(emb.cpu().view(4, B, -1), emb32, rtol=0, atol=2e-3)
 
