@@ -1,0 +1,470 @@
+"""`SentenceTransformer`-compatible front end over the HIP encoder (host-side mirror of the
+sentence-transformers 2.2.2 surface the reference uses).
+
+What the reference's unchanged callers need and get here:
+  * training/main.py:114-148  -> SentenceTransformer(model_name_or_path=, device=), .fit(<20 kwargs>)
+  * models/quadruplet_sentence_transformer.py:42-60 -> model(features)['sentence_embedding'] with autograd
+  * models/evaluators.py:68-96 -> model.smart_batching_collate, model.device, no_grad forward
+  * ir_evauation_script.py:127-131, ST evaluators -> .encode(...)
+
+The module executes nothing in torch: __call__ goes through an autograd.Function whose forward/backward
+call libqst.so; fit() steps the fused clip+AdamW kernel on the flat arena. torch.nn.Parameter objects exist
+only as HF-named VIEWS of the arena (so `named_parameters()` and name-based decay filters see what ST shows).
+"""
+from __future__ import annotations
+
+import json
+import logging
+import math
+import os
+import shutil
+import zlib
+from collections import OrderedDict
+from typing import Callable, Dict, Iterable, List, Optional, Tuple, Type, Union
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .config import ARCH_BERT, ARCH_MPNET, PRESETS, EncoderConfig, hf_param_views
+from .encoder import HipEncoder
+from .synthetic import synthetic_params
+from .trainer import warmup_linear_lr
+
+logger = logging.getLogger(__name__)
+
+
+class InputExample:
+    """sentence_transformers.InputExample (used by models/quadruplet_sentence_transformer.py:83-97)."""
+
+    def __init__(self, guid: str = "", texts: Optional[List[str]] = None, label: Union[int, float] = 0):
+        self.guid = guid
+        self.texts = texts
+        self.label = label
+
+    def __str__(self):
+        return "<InputExample> label: {}, texts: {}".format(str(self.label), "; ".join(self.texts))
+
+
+def batch_to_device(batch, target_device):
+    """sentence_transformers.util.batch_to_device: move every tensor value of a dict."""
+    for key in batch:
+        if isinstance(batch[key], torch.Tensor):
+            batch[key] = batch[key].to(target_device)
+    return batch
+
+
+# ------------------------------------------------------------------------------------------------ tokenizer
+class SyntheticTokenizer:
+    """Stand-in used ONLY when a model directory has no vocabulary (there are no vocab files offline):
+    lower-cased whitespace/punctuation split, token id = stable hash into [1000, V). Real model
+    directories with tokenizer files go through transformers.AutoTokenizer instead."""
+
+    def __init__(self, cfg: EncoderConfig):
+        self.cfg = cfg
+        if cfg.arch == ARCH_MPNET:
+            self.cls_id, self.sep_id, self.pad_id = 0, 2, 1
+        else:
+            self.cls_id, self.sep_id, self.pad_id = 101 % cfg.vocab_size, 102 % cfg.vocab_size, 0
+
+    def _ids(self, text: str) -> List[int]:
+        import re
+        lo = min(1000, self.cfg.vocab_size // 4)
+        toks = re.findall(r"\w+|[^\w\s]", str(text).lower())
+        return [lo + zlib.crc32(t.encode("utf-8")) % (self.cfg.vocab_size - lo) for t in toks]
+
+    def __call__(self, texts: List[str], max_length: int):
+        rows = []
+        for t in texts:
+            ids = self._ids(t)[: max(0, max_length - 2)]
+            rows.append([self.cls_id] + ids + [self.sep_id])
+        L = max(len(r) for r in rows) if rows else 1
+        input_ids = torch.full((len(rows), L), self.pad_id, dtype=torch.int64)
+        mask = torch.zeros((len(rows), L), dtype=torch.int64)
+        for i, r in enumerate(rows):
+            input_ids[i, : len(r)] = torch.tensor(r, dtype=torch.int64)
+            mask[i, : len(r)] = 1
+        out = {"input_ids": input_ids, "attention_mask": mask}
+        if self.cfg.type_vocab_size > 0:
+            out["token_type_ids"] = torch.zeros_like(input_ids)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------ autograd bridge
+class _EncodeFn(torch.autograd.Function):
+    """forward: qst_encoder_forward; backward: qst_encoder_backward accumulating straight into the gradient
+    arena (the HF-named parameters' .grad are views of it), so no per-parameter tensors cross autograd."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, ids, mask, types, training):
+        enc: HipEncoder = model._enc
+        saved = None
+        if training:
+            n, L = ids.shape
+            nbytes = enc.lib.qst_encoder_saved_bytes(enc.handle, n, L, 1)
+            saved = torch.empty(nbytes, dtype=torch.uint8, device=enc.device)   # one arena per live graph
+        emb, _, saved = enc.forward(ids, mask, types, training=training, saved=saved)
+        ctx.model, ctx.saved, ctx.inputs = model, saved, (ids, mask, types)
+        return emb
+
+    @staticmethod
+    def backward(ctx, grad_emb):
+        model = ctx.model
+        ids, mask, types = ctx.inputs
+        model._enc.backward(ids, mask, types, grad_emb.to(torch.float32), ctx.saved)
+        ctx.saved = None
+        return None, None, None, None, None, None
+
+
+class _Holder(nn.Module):
+    """Plain container used to build the HF-style dotted parameter names."""
+
+
+# ------------------------------------------------------------------------------------------------ the model
+class SentenceTransformer(nn.Module):
+    def __init__(self, model_name_or_path: Optional[str] = None, modules=None, device=None,
+                 cache_folder: Optional[str] = None, config: Optional[EncoderConfig] = None, seed: int = 14):
+        super().__init__()
+        if modules is not None:
+            raise NotImplementedError("custom module lists are outside the hot path this build covers")
+        self._model_card_name = model_name_or_path
+        arena = None
+        tok_dir = None
+        if config is not None:
+            cfg = config
+        elif model_name_or_path is not None and os.path.isdir(str(model_name_or_path)):
+            cfg, arena, tok_dir = _load_model_dir(str(model_name_or_path))
+        else:
+            name = str(model_name_or_path or "all-MiniLM-L6-v2").split("/")[-1]
+            if name not in PRESETS:
+                raise ValueError(f"unknown model '{model_name_or_path}': pass a local model directory or one of "
+                                 f"{sorted(PRESETS)} (no network access to fetch checkpoints)")
+            cfg = PRESETS[name]
+            logger.warning("No checkpoint for '%s' is available offline: using seeded random-init weights of that "
+                           "architecture (seed %d).", name, seed)
+        self.cfg = cfg
+        if device is None:
+            device = "cuda"
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise _lib.QstError(f"SentenceTransformer needs a HIP device (got '{device}'): this build has no CPU path")
+        if not torch.cuda.is_available():
+            raise _lib.QstError("SentenceTransformer needs a HIP device and none is visible: this build has no CPU path")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self._target_device = dev
+        self._enc = HipEncoder(cfg, device=dev)
+        self._enc.load_arena(arena if arena is not None else synthetic_params(cfg, seed=seed))
+        self.max_seq_length = cfg.max_seq_length
+        self.tokenizer = None
+        if tok_dir is not None:
+            try:
+                from transformers import AutoTokenizer
+                self.tokenizer = AutoTokenizer.from_pretrained(tok_dir, local_files_only=True)
+            except Exception as e:   # no vocab in the directory
+                logger.warning("no usable tokenizer in %s (%s): falling back to SyntheticTokenizer", tok_dir, e)
+        if self.tokenizer is None:
+            self._synthetic_tokenizer = SyntheticTokenizer(cfg)
+        self._anchor = nn.Parameter(torch.zeros((), device=dev))      # makes the Function's output require grad
+        self._build_named_parameters()
+        self.best_score = -9999999
+
+    # ---- parameters as views of the arena
+    def _build_named_parameters(self):
+        root = _Holder()
+        auto = _Holder()
+        root.add_module("auto_model", auto)
+        self.add_module("0", root)
+        self._enc.ensure_train_state()
+        views, gviews = self._enc.named_views(), self._enc.grad_views()
+        for name, view in views.items():
+            parts = name.split(".")
+            mod = auto
+            for p in parts[:-1]:
+                if p not in mod._modules:
+                    mod.add_module(p, _Holder())
+                mod = mod._modules[p]
+            par = nn.Parameter(view, requires_grad=True)
+            par.grad = gviews[name]
+            mod.register_parameter(parts[-1], par)
+
+    @property
+    def device(self) -> torch.device:
+        return self._target_device
+
+    def to(self, *args, **kwargs):
+        dev = None
+        if args and isinstance(args[0], (str, torch.device)):
+            dev = torch.device(args[0])
+        dev = torch.device(kwargs["device"]) if "device" in kwargs else dev
+        if dev is not None and (dev.type != "cuda" or (dev.index is not None and dev.index != self._target_device.index)):
+            raise _lib.QstError(f"this model lives on {self._target_device}; moving the arena to {dev} is not supported")
+        return self
+
+    def get_sentence_embedding_dimension(self) -> int:
+        return self.cfg.hidden_size
+
+    def get_max_seq_length(self) -> int:
+        return self.max_seq_length
+
+    # ---- tokenisation
+    def tokenize(self, texts: Union[List[str], List[Dict], List[Tuple[str, str]]]):
+        texts = [str(t).strip() for t in texts]
+        max_len = min(self.max_seq_length, 512)
+        if self.tokenizer is not None:
+            out = self.tokenizer(texts, padding=True, truncation="longest_first", return_tensors="pt", max_length=max_len)
+            out = {k: v for k, v in out.items()}
+            if self.cfg.type_vocab_size > 0 and "token_type_ids" not in out:
+                out["token_type_ids"] = torch.zeros_like(out["input_ids"])
+            return out
+        return self._synthetic_tokenizer(texts, max_len)
+
+    def smart_batching_collate(self, batch):
+        """[InputExample] -> (list of per-column tokenised dicts, labels tensor) as ST 2.2.2 does."""
+        num_texts = len(batch[0].texts)
+        texts = [[] for _ in range(num_texts)]
+        labels = []
+        for example in batch:
+            for idx, text in enumerate(example.texts):
+                texts[idx].append(text)
+            labels.append(example.label)
+        labels = torch.tensor(labels)
+        return [self.tokenize(col) for col in texts], labels
+
+    # ---- forward
+    def forward(self, features: Dict[str, torch.Tensor], **kwargs) -> Dict[str, torch.Tensor]:
+        ids = features["input_ids"]
+        mask = features["attention_mask"]
+        types = features.get("token_type_ids") if self.cfg.type_vocab_size > 0 else None
+        dev = self._target_device
+        ids = ids.to(dev, torch.int64)
+        mask = mask.to(dev, torch.int64)
+        types = types.to(dev, torch.int64) if types is not None else None
+        ids, mask, types, _ = HipEncoder.pad_inputs(ids, mask, types, self.cfg.pad_token_id)
+        training = torch.is_grad_enabled() and self.training
+        with torch.cuda.device(dev):
+            emb = _EncodeFn.apply(self._anchor, self, ids, mask, types, training)
+        features.update({"sentence_embedding": emb})
+        return features
+
+    # ---- encode
+    def encode(self, sentences: Union[str, List[str]], batch_size: int = 32, show_progress_bar: Optional[bool] = None,
+               output_value: str = "sentence_embedding", convert_to_numpy: bool = True,
+               convert_to_tensor: bool = False, device: Optional[str] = None, normalize_embeddings: bool = False):
+        if output_value != "sentence_embedding":
+            raise NotImplementedError("only output_value='sentence_embedding' is on the accelerated path")
+        was_training = self.training
+        self.eval()
+        if convert_to_tensor:
+            convert_to_numpy = False
+        single = isinstance(sentences, str) or not hasattr(sentences, "__len__")
+        if single:
+            sentences = [sentences]
+        order = np.argsort([-len(str(s)) for s in sentences])
+        sorted_s = [sentences[i] for i in order]
+        chunks = []
+        with torch.no_grad():
+            for start in range(0, len(sorted_s), batch_size):
+                feats = self.tokenize(sorted_s[start:start + batch_size])
+                emb = self.forward(feats)["sentence_embedding"].detach()
+                if normalize_embeddings:
+                    emb = torch.nn.functional.normalize(emb, p=2, dim=1)
+                chunks.append(emb.cpu() if convert_to_numpy else emb)
+        allemb = torch.cat(chunks, 0) if chunks else torch.zeros(0, self.cfg.hidden_size)
+        inv = np.argsort(order)
+        allemb = allemb[torch.as_tensor(inv, device=allemb.device)] if len(inv) else allemb
+        if convert_to_numpy:
+            allemb = allemb.numpy()
+        if single:
+            allemb = allemb[0]
+        self.train(was_training)
+        return allemb
+
+    # ---- fit (kwargs = training/main.py:128-148)
+    def fit(self, train_objectives: Iterable[Tuple[object, nn.Module]], evaluator=None, epochs: int = 1,
+            steps_per_epoch=None, scheduler: str = "WarmupLinear", warmup_steps: int = 10000,
+            optimizer_class: Type = torch.optim.AdamW, optimizer_params: Dict[str, object] = None,
+            weight_decay: float = 0.01, evaluation_steps: int = 0, output_path: str = None,
+            save_best_model: bool = True, max_grad_norm: float = 1, use_amp: bool = False,
+            callback: Callable[[float, int, int], None] = None, show_progress_bar: bool = True,
+            checkpoint_path: str = None, checkpoint_save_steps: int = 500, checkpoint_save_total_limit: int = 0):
+        optimizer_params = dict(optimizer_params or {"lr": 2e-5})
+        if optimizer_class not in (torch.optim.AdamW,):
+            raise NotImplementedError(f"fit() drives the fused HIP AdamW; optimizer_class={optimizer_class} is not supported")
+        lr = float(optimizer_params.get("lr", 2e-5))
+        betas = tuple(optimizer_params.get("betas", (0.9, 0.999)))
+        eps = float(optimizer_params.get("eps", 1e-8))
+        if use_amp:
+            logger.info("use_amp is a no-op: the HIP path already runs bf16 MFMA operands with fp32 accumulation")
+        dataloaders = [dl for dl, _ in train_objectives]
+        loss_models = [lm for _, lm in train_objectives]
+        for dl in dataloaders:
+            dl.collate_fn = self.smart_batching_collate
+        for lm in loss_models:
+            lm.to(self._target_device)
+        self.best_score = -9999999
+        if steps_per_epoch is None or steps_per_epoch == 0:
+            steps_per_epoch = min(len(dl) for dl in dataloaders)
+        t_total = int(steps_per_epoch * epochs)
+        sched = scheduler.lower()
+        if sched not in ("warmuplinear", "constantlr", "warmupconstant"):
+            raise ValueError(f"Unknown scheduler {scheduler}")
+
+        def lr_at(step):
+            if sched == "constantlr":
+                return lr
+            if sched == "warmupconstant":
+                return lr * min(1.0, float(step) / float(max(1, warmup_steps)))
+            return warmup_linear_lr(lr, step, warmup_steps, t_total)
+
+        enc = self._enc
+        enc.ensure_train_state()
+        enc.grads.zero_()
+        global_step = 0
+        iters = [iter(dl) for dl in dataloaders]
+        for epoch in range(epochs):
+            training_steps = 0
+            for lm in loss_models:
+                lm.train()
+            self._rebind_grads()
+            for _ in range(steps_per_epoch):
+                for idx, lm in enumerate(loss_models):
+                    try:
+                        data = next(iters[idx])
+                    except StopIteration:
+                        iters[idx] = iter(dataloaders[idx])
+                        data = next(iters[idx])
+                    features, labels = data
+                    labels = labels.to(self._target_device)
+                    features = [batch_to_device(f, self._target_device) for f in features]
+                    loss_value = lm(features, labels)
+                    loss_value.backward()
+                    # clip_grad_norm_ + AdamW.step + zero_grad, one pass over the arena, norm stays on the device
+                    enc.adamw_step(lr_at(global_step), betas, eps, weight_decay, float(max_grad_norm))
+                training_steps += 1
+                global_step += 1
+                if evaluation_steps > 0 and training_steps % evaluation_steps == 0:
+                    self._eval_during_training(evaluator, output_path, save_best_model, epoch, training_steps, callback)
+                    for lm in loss_models:
+                        lm.train()
+                if checkpoint_path is not None and checkpoint_save_steps is not None and checkpoint_save_steps > 0 \
+                        and global_step % checkpoint_save_steps == 0:
+                    self._save_checkpoint(checkpoint_path, checkpoint_save_total_limit, global_step)
+            self._eval_during_training(evaluator, output_path, save_best_model, epoch, -1, callback)
+        if evaluator is None and output_path is not None:
+            self.save(output_path)
+        if checkpoint_path is not None:
+            self._save_checkpoint(checkpoint_path, checkpoint_save_total_limit, global_step)
+
+    def _rebind_grads(self):
+        gv = self._enc.grad_views()
+        auto = self._modules["0"]._modules["auto_model"]
+        for name, p in auto.named_parameters():
+            if p.grad is None or p.grad.data_ptr() != gv[name].data_ptr():
+                p.grad = gv[name]
+
+    def _eval_during_training(self, evaluator, output_path, save_best_model, epoch, steps, callback):
+        eval_path = output_path
+        if output_path is not None:
+            os.makedirs(output_path, exist_ok=True)
+            eval_path = os.path.join(output_path, "eval")
+            os.makedirs(eval_path, exist_ok=True)
+        if evaluator is not None:
+            score = evaluator(self, output_path=eval_path, epoch=epoch, steps=steps)
+            if callback is not None:
+                callback(score, epoch, steps)          # EarlyStoppingException(BaseException) propagates (callbacks.py:47)
+            if score > self.best_score:
+                self.best_score = score
+                if save_best_model:
+                    self.save(output_path)
+
+    def _save_checkpoint(self, checkpoint_path, checkpoint_save_total_limit, step):
+        self.save(os.path.join(checkpoint_path, str(step)))
+        if checkpoint_save_total_limit is not None and checkpoint_save_total_limit > 0:
+            old = sorted(int(d) for d in os.listdir(checkpoint_path) if d.isdigit())
+            for s in old[:-checkpoint_save_total_limit]:
+                shutil.rmtree(os.path.join(checkpoint_path, str(s)), ignore_errors=True)
+
+    # ---- save / load: ST model-directory layout (modules.json, config.json, model.safetensors, 1_Pooling/...)
+    def save(self, path: str, model_name: Optional[str] = None, create_model_card: bool = False, **kwargs):
+        if path is None:
+            return
+        os.makedirs(path, exist_ok=True)
+        cfg = self.cfg
+        from safetensors.torch import save_file
+        tensors = OrderedDict((k, v.detach().cpu().contiguous().clone()) for k, v in self._enc.named_views().items())
+        save_file(tensors, os.path.join(path, "model.safetensors"))
+        hf = {"model_type": "bert" if cfg.arch == ARCH_BERT else "mpnet", "vocab_size": cfg.vocab_size,
+              "hidden_size": cfg.hidden_size, "num_hidden_layers": cfg.num_layers,
+              "num_attention_heads": cfg.num_heads, "intermediate_size": cfg.intermediate_size,
+              "max_position_embeddings": cfg.max_position, "type_vocab_size": cfg.type_vocab_size,
+              "layer_norm_eps": cfg.layer_norm_eps, "hidden_act": "gelu", "pad_token_id": cfg.pad_token_id,
+              "relative_attention_num_buckets": cfg.rel_buckets}
+        json.dump(hf, open(os.path.join(path, "config.json"), "w"), indent=2)
+        json.dump({"max_seq_length": self.max_seq_length, "do_lower_case": False},
+                  open(os.path.join(path, "sentence_bert_config.json"), "w"), indent=2)
+        modules = [{"idx": 0, "name": "0", "path": "", "type": "sentence_transformers.models.Transformer"},
+                   {"idx": 1, "name": "1", "path": "1_Pooling", "type": "sentence_transformers.models.Pooling"}]
+        os.makedirs(os.path.join(path, "1_Pooling"), exist_ok=True)
+        json.dump({"word_embedding_dimension": cfg.hidden_size, "pooling_mode_cls_token": False,
+                   "pooling_mode_mean_tokens": True, "pooling_mode_max_tokens": False,
+                   "pooling_mode_mean_sqrt_len_tokens": False},
+                  open(os.path.join(path, "1_Pooling", "config.json"), "w"), indent=2)
+        if cfg.normalize:
+            modules.append({"idx": 2, "name": "2", "path": "2_Normalize", "type": "sentence_transformers.models.Normalize"})
+            os.makedirs(os.path.join(path, "2_Normalize"), exist_ok=True)
+        json.dump(modules, open(os.path.join(path, "modules.json"), "w"), indent=2)
+        if self.tokenizer is not None:
+            self.tokenizer.save_pretrained(path)
+
+
+def _load_model_dir(path: str):
+    """Read an ST/HF model directory (as written by save() above or by sentence-transformers)."""
+    cfg_path = os.path.join(path, "config.json")
+    if not os.path.exists(cfg_path):
+        raise FileNotFoundError(f"{path} has no config.json")
+    hf = json.load(open(cfg_path))
+    mt = hf.get("model_type", "bert")
+    if mt not in ("bert", "mpnet"):
+        raise NotImplementedError(f"model_type '{mt}' is not on the accelerated path (bert, mpnet)")
+    normalize, max_seq = False, min(512, int(hf.get("max_position_embeddings", 512)))
+    mj = os.path.join(path, "modules.json")
+    if os.path.exists(mj):
+        normalize = any(m.get("type", "").endswith("Normalize") for m in json.load(open(mj)))
+    sb = os.path.join(path, "sentence_bert_config.json")
+    if os.path.exists(sb):
+        max_seq = int(json.load(open(sb)).get("max_seq_length", max_seq))
+    arch = ARCH_BERT if mt == "bert" else ARCH_MPNET
+    cfg = EncoderConfig(arch=arch, vocab_size=hf["vocab_size"], hidden_size=hf["hidden_size"],
+                        num_layers=hf["num_hidden_layers"], num_heads=hf["num_attention_heads"],
+                        intermediate_size=hf["intermediate_size"], max_position=hf["max_position_embeddings"],
+                        type_vocab_size=0 if arch == ARCH_MPNET else hf.get("type_vocab_size", 2),
+                        layer_norm_eps=hf.get("layer_norm_eps", 1e-12), normalize=normalize, max_seq_length=max_seq,
+                        rel_buckets=hf.get("relative_attention_num_buckets", 32),
+                        pad_token_id=hf.get("pad_token_id", 1 if arch == ARCH_MPNET else 0))
+    st_path = os.path.join(path, "model.safetensors")
+    if os.path.exists(st_path):
+        from safetensors.torch import load_file
+        sd = load_file(st_path)
+    elif os.path.exists(os.path.join(path, "pytorch_model.bin")):
+        sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+    else:
+        raise FileNotFoundError(f"{path} has neither model.safetensors nor pytorch_model.bin")
+    sd = {k[len("bert."):] if k.startswith("bert.") else (k[len("mpnet."):] if k.startswith("mpnet.") else k): v
+          for k, v in sd.items()}
+    from .config import build_layout
+    segs, total = build_layout(cfg)
+    so = {s.name: s for s in segs}
+    arena = np.zeros(total, np.float32)
+    missing = []
+    for name, seg, off, shape in hf_param_views(cfg):
+        if name not in sd:
+            missing.append(name)
+            continue
+        s = so[seg]
+        n = int(np.prod(shape))
+        arena[s.offset + off:s.offset + off + n] = sd[name].to(torch.float32).numpy().reshape(-1)
+    if missing:
+        raise KeyError(f"{path}: checkpoint lacks {len(missing)} tensors, e.g. {missing[:3]}")
+    return cfg, arena, path

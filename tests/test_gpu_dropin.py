@@ -1,0 +1,130 @@
+"""GPU: the SentenceTransformer-compatible surface (encode / __call__ / fit / save+load) and the reference's
+loss-model call pattern, all executing through libqst.so."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from torch.utils.data import DataLoader
+
+pytestmark = pytest.mark.gpu
+
+import quadruplet_sentence_transformer_amd  # noqa: E402,F401
+from quadruplet_sentence_transformer_amd.evaluation import SentenceEvaluator  # noqa: E402
+from quadruplet_sentence_transformer_amd.losses import GammaQuadrupletLoss  # noqa: E402
+from quadruplet_sentence_transformer_amd.quadruplet_model import (NEG_EXAMPLES, PART_POS_EXAMPLES, POS_EXAMPLES,  # noqa: E402
+                                                                  REFERENCE_EXAMPLE, QuadrupletSentenceTransformerLossModel,
+                                                                  to_input_example)
+from quadruplet_sentence_transformer_amd.sentence_transformer import InputExample, SentenceTransformer  # noqa: E402
+
+WORDS = "a man rides red horse two dogs play in park woman eats green apple near old bridge small cat sleeps".split()
+
+
+def sent(i, n):
+    rng = np.random.RandomState(i)
+    return " ".join(rng.choice(WORDS, size=n))
+
+
+def quad(i):
+    return {REFERENCE_EXAMPLE: sent(i, 9), POS_EXAMPLES: [sent(i, 9) + " today", sent(i, 9) + " now"],
+            PART_POS_EXAMPLES: sent(i, 4), NEG_EXAMPLES: sent(1000 + i, 11)}
+
+
+@pytest.fixture(scope="module")
+def model():
+    return SentenceTransformer("tiny-bert", device="cuda")
+
+
+def test_encode_shapes_order_and_determinism(model):
+    texts = [sent(i, 3 + i % 7) for i in range(11)]
+    e = model.encode(texts, batch_size=4)
+    assert isinstance(e, np.ndarray) and e.shape == (11, 64) and np.isfinite(e).all()
+    np.testing.assert_allclose(np.linalg.norm(e, axis=1), 1.0, rtol=1e-4)        # Normalize module
+    one = model.encode(texts[5])
+    assert one.shape == (64,)
+    np.testing.assert_allclose(one, e[5], rtol=0, atol=2e-3)    # batch composition changes padding only
+    t = model.encode(texts, convert_to_tensor=True)
+    assert torch.is_tensor(t) and t.is_cuda and t.shape == (11, 64)
+    np.testing.assert_allclose(t.cpu().numpy(), model.encode(texts, batch_size=32), rtol=0, atol=2e-3)
+
+
+def test_four_call_pattern_equals_fused_pass(model):
+    """models/quadruplet_sentence_transformer.py:42-75 runs 4 encoder calls; the fused [4B, L] pass must agree."""
+    loss = GammaQuadrupletLoss(gamma=0.6, margin_pos_neg=1.0, margin_pos_part=0.5, margin_part_neg=0.5, p=2.0)
+    lm4 = QuadrupletSentenceTransformerLossModel(model, loss, fused=False)
+    lm1 = QuadrupletSentenceTransformerLossModel(model, loss, fused=True)
+    batch = [to_input_example(quad(i)) for i in range(6)]
+    feats, labels = model.smart_batching_collate(batch)
+    assert len(feats) == 4 and labels.shape == (6,)
+    model.train()
+    enc = model._enc
+    enc.grads.zero_()
+    l4 = lm4([dict(f) for f in feats], labels)
+    l4.backward()
+    g4 = enc.grads.clone()
+    enc.grads.zero_()
+    l1 = lm1([dict(f) for f in feats], labels)
+    l1.backward()
+    g1 = enc.grads.clone()
+    assert abs(l4.item() - l1.item()) < 2e-4
+    assert (g4 - g1).norm().item() <= 2e-2 * g1.norm().item()
+    # dict-keyed features (quadruplet_sentence_transformer.py:24-28)
+    keyed = {k: dict(f) for k, f in zip((REFERENCE_EXAMPLE, POS_EXAMPLES, PART_POS_EXAMPLES, NEG_EXAMPLES), feats)}
+    assert abs(lm1(keyed).item() - l1.item()) < 1e-6
+    enc.grads.zero_()
+
+
+class CountingEvaluator(SentenceEvaluator):
+    def __init__(self, loss_model, batch):
+        self.calls, self.loss_model, self.batch = [], loss_model, batch
+
+    def __call__(self, model, output_path=None, epoch=-1, steps=-1):
+        feats, labels = model.smart_batching_collate(self.batch)
+        with torch.no_grad():
+            v = self.loss_model(feats, labels).item()
+        self.calls.append((epoch, steps, v))
+        return -v            # higher is better for save_best_model
+
+
+class Stop(BaseException):
+    pass
+
+
+def test_fit_trains_saves_and_reloads(model, tmp_path):
+    loss = GammaQuadrupletLoss(gamma=0.6, margin_pos_neg=1.0, margin_pos_part=0.5, margin_part_neg=0.5, p=2.0)
+    lm = QuadrupletSentenceTransformerLossModel(model, loss)
+    data = [to_input_example(quad(i)) for i in range(32)]
+    dl = DataLoader(data, batch_size=8, shuffle=True, num_workers=0)
+    ev = CountingEvaluator(lm, data[:8])
+    before = model._enc.params.clone()
+    seen = []
+    model.fit(train_objectives=[(dl, lm)], evaluator=ev, epochs=3, steps_per_epoch=None, scheduler="warmuplinear",
+              warmup_steps=2, optimizer_class=torch.optim.AdamW, optimizer_params={"lr": 2e-3}, weight_decay=0.01,
+              evaluation_steps=2, output_path=str(tmp_path / "out"), save_best_model=True, max_grad_norm=1.0,
+              use_amp=False, callback=lambda score, epoch, steps: seen.append((score, epoch, steps)),
+              show_progress_bar=False, checkpoint_path=str(tmp_path / "ckpt"), checkpoint_save_steps=4,
+              checkpoint_save_total_limit=2)
+    assert not torch.equal(before, model._enc.params)
+    assert len(ev.calls) == 3 * (2 + 1) and len(seen) == len(ev.calls)      # every 2 steps + end of each epoch
+    assert ev.calls[-1][2] < ev.calls[0][2], "validation loss did not go down"
+    assert sorted(os.listdir(tmp_path / "ckpt")) == ["12", "8"]
+    assert os.path.exists(tmp_path / "out" / "model.safetensors") and os.path.exists(tmp_path / "out" / "modules.json")
+    # reload the saved best model from its directory (ir_evauation_script.py:128) and compare embeddings
+    best = SentenceTransformer(str(tmp_path / "ckpt" / "12"), device="cuda")
+    texts = [sent(i, 6) for i in range(5)]
+    np.testing.assert_allclose(best.encode(texts), model.encode(texts), rtol=0, atol=1e-6)
+    # a callback raising a BaseException subclass must propagate out of fit (training/callbacks.py:47, main.py:149)
+    def boom(score, epoch, steps):
+        raise Stop()
+    with pytest.raises(Stop):
+        model.fit(train_objectives=[(dl, lm)], evaluator=ev, epochs=1, evaluation_steps=1, callback=boom,
+                  optimizer_params={"lr": 1e-4}, output_path=str(tmp_path / "out2"), show_progress_bar=False)
+
+
+def test_named_parameters_are_views_with_hf_names(model):
+    names = dict(model.named_parameters())
+    assert "0.auto_model.embeddings.word_embeddings.weight" in names
+    assert "0.auto_model.encoder.layer.1.attention.self.query.weight" in names
+    w = names["0.auto_model.encoder.layer.0.output.LayerNorm.weight"]
+    assert w.data_ptr() >= model._enc.params.data_ptr()
+    assert w.data_ptr() < model._enc.params.data_ptr() + model._enc.params.numel() * 4
