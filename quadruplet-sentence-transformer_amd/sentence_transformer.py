@@ -158,7 +158,9 @@ class SentenceTransformer(nn.Module):
         self._enc.load_arena(arena if arena is not None else synthetic_params(cfg, seed=seed))
         self.max_seq_length = cfg.max_seq_length
         self.tokenizer = None
-        if tok_dir is not None:
+        has_vocab = tok_dir is not None and any(os.path.exists(os.path.join(tok_dir, f))
+                                                 for f in ("tokenizer.json", "vocab.txt", "vocab.json", "sentencepiece.bpe.model"))
+        if has_vocab:
             try:
                 from transformers import AutoTokenizer
                 self.tokenizer = AutoTokenizer.from_pretrained(tok_dir, local_files_only=True)
