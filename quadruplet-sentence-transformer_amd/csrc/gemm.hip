@@ -4,16 +4,44 @@
 //   gemm_tn : C[N,K] += A[M,N]^T . B[M,K]  (fp32 atomics, split over M)  wgrad; optional column sums (bias grad)
 //
 // These replace nn.Linear forward/backward inside BertLayer (transformers modeling_bert.py:154-156,
-// 282-293, 325-351). Tiles: 128x128 output per 256-thread workgroup (4 waves,
-// 2x2, 64x64 per wave = 2x2 MFMA 32x32 tiles), K-step 64, LDS double-buffered through registers
-// (16-byte buffer loads with hardware range check -> ragged M/N need no branches in the main loop).
-// LDS images are XOR-swizzled so ds_read_b128 (nt) and ds_read_b64_tr_b16 (tn) are conflict-free.
+// 282-293, 325-351).
+//
+// Structure (both kernels): 128x128 output tile per 256-thread workgroup (4 waves, 2x2, 64x64 per wave = 2x2 MFMA
+// 32x32 tiles); the reduction dimension is streamed in 32-deep stages through a 4-slot LDS ring filled by LDS-DMA
+// (buffer_load_dwordx4 ... lds: no staging registers, hardware range check zero-fills ragged M/N), three stages in
+// flight across ONE raw s_barrier per stage with counted s_waitcnt vmcnt -- the short-K shapes here (K = 384) are
+// latency-bound, not MFMA-bound, so memory-level parallelism is what the loop is built around.
+// LDS images are XOR-swizzled (applied on the DMA SOURCE address, the destination is lane-linear) so that
+// ds_read_b128 (nt) and ds_read_b64_tr_b16 (tn) fragment reads are bank-conflict-free.
 #include "qst_common.h"
 #include "qst_kernels.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BM = 128, BN = 128, BK = 32, STAGES = 2;
+constexpr int TILE_BYTES = 128 * BK * 2;            // 8 KB per operand tile per stage (nt: 128 rows x 64 B; tn: 32 rows x 256 B)
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;         // 16 KB
+constexpr int RING_BYTES = STAGES * STAGE_BYTES;
+constexpr int NT_LDS_BYTES = 65536;   // 2 stages x (16 KB A + 16 KB B); the epilogue staging (34 KB) fits inside
+constexpr uint32_t kOOB = 0x7FFFFFF0u;              // voffset that always fails the buffer range check -> zero fill
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* lds_wave_base, uint32_t voff, uint32_t soff) {
+    // one wave-instruction writes 64 x 16 B = 1 KB at lds_wave_base + lane*16 (base must be wave-uniform)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+// wait until all but the `stages_behind` most recently issued stages (4 DMA per thread each) have landed
+__device__ __forceinline__ void wait_stage(int stages_behind) {
+    if (stages_behind >= 2) wait_vmcnt<8>();
+    else if (stages_behind == 1) wait_vmcnt<4>();
+    else wait_vmcnt<0>();
+}
 
 __device__ __forceinline__ int xcd_remap(int b, int nwg) {
     // bijective XCD-contiguous remap (blocks b and b+8 share an XCD): neighbours in the remapped id
@@ -23,16 +51,20 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 }
 
 // ---------------------------------------------------------------- NT
-// LDS image per operand tile: [128 rows][64 bf16] = 128-byte rows, 16-byte chunk c of row r stored at
-// chunk (c ^ ((r >> 1) & 7)).
+// LDS image per operand tile: [128 rows][32 bf16] = 64-byte rows; 16-byte chunk c of row r sits at chunk
+// position c ^ ((r >> 2) & 3)  (conflict-free for the MFMA A/B fragment ds_read_b128).
+constexpr int NBK = 64;                              // nt K-step: 128-byte rows = whole cache lines per DMA row
+constexpr int NT_TILE = 128 * NBK * 2;               // 16 KB
+constexpr int NT_STAGES = 2;
 __device__ __forceinline__ uint32_t nt_off(int row, int chunk) {
     return (uint32_t)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(QstGemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (16K A + 16K B); reused by the epilogue (4 x 17K)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4-stage ring (64 KB); reused by the epilogue
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
     const int wg = xcd_remap(blockIdx.x, ntm * ntn);
@@ -44,32 +76,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(QstGemmArgs g) {
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(Ab, (uint32_t)rows_a * g.lda * 2u);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(Bb, (uint32_t)rows_b * g.ldb * 2u);
 
-    // staging map: 4 chunks of A and 4 of B per thread; row = tid/8 + 32*i, chunk = tid%8
-    const int srow = tid >> 3, sch = tid & 7;
-    uint32_t goff_a[4], goff_b[4], loff[4];
+    // DMA map: a tile is 8 wave-instructions of 1 KB (16 rows x 64 B); wave w issues instructions 2w, 2w+1.
+    // LDS position p (16-B units) = q*64 + lane -> row p/4, chunk position p%4 -> logical chunk = pos ^ swz(row)
+    // (NBK = 64: a tile is 16 wave-instructions of 8 rows x 128 B; wave w issues instructions 4w .. 4w+3)
+    uint32_t va[4], vb[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = srow + 32 * i;
-        goff_a[i] = (uint32_t)r * g.lda * 2u + sch * 16u;
-        goff_b[i] = (uint32_t)r * g.ldb * 2u + sch * 16u;
-        loff[i] = nt_off(r, sch);
+    for (int t = 0; t < 4; ++t) {
+        const int q = wave * 4 + t;
+        const int row = q * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        va[t] = (uint32_t)row * g.lda * 2u + chunk * 16u;
+        vb[t] = (uint32_t)row * g.ldb * 2u + chunk * 16u;
     }
-    u32x4 sa[4], sb[4];
-    auto gload = [&](int kt) {
-        const uint32_t kb = (uint32_t)kt * BK * 2u;
+    auto issue = [&](int kt) {
+        char* st = smem + (kt % NT_STAGES) * (2 * NT_TILE) + wave * 4096;
+        const uint32_t ko = (uint32_t)kt * (NBK * 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            sa[i] = buf_load16(ra, goff_a[i] + kb);
-            sb[i] = buf_load16(rb, goff_b[i] + kb);
-        }
-    };
-    auto lstore = [&](int buf) {
-        char* pa = smem + buf * 32768;
-        char* pb = pa + 16384;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *(u32x4*)(pa + loff[i]) = sa[i];
-            *(u32x4*)(pb + loff[i]) = sb[i];
+        for (int t = 0; t < 4; ++t) {
+            dma16(ra, st + t * 1024, va[t], ko);
+            dma16(rb, st + NT_TILE + t * 1024, vb[t], ko);
         }
     };
 
@@ -81,16 +106,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(QstGemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = g.K / BK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
+    const int nk = g.K / NBK;
     const int fr = lane & 31, fh = lane >> 5;
+    issue(0);
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
-        const char* pa = smem + cur * 32768;
-        const char* pb = pa + 16384;
+        wait_vmcnt<0>();                              // stage kt has landed for this wave's DMAs
+        __builtin_amdgcn_s_barrier();                 // ... for everyone's; and everyone is done reading slot (kt-1)%2
+        if (kt + 1 < nk) issue(kt + 1);
+        const char* pa = smem + (kt % NT_STAGES) * (2 * NT_TILE);
+        const char* pb = pa + NT_TILE;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 fa[2], fb[2];
@@ -105,17 +129,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(QstGemmArgs g) {
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // D rows = n, col = m
         }
-        if (kt + 1 < nk) lstore(cur ^ 1);
-        __syncthreads();
     }
+    __builtin_amdgcn_s_barrier();                     // all waves done with the ring before the epilogue reuses it
 
     // ---- epilogue. The MFMA operands were swapped (D rows = n in registers, D column = m on the lane), so each
-    // lane holds 4 consecutive n per register group: stage the wave's 64x64 fp32 sub-tile through LDS as [m][n]
-    // (row stride 68 floats: conflict-free ds_write_b128) and read it back row-wise, so bias / residual / GELU
-    // and the global stores all run on 16-byte row-contiguous vectors (16 lanes = one 256-byte row segment).
-    float* stg = (float*)smem + wave * (64 * 68);
+    // lane holds 4 consecutive n per register group: stage 32 rows of the wave's 64x64 fp32 sub-tile at a time
+    // through LDS as [m][n] (row stride 68 floats: conflict-free ds_write_b128) and read it back row-wise, so
+    // bias / residual / GELU and the global stores run on 16-byte row-contiguous vectors (16 lanes = 256-B segment).
+    float* stg = (float*)smem + wave * (32 * 68);
+    const int c4 = lane & 15, rsub = lane >> 4;
+    const int n = n0 + wn * 64 + c4 * 4;
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias && n < g.N) bias = *(const f32x4*)(g.bias + n);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -123,65 +150,69 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(QstGemmArgs g) {
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g4 + e];
-                *(f32x4*)(stg + (i * 32 + fr) * 68 + j * 32 + 8 * g4 + 4 * fh) = v;
+                *(f32x4*)(stg + fr * 68 + j * 32 + 8 * g4 + 4 * fh) = v;
             }
-    // same wave reads what it wrote: no workgroup barrier needed (the K loop ended with one)
-    const int c4 = lane & 15, rsub = lane >> 4;
-    const int n = n0 + wn * 64 + c4 * 4;
-    if (n < g.N) {
-        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-        if (g.bias) bias = *(const f32x4*)(g.bias + n);
+        // the same wave reads back what it wrote (wave-private region): no workgroup barrier needed
+        if (n < g.N) {
 #pragma unroll 4
-        for (int t = 0; t < 16; ++t) {
-            const int row = t * 4 + rsub;
-            const int m = m0 + wm * 64 + row;
-            if (m >= g.M) continue;
-            f32x4 v = *(const f32x4*)(stg + row * 68 + c4 * 4);
-            v += bias;
-            const size_t o = (size_t)m * g.ldc + n;
-            if (EPI == QST_EPI_BF16) {
-                u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
-                *(u32x2*)((bf16*)g.C + o) = pk;
-            } else if (EPI == QST_EPI_F32_RESID || EPI == QST_EPI_F32_RESID_BF16) {
-                if (g.resid) v += *(const f32x4*)(g.resid + (size_t)m * g.ldr + n);
-                *(f32x4*)((float*)g.C + o) = v;
-                if (EPI == QST_EPI_F32_RESID_BF16) {
+            for (int t = 0; t < 8; ++t) {
+                const int row = t * 4 + rsub;
+                const int m = m0 + wm * 64 + i * 32 + row;
+                if (m >= g.M) continue;
+                f32x4 v = *(const f32x4*)(stg + row * 68 + c4 * 4);
+                v += bias;
+                const size_t o = (size_t)m * g.ldc + n;
+                if (EPI == QST_EPI_BF16) {
                     u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
-                    *(u32x2*)((bf16*)g.C2 + o) = pk;
+                    *(u32x2*)((bf16*)g.C + o) = pk;
+                } else if (EPI == QST_EPI_F32_RESID || EPI == QST_EPI_F32_RESID_BF16) {
+                    if (g.resid) v += *(const f32x4*)(g.resid + (size_t)m * g.ldr + n);
+                    *(f32x4*)((float*)g.C + o) = v;
+                    if (EPI == QST_EPI_F32_RESID_BF16) {
+                        u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
+                        *(u32x2*)((bf16*)g.C2 + o) = pk;
+                    }
+                } else if (EPI == QST_EPI_GELU) {
+                    u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
+                    *(u32x2*)((bf16*)g.C + o) = pk;                                   // u (pre-activation), saved for backward
+                    pk[0] = pack_bf16x2(gelu_erf(v[0]), gelu_erf(v[1])); pk[1] = pack_bf16x2(gelu_erf(v[2]), gelu_erf(v[3]));
+                    *(u32x2*)((bf16*)g.C2 + o) = pk;                                  // h
+                } else if (EPI == QST_EPI_GELU_BWD) {
+                    const u32x2 ua = *(const u32x2*)((const bf16*)g.aux + o);
+                    u32x2 pk;
+                    pk[0] = pack_bf16x2(v[0] * gelu_erf_grad(bf16lo(ua[0])), v[1] * gelu_erf_grad(bf16hi(ua[0])));
+                    pk[1] = pack_bf16x2(v[2] * gelu_erf_grad(bf16lo(ua[1])), v[3] * gelu_erf_grad(bf16hi(ua[1])));
+                    *(u32x2*)((bf16*)g.C + o) = pk;
                 }
-            } else if (EPI == QST_EPI_GELU) {
-                u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
-                *(u32x2*)((bf16*)g.C + o) = pk;                                   // u (pre-activation), saved for backward
-                pk[0] = pack_bf16x2(gelu_erf(v[0]), gelu_erf(v[1])); pk[1] = pack_bf16x2(gelu_erf(v[2]), gelu_erf(v[3]));
-                *(u32x2*)((bf16*)g.C2 + o) = pk;                                  // h
-            } else if (EPI == QST_EPI_GELU_BWD) {
-                const u32x2 ua = *(const u32x2*)((const bf16*)g.aux + o);
-                u32x2 pk;
-                pk[0] = pack_bf16x2(v[0] * gelu_erf_grad(bf16lo(ua[0])), v[1] * gelu_erf_grad(bf16hi(ua[0])));
-                pk[1] = pack_bf16x2(v[2] * gelu_erf_grad(bf16lo(ua[1])), v[3] * gelu_erf_grad(bf16hi(ua[1])));
-                *(u32x2*)((bf16*)g.C + o) = pk;
             }
         }
     }
 }
 
 // ---------------------------------------------------------------- TN
-// LDS image per operand tile: [64 m-rows][128 bf16] = 256-byte rows; chunk c (16 B) of row r at
-// chunk c ^ (((r&3)<<2) | ((r>>2)&3))  -- conflict-free for the 32x32x16 transposed reads.
+// LDS image per operand tile: [32 m-rows][128 bf16] = 256-byte rows; chunk c (16 B) of row r at chunk position
+// c ^ (((r&3)<<2) | ((r>>2)&3))  -- conflict-free for the 32x32x16 transposed reads (cdna guide T10, image (b)).
+__device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 __device__ __forceinline__ uint32_t tn_off(int row, int chunk) {
-    return (uint32_t)(row * 256 + ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4));
+    return (uint32_t)(row * 256 + ((chunk ^ tn_swz(row)) << 4));
 }
 __device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(QstGemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (16K A + 16K B)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(256, 3) void gemm_tn_kernel(QstGemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4-stage ring (64 KB)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     // output C[N, K]; reduction over M split into g.splits contiguous ranges
     const int ntn = (g.N + BM - 1) / BM, ntk = (g.K + BN - 1) / BN;
-    const int tile = blockIdx.x % (ntn * ntk), split = blockIdx.x / (ntn * ntk);
+    // Blocks b and b+8 share an XCD (round-robin dispatch). All output tiles of one M-range ("split") are placed
+    // on ONE XCD so the re-reads of that range (every A row by each k-tile, every B row by each n-tile) hit its L2
+    // instead of going back to HBM/Infinity Cache 8 times. Placement is a speed choice only.
+    const int tiles = ntn * ntk;
+    const int xcd = blockIdx.x & 7, jloc = blockIdx.x >> 3;
+    const int tile = jloc % tiles, split = xcd + 8 * (jloc / tiles);
     const int n0 = (tile / ntk) * BM, k0 = (tile % ntk) * BN;
     const int per = (((g.M + g.splits - 1) / g.splits) + BK - 1) / BK * BK;
     const int mbeg = split * per, mend = min(g.M, mbeg + per);
@@ -190,40 +221,30 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(QstGemmArgs g) {
     const bf16* Ab = (const bf16*)g.A + (size_t)mbeg * g.lda + n0;
     const bf16* Bb = (const bf16*)g.B + (size_t)mbeg * g.ldb + k0;
     // range = rows [mbeg, mend); the last row's tail past the allocation reads as zero
-    const uint32_t bytes_a = (uint32_t)min((size_t)(mend - mbeg) * g.lda * 2u - (size_t)n0 * 2u, (size_t)0xFFFFFFF0u);
-    const uint32_t bytes_b = (uint32_t)min((size_t)(mend - mbeg) * g.ldb * 2u - (size_t)k0 * 2u, (size_t)0xFFFFFFF0u);
+    const uint32_t bytes_a = (uint32_t)min((size_t)(mend - mbeg) * g.lda * 2u - (size_t)n0 * 2u, (size_t)0x7FFFFF00u);
+    const uint32_t bytes_b = (uint32_t)min((size_t)(mend - mbeg) * g.ldb * 2u - (size_t)k0 * 2u, (size_t)0x7FFFFF00u);
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(Ab, bytes_a);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(Bb, bytes_b);
 
-    // staging: 64 rows x 16 chunks per operand = 1024 chunks -> 4 per thread: row = tid/16 + 16*i, chunk = tid%16
-    const int srow = tid >> 4, sch = tid & 15;
-    uint32_t goff_a[4], goff_b[4], loff[4];
+    // DMA map: a tile is 8 wave-instructions of 1 KB (4 rows x 256 B); wave w issues instructions 2w, 2w+1.
+    // LDS position p = q*64 + lane -> row p/16, chunk position p%16 -> logical chunk = pos ^ swz(row).
+    // Columns beyond the matrix width must not alias the next row: those lanes get an out-of-range offset (-> 0).
+    uint32_t va[2], vb[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = srow + 16 * i;
-        goff_a[i] = (uint32_t)r * g.lda * 2u + sch * 16u;
-        goff_b[i] = (uint32_t)r * g.ldb * 2u + sch * 16u;
-        loff[i] = tn_off(r, sch);
+    for (int t = 0; t < 2; ++t) {
+        const int q = wave * 2 + t;
+        const int row = q * 4 + (lane >> 4);
+        const int chunk = (lane & 15) ^ tn_swz(row);
+        va[t] = (n0 + chunk * 8 < g.N) ? (uint32_t)row * g.lda * 2u + chunk * 16u : kOOB;
+        vb[t] = (k0 + chunk * 8 < g.K) ? (uint32_t)row * g.ldb * 2u + chunk * 16u : kOOB;
     }
-    // columns beyond the matrix width must not alias the next row: mask those chunks to zero
-    const bool a_ok = (n0 + sch * 8) < g.N, b_ok = (k0 + sch * 8) < g.K;
-    u32x4 sa[4], sb[4];
-    const u32x4 z = {0, 0, 0, 0};
-    auto gload = [&](int mt) {
-        const uint32_t ra_off = (uint32_t)mt * BK * g.lda * 2u, rb_off = (uint32_t)mt * BK * g.ldb * 2u;
+    auto issue = [&](int mt) {
+        char* st = smem + (mt % STAGES) * STAGE_BYTES + wave * 2048;
+        const uint32_t soa = (uint32_t)mt * BK * g.lda * 2u, sob = (uint32_t)mt * BK * g.ldb * 2u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            sa[i] = a_ok ? buf_load16(ra, goff_a[i] + ra_off) : z;
-            sb[i] = b_ok ? buf_load16(rb, goff_b[i] + rb_off) : z;
-        }
-    };
-    auto lstore = [&](int buf) {
-        char* pa = smem + buf * 32768;
-        char* pb = pa + 16384;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *(u32x4*)(pa + loff[i]) = sa[i];
-            *(u32x4*)(pb + loff[i]) = sb[i];
+        for (int t = 0; t < 2; ++t) {
+            dma16(ra, st + t * 1024, va[t], soa);       // kOOB + soa < 2^32: no wrap, still out of range
+            dma16(rb, st + TILE_BYTES + t * 1024, vb[t], sob);
         }
     };
 
@@ -243,18 +264,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(QstGemmArgs g) {
     for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
     const int nm = (mend - mbeg + BK - 1) / BK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    // transposed-read lane geometry (cdna guide T10): 16-lane group gq, lane i=4q+p supplies row q, cols 4p..4p+3
+    // transposed-read lane geometry (cdna guide T10): lane i = 4q+p of a 16-lane group supplies row q, cols 4p..4p+3
     const int li = lane & 15, q = li >> 2, p = li & 3, gsel = (lane >> 4) & 1, fh = lane >> 5;
-    for (int mt = 0; mt < nm; ++mt) {
-        const int cur = mt & 1;
-        if (mt + 1 < nm) gload(mt + 1);
-        const char* pa = smem + cur * 32768;
-        const char* pb = pa + 16384;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nm) issue(s);
+    for (int mt = 0; mt < nm; ++mt) {
+        wait_stage(min(STAGES - 2, nm - 1 - mt));
+        __builtin_amdgcn_s_barrier();
+        if (mt + STAGES - 1 < nm) issue(mt + STAGES - 1);
+        const char* pa = smem + (mt % STAGES) * STAGE_BYTES;
+        const char* pb = pa + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
             bf16x8 fa[2], fb[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -280,8 +302,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(QstGemmArgs g) {
                     bacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], ones, bacc[i], 0, 0, 0);
             }
         }
-        if (mt + 1 < nm) lstore(cur ^ 1);
-        __syncthreads();
     }
 
     const int fr = lane & 31;
@@ -314,11 +334,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(QstGemmArgs g) {
 
 extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
     if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
-    if (a->K % BK != 0 || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->N % 4 != 0 || a->ldc % 4 != 0) return QST_ERR_UNSUPPORTED;
+    if (a->K % 64 != 0 || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->N % 4 != 0 || a->ldc % 4 != 0) return QST_ERR_UNSUPPORTED;
+    if ((int64_t)128 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)128 * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
     const int ntm = (a->M + BM - 1) / BM, ntn = (a->N + BN - 1) / BN;
     dim3 grid(ntm * ntn), block(256);
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = 4 * 64 * 68 * sizeof(float);   // 69632: epilogue staging is the larger user
+    const size_t lds = NT_LDS_BYTES;
 #define QST_NT_CASE(E)                                                                                  \
     case E: {                                                                                           \
         static bool attr_set = false;                                                                   \
@@ -345,20 +366,23 @@ extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
 extern "C" int qst_gemm_tn(const QstGemmArgs* a, void* stream) {
     if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
     if (a->lda % 8 != 0 || a->ldb % 8 != 0 || a->N % 8 != 0 || a->K % 8 != 0) return QST_ERR_UNSUPPORTED;
+    if ((int64_t)a->M * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)a->M * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
     QstGemmArgs g = *a;
     const int tiles = ((g.N + BM - 1) / BM) * ((g.K + BN - 1) / BN);
     if (g.splits <= 0) {
-        // fill ~2 waves of workgroups over 256 CUs, keep >= 512 reduction rows per split
-        int s = (512 + tiles - 1) / tiles;
-        const int max_s = (g.M + 511) / 512;
-        g.splits = s < 1 ? 1 : (s > max_s ? max_s : s);
+        // splits = 8*q: one M-range per XCD and round; q chosen so one XCD's 32 CUs x 2 blocks are about filled
+        int q = 64 / tiles;
+        q = q < 1 ? 1 : (q > 8 ? 8 : q);
+        while (q > 1 && (int64_t)g.M < (int64_t)8 * q * 256) --q;      // keep >= 256 reduction rows per split
+        g.splits = 8 * q;
     }
+    g.splits = (g.splits + 7) / 8 * 8;
     static bool attr_set = false;
     if (!attr_set) {
-        QST_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        QST_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING_BYTES));
         attr_set = true;
     }
-    gemm_tn_kernel<<<dim3(tiles * g.splits), dim3(256), 65536, (hipStream_t)stream>>>(g);
+    gemm_tn_kernel<<<dim3(tiles * g.splits), dim3(256), RING_BYTES, (hipStream_t)stream>>>(g);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }

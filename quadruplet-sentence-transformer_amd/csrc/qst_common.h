@@ -28,15 +28,41 @@ extern "C" int qst_set_hip_error(int code);
 
 #define QST_LAUNCH_CHECK() QST_HIP_CHECK(hipGetLastError())
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Wave64 all-reduce on the VALU cross-lane path (DPP + readlane) instead of __shfl_xor, which lowers to
+// ds_bpermute: six dependent LDS round trips per reduction made the row kernels latency-bound.
+// Butterfly inside each row of 16 lanes (quad_perm xor1, xor2, row_half_mirror, row_mirror: sums are symmetric,
+// so mirrors work as butterflies), then the four row totals are combined through SGPRs.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);    // row_half_mirror
+    v += dpp_mov<0x140>(v);    // row_mirror
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
     return v;
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = row16_max(v);
+    return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
+}
+// exchange with the lane 32 away (the other half of an MFMA 32x32 accumulator column)
+__device__ __forceinline__ float swap32(float v) {
+    return __shfl_xor(v, 32, 64);
 }
 
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the step's GEMM launches at BASELINE configs[1] shapes (M = 4*64*128 = 32768)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import quadruplet_sentence_transformer_amd  # noqa: E402,F401
+from quadruplet_sentence_transformer_amd import _lib  # noqa: E402
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def main():
+    M = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+    lib = _lib.load()
+    st = _lib.current_stream_ptr()
+    dev = "cuda"
+    H, I = 384, 1536
+    bf = torch.bfloat16
+    tot = 0.0
+    print(f"{'launch':34s} {'us':>8s} {'TFLOP/s':>8s}")
+    cases = [("QKV fwd  epi0", 3 * H, H, 0, 1), ("out fwd  epi1", H, H, 1, 1), ("FFN1 fwd epi2", I, H, 2, 1),
+             ("FFN2 fwd epi1", H, I, 1, 1), ("FFN2 dgrad epi3", I, H, 3, 1), ("FFN1 dgrad epi1", H, I, 1, 1),
+             ("out dgrad epi0", H, H, 0, 1), ("QKV dgrad epi1", H, 3 * H, 1, 1)]
+    for name, N, K, epi, _ in cases:
+        A = torch.randn(M, K, device=dev).to(bf)
+        B = (torch.randn(N, K, device=dev) * 0.02).to(bf)
+        bias = torch.zeros(N, device=dev)
+        resid = torch.randn(M, N, device=dev)
+        aux = torch.randn(M, N, device=dev).to(bf)
+        C = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == 1 else bf)
+        C2 = torch.empty(M, N, device=dev, dtype=bf)
+        g = _lib.QstGemmArgs()
+        g.A, g.B, g.C, g.C2, g.aux, g.bias, g.resid = A.data_ptr(), B.data_ptr(), C.data_ptr(), C2.data_ptr(), aux.data_ptr(), bias.data_ptr(), resid.data_ptr()
+        g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.ldr = M, N, K, K, K, N, N
+        us = timeit(lambda: _lib.check(lib.qst_gemm_nt(g, epi, st)))
+        tot += us
+        print(f"nt {name:31s} {us:8.1f} {2.0 * M * N * K / us / 1e6:8.1f}")
+    for name, N, K in [("dW2 [H,I]", H, I), ("dW1 [I,H]", I, H), ("dWo [H,H]", H, H), ("dWqkv [3H,H]", 3 * H, H)]:
+        A = torch.randn(M, N, device=dev).to(bf)
+        B = torch.randn(M, K, device=dev).to(bf)
+        C = torch.zeros(N, K, device=dev)
+        cs = torch.zeros(N, device=dev)
+        g = _lib.QstGemmArgs()
+        g.A, g.B, g.C, g.colsum = A.data_ptr(), B.data_ptr(), C.data_ptr(), cs.data_ptr()
+        g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.splits = M, N, K, N, K, K, 0
+        us = timeit(lambda: _lib.check(lib.qst_gemm_tn(g, st)))
+        tot += us
+        print(f"tn {name:31s} {us:8.1f} {2.0 * M * N * K / us / 1e6:8.1f}")
+    print(f"sum per layer {tot:.1f} us -> x6 layers = {tot * 6 / 1e3:.2f} ms")
+
+
+if __name__ == "__main__":
+    main()
