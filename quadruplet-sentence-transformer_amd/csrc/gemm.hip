@@ -88,14 +88,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(QstGemmArgs g) {
         va[t] = (uint32_t)row * g.lda * 2u + chunk * 16u;
         vb[t] = (uint32_t)row * g.ldb * 2u + chunk * 16u;
     }
-    auto issue = [&](int kt) {
+    // issue DMA piece t (one A + one B instruction) of stage kt
+    auto issue_piece = [&](int kt, int t) {
         char* st = smem + (kt % NT_STAGES) * (2 * NT_TILE) + wave * 4096;
         const uint32_t ko = (uint32_t)kt * (NBK * 2);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            dma16(ra, st + t * 1024, va[t], ko);
-            dma16(rb, st + NT_TILE + t * 1024, vb[t], ko);
-        }
+        dma16(ra, st + t * 1024, va[t], ko);
+        dma16(rb, st + NT_TILE + t * 1024, vb[t], ko);
     };
 
     f32x16 acc[2][2];
@@ -108,13 +106,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(QstGemmArgs g) {
 
     const int nk = g.K / NBK;
     const int fr = lane & 31, fh = lane >> 5;
-    issue(0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) issue_piece(0, t);
     for (int kt = 0; kt < nk; ++kt) {
         wait_vmcnt<0>();                              // stage kt has landed for this wave's DMAs
         __builtin_amdgcn_s_barrier();                 // ... for everyone's; and everyone is done reading slot (kt-1)%2
-        if (kt + 1 < nk) issue(kt + 1);
         const char* pa = smem + (kt % NT_STAGES) * (2 * NT_TILE);
         const char* pb = pa + NT_TILE;
+        const bool more = kt + 1 < nk;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 fa[2], fb[2];
@@ -128,6 +127,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(QstGemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // D rows = n, col = m
+            // the next stage's DMA pieces are issued in the shadow of this k-step's MFMAs (the MFMA pipe runs
+            // asynchronously; an in-order wave would otherwise pay the DMA issue cost up front)
+            if (more) issue_piece(kt + 1, ks);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __builtin_amdgcn_s_barrier();                     // all waves done with the ring before the epilogue reuses it
@@ -370,9 +373,10 @@ extern "C" int qst_gemm_tn(const QstGemmArgs* a, void* stream) {
     QstGemmArgs g = *a;
     const int tiles = ((g.N + BM - 1) / BM) * ((g.K + BN - 1) / BN);
     if (g.splits <= 0) {
-        // splits = 8*q: one M-range per XCD and round; q chosen so one XCD's 32 CUs x 2 blocks are about filled
-        int q = 64 / tiles;
-        q = q < 1 ? 1 : (q > 8 ? 8 : q);
+        // splits = 8*q: every XCD gets q M-ranges; q ~ 64/tiles so an XCD's 32 CUs hold about two blocks each
+        // (measured at M = 32768: 36 tiles -> 16 splits 78 us vs 8 splits 102 us, 24+ splits lose to atomic traffic)
+        int q = (64 + tiles / 2) / tiles;
+        q = q < 1 ? 1 : (q > 3 ? 3 : q);
         while (q > 1 && (int64_t)g.M < (int64_t)8 * q * 256) --q;      // keep >= 256 reduction rows per split
         g.splits = 8 * q;
     }

@@ -221,7 +221,7 @@ ActPlan plan_acts(const qst_config& c, int nseq, int L, bool training) {
     return p;
 }
 
-struct BwdPlan { size_t dxa, dxb, ds, dsb, du, dctx, dqkv, drel, total; };
+struct BwdPlan { size_t dxa, dxb, ds, dsb, du, dctx, dqkv, drel, lnred, total; };
 BwdPlan plan_bwd(const qst_config& c, int nseq, int L) {
     BwdPlan p;
     const size_t M = (size_t)nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads;
@@ -230,6 +230,7 @@ BwdPlan plan_bwd(const qst_config& c, int nseq, int L) {
     p.dxa = take(M * H * 4); p.dxb = take(M * H * 4); p.ds = take(M * H * 4); p.dsb = take(M * H * 2);
     p.du = take(M * I * 2); p.dctx = take(M * H * 2); p.dqkv = take(M * 3 * H * 2);
     p.drel = (c.arch == QST_ARCH_MPNET) ? take(A * (size_t)L * L * 4) : 0;
+    p.lnred = take(qst_ln_bwd_scratch_bytes((int)M, (int)H));
     p.total = off;
     return p;
 }
@@ -367,6 +368,7 @@ extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, 
     void* du = ws + w.du;
     void* dctx = ws + w.dctx;
     void* dqkv = ws + w.dqkv;
+    float* lnred = (float*)(ws + w.lnred);
     float* drel = nullptr;
     const float* rel = nullptr;
     if (c.arch == QST_ARCH_MPNET) {
@@ -382,7 +384,7 @@ extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, 
         const void* xin_b = (l == 0) ? (const void*)(sv + p.x0b) : (const void*)(sv + p.layers[l - 1].xb);
         // LN2
         QST_TRY(qst_ln_bwd(dxa, sv + a.xh2, (const float*)(sv + a.rs2), P(b + LN2_G), M, H, ds, dsb, G(b + LN2_G),
-                           G(b + LN2_B), st));
+                           G(b + LN2_B), lnred, st));
         // FFN2: wgrad [H, I] (+ bias), dgrad through GELU
         QST_TRY(tn(dsb, H, sv + a.hact, I, G(b + W_2), I, G(b + B_2), M, H, I, st));
         QST_TRY(nt(dsb, H, WT(b + W_2), H, du, I, nullptr, sv + a.u, nullptr, nullptr, 0, M, I, H, QST_EPI_GELU_BWD, st));
@@ -391,7 +393,7 @@ extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, 
         QST_TRY(nt(du, I, WT(b + W_1), I, dxb, H, nullptr, nullptr, nullptr, ds, H, M, H, I, QST_EPI_F32_RESID, st));
         // LN1
         QST_TRY(qst_ln_bwd(dxb, sv + a.xh1, (const float*)(sv + a.rs1), P(b + LN1_G), M, H, ds, dsb, G(b + LN1_G),
-                           G(b + LN1_B), st));
+                           G(b + LN1_B), lnred, st));
         // attention output projection
         QST_TRY(tn(dsb, H, sv + a.ctx, H, G(b + W_O), H, G(b + B_O), M, H, H, st));
         QST_TRY(nt(dsb, H, WT(b + W_O), H, dctx, H, nullptr, nullptr, nullptr, nullptr, 0, M, H, H, QST_EPI_BF16, st));
@@ -405,7 +407,7 @@ extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, 
     }
     if (!do_embed) return QST_OK;
     // embeddings
-    QST_TRY(qst_ln_bwd(dxa, sv + p.xh0, (const float*)(sv + p.rs0), P(lay.eg), M, H, ds, nullptr, G(lay.eg), G(lay.eb), st));
+    QST_TRY(qst_ln_bwd(dxa, sv + p.xh0, (const float*)(sv + p.rs0), P(lay.eg), M, H, ds, nullptr, G(lay.eg), G(lay.eb), lnred, st));
     QST_TRY(qst_embed_bwd(ds, ids, type_ids, (const int32_t*)(sv + p.pos_ids), nseq, L, H, c.type_vocab_size,
                           G(lay.word), G(lay.pos), lay.type >= 0 ? G(lay.type) : nullptr, st));
     if (c.arch == QST_ARCH_MPNET) {

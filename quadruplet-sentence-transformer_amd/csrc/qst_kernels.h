@@ -46,8 +46,11 @@ int qst_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int32_t*
 int qst_ln_fwd(const float* s, const float* gamma, const float* beta, float eps, int M, int H,
                float* y, void* y_bf16, void* xhat_bf16, float* rstd, void* stream);
 /* LayerNorm backward: ds = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)); dgamma += sum dy*xhat; dbeta += sum dy. */
+/* scratch: qst_ln_bwd_scratch_bytes(M, H) of per-block partial sums reduced in a fixed order (deterministic);
+ * NULL falls back to float atomics on dgamma/dbeta. */
+size_t qst_ln_bwd_scratch_bytes(int M, int H);
 int qst_ln_bwd(const float* dy, const void* xhat_bf16, const float* rstd, const float* gamma, int M, int H,
-               float* ds, void* ds_bf16, float* dgamma, float* dbeta, void* stream);
+               float* ds, void* ds_bf16, float* dgamma, float* dbeta, float* scratch, void* stream);
 /* Embedding backward: scatter ds rows into word/pos/type gradient tables. */
 int qst_embed_bwd(const float* ds, const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
                   int nseq, int L, int H, int num_types, float* dword, float* dpos, float* dtype_, void* stream);

@@ -104,7 +104,7 @@ constexpr int LN_BWD_ROWS_PER_WAVE = 8;
 template <int VPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const bf16* xh, const float* rstd,
                                                      const float* gamma, int M, int H, float* ds, bf16* dsb,
-                                                     float* dgamma, float* dbeta) {
+                                                     float* dgamma, float* dbeta, float* partials) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [4 waves][2][H] floats
     float* sh = (float*)smem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -166,8 +166,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const bf16
         float a = 0.f, b = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { a += sh[(w * 2 + 0) * H + c]; b += sh[(w * 2 + 1) * H + c]; }
-        atomicAdd(dgamma + c, a);
-        atomicAdd(dbeta + c, b);
+        if (partials) {           // [gridDim.x][2][H]: reduced by ln_bwd_reduce_kernel in a fixed order
+            partials[((size_t)blockIdx.x * 2 + 0) * H + c] = a;
+            partials[((size_t)blockIdx.x * 2 + 1) * H + c] = b;
+        } else {
+            atomicAdd(dgamma + c, a);
+            atomicAdd(dbeta + c, b);
+        }
+    }
+}
+
+// dgamma[c] += sum_b partials[b][0][c], dbeta[c] += sum_b partials[b][1][c]; 16 row-slices per column in LDS
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* partials, int nblocks, int H, float* dgamma,
+                                                            float* dbeta) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + cl;              // column of the flattened [2][H] pair
+    float acc = 0.f;
+    if (col < 2 * H)
+        for (int b = sl; b < nblocks; b += 16) acc += partials[(size_t)b * 2 * H + col];
+    red[sl][cl] = acc;
+    __syncthreads();
+    if (threadIdx.x < 16 && blockIdx.x * 16 + threadIdx.x < 2 * H) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+        const int c = blockIdx.x * 16 + threadIdx.x;
+        if (c < H) dgamma[c] += t; else dbeta[c - H] += t;
     }
 }
 
@@ -404,8 +429,13 @@ extern "C" int qst_ln_fwd(const float* s, const float* gamma, const float* beta,
     return QST_OK;
 }
 
+extern "C" size_t qst_ln_bwd_scratch_bytes(int M, int H) {
+    const int rows_per_block = 4 * LN_BWD_ROWS_PER_WAVE;
+    return (size_t)((M + rows_per_block - 1) / rows_per_block) * 2 * H * sizeof(float);
+}
+
 extern "C" int qst_ln_bwd(const float* dy, const void* xhat_bf16, const float* rstd, const float* gamma, int M, int H,
-                          float* ds, void* ds_bf16, float* dgamma, float* dbeta, void* stream) {
+                          float* ds, void* ds_bf16, float* dgamma, float* dbeta, float* scratch, void* stream) {
     if (!dy || !xhat_bf16 || !rstd || !gamma || !ds || !dgamma || !dbeta || M <= 0 || H <= 0 || (H & 1))
         return QST_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -413,8 +443,12 @@ extern "C" int qst_ln_bwd(const float* dy, const void* xhat_bf16, const float* r
     const int grid = (M + rows_per_block - 1) / rows_per_block;
     const size_t lds = (size_t)8 * H * sizeof(float);
     QST_VPL_DISPATCH(H, (ln_bwd_kernel<VPL><<<grid, 256, lds, st>>>(dy, (const bf16*)xhat_bf16, rstd, gamma, M, H, ds,
-                                                                   (bf16*)ds_bf16, dgamma, dbeta)));
+                                                                   (bf16*)ds_bf16, dgamma, dbeta, scratch)));
     QST_LAUNCH_CHECK();
+    if (scratch) {
+        ln_bwd_reduce_kernel<<<(2 * H + 15) / 16, 256, 0, st>>>(scratch, grid, H, dgamma, dbeta);
+        QST_LAUNCH_CHECK();
+    }
     return QST_OK;
 }
 

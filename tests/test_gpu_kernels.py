@@ -175,8 +175,15 @@ def test_layernorm_fwd_bwd(lib, M, H):
     dsb = torch.empty(M, H, dtype=torch.bfloat16, device="cuda")
     dg = torch.zeros(H, device="cuda")
     db = torch.zeros(H, device="cuda")
+    scratch = torch.empty(lib.qst_ln_bwd_scratch_bytes(M, H) // 4, device="cuda")
     _lib.check(lib.qst_ln_bwd(dyd.data_ptr(), xh.data_ptr(), rs.data_ptr(), gd.data_ptr(), M, H, ds.data_ptr(),
-                              dsb.data_ptr(), dg.data_ptr(), db.data_ptr(), stream()))
+                              dsb.data_ptr(), dg.data_ptr(), db.data_ptr(), scratch.data_ptr(), stream()))
+    dg2 = torch.zeros(H, device="cuda")
+    db2 = torch.zeros(H, device="cuda")
+    _lib.check(lib.qst_ln_bwd(dyd.data_ptr(), xh.data_ptr(), rs.data_ptr(), gd.data_ptr(), M, H, ds.data_ptr(),
+                              dsb.data_ptr(), dg2.data_ptr(), db2.data_ptr(), None, stream()))      # atomic fallback
+    torch.testing.assert_close(dg2, dg, rtol=1e-4, atol=1e-4 * math.sqrt(M))
+    torch.testing.assert_close(db2, db, rtol=1e-4, atol=1e-4 * math.sqrt(M))
     # xhat is stored in bf16 -> 2^-9 relative perturbation of the xhat terms
     torch.testing.assert_close(ds.cpu(), sr.grad, rtol=2e-2, atol=2e-2 * sr.grad.abs().max().item())
     torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-4, atol=1e-4 * math.sqrt(M))
