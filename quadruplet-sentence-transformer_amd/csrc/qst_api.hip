@@ -149,7 +149,7 @@ extern "C" int qst_encoder_create(const qst_config* cfg, qst_encoder** out) {
     if (cfg->hidden_size % cfg->num_heads != 0 || (d != 32 && d != 64)) return QST_ERR_UNSUPPORTED;
     if (cfg->hidden_size % 64 != 0 || cfg->intermediate_size % 64 != 0 || cfg->hidden_size > 1024) return QST_ERR_UNSUPPORTED;
     if (cfg->type_vocab_size > 2) return QST_ERR_UNSUPPORTED;
-    if (cfg->precision != QST_PREC_BF16) return QST_ERR_UNSUPPORTED;
+    if (cfg->precision != QST_PREC_BF16 && cfg->precision != QST_PREC_BF16X3) return QST_ERR_UNSUPPORTED;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return QST_ERR_NO_DEVICE;
     qst_encoder* e = new qst_encoder();
@@ -221,6 +221,23 @@ ActPlan plan_acts(const qst_config& c, int nseq, int L, bool training) {
     return p;
 }
 
+// QST_PREC_BF16X3 forward: fp32 activations, inference only (two residual slots ping-pong)
+struct X3Plan { size_t pos_ids, x[2], qkv, ctx, s, y1, h, pooled, rel, total; };
+X3Plan plan_x3(const qst_config& c, int nseq, int L) {
+    X3Plan p;
+    const size_t M = (size_t)nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    p.pos_ids = take(M * 4);
+    p.x[0] = take(M * H * 4); p.x[1] = take(M * H * 4);
+    p.qkv = take(M * 3 * H * 4); p.ctx = take(M * H * 4); p.s = take(M * H * 4); p.y1 = take(M * H * 4);
+    p.h = take(M * I * 4);
+    p.pooled = take((size_t)nseq * H * 4);
+    p.rel = (c.arch == QST_ARCH_MPNET) ? take(A * (size_t)L * L * 4) : 0;
+    p.total = off;
+    return p;
+}
+
 struct BwdPlan { size_t dxa, dxb, ds, dsb, du, dctx, dqkv, drel, lnred, total; };
 BwdPlan plan_bwd(const qst_config& c, int nseq, int L) {
     BwdPlan p;
@@ -244,6 +261,13 @@ int shape_ok(const qst_encoder* e, int nseq, int L) {
     return QST_OK;
 }
 
+int nt3(const float* A, int lda, const float* B, int ldb, float* C, int ldc, const float* bias, const float* resid, int ldr,
+        int M, int N, int K, int epi, hipStream_t st) {
+    QstGemmArgs g{};
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.resid = resid;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
+    return qst_gemm_nt_x3(&g, epi, st);
+}
 int nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* C2, const void* aux, const float* bias,
        const float* resid, int ldr, int M, int N, int K, int epi, hipStream_t st) {
     QstGemmArgs g{};
@@ -265,6 +289,7 @@ int tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, float*
 
 extern "C" size_t qst_encoder_saved_bytes(const qst_encoder* e, int nseq, int L, int training) {
     if (shape_ok(e, nseq, L) != QST_OK) return 0;
+    if (e->cfg.precision == QST_PREC_BF16X3) return training ? 0 : plan_x3(e->cfg, nseq, L).total;
     return plan_acts(e->cfg, nseq, L, training != 0).total;
 }
 extern "C" size_t qst_encoder_bwd_workspace_bytes(const qst_encoder* e, int nseq, int L) {
@@ -283,12 +308,56 @@ extern "C" int qst_refresh_shadow(const qst_encoder* e, const float* params, voi
     return QST_OK;
 }
 
+// Parity-precision forward (QST_PREC_BF16X3): same operator sequence as below on fp32 activations and the fp32
+// master weights, contractions through split-bf16 x3 MFMA kernels (csrc/x3.hip).
+static int forward_x3(qst_encoder* e, const int64_t* ids, const int64_t* mask, const int64_t* type_ids, int nseq, int L,
+                      const float* params, float* out_emb, float* out_tok, void* saved, size_t saved_bytes, hipStream_t st) {
+    const qst_config& c = e->cfg;
+    const X3Plan p = plan_x3(c, nseq, L);
+    if (saved_bytes < p.total) return QST_ERR_WORKSPACE;
+    char* sv = (char*)saved;
+    const int M = nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads, d = H / A;
+    const Layout& lay = e->lay;
+    auto P = [&](int seg) { return params + lay.segs[seg].off; };
+    int32_t* pos_ids = (int32_t*)(sv + p.pos_ids);
+    QST_TRY(qst_position_ids(ids, nseq, L, c.arch, c.pad_token_id, pos_ids, st));
+    float* x = (float*)(sv + p.x[0]);
+    QST_TRY(qst_embed_ln_fwd(ids, type_ids, pos_ids, P(lay.word), P(lay.pos), lay.type >= 0 ? P(lay.type) : nullptr,
+                             P(lay.eg), P(lay.eb), c.layer_norm_eps, M, H, x, nullptr, nullptr, nullptr, st));
+    const float* rel = nullptr;
+    if (c.arch == QST_ARCH_MPNET) {
+        QST_TRY(qst_rel_bias_fwd(P(lay.rel), e->rel_lut, A, L, (float*)(sv + p.rel), st));
+        rel = (const float*)(sv + p.rel);
+    }
+    float* qkv = (float*)(sv + p.qkv); float* ctx = (float*)(sv + p.ctx); float* s = (float*)(sv + p.s);
+    float* y1 = (float*)(sv + p.y1); float* h = (float*)(sv + p.h);
+    for (int l = 0; l < c.num_layers; ++l) {
+        const int b = lay.layer0[l];
+        float* xn = (float*)(sv + p.x[(l + 1) & 1]);
+        QST_TRY(nt3(x, H, P(b + W_QKV), H, qkv, 3 * H, P(b + B_QKV), nullptr, 0, M, 3 * H, H, 0, st));
+        QST_TRY(qst_attention_fwd_x3(qkv, mask, rel, nseq, L, A, d, ctx, st));
+        QST_TRY(nt3(ctx, H, P(b + W_O), H, s, H, P(b + B_O), x, H, M, H, H, 1, st));
+        QST_TRY(qst_ln_fwd(s, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, y1, nullptr, nullptr, nullptr, st));
+        QST_TRY(nt3(y1, H, P(b + W_1), H, h, I, P(b + B_1), nullptr, 0, M, I, H, 2, st));
+        QST_TRY(nt3(h, I, P(b + W_2), I, s, H, P(b + B_2), y1, H, M, H, I, 1, st));
+        QST_TRY(qst_ln_fwd(s, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, M, H, xn, nullptr, nullptr, nullptr, st));
+        x = xn;
+    }
+    QST_TRY(qst_pool_norm_fwd(x, mask, nseq, L, H, c.normalize, out_emb, (float*)(sv + p.pooled), st));
+    if (out_tok) QST_HIP_CHECK(hipMemcpyAsync(out_tok, x, (size_t)M * H * 4, hipMemcpyDeviceToDevice, st));
+    return QST_OK;
+}
+
 extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int64_t* mask, const int64_t* type_ids,
                                    int nseq, int L, const float* params, const void* shadow, float* out_emb,
                                    float* out_tok, void* saved, size_t saved_bytes, int training, void* stream) {
-    if (!e || !ids || !mask || !params || !shadow || !out_emb || !saved) return QST_ERR_BAD_ARG;
+    if (!e || !ids || !mask || !params || !out_emb || !saved) return QST_ERR_BAD_ARG;
     QST_TRY(shape_ok(e, nseq, L));
     const qst_config& c = e->cfg;
+    if (c.precision == QST_PREC_BF16X3)
+        return training ? QST_ERR_UNSUPPORTED
+                        : forward_x3(e, ids, mask, type_ids, nseq, L, params, out_emb, out_tok, saved, saved_bytes, (hipStream_t)stream);
+    if (!shadow) return QST_ERR_BAD_ARG;
     const ActPlan p = plan_acts(c, nseq, L, training != 0);
     if (saved_bytes < p.total) return QST_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -344,6 +413,7 @@ extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, 
                                             size_t saved_bytes, void* workspace, size_t workspace_bytes,
                                             int do_head, int layer_hi, int layer_lo, int do_embed, void* stream) {
     if (!e || !ids || !mask || !params || !shadow || !grads || !saved || !workspace) return QST_ERR_BAD_ARG;
+    if (e->cfg.precision != QST_PREC_BF16) return QST_ERR_UNSUPPORTED;      // training runs the bf16 path
     if (do_head && !grad_emb) return QST_ERR_BAD_ARG;
     if (layer_lo < 0 || layer_hi > e->cfg.num_layers || layer_lo > layer_hi) return QST_ERR_BAD_ARG;
     QST_TRY(shape_ok(e, nseq, L));

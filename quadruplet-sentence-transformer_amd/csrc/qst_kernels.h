@@ -77,6 +77,12 @@ int qst_rel_bucket_host(int rel, int num_buckets, int max_distance);
 int qst_rel_bias_fwd(const float* table, const int32_t* lut, int A, int L, float* rel_bias, void* stream);
 int qst_rel_bias_bwd(const float* drel, const int32_t* lut, int buckets, int A, int L, float* dtable, void* stream);
 
+/* Parity-precision (QST_PREC_BF16X3) forward kernels: fp32 operands split into hi+lo bf16 on the fly, three MFMAs
+ * per product, fp32 out. epi: 0 = +bias, 1 = +bias +resid, 2 = gelu(+bias). K % 32 == 0. */
+int qst_gemm_nt_x3(const QstGemmArgs* a, int epi, void* stream);
+int qst_attention_fwd_x3(const float* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A, int d,
+                         float* ctx, void* stream);
+
 /* bf16 shadow: dst[i] = bf16(src[i]) and dstT = transpose for a [rows, cols] matrix. */
 int qst_shadow_matrix(const float* src, int rows, int cols, void* dst_bf16, void* dstT_bf16, void* stream);
 

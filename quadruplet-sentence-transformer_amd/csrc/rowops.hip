@@ -176,24 +176,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const bf16
     }
 }
 
-// dgamma[c] += sum_b partials[b][0][c], dbeta[c] += sum_b partials[b][1][c]; 16 row-slices per column in LDS
+// dgamma[c] += sum_b partials[b][0][c], dbeta[c] += sum_b partials[b][1][c]: thread per column (coalesced rows),
+// 32 row-slices; each slice adds its partial sum with one atomic (32 adds per address: no contention to speak of)
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* partials, int nblocks, int H, float* dgamma,
                                                             float* dbeta) {
-    __shared__ float red[16][17];
-    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int col = blockIdx.x * 16 + cl;              // column of the flattened [2][H] pair
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= 2 * H) return;
     float acc = 0.f;
-    if (col < 2 * H)
-        for (int b = sl; b < nblocks; b += 16) acc += partials[(size_t)b * 2 * H + col];
-    red[sl][cl] = acc;
-    __syncthreads();
-    if (threadIdx.x < 16 && blockIdx.x * 16 + threadIdx.x < 2 * H) {
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
-        const int c = blockIdx.x * 16 + threadIdx.x;
-        if (c < H) dgamma[c] += t; else dbeta[c - H] += t;
-    }
+    for (int b = blockIdx.y; b < nblocks; b += gridDim.y) acc += partials[(size_t)b * 2 * H + col];
+    atomicAdd(col < H ? dgamma + col : dbeta + (col - H), acc);
 }
 
 // Embedding backward.
@@ -446,7 +437,7 @@ extern "C" int qst_ln_bwd(const float* dy, const void* xhat_bf16, const float* r
                                                                    (bf16*)ds_bf16, dgamma, dbeta, scratch)));
     QST_LAUNCH_CHECK();
     if (scratch) {
-        ln_bwd_reduce_kernel<<<(2 * H + 15) / 16, 256, 0, st>>>(scratch, grid, H, dgamma, dbeta);
+        ln_bwd_reduce_kernel<<<dim3((2 * H + 255) / 256, 32), 256, 0, st>>>(scratch, grid, H, dgamma, dbeta);
         QST_LAUNCH_CHECK();
     }
     return QST_OK;

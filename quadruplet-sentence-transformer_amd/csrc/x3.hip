@@ -1,0 +1,325 @@
+// x3.hip -- the parity-precision forward path (QST_PREC_BF16X3): fp32 activations and weights, every MFMA operand
+// split on the fly into hi + lo bf16 (hi = bf16(x), lo = bf16(x - hi)) and every product issued as three MFMAs
+// (hi*hi + hi*lo + lo*hi; the dropped lo*lo term is ~2^-18 relative). Accumulation stays fp32, so the
+// contractions are fp32-class (~2^-17) and the embeddings meet rtol 1e-3 / atol 1e-4 against the fp32 CPU
+// reference, which single-rounded bf16 operands cannot. Forward only: encode() and
+// evaluation use it; training runs the bf16 path.
+//
+//   gemm_nt_x3 : C[M,N] (fp32) = A[M,K] (fp32) . B[N,K]^T (fp32) + bias [+ resid] [GELU]
+//   attn_fwd_x3: softmax(Q K^T / sqrt(d) + rel + mask) V on fp32 qkv -> fp32 ctx
+#include "qst_common.h"
+#include "qst_kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+__device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
+    float r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = v[e] - bf2f(f2bf(v[e]));
+    hi[0] = pack_bf16x2(v[0], v[1]); hi[1] = pack_bf16x2(v[2], v[3]);
+    lo[0] = pack_bf16x2(r[0], r[1]); lo[1] = pack_bf16x2(r[2], r[3]);
+}
+__device__ __forceinline__ f32x16 mfma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+    return c;
+}
+
+// ---------------------------------------------------------------- GEMM
+constexpr int XBK = 32;
+// per-operand image [128 rows][32 bf16] (64-byte rows), chunk c of row r at position c ^ ((r>>2)&3)
+__device__ __forceinline__ uint32_t x_off(int row, int chunk) {
+    return (uint32_t)(row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4));
+}
+
+template <int EPI>   // 0: +bias ; 1: +bias +resid ; 2: gelu(+bias)
+__global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(QstGemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // A hi | A lo | B hi | B lo (8 KB each); epilogue 34 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (g.N + 127) / 128;
+    const int m0 = (blockIdx.x / ntn) * 128, n0 = (blockIdx.x % ntn) * 128;
+    const float* A = (const float*)g.A;
+    const float* B = (const float*)g.B;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(A + (size_t)m0 * g.lda, (uint32_t)min(128, g.M - m0) * g.lda * 4u);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(B + (size_t)n0 * g.ldb, (uint32_t)min(128, g.N - n0) * g.ldb * 4u);
+    // staging: a tile is 128 rows x 32 floats = 1024 float4; thread t takes rows t/8 + 32 i, float4 column t%8
+    const int srow = tid >> 3, sc4 = tid & 7;
+    u32x4 sa[4], sb[4];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = srow + 32 * i;
+            sa[i] = buf_load16(ra, (uint32_t)r * g.lda * 4u + (uint32_t)(kt * XBK + sc4 * 4) * 4u);
+            sb[i] = buf_load16(rb, (uint32_t)r * g.ldb * 4u + (uint32_t)(kt * XBK + sc4 * 4) * 4u);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = srow + 32 * i;
+            const uint32_t o = x_off(r, sc4 >> 1) + (sc4 & 1) * 8;
+            u32x2 hi, lo;
+            split4(__builtin_bit_cast(f32x4, sa[i]), hi, lo);
+            *(u32x2*)(smem + o) = hi;
+            *(u32x2*)(smem + 8192 + o) = lo;
+            split4(__builtin_bit_cast(f32x4, sb[i]), hi, lo);
+            *(u32x2*)(smem + 16384 + o) = hi;
+            *(u32x2*)(smem + 24576 + o) = lo;
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nk = g.K / XBK;
+    const int fr = lane & 31, fh = lane >> 5;
+    gload(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                 // previous tile's fragment reads are done
+        lstore();
+        __syncthreads();
+        if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t oa = x_off(wm * 64 + i * 32 + fr, ks * 2 + fh), ob = x_off(wn * 64 + i * 32 + fr, ks * 2 + fh);
+                ah[i] = *(const bf16x8*)(smem + oa);
+                al[i] = *(const bf16x8*)(smem + 8192 + oa);
+                bh[i] = *(const bf16x8*)(smem + 16384 + ob);
+                bl[i] = *(const bf16x8*)(smem + 24576 + ob);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma3(bh[j], bl[j], ah[i], al[i], acc[i][j]);   // D rows = n, col = m
+        }
+    }
+    __syncthreads();
+    float* stg = (float*)smem + wave * (32 * 68);
+    const int c4 = lane & 15, rsub = lane >> 4;
+    const int n = n0 + wn * 64 + c4 * 4;
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias && n < g.N) bias = *(const f32x4*)(g.bias + n);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g4 + e];
+                *(f32x4*)(stg + fr * 68 + j * 32 + 8 * g4 + 4 * fh) = v;
+            }
+        if (n < g.N) {
+#pragma unroll 4
+            for (int t = 0; t < 8; ++t) {
+                const int row = t * 4 + rsub;
+                const int m = m0 + wm * 64 + i * 32 + row;
+                if (m >= g.M) continue;
+                f32x4 v = *(const f32x4*)(stg + row * 68 + c4 * 4);
+                v += bias;
+                if (EPI == 1 && g.resid) v += *(const f32x4*)(g.resid + (size_t)m * g.ldr + n);
+                if (EPI == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));   // exact erf here
+                }
+                *(f32x4*)((float*)g.C + (size_t)m * g.ldc + n) = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- attention
+constexpr float kMaskMin = -3.4028234663852886e38f;
+template <int D> __device__ __forceinline__ uint32_t rr_off(int row, int chunk) {
+    if (D == 32) return (uint32_t)(row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4));
+    return (uint32_t)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+}
+template <int D> __device__ __forceinline__ uint32_t tr_off(int row, int byte) {
+    if (D == 32) return (uint32_t)(row * 64 + byte);
+    return (uint32_t)(row * 128 + (byte ^ (((row >> 1) & 1) << 6)));
+}
+__device__ __forceinline__ bf16x4 lds_tr(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
+}
+template <int D> __device__ __forceinline__ bf16x8 tr_frag(const char* img, int row0, int ddb, int lane) {
+    const int li = lane & 15, q = li >> 2, p = li & 3, gsel = (lane >> 4) & 1, h = lane >> 5;
+    const int byte = ddb * 64 + gsel * 32 + 8 * p;
+    const bf16x4 a = lds_tr(img + tr_off<D>(row0 + 4 * h + q, byte));
+    const bf16x4 b = lds_tr(img + tr_off<D>(row0 + 8 + 4 * h + q, byte));
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[e] = a[e]; f[4 + e] = b[e]; }
+    return f;
+}
+// stage rows x D fp32 (row stride ld floats) into hi and lo bf16 LDS images
+template <int D, bool TR>
+__device__ __forceinline__ void stage_x3(char* hi_img, char* lo_img, const float* g, int ld, int rows, int tid) {
+    constexpr int C4 = D / 4;
+    for (int idx = tid; idx < rows * C4; idx += 256) {
+        const int row = idx / C4, c = idx % C4;
+        const f32x4 v = *(const f32x4*)(g + (size_t)row * ld + c * 4);
+        u32x2 hi, lo;
+        split4(v, hi, lo);
+        const uint32_t off = (TR ? tr_off<D>(row, (c >> 1) * 16) : rr_off<D>(row, c >> 1)) + (c & 1) * 8;
+        *(u32x2*)(hi_img + off) = hi;
+        *(u32x2*)(lo_img + off) = lo;
+    }
+}
+__device__ __forceinline__ void load_frag_x3(const float* p, bf16x8& hi, bf16x8& lo) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi[e] = f2bf(a[e]); lo[e] = f2bf(a[e] - bf2f(hi[e]));
+        hi[4 + e] = f2bf(b[e]); lo[4 + e] = f2bf(b[e] - bf2f(hi[4 + e]));
+    }
+}
+
+struct AttnX3Args {
+    const float* qkv; const int64_t* mask; const float* rel; float* out;
+    int nseq, L, A, H; float scale;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_x3_kernel(AttnX3Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = D / 16, DB = D / 32, IMG = 128 * D * 2;
+    char* khi = smem; char* klo = smem + IMG; char* vhi = smem + 2 * IMG; char* vlo = smem + 3 * IMG;
+    float* madd = (float*)(smem + 4 * IMG);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, fr = lane & 31;
+    const int nqb = (a.L + 127) / 128;
+    const int qb = blockIdx.x % nqb, head = (blockIdx.x / nqb) % a.A, seq = blockIdx.x / (nqb * a.A);
+    const int ld = 3 * a.H;
+    const float* base = a.qkv + (size_t)seq * a.L * ld + head * D;
+    const int i0 = qb * 128 + wave * 32;
+    const bool active = i0 < a.L;
+    const int qi = i0 + fr;
+    for (int t = tid; t < a.L; t += 256) madd[t] = a.mask[(size_t)seq * a.L + t] ? 0.f : kMaskMin;
+    bf16x8 qh[KS], ql[KS];
+    if (active) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) load_frag_x3(base + (size_t)qi * ld + 16 * s + 8 * h, qh[s], ql[s]);
+    }
+    f32x16 o[DB];
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const int nchunk = (a.L + 127) / 128;
+    for (int c = 0; c < nchunk; ++c) {
+        const int rows = min(128, a.L - c * 128);
+        __syncthreads();
+        stage_x3<D, false>(khi, klo, base + (size_t)c * 128 * ld + a.H, ld, rows, tid);
+        stage_x3<D, true>(vhi, vlo, base + (size_t)c * 128 * ld + 2 * a.H, ld, rows, tid);
+        __syncthreads();
+        if (!active) continue;
+        for (int jt = 0; jt < rows / 32; ++jt) {
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const uint32_t off = rr_off<D>(jt * 32 + fr, 2 * ks + h);
+                s = mfma3(*(const bf16x8*)(khi + off), *(const bf16x8*)(klo + off), qh[ks], ql[ks], s);
+            }
+            const int j0 = c * 128 + jt * 32;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float v = s[r] * a.scale;
+                if (a.rel) v += a.rel[((size_t)head * a.L + qi) * a.L + j];
+                v += madd[j];
+                s[r] = v;
+                mx = fmaxf(mx, v);
+            }
+            mx = fmaxf(mx, swap32(mx));
+            const float mn = fmaxf(m, mx);
+            const float alpha = expf(m - mn);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = expf(s[r] - mn); ps += s[r]; }
+            ps += swap32(ps);
+            l = l * alpha + ps;
+            m = mn;
+#pragma unroll
+            for (int b = 0; b < DB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 ph, pl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ph[e] = f2bf(s[8 * ks + e]); pl[e] = f2bf(s[8 * ks + e] - bf2f(ph[e])); }
+#pragma unroll
+                for (int b = 0; b < DB; ++b)
+                    o[b] = mfma3(tr_frag<D>(vhi, jt * 32 + 16 * ks, b, lane), tr_frag<D>(vlo, jt * 32 + 16 * ks, b, lane), ph, pl, o[b]);
+            }
+        }
+    }
+    if (!active) return;
+    const float inv = 1.0f / l;
+    float* orow = a.out + ((size_t)seq * a.L + qi) * a.H + head * D;
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = o[b][4 * g + e] * inv;
+            *(f32x4*)(orow + b * 32 + 8 * g + 4 * h) = v;
+        }
+}
+
+}  // namespace
+
+extern "C" int qst_gemm_nt_x3(const QstGemmArgs* a, int epi, void* stream) {
+    if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
+    if (a->K % XBK != 0 || a->lda % 4 != 0 || a->ldb % 4 != 0 || a->N % 4 != 0 || a->ldc % 4 != 0) return QST_ERR_UNSUPPORTED;
+    const int grid = ((a->M + 127) / 128) * ((a->N + 127) / 128);
+    const size_t lds = 4 * 32 * 68 * sizeof(float);    // 34816 >= 32 KB of operand images
+    hipStream_t st = (hipStream_t)stream;
+    switch (epi) {
+        case 0: gemm_nt_x3_kernel<0><<<grid, 256, lds, st>>>(*a); break;
+        case 1: gemm_nt_x3_kernel<1><<<grid, 256, lds, st>>>(*a); break;
+        case 2: gemm_nt_x3_kernel<2><<<grid, 256, lds, st>>>(*a); break;
+        default: return QST_ERR_BAD_ARG;
+    }
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+extern "C" int qst_attention_fwd_x3(const float* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A,
+                                    int d, float* ctx, void* stream) {
+    if (!qkv || !mask || !ctx || nseq <= 0 || L <= 0 || A <= 0) return QST_ERR_BAD_ARG;
+    if ((d != 32 && d != 64) || (L % 32) != 0 || L > 512) return QST_ERR_UNSUPPORTED;
+    AttnX3Args a{};
+    a.qkv = qkv; a.mask = mask; a.rel = rel_bias; a.out = ctx;
+    a.nseq = nseq; a.L = L; a.A = A; a.H = A * d; a.scale = 1.0f / sqrtf((float)d);
+    const int grid = nseq * A * ((L + 127) / 128);
+    const size_t lds = (size_t)4 * 128 * d * 2 + (size_t)L * 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (d == 32) {
+        attn_fwd_x3_kernel<32><<<grid, 256, lds, st>>>(a);
+    } else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            QST_HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_x3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 70000));
+            attr_set = true;
+        }
+        attn_fwd_x3_kernel<64><<<grid, 256, lds, st>>>(a);
+    }
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}

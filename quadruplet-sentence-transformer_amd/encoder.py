@@ -36,6 +36,7 @@ class HipEncoder:
         h = _lib.vp()
         _lib.check(self.lib.qst_encoder_create(self.ccfg, h), "qst_encoder_create")
         self.handle = h
+        self.handle_x3 = None         # QST_PREC_BF16X3 handle over the SAME arenas, created on first use
         self.params = torch.zeros(self.total, dtype=torch.float32, device=self.device)
         self.grads: Optional[torch.Tensor] = None
         self.exp_avg: Optional[torch.Tensor] = None
@@ -50,9 +51,10 @@ class HipEncoder:
 
     def __del__(self):
         try:
-            if getattr(self, "handle", None):
-                self.lib.qst_encoder_destroy(self.handle)
-                self.handle = None
+            for attr in ("handle", "handle_x3"):
+                if getattr(self, attr, None):
+                    self.lib.qst_encoder_destroy(getattr(self, attr))
+                    setattr(self, attr, None)
         except Exception:
             pass
 
@@ -118,14 +120,30 @@ class HipEncoder:
         return buf
 
     # ------------------------------------------------------------------ forward / backward
+    def _handle_for(self, precision: str):
+        if precision in ("bf16", 0, None):
+            return self.handle
+        if precision not in ("bf16x3", 1):
+            raise ValueError(f"unknown precision {precision!r} (bf16 | bf16x3)")
+        if self.handle_x3 is None:
+            h = _lib.vp()
+            _lib.check(self.lib.qst_encoder_create(_lib.make_config(self.cfg, 1), h), "qst_encoder_create(x3)")
+            self.handle_x3 = h
+        return self.handle_x3
+
     def forward(self, ids: torch.Tensor, mask: torch.Tensor, type_ids: Optional[torch.Tensor] = None,
-                training: bool = False, want_tokens: bool = False, saved: Optional[torch.Tensor] = None):
-        """ids/mask int64 [n, L] on this device, L % 32 == 0. Returns (emb [n,H], tok [n,L,H] or None, saved)."""
+                training: bool = False, want_tokens: bool = False, saved: Optional[torch.Tensor] = None,
+                precision: str = "bf16"):
+        """ids/mask int64 [n, L] on this device, L % 32 == 0. Returns (emb [n,H], tok [n,L,H] or None, saved).
+        precision="bf16x3" runs the fp32-class parity path (forward only)."""
         assert ids.dtype == torch.int64 and mask.dtype == torch.int64 and ids.is_cuda and ids.is_contiguous()
         n, L = ids.shape
-        if self.shadow_stale:
+        handle = self._handle_for(precision)
+        if handle is self.handle and self.shadow_stale:
             self.refresh_shadow()
-        nbytes = self.lib.qst_encoder_saved_bytes(self.handle, n, L, int(training))
+        if handle is not self.handle and training:
+            raise _lib.QstError("precision='bf16x3' is forward-only; training runs the bf16 path")
+        nbytes = self.lib.qst_encoder_saved_bytes(handle, n, L, int(training))
         if nbytes == 0:
             raise _lib.QstError(f"unsupported shape nseq={n} L={L} for this encoder (L % 32 == 0, L <= 512)")
         if saved is None:
@@ -133,7 +151,7 @@ class HipEncoder:
         emb = torch.empty(n, self.cfg.hidden_size, dtype=torch.float32, device=self.device)
         tok = torch.empty(n, L, self.cfg.hidden_size, dtype=torch.float32, device=self.device) if want_tokens else None
         _lib.check(self.lib.qst_encoder_forward(
-            self.handle, ids.data_ptr(), mask.data_ptr(), _lib.ptr(type_ids), n, L, self.params.data_ptr(),
+            handle, ids.data_ptr(), mask.data_ptr(), _lib.ptr(type_ids), n, L, self.params.data_ptr(),
             self.shadow.data_ptr(), emb.data_ptr(), _lib.ptr(tok), saved.data_ptr(), saved.numel(), int(training),
             _lib.current_stream_ptr()), "qst_encoder_forward")
         return emb, tok, saved

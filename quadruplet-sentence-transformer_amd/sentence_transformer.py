@@ -99,6 +99,9 @@ class _EncodeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, ids, mask, types, training):
         enc: HipEncoder = model._enc
+        if not training and model.inference_precision != "bf16":
+            emb, _, _ = enc.forward(ids, mask, types, training=False, precision=model.inference_precision)
+            return emb
         saved = None
         if training:
             n, L = ids.shape
@@ -168,6 +171,8 @@ class SentenceTransformer(nn.Module):
                 logger.warning("no usable tokenizer in %s (%s): falling back to SyntheticTokenizer", tok_dir, e)
         if self.tokenizer is None:
             self._synthetic_tokenizer = SyntheticTokenizer(cfg)
+        # "bf16" (throughput) or "bf16x3" (fp32-class parity path) for no-grad forwards: encode() and evaluators
+        self.inference_precision = "bf16"
         self._anchor = nn.Parameter(torch.zeros((), device=dev))      # makes the Function's output require grad
         self._build_named_parameters()
         self.best_score = -9999999
@@ -253,10 +258,14 @@ class SentenceTransformer(nn.Module):
     # ---- encode
     def encode(self, sentences: Union[str, List[str]], batch_size: int = 32, show_progress_bar: Optional[bool] = None,
                output_value: str = "sentence_embedding", convert_to_numpy: bool = True,
-               convert_to_tensor: bool = False, device: Optional[str] = None, normalize_embeddings: bool = False):
+               convert_to_tensor: bool = False, device: Optional[str] = None, normalize_embeddings: bool = False,
+               precision: Optional[str] = None):
+        """precision: None = self.inference_precision; "bf16x3" = embeddings within rtol 1e-3/atol 1e-4 of fp32."""
         if output_value != "sentence_embedding":
             raise NotImplementedError("only output_value='sentence_embedding' is on the accelerated path")
-        was_training = self.training
+        was_training, was_prec = self.training, self.inference_precision
+        if precision is not None:
+            self.inference_precision = precision
         self.eval()
         if convert_to_tensor:
             convert_to_numpy = False
@@ -281,6 +290,7 @@ class SentenceTransformer(nn.Module):
         if single:
             allemb = allemb[0]
         self.train(was_training)
+        self.inference_precision = was_prec
         return allemb
 
     # ---- fit (kwargs = training/main.py:128-148)

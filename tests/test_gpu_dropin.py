@@ -48,6 +48,15 @@ def test_encode_shapes_order_and_determinism(model):
     np.testing.assert_allclose(t.cpu().numpy(), model.encode(texts, batch_size=32), rtol=0, atol=2e-3)
 
 
+def test_encode_parity_precision(model):
+    texts = [sent(i, 3 + i % 7) for i in range(9)]
+    fast = model.encode(texts)
+    exact = model.encode(texts, precision="bf16x3")
+    assert np.abs(fast - exact).max() < 3e-3 and np.abs(fast - exact).max() > 0      # bf16 floor vs fp32-class
+    assert model.inference_precision == "bf16"
+    np.testing.assert_allclose(model.encode(texts, precision="bf16x3", batch_size=2), exact, rtol=1e-3, atol=1e-4)
+
+
 def test_four_call_pattern_equals_fused_pass(model):
     """models/quadruplet_sentence_transformer.py:42-75 runs 4 encoder calls; the fused [4B, L] pass must agree."""
     loss = GammaQuadrupletLoss(gamma=0.6, margin_pos_neg=1.0, margin_pos_part=0.5, margin_part_neg=0.5, p=2.0)

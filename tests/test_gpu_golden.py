@@ -90,3 +90,27 @@ def test_hip_encoder_matches_hf_vectors(enc_g, key, preset, B, L, wkw, store):
     else:
         norms = np.array([np.linalg.norm(ga[s.offset:s.offset + s.numel]) for s in segs])
         np.testing.assert_allclose(norms, enc_g[key + "_gradnorms"], rtol=3e-2, atol=1e-6)
+
+
+@pytest.mark.parametrize("key,preset,B,L,wkw,store", ENC_CASES + [("minilm_l128", "all-MiniLM-L6-v2", 2, 128, dict(std=0.02), "norms")])
+def test_hip_parity_precision_matches_hf_vectors(enc_g, key, preset, B, L, wkw, store):
+    """QST_PREC_BF16X3 (split-bf16 x3 MFMA, fp32 activations) against the fp32 HF reference vectors at the
+    north-star tolerance: embeddings rtol 1e-3 / atol 1e-4, loss within 1e-4."""
+    cfg = PRESETS[preset]
+    arena = synthetic_params(cfg, seed=14, **wkw)
+    ids, mask, types = synthetic_quadruplets(cfg, B, L, seed=14, ragged=True)
+    enc = HipEncoder(cfg)
+    enc.load_arena(arena)
+    n = 4 * B
+    idd = torch.from_numpy(ids).view(n, L).cuda()
+    mdd = torch.from_numpy(mask).view(n, L).cuda()
+    tdd = torch.from_numpy(types).view(n, L).cuda() if cfg.type_vocab_size else None
+    emb, tok, _ = enc.forward(idd, mdd, tdd, training=False, want_tokens=True, precision="bf16x3")
+    e4 = emb.view(4, B, -1)
+    np.testing.assert_allclose(e4.cpu().numpy(), enc_g[key + "_emb"], rtol=1e-3, atol=1e-4)
+    loss, _ = quadruplet_loss_raw(e4[0], e4[1], e4[2], e4[3], 0.6, 1.0, 0.5, 0.5, 2.0, False, 2)
+    assert abs(loss.item() - float(enc_g[key + "_loss"])) < 1e-4
+    if store == "full":      # token embeddings of the valid positions
+        ref = enc_g[key + "_tok"]
+        m = mask.reshape(n, L).astype(bool)
+        np.testing.assert_allclose(tok.cpu().numpy()[m], ref[m], rtol=1e-3, atol=2e-4)
