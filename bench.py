@@ -114,10 +114,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(1, ndev)          # rehearsal on a 1-GPU box: several ranks share the card (gloo only)
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("QST_DIST_BACKEND", "nccl")      # "nccl" = RCCL over xGMI; "gloo" only to rehearse
+        if backend == "nccl":
+            assert ndev >= world, f"{world} ranks need {world} GPUs for RCCL (found {ndev})"
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from quadruplet_sentence_transformer_amd.config import PRESETS, forward_flops_per_sequence
     from quadruplet_sentence_transformer_amd.synthetic import synthetic_params, synthetic_quadruplets
@@ -126,7 +133,7 @@ def main():
     cfg = PRESETS[args.model]
     B, L = args.batch, args.seq_len
     arena = synthetic_params(cfg, seed=14)          # same replica on every rank
-    trainer = QuadrupletTrainer(cfg, arena=arena, device=f"cuda:{local_rank}", lr=2e-5, weight_decay=0.01,
+    trainer = QuadrupletTrainer(cfg, arena=arena, device=f"cuda:{dev_index}", lr=2e-5, weight_decay=0.01,
                                 max_grad_norm=1.0, warmup_steps=10000, total_steps=1000000,
                                 process_group=None, world_size=world, overlap=not args.no_overlap)
     # a few distinct synthetic batches, resident in HBM before the timed region (rank-offset streams)
@@ -151,7 +158,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda", dtype=torch.float32)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
@@ -173,7 +180,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "quadruplets/sec (seq_len=128, all-MiniLM-L6) training step", "value": round(value, 1),
+            "metric": f"quadruplets/sec (seq_len={L}, {args.model}) training step", "value": round(value, 1),
             "unit": "quadruplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",

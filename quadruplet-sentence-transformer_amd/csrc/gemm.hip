@@ -22,7 +22,6 @@ constexpr int BM = 128, BN = 128, BK = 32, STAGES = 2;
 constexpr int TILE_BYTES = 128 * BK * 2;            // 8 KB per operand tile per stage (nt: 128 rows x 64 B; tn: 32 rows x 256 B)
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;         // 16 KB
 constexpr int RING_BYTES = STAGES * STAGE_BYTES;
-constexpr int NT_LDS_BYTES = 65536;   // 2 stages x (16 KB A + 16 KB B); the epilogue staging (34 KB) fits inside
 constexpr uint32_t kOOB = 0x7FFFFFF0u;              // voffset that always fails the buffer range check -> zero fill
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -51,142 +50,143 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 }
 
 // ---------------------------------------------------------------- NT
-// LDS image per operand tile: [128 rows][32 bf16] = 64-byte rows; 16-byte chunk c of row r sits at chunk
-// position c ^ ((r >> 2) & 3)  (conflict-free for the MFMA A/B fragment ds_read_b128).
-constexpr int NBK = 64;                              // nt K-step: 128-byte rows = whole cache lines per DMA row
-constexpr int NT_TILE = 128 * NBK * 2;               // 16 KB
-constexpr int NT_STAGES = 2;
+// 256 x 192 output tile, 512 threads = 8 waves as 4 (M) x 2 (N), 64 x 96 per wave (2 x 3 MFMA tiles).
+// Why this shape: in-kernel stamps on the 128x128 version showed every stage waiting ~850 cycles on its own DMA
+// and ~1100 cycles computing -- the CU's L2->LDS ingest (<= ~56 B/clk), not HBM and not the MFMA pipe, was the
+// limiter (the kernel ran at the same speed with zero-filled out-of-range operands). Ingest per MFMA-cycle scales
+// with (BM+BN)/(BM*BN): 1/64 at 128x128, 1/110 here. 192 divides every N of the three model families
+// (384/1152/1536, 768/2304/3072), so no tile is padded along N, and M = 32768 gives 1-4 whole tiles per CU.
+// LDS image per operand tile: [rows][64 bf16] = 128-byte rows (whole cache lines per DMA row); 16-byte chunk c of
+// row r sits at chunk position c ^ ((r >> 1) & 7)  (conflict-free for the MFMA fragment ds_read_b128).
+constexpr int NBM = 256, NBN = 192, NBK = 64;
+constexpr int NT_A_BYTES = NBM * NBK * 2;            // 32 KB
+constexpr int NT_B_BYTES = NBN * NBK * 2;            // 24 KB
+constexpr int NT_STAGE = NT_A_BYTES + NT_B_BYTES;    // 56 KB
+constexpr int NT_LDS_BYTES = 2 * NT_STAGE;           // 112 KB ring; the epilogue staging (8 x 32 x 100 floats = 100 KB) fits
+constexpr int NT_STG_LD = 100;                       // staging row stride in floats (400 B: ds_write_b128 conflict-free)
 __device__ __forceinline__ uint32_t nt_off(int row, int chunk) {
     return (uint32_t)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
 
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(QstGemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4-stage ring (64 KB); reused by the epilogue
+__global__ __launch_bounds__(512, 2) void gemm_nt_kernel(QstGemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
+    const int ntn = (g.N + NBN - 1) / NBN, ntm = (g.M + NBM - 1) / NBM;
     const int wg = xcd_remap(blockIdx.x, ntm * ntn);
-    const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
+    const int m0 = (wg / ntn) * NBM, n0 = (wg % ntn) * NBN;
 
-    const int rows_a = min(BM, g.M - m0), rows_b = min(BN, g.N - n0);
+    const int rows_a = min(NBM, g.M - m0), rows_b = min(NBN, g.N - n0);
     const bf16* Ab = (const bf16*)g.A + (size_t)m0 * g.lda;
     const bf16* Bb = (const bf16*)g.B + (size_t)n0 * g.ldb;
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(Ab, (uint32_t)rows_a * g.lda * 2u);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(Bb, (uint32_t)rows_b * g.ldb * 2u);
 
-    // DMA map: a tile is 8 wave-instructions of 1 KB (16 rows x 64 B); wave w issues instructions 2w, 2w+1.
-    // LDS position p (16-B units) = q*64 + lane -> row p/4, chunk position p%4 -> logical chunk = pos ^ swz(row)
-    // (NBK = 64: a tile is 16 wave-instructions of 8 rows x 128 B; wave w issues instructions 4w .. 4w+3)
-    uint32_t va[4], vb[4];
+    // DMA map: one wave-instruction = 1 KB = 8 rows x 128 B. A tile = 32 instructions (4 per wave), B tile = 24 (3 per
+    // wave). LDS position p (16-B units) = q*64 + lane -> row p/8, chunk position p%8 -> logical chunk = pos ^ swz(row).
+    uint32_t va[4], vb[3];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const int q = wave * 4 + t;
-        const int row = q * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        va[t] = (uint32_t)row * g.lda * 2u + chunk * 16u;
-        vb[t] = (uint32_t)row * g.ldb * 2u + chunk * 16u;
+        const int row = (wave * 4 + t) * 8 + (lane >> 3);
+        va[t] = (uint32_t)row * g.lda * 2u + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
     }
-    // issue DMA piece t (one A + one B instruction) of stage kt
-    auto issue_piece = [&](int kt, int t) {
-        char* st = smem + (kt % NT_STAGES) * (2 * NT_TILE) + wave * 4096;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int row = (wave * 3 + t) * 8 + (lane >> 3);
+        vb[t] = (uint32_t)row * g.ldb * 2u + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+    }
+    auto issue = [&](int kt) {
+        char* st = smem + (kt & 1) * NT_STAGE;
         const uint32_t ko = (uint32_t)kt * (NBK * 2);
-        dma16(ra, st + t * 1024, va[t], ko);
-        dma16(rb, st + NT_TILE + t * 1024, vb[t], ko);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dma16(ra, st + (wave * 4 + t) * 1024, va[t], ko);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) dma16(rb, st + NT_A_BYTES + (wave * 3 + t) * 1024, vb[t], ko);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][3];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = g.K / NBK;
     const int fr = lane & 31, fh = lane >> 5;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) issue_piece(0, t);
+    issue(0);
     for (int kt = 0; kt < nk; ++kt) {
         wait_vmcnt<0>();                              // stage kt has landed for this wave's DMAs
-        __builtin_amdgcn_s_barrier();                 // ... for everyone's; and everyone is done reading slot (kt-1)%2
-        const char* pa = smem + (kt % NT_STAGES) * (2 * NT_TILE);
-        const char* pb = pa + NT_TILE;
-        const bool more = kt + 1 < nk;
+        __builtin_amdgcn_s_barrier();                 // ... for everyone's; and everyone is done reading slot (kt-1)&1
+        if (kt + 1 < nk) issue(kt + 1);
+        const char* pa = smem + (kt & 1) * NT_STAGE;
+        const char* pb = pa + NT_A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 fa[2], fb[2];
+            bf16x8 fa[2], fb[3];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fa[i] = *(const bf16x8*)(pa + nt_off(wm * 64 + i * 32 + fr, ks * 2 + fh));
-                fb[i] = *(const bf16x8*)(pb + nt_off(wn * 64 + i * 32 + fr, ks * 2 + fh));
-            }
+            for (int i = 0; i < 2; ++i) fa[i] = *(const bf16x8*)(pa + nt_off(wm * 64 + i * 32 + fr, ks * 2 + fh));
+#pragma unroll
+            for (int j = 0; j < 3; ++j) fb[j] = *(const bf16x8*)(pb + nt_off(wn * 96 + j * 32 + fr, ks * 2 + fh));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 3; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // D rows = n, col = m
-            // the next stage's DMA pieces are issued in the shadow of this k-step's MFMAs (the MFMA pipe runs
-            // asynchronously; an in-order wave would otherwise pay the DMA issue cost up front)
-            if (more) issue_piece(kt + 1, ks);
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __builtin_amdgcn_s_barrier();                     // all waves done with the ring before the epilogue reuses it
 
     // ---- epilogue. The MFMA operands were swapped (D rows = n in registers, D column = m on the lane), so each
-    // lane holds 4 consecutive n per register group: stage 32 rows of the wave's 64x64 fp32 sub-tile at a time
-    // through LDS as [m][n] (row stride 68 floats: conflict-free ds_write_b128) and read it back row-wise, so
-    // bias / residual / GELU and the global stores run on 16-byte row-contiguous vectors (16 lanes = 256-B segment).
-    float* stg = (float*)smem + wave * (32 * 68);
-    const int c4 = lane & 15, rsub = lane >> 4;
-    const int n = n0 + wn * 64 + c4 * 4;
-    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-    if (g.bias && n < g.N) bias = *(const f32x4*)(g.bias + n);
+    // lane holds 4 consecutive n per register group: stage 32 rows x 96 columns of the wave's sub-tile at a time
+    // through LDS as [m][n] (conflict-free ds_write_b128) and read it back row-wise, so bias / residual / GELU and
+    // the global stores run on 16-byte row-contiguous vectors (24 lanes = one 384-byte fp32 row segment).
+    float* stg = (float*)smem + wave * (32 * NT_STG_LD);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g4 + e];
-                *(f32x4*)(stg + fr * 68 + j * 32 + 8 * g4 + 4 * fh) = v;
+                *(f32x4*)(stg + fr * NT_STG_LD + j * 32 + 8 * g4 + 4 * fh) = v;
             }
         // the same wave reads back what it wrote (wave-private region): no workgroup barrier needed
-        if (n < g.N) {
 #pragma unroll 4
-            for (int t = 0; t < 8; ++t) {
-                const int row = t * 4 + rsub;
-                const int m = m0 + wm * 64 + i * 32 + row;
-                if (m >= g.M) continue;
-                f32x4 v = *(const f32x4*)(stg + row * 68 + c4 * 4);
-                v += bias;
-                const size_t o = (size_t)m * g.ldc + n;
-                if (EPI == QST_EPI_BF16) {
+        for (int t = 0; t < 12; ++t) {
+            const int idx = t * 64 + lane;
+            const int row = idx / 24, c4 = idx % 24;
+            const int m = m0 + wm * 64 + i * 32 + row;
+            const int n = n0 + wn * 96 + c4 * 4;
+            if (m >= g.M || n >= g.N) continue;
+            f32x4 v = *(const f32x4*)(stg + row * NT_STG_LD + c4 * 4);
+            if (g.bias) v += *(const f32x4*)(g.bias + n);
+            const size_t o = (size_t)m * g.ldc + n;
+            if (EPI == QST_EPI_BF16) {
+                u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
+                *(u32x2*)((bf16*)g.C + o) = pk;
+            } else if (EPI == QST_EPI_F32_RESID || EPI == QST_EPI_F32_RESID_BF16) {
+                if (g.resid) v += *(const f32x4*)(g.resid + (size_t)m * g.ldr + n);
+                *(f32x4*)((float*)g.C + o) = v;
+                if (EPI == QST_EPI_F32_RESID_BF16) {
                     u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
-                    *(u32x2*)((bf16*)g.C + o) = pk;
-                } else if (EPI == QST_EPI_F32_RESID || EPI == QST_EPI_F32_RESID_BF16) {
-                    if (g.resid) v += *(const f32x4*)(g.resid + (size_t)m * g.ldr + n);
-                    *(f32x4*)((float*)g.C + o) = v;
-                    if (EPI == QST_EPI_F32_RESID_BF16) {
-                        u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
-                        *(u32x2*)((bf16*)g.C2 + o) = pk;
-                    }
-                } else if (EPI == QST_EPI_GELU) {
-                    u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
-                    *(u32x2*)((bf16*)g.C + o) = pk;                                   // u (pre-activation), saved for backward
-                    pk[0] = pack_bf16x2(gelu_erf(v[0]), gelu_erf(v[1])); pk[1] = pack_bf16x2(gelu_erf(v[2]), gelu_erf(v[3]));
-                    *(u32x2*)((bf16*)g.C2 + o) = pk;                                  // h
-                } else if (EPI == QST_EPI_GELU_BWD) {
-                    const u32x2 ua = *(const u32x2*)((const bf16*)g.aux + o);
-                    u32x2 pk;
-                    pk[0] = pack_bf16x2(v[0] * gelu_erf_grad(bf16lo(ua[0])), v[1] * gelu_erf_grad(bf16hi(ua[0])));
-                    pk[1] = pack_bf16x2(v[2] * gelu_erf_grad(bf16lo(ua[1])), v[3] * gelu_erf_grad(bf16hi(ua[1])));
-                    *(u32x2*)((bf16*)g.C + o) = pk;
+                    *(u32x2*)((bf16*)g.C2 + o) = pk;
                 }
+            } else if (EPI == QST_EPI_GELU) {
+                u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
+                *(u32x2*)((bf16*)g.C + o) = pk;                                   // u (pre-activation), saved for backward
+                pk[0] = pack_bf16x2(gelu_erf(v[0]), gelu_erf(v[1])); pk[1] = pack_bf16x2(gelu_erf(v[2]), gelu_erf(v[3]));
+                *(u32x2*)((bf16*)g.C2 + o) = pk;                                  // h
+            } else if (EPI == QST_EPI_GELU_BWD) {
+                const u32x2 ua = *(const u32x2*)((const bf16*)g.aux + o);
+                u32x2 pk;
+                pk[0] = pack_bf16x2(v[0] * gelu_erf_grad(bf16lo(ua[0])), v[1] * gelu_erf_grad(bf16hi(ua[0])));
+                pk[1] = pack_bf16x2(v[2] * gelu_erf_grad(bf16lo(ua[1])), v[3] * gelu_erf_grad(bf16hi(ua[1])));
+                *(u32x2*)((bf16*)g.C + o) = pk;
             }
         }
     }
@@ -337,10 +337,10 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(QstGemmArgs g) {
 
 extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
     if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
-    if (a->K % 64 != 0 || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->N % 4 != 0 || a->ldc % 4 != 0) return QST_ERR_UNSUPPORTED;
-    if ((int64_t)128 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)128 * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
-    const int ntm = (a->M + BM - 1) / BM, ntn = (a->N + BN - 1) / BN;
-    dim3 grid(ntm * ntn), block(256);
+    if (a->K % NBK != 0 || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->N % 4 != 0 || a->ldc % 4 != 0) return QST_ERR_UNSUPPORTED;
+    if ((int64_t)NBM * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)NBN * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
+    const int ntm = (a->M + NBM - 1) / NBM, ntn = (a->N + NBN - 1) / NBN;
+    dim3 grid(ntm * ntn), block(512);
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = NT_LDS_BYTES;
 #define QST_NT_CASE(E)                                                                                  \
