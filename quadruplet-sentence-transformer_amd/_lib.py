@@ -37,6 +37,11 @@ class QstGemmArgs(C.Structure):
                 ("ldb", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32), ("splits", C.c_int32)]
 
 
+class QstTnGroup(C.Structure):
+    _fields_ = [("nprob", C.c_int32), ("splits", C.c_int32), ("total_tiles", C.c_int32), ("tiles", C.c_int32 * 8),
+                ("prob", QstGemmArgs * 8)]
+
+
 # name -> (restype, argtypes). Every symbol the two public headers declare.
 SIGNATURES = {
     "qst_strerror": (C.c_char_p, [C.c_int]),
@@ -62,6 +67,7 @@ SIGNATURES = {
     # kernel level (include/qst_kernels.h)
     "qst_gemm_nt": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int, vp]),
     "qst_gemm_tn": (C.c_int, [C.POINTER(QstGemmArgs), vp]),
+    "qst_gemm_tn_group": (C.c_int, [C.POINTER(QstTnGroup), vp]),
     "qst_embed_ln_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "qst_ln_fwd": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "qst_ln_bwd_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),

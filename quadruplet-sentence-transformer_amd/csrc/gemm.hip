@@ -18,10 +18,6 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, STAGES = 2;
-constexpr int TILE_BYTES = 128 * BK * 2;            // 8 KB per operand tile per stage (nt: 128 rows x 64 B; tn: 32 rows x 256 B)
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;         // 16 KB
-constexpr int RING_BYTES = STAGES * STAGE_BYTES;
 constexpr uint32_t kOOB = 0x7FFFFFF0u;              // voffset that always fails the buffer range check -> zero fill
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -192,32 +188,50 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(QstGemmArgs g) {
     }
 }
 
-// ---------------------------------------------------------------- TN
-// LDS image per operand tile: [32 m-rows][128 bf16] = 256-byte rows; chunk c (16 B) of row r at chunk position
-// c ^ (((r&3)<<2) | ((r>>2)&3))  -- conflict-free for the 32x32x16 transposed reads (cdna guide T10, image (b)).
-__device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+// ---------------------------------------------------------------- TN (grouped wgrad)
+// One launch computes ALL weight gradients of a layer (dW_qkv, dW_o, dW_1, dW_2 and their bias gradients):
+//   C_p[N_p, K_p] += A_p[M, N_p]^T . B_p[M, K_p]        (A = dY, B = layer input X; both row-major, bf16)
+// 192 x 192 output tile per 256-thread workgroup (4 waves as 2 x 2, 96 x 96 per wave = 3 x 3 MFMA tiles: 12
+// transposed fragment reads feed 9 MFMAs per k-step, and the tile's L2->LDS ingest per MFMA-cycle is 1/96 against
+// 1/64 for 128 x 128). 192 divides every weight dimension of the three model families, so no tile is padded.
+// The reduction over M is split into 8 ranges, ONE PER XCD: every tile of every problem for range s runs on XCD s,
+// so each XCD streams its M/8 rows of dY and X from HBM once and serves all re-reads (each dY row by K/192 tiles,
+// each X row by N/192 tiles) from its own L2. Partial tiles are combined with fp32 atomics in 128-byte segments
+// (8 adders per element). Operands are consumed straight from row-major [M, *] images with ds_read_b64_tr_b16.
+// LDS image per operand stage: [32 m-rows][192 bf16] = 384-byte rows (24 chunks of 16 B); chunk c of row r sits at
+// chunk position c ^ (((r >> 1) & 1) << 2): the 4 rows x 64 B that one half-wave reads land in 16 distinct 16-B slots.
+constexpr int TT = 192, TBK = 32, TSTAGES = 3;
+constexpr int TT_TILE = TBK * TT * 2;                // 12 KB per operand per stage
+constexpr int TT_STAGE = 2 * TT_TILE;                // 24 KB
+constexpr int TT_LDS = TSTAGES * TT_STAGE;           // 72 KB -> two workgroups per CU
+__device__ __forceinline__ int tn_swz(int row) { return ((row >> 1) & 1) << 2; }
 __device__ __forceinline__ uint32_t tn_off(int row, int chunk) {
-    return (uint32_t)(row * 256 + ((chunk ^ tn_swz(row)) << 4));
+    return (uint32_t)(row * 384 + ((chunk ^ tn_swz(row)) << 4));
 }
 __device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
 }
+template <int N> __device__ __forceinline__ void wait_vmcnt_n() {
+    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+}
 
-__global__ __launch_bounds__(256, 3) void gemm_tn_kernel(QstGemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4-stage ring (64 KB)
+__global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(QstTnGroup grp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    // output C[N, K]; reduction over M split into g.splits contiguous ranges
-    const int ntn = (g.N + BM - 1) / BM, ntk = (g.K + BN - 1) / BN;
-    // Blocks b and b+8 share an XCD (round-robin dispatch). All output tiles of one M-range ("split") are placed
-    // on ONE XCD so the re-reads of that range (every A row by each k-tile, every B row by each n-tile) hit its L2
-    // instead of going back to HBM/Infinity Cache 8 times. Placement is a speed choice only.
-    const int tiles = ntn * ntk;
+    // block -> (M-range = XCD-aligned split, problem, tile)
     const int xcd = blockIdx.x & 7, jloc = blockIdx.x >> 3;
-    const int tile = jloc % tiles, split = xcd + 8 * (jloc / tiles);
-    const int n0 = (tile / ntk) * BM, k0 = (tile % ntk) * BN;
-    const int per = (((g.M + g.splits - 1) / g.splits) + BK - 1) / BK * BK;
+    int tile = jloc % grp.total_tiles;
+    const int split = xcd + 8 * (jloc / grp.total_tiles);
+    int pi = 0;
+#pragma unroll 1
+    while (pi + 1 < grp.nprob && tile >= grp.tiles[pi]) { tile -= grp.tiles[pi]; ++pi; }
+    const QstGemmArgs& g = grp.prob[pi];
+    const int ntk = (g.K + TT - 1) / TT;
+    const int n0 = (tile / ntk) * TT, k0 = (tile % ntk) * TT;
+    const int per = (((g.M + grp.splits - 1) / grp.splits) + TBK - 1) / TBK * TBK;
     const int mbeg = split * per, mend = min(g.M, mbeg + per);
     if (mbeg >= mend) return;
 
@@ -229,35 +243,34 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(QstGemmArgs g) {
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(Ab, bytes_a);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(Bb, bytes_b);
 
-    // DMA map: a tile is 8 wave-instructions of 1 KB (4 rows x 256 B); wave w issues instructions 2w, 2w+1.
-    // LDS position p = q*64 + lane -> row p/16, chunk position p%16 -> logical chunk = pos ^ swz(row).
+    // DMA map: an operand stage is 768 chunks = 12 wave-instructions of 1 KB; wave w issues 3w .. 3w+2.
+    // LDS position p = q*64 + lane -> row p/24, chunk position p%24 -> logical chunk = pos ^ swz(row).
     // Columns beyond the matrix width must not alias the next row: those lanes get an out-of-range offset (-> 0).
-    uint32_t va[2], vb[2];
+    uint32_t va[3], vb[3];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int q = wave * 2 + t;
-        const int row = q * 4 + (lane >> 4);
-        const int chunk = (lane & 15) ^ tn_swz(row);
+    for (int t = 0; t < 3; ++t) {
+        const int p = (wave * 3 + t) * 64 + lane;
+        const int row = p / 24, chunk = (p % 24) ^ tn_swz(row);
         va[t] = (n0 + chunk * 8 < g.N) ? (uint32_t)row * g.lda * 2u + chunk * 16u : kOOB;
         vb[t] = (k0 + chunk * 8 < g.K) ? (uint32_t)row * g.ldb * 2u + chunk * 16u : kOOB;
     }
     auto issue = [&](int mt) {
-        char* st = smem + (mt % STAGES) * STAGE_BYTES + wave * 2048;
-        const uint32_t soa = (uint32_t)mt * BK * g.lda * 2u, sob = (uint32_t)mt * BK * g.ldb * 2u;
+        char* st = smem + (mt % TSTAGES) * TT_STAGE + wave * 3072;
+        const uint32_t soa = (uint32_t)mt * TBK * g.lda * 2u, sob = (uint32_t)mt * TBK * g.ldb * 2u;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            dma16(ra, st + t * 1024, va[t], soa);       // kOOB + soa < 2^32: no wrap, still out of range
-            dma16(rb, st + TILE_BYTES + t * 1024, vb[t], sob);
+        for (int t = 0; t < 3; ++t) {
+            dma16(ra, st + t * 1024, va[t], soa);                  // kOOB + soa < 2^32: no wrap, still out of range
+            dma16(rb, st + TT_TILE + t * 1024, vb[t], sob);
         }
     };
 
-    f32x16 acc[2][2], bacc[2];
+    f32x16 acc[3][3], bacc[3];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) bacc[i][r] = 0.f;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     }
@@ -266,28 +279,27 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(QstGemmArgs g) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
-    const int nm = (mend - mbeg + BK - 1) / BK;
+    const int nm = (mend - mbeg + TBK - 1) / TBK;
     // transposed-read lane geometry (cdna guide T10): lane i = 4q+p of a 16-lane group supplies row q, cols 4p..4p+3
     const int li = lane & 15, q = li >> 2, p = li & 3, gsel = (lane >> 4) & 1, fh = lane >> 5;
-#pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nm) issue(s);
+    issue(0);
+    if (nm > 1) issue(1);
     for (int mt = 0; mt < nm; ++mt) {
-        wait_stage(min(STAGES - 2, nm - 1 - mt));
-        __builtin_amdgcn_s_barrier();
-        if (mt + STAGES - 1 < nm) issue(mt + STAGES - 1);
-        const char* pa = smem + (mt % STAGES) * STAGE_BYTES;
-        const char* pb = pa + TILE_BYTES;
+        if (mt + 1 < nm) wait_vmcnt_n<6>(); else wait_vmcnt_n<0>();   // stage mt landed (one younger stage may be in flight)
+        __builtin_amdgcn_s_barrier();                                  // for everyone; and slot (mt-1)%3 is free
+        if (mt + 2 < nm) issue(mt + 2);
+        const char* pa = smem + (mt % TSTAGES) * TT_STAGE;
+        const char* pb = pa + TT_TILE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[2], fb[2];
+            bf16x8 fa[3], fb[3];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < 3; ++i) {
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
                     const int row = ks * 16 + 8 * fh + 4 * jj + q;
-                    const int ca = (wm * 64 + i * 32 + gsel * 16) / 8 + (p >> 1);
-                    const int cb = (wn * 64 + i * 32 + gsel * 16) / 8 + (p >> 1);
+                    const int ca = wm * 12 + i * 4 + gsel * 2 + (p >> 1);
+                    const int cb = wn * 12 + i * 4 + gsel * 2 + (p >> 1);
                     const bf16x4 ta = lds_tr16(pa + tn_off(row, ca) + 8 * (p & 1));
                     const bf16x4 tb = lds_tr16(pb + tn_off(row, cb) + 8 * (p & 1));
 #pragma unroll
@@ -295,13 +307,13 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(QstGemmArgs g) {
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 3; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             if (do_bias) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 3; ++i)
                     bacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], ones, bacc[i], 0, 0, 0);
             }
         }
@@ -310,24 +322,24 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(QstGemmArgs g) {
     const int fr = lane & 31;
     float* C = (float*)g.C;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int k = k0 + wn * 64 + j * 32 + fr;
+    for (int j = 0; j < 3; ++j) {
+        const int k = k0 + wn * 96 + j * 32 + fr;
         if (k >= g.K) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 3; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int n = n0 + wm * 96 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (n < g.N) atomicAdd(&C[(size_t)n * g.ldc + k], acc[i][j][r]);
             }
         }
     }
     if (do_bias && fr == 0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int n = n0 + wm * 96 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (n < g.N) atomicAdd(&g.colsum[n], bacc[i][r]);
             }
     }
@@ -366,27 +378,42 @@ extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
     return QST_OK;
 }
 
-extern "C" int qst_gemm_tn(const QstGemmArgs* a, void* stream) {
-    if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
-    if (a->lda % 8 != 0 || a->ldb % 8 != 0 || a->N % 8 != 0 || a->K % 8 != 0) return QST_ERR_UNSUPPORTED;
-    if ((int64_t)a->M * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)a->M * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
-    QstGemmArgs g = *a;
-    const int tiles = ((g.N + BM - 1) / BM) * ((g.K + BN - 1) / BN);
+extern "C" int qst_gemm_tn_group(const QstTnGroup* grp_in, void* stream) {
+    if (!grp_in || grp_in->nprob <= 0 || grp_in->nprob > QST_TN_MAX_PROB) return QST_ERR_BAD_ARG;
+    QstTnGroup g = *grp_in;
+    g.total_tiles = 0;
+    for (int i = 0; i < g.nprob; ++i) {
+        const QstGemmArgs& a = g.prob[i];
+        if (!a.A || !a.B || !a.C || a.M <= 0 || a.N <= 0 || a.K <= 0 || a.M != g.prob[0].M) return QST_ERR_BAD_ARG;
+        if (a.lda % 8 != 0 || a.ldb % 8 != 0 || a.N % 8 != 0 || a.K % 8 != 0) return QST_ERR_UNSUPPORTED;
+        if ((int64_t)a.M * a.lda * 2 >= 0x7FFFFF00LL || (int64_t)a.M * a.ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
+        g.tiles[i] = ((a.N + TT - 1) / TT) * ((a.K + TT - 1) / TT);
+        g.total_tiles += g.tiles[i];
+    }
     if (g.splits <= 0) {
-        // splits = 8*q: every XCD gets q M-ranges; q ~ 64/tiles so an XCD's 32 CUs hold about two blocks each
-        // (measured at M = 32768: 36 tiles -> 16 splits 78 us vs 8 splits 102 us, 24+ splits lose to atomic traffic)
-        int q = (64 + tiles / 2) / tiles;
-        q = q < 1 ? 1 : (q > 3 ? 3 : q);
-        while (q > 1 && (int64_t)g.M < (int64_t)8 * q * 256) --q;      // keep >= 256 reduction rows per split
+        // one M-range per XCD; more ranges only while the launch cannot fill two workgroups per CU and each range
+        // keeps >= 256 reduction rows (every extra range adds one more atomic pass over the outputs)
+        int q = (64 + g.total_tiles / 2) / g.total_tiles;
+        q = q < 1 ? 1 : (q > 4 ? 4 : q);
+        while (q > 1 && (int64_t)g.prob[0].M < (int64_t)8 * q * 256) --q;
         g.splits = 8 * q;
     }
     g.splits = (g.splits + 7) / 8 * 8;
     static bool attr_set = false;
     if (!attr_set) {
-        QST_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING_BYTES));
+        QST_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TT_LDS));
         attr_set = true;
     }
-    gemm_tn_kernel<<<dim3(tiles * g.splits), dim3(256), RING_BYTES, (hipStream_t)stream>>>(g);
+    gemm_tn_group_kernel<<<dim3(g.total_tiles * g.splits), dim3(256), TT_LDS, (hipStream_t)stream>>>(g);
     QST_LAUNCH_CHECK();
     return QST_OK;
+}
+
+extern "C" int qst_gemm_tn(const QstGemmArgs* a, void* stream) {
+    if (!a) return QST_ERR_BAD_ARG;
+    QstTnGroup g{};
+    g.nprob = 1;
+    g.splits = a->splits;
+    g.prob[0] = *a;
+    return qst_gemm_tn_group(&g, stream);
 }

@@ -238,13 +238,14 @@ X3Plan plan_x3(const qst_config& c, int nseq, int L) {
     return p;
 }
 
-struct BwdPlan { size_t dxa, dxb, ds, dsb, du, dctx, dqkv, drel, lnred, total; };
+struct BwdPlan { size_t dxa, dxb, ds, dsb, dsb1, du, dctx, dqkv, drel, lnred, total; };
 BwdPlan plan_bwd(const qst_config& c, int nseq, int L) {
     BwdPlan p;
     const size_t M = (size_t)nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     p.dxa = take(M * H * 4); p.dxb = take(M * H * 4); p.ds = take(M * H * 4); p.dsb = take(M * H * 2);
+    p.dsb1 = take(M * H * 2);
     p.du = take(M * I * 2); p.dctx = take(M * H * 2); p.dqkv = take(M * 3 * H * 2);
     p.drel = (c.arch == QST_ARCH_MPNET) ? take(A * (size_t)L * L * 4) : 0;
     p.lnred = take(qst_ln_bwd_scratch_bytes((int)M, (int)H));
@@ -435,6 +436,7 @@ extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, 
     float* dxb = (float*)(ws + w.dxb);
     float* ds = (float*)(ws + w.ds);
     void* dsb = ws + w.dsb;
+    void* dsb1 = ws + w.dsb1;
     void* du = ws + w.du;
     void* dctx = ws + w.dctx;
     void* dqkv = ws + w.dqkv;
@@ -452,26 +454,37 @@ extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, 
         const LayerAct& a = p.layers[l];
         const int b = lay.layer0[l];
         const void* xin_b = (l == 0) ? (const void*)(sv + p.x0b) : (const void*)(sv + p.layers[l - 1].xb);
-        // LN2
+        // LN2 -> ds2 (fp32 for the residual path, bf16 for the GEMMs)
         QST_TRY(qst_ln_bwd(dxa, sv + a.xh2, (const float*)(sv + a.rs2), P(b + LN2_G), M, H, ds, dsb, G(b + LN2_G),
                            G(b + LN2_B), lnred, st));
-        // FFN2: wgrad [H, I] (+ bias), dgrad through GELU
-        QST_TRY(tn(dsb, H, sv + a.hact, I, G(b + W_2), I, G(b + B_2), M, H, I, st));
+        // FFN2 dgrad through GELU': du = (ds2 . W2) * gelu'(u)
         QST_TRY(nt(dsb, H, WT(b + W_2), H, du, I, nullptr, sv + a.u, nullptr, nullptr, 0, M, I, H, QST_EPI_GELU_BWD, st));
-        // FFN1
-        QST_TRY(tn(du, I, sv + a.y1b, H, G(b + W_1), H, G(b + B_1), M, I, H, st));
+        // FFN1 dgrad + residual: dy1 = du . W1 + ds2
         QST_TRY(nt(du, I, WT(b + W_1), I, dxb, H, nullptr, nullptr, nullptr, ds, H, M, H, I, QST_EPI_F32_RESID, st));
-        // LN1
-        QST_TRY(qst_ln_bwd(dxb, sv + a.xh1, (const float*)(sv + a.rs1), P(b + LN1_G), M, H, ds, dsb, G(b + LN1_G),
+        // LN1 -> ds1
+        QST_TRY(qst_ln_bwd(dxb, sv + a.xh1, (const float*)(sv + a.rs1), P(b + LN1_G), M, H, ds, dsb1, G(b + LN1_G),
                            G(b + LN1_B), lnred, st));
-        // attention output projection
-        QST_TRY(tn(dsb, H, sv + a.ctx, H, G(b + W_O), H, G(b + B_O), M, H, H, st));
-        QST_TRY(nt(dsb, H, WT(b + W_O), H, dctx, H, nullptr, nullptr, nullptr, nullptr, 0, M, H, H, QST_EPI_BF16, st));
-        // attention core
+        // attention output projection dgrad, attention core
+        QST_TRY(nt(dsb1, H, WT(b + W_O), H, dctx, H, nullptr, nullptr, nullptr, nullptr, 0, M, H, H, QST_EPI_BF16, st));
         QST_TRY(qst_attention_bwd(sv + a.qkv, sv + a.ctx, dctx, (const float*)(sv + a.lse), mask, rel, nseq, L, A, d,
                                   dqkv, drel, st));
-        // QKV projection
-        QST_TRY(tn(dqkv, 3 * H, xin_b, H, G(b + W_QKV), H, G(b + B_QKV), M, 3 * H, H, st));
+        // all four weight gradients (+ bias gradients) of the layer in one grouped launch
+        {
+            QstTnGroup grp{};
+            grp.nprob = 4;
+            grp.splits = 0;
+            auto set = [&](int i, const void* dY, int N, const void* X, int K, int wseg, int bseg) {
+                QstGemmArgs& q = grp.prob[i];
+                q.A = dY; q.B = X; q.C = G(wseg); q.colsum = G(bseg); q.M = M; q.N = N; q.K = K;
+                q.lda = N; q.ldb = K; q.ldc = K;
+            };
+            set(0, dsb, H, sv + a.hact, I, b + W_2, b + B_2);          // dW2 [H, I]
+            set(1, du, I, sv + a.y1b, H, b + W_1, b + B_1);            // dW1 [I, H]
+            set(2, dsb1, H, sv + a.ctx, H, b + W_O, b + B_O);          // dWo [H, H]
+            set(3, dqkv, 3 * H, xin_b, H, b + W_QKV, b + B_QKV);       // dWqkv [3H, H]
+            QST_TRY(qst_gemm_tn_group(&grp, st));
+        }
+        // QKV projection dgrad + residual: dx_in = dqkv . Wqkv + ds1
         QST_TRY(nt(dqkv, 3 * H, WT(b + W_QKV), 3 * H, dxa, H, nullptr, nullptr, nullptr, ds, H, M, H, 3 * H,
                    QST_EPI_F32_RESID, st));
     }

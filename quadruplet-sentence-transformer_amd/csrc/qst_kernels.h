@@ -35,6 +35,16 @@ typedef struct {
 int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream);
 /* C[N,K] (f32, atomically accumulated) += A[M,N]^T . B[M,K]; colsum[N] += sum_m A[m,:]. */
 int qst_gemm_tn(const QstGemmArgs* a, void* stream);
+/* Several such products over the same M in ONE launch (all weight gradients of a layer). */
+#define QST_TN_MAX_PROB 8
+typedef struct {
+    int32_t nprob;
+    int32_t splits;               /* reduction ranges over M, rounded up to a multiple of 8; 0 = auto */
+    int32_t total_tiles;          /* filled by the library */
+    int32_t tiles[QST_TN_MAX_PROB];
+    QstGemmArgs prob[QST_TN_MAX_PROB];
+} QstTnGroup;
+int qst_gemm_tn_group(const QstTnGroup* grp, void* stream);
 
 /* Embedding gather + LayerNorm (BertEmbeddings / MPNetEmbeddings forward).
  * pos_ids: int32 [M] position row per token. type_emb may be NULL. Outputs: y f32, y bf16, xhat bf16, rstd f32. */

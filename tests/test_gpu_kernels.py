@@ -150,6 +150,32 @@ def test_gemm_tn_wgrad(lib, M, N, K):
     torch.testing.assert_close(C.cpu(), 2 * ref, rtol=1e-3, atol=2e-3 * scale)
 
 
+def test_gemm_tn_group_matches_individual(lib):
+    """All four weight gradients of a MiniLM-shaped layer in one grouped launch."""
+    M, H, I = 1000, 384, 1536
+    g = torch.Generator().manual_seed(5)
+    shapes = [(H, I), (I, H), (H, H), (3 * H, H)]
+    grp = _lib.QstTnGroup()
+    grp.nprob, grp.splits = 4, 0
+    keep, refs, outs = [], [], []
+    for i, (N, K) in enumerate(shapes):
+        A = bfr(torch.randn(M, N, generator=g))
+        B = bfr(torch.randn(M, K, generator=g))
+        Ad, Bd = dev(A.to(torch.bfloat16)), dev(B.to(torch.bfloat16))
+        C = torch.zeros(N, K, device="cuda")
+        cs = torch.zeros(N, device="cuda")
+        q = grp.prob[i]
+        q.A, q.B, q.C, q.colsum = Ad.data_ptr(), Bd.data_ptr(), C.data_ptr(), cs.data_ptr()
+        q.M, q.N, q.K, q.lda, q.ldb, q.ldc = M, N, K, N, K, K
+        keep += [Ad, Bd]
+        refs.append((A.t() @ B, A.sum(0)))
+        outs.append((C, cs))
+    _lib.check(lib.qst_gemm_tn_group(grp, stream()))
+    for (C, cs), (rC, rcs) in zip(outs, refs):
+        torch.testing.assert_close(C.cpu(), rC, rtol=1e-3, atol=1e-3 * math.sqrt(M))
+        torch.testing.assert_close(cs.cpu(), rcs, rtol=1e-3, atol=1e-3 * math.sqrt(M))
+
+
 # ------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("M,H", [(37, 64), (128, 128), (300, 384), (129, 768), (5, 1024)])
 def test_layernorm_fwd_bwd(lib, M, H):
