@@ -54,18 +54,22 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 // (384/1152/1536, 768/2304/3072), so no tile is padded along N, and M = 32768 gives 1-4 whole tiles per CU.
 // LDS image per operand tile: [rows][64 bf16] = 128-byte rows (whole cache lines per DMA row); 16-byte chunk c of
 // row r sits at chunk position c ^ ((r >> 1) & 7)  (conflict-free for the MFMA fragment ds_read_b128).
-constexpr int NBM = 256, NBN = 192, NBK = 64;
-constexpr int NT_A_BYTES = NBM * NBK * 2;            // 32 KB
+constexpr int NBN = 192, NBK = 64;
 constexpr int NT_B_BYTES = NBN * NBK * 2;            // 24 KB
-constexpr int NT_STAGE = NT_A_BYTES + NT_B_BYTES;    // 56 KB
-constexpr int NT_LDS_BYTES = 2 * NT_STAGE;           // 112 KB ring; the epilogue staging (8 x 32 x 100 floats = 100 KB) fits
+// WAVES_M = 4: 256 x 192 tile, 8 waves, 112 KB ring (one workgroup per CU)
+// WAVES_M = 2: 128 x 192 tile, 4 waves,  80 KB ring (two workgroups per CU: their phases interleave) -- used when the
+//              256-row tiling would give fewer than two workgroups per CU (N = 384 GEMMs at M = 32768)
 constexpr int NT_STG_LD = 100;                       // staging row stride in floats (400 B: ds_write_b128 conflict-free)
 __device__ __forceinline__ uint32_t nt_off(int row, int chunk) {
     return (uint32_t)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
 
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt_kernel(QstGemmArgs g) {
+template <int EPI, int WAVES_M>
+__global__ __launch_bounds__(128 * WAVES_M, 2) void gemm_nt_kernel(QstGemmArgs g) {
+    constexpr int NBM = 64 * WAVES_M;
+    constexpr int NT_A_BYTES = NBM * NBK * 2;
+    constexpr int NT_STAGE = NT_A_BYTES + NT_B_BYTES;
+    constexpr int B_PER_WAVE = 24 / (2 * WAVES_M);       // B tile = 24 DMA instructions
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,15 +86,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(QstGemmArgs g) {
 
     // DMA map: one wave-instruction = 1 KB = 8 rows x 128 B. A tile = 32 instructions (4 per wave), B tile = 24 (3 per
     // wave). LDS position p (16-B units) = q*64 + lane -> row p/8, chunk position p%8 -> logical chunk = pos ^ swz(row).
-    uint32_t va[4], vb[3];
+    uint32_t va[4], vb[B_PER_WAVE];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int row = (wave * 4 + t) * 8 + (lane >> 3);
         va[t] = (uint32_t)row * g.lda * 2u + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
     }
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int row = (wave * 3 + t) * 8 + (lane >> 3);
+    for (int t = 0; t < B_PER_WAVE; ++t) {
+        const int row = (wave * B_PER_WAVE + t) * 8 + (lane >> 3);
         vb[t] = (uint32_t)row * g.ldb * 2u + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
     }
     auto issue = [&](int kt) {
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(QstGemmArgs g) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) dma16(ra, st + (wave * 4 + t) * 1024, va[t], ko);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) dma16(rb, st + NT_A_BYTES + (wave * 3 + t) * 1024, vb[t], ko);
+        for (int t = 0; t < B_PER_WAVE; ++t) dma16(rb, st + NT_A_BYTES + (wave * B_PER_WAVE + t) * 1024, vb[t], ko);
     };
 
     f32x16 acc[2][3];
@@ -347,24 +351,31 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(QstTnGroup grp) {
 
 }  // namespace
 
+template <int EPI, int WAVES_M>
+static int launch_nt(const QstGemmArgs* a, hipStream_t st) {
+    constexpr int NBM = 64 * WAVES_M;
+    constexpr int lds = 2 * (NBM * NBK * 2 + NT_B_BYTES);       // ring; the epilogue staging (WAVES x 12.8 KB) fits inside
+    static bool attr_set = false;
+    if (!attr_set) {
+        QST_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, WAVES_M>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int ntm = (a->M + NBM - 1) / NBM, ntn = (a->N + NBN - 1) / NBN;
+    gemm_nt_kernel<EPI, WAVES_M><<<dim3(ntm * ntn), dim3(128 * WAVES_M), lds, st>>>(*a);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
 extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
     if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
     if (a->K % NBK != 0 || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->N % 4 != 0 || a->ldc % 4 != 0) return QST_ERR_UNSUPPORTED;
-    if ((int64_t)NBM * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)NBN * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
-    const int ntm = (a->M + NBM - 1) / NBM, ntn = (a->N + NBN - 1) / NBN;
-    dim3 grid(ntm * ntn), block(512);
+    if ((int64_t)256 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)NBN * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = NT_LDS_BYTES;
-#define QST_NT_CASE(E)                                                                                  \
-    case E: {                                                                                           \
-        static bool attr_set = false;                                                                   \
-        if (!attr_set) {                                                                                \
-            QST_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<E>,                           \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
-            attr_set = true;                                                                            \
-        }                                                                                               \
-        gemm_nt_kernel<E><<<grid, block, lds, st>>>(*a);                                                \
-    } break;
+    // a->splits (unused by nt otherwise) can force the tile height: 1 = 128 rows, 2 = 256 rows
+    const int64_t blocks256 = (int64_t)((a->M + 255) / 256) * ((a->N + NBN - 1) / NBN);
+    const bool small = a->splits == 1 || (a->splits != 2 && blocks256 < 512);
+#define QST_NT_CASE(E) case E: return small ? launch_nt<E, 2>(a, st) : launch_nt<E, 4>(a, st);
     switch (epi) {
         QST_NT_CASE(QST_EPI_BF16)
         QST_NT_CASE(QST_EPI_F32_RESID)
@@ -374,8 +385,6 @@ extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
         default: return QST_ERR_BAD_ARG;
     }
 #undef QST_NT_CASE
-    QST_LAUNCH_CHECK();
-    return QST_OK;
 }
 
 extern "C" int qst_gemm_tn_group(const QstTnGroup* grp_in, void* stream) {

@@ -45,9 +45,14 @@ def main():
         g = _lib.QstGemmArgs()
         g.A, g.B, g.C, g.C2, g.aux, g.bias, g.resid = A.data_ptr(), B.data_ptr(), C.data_ptr(), C2.data_ptr(), aux.data_ptr(), bias.data_ptr(), resid.data_ptr()
         g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.ldr = M, N, K, K, K, N, N
+        res = []
+        for force in (1, 2):
+            g.splits = force
+            res.append(timeit(lambda: _lib.check(lib.qst_gemm_nt(g, epi, st))))
+        g.splits = 0
         us = timeit(lambda: _lib.check(lib.qst_gemm_nt(g, epi, st)))
         tot += us
-        print(f"nt {name:31s} {us:8.1f} {2.0 * M * N * K / us / 1e6:8.1f}")
+        print(f"nt {name:31s} {us:8.1f} {2.0 * M * N * K / us / 1e6:8.1f}   (128-row tile {res[0]:.1f} us, 256-row tile {res[1]:.1f} us)")
     for name, N, K in [("dW2 [H,I]", H, I), ("dW1 [I,H]", I, H), ("dWo [H,H]", H, H), ("dWqkv [3H,H]", 3 * H, H)]:
         A = torch.randn(M, N, device=dev).to(bf)
         B = torch.randn(M, K, device=dev).to(bf)
