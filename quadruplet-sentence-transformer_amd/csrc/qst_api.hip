@@ -105,6 +105,8 @@ struct qst_encoder {
     Layout lay;
     uint8_t* chunk_decay = nullptr;   // device: decay flag per 256-element chunk
     int32_t* rel_lut = nullptr;       // device: MPNet bucket of (j - i), index (j - i) + 511
+    int64_t* shadow_tab = nullptr;    // device: one row per GEMM weight for qst_shadow_all
+    int shadow_nseg = 0, shadow_blocks = 0;
 };
 
 extern "C" int64_t qst_arena_elems(const qst_config* cfg) { return cfg_ok(cfg) ? build_layout(cfg).total : QST_ERR_BAD_ARG; }
@@ -143,6 +145,7 @@ extern "C" int qst_rel_bucket_host(int rel /* j - i */, int num_buckets, int max
     return ret + large;
 }
 
+extern "C" void qst_encoder_destroy(qst_encoder* e);
 extern "C" int qst_encoder_create(const qst_config* cfg, qst_encoder** out) {
     if (!cfg_ok(cfg) || !out) return QST_ERR_BAD_ARG;
     const int d = cfg->hidden_size / cfg->num_heads;
@@ -172,6 +175,23 @@ extern "C" int qst_encoder_create(const qst_config* cfg, qst_encoder** out) {
             hipFree(e->chunk_decay); if (e->rel_lut) hipFree(e->rel_lut); delete e; return QST_ERR_HIP;
         }
     }
+    {
+        std::vector<int64_t> tab;
+        int64_t blocks = 0;
+        for (const Seg& s : e->lay.segs) {
+            if (!s.gemm) continue;
+            tab.insert(tab.end(), {s.off, (int64_t)s.rows, (int64_t)s.cols, s.shadow_off,
+                                   s.shadow_off + qst_align_up(s.numel, kAlign), blocks});
+            blocks += (int64_t)((s.cols + 31) / 32) * ((s.rows + 31) / 32);
+        }
+        e->shadow_nseg = (int)(tab.size() / 6);
+        e->shadow_blocks = (int)blocks;
+        if (hipMalloc((void**)&e->shadow_tab, tab.size() * sizeof(int64_t)) != hipSuccess ||
+            hipMemcpy(e->shadow_tab, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) {
+            qst_encoder_destroy(e);
+            return QST_ERR_HIP;
+        }
+    }
     *out = e;
     return QST_OK;
 }
@@ -180,6 +200,7 @@ extern "C" void qst_encoder_destroy(qst_encoder* e) {
     if (!e) return;
     if (e->chunk_decay) hipFree(e->chunk_decay);
     if (e->rel_lut) hipFree(e->rel_lut);
+    if (e->shadow_tab) hipFree(e->shadow_tab);
     delete e;
 }
 
@@ -300,13 +321,7 @@ extern "C" size_t qst_encoder_bwd_workspace_bytes(const qst_encoder* e, int nseq
 
 extern "C" int qst_refresh_shadow(const qst_encoder* e, const float* params, void* shadow, void* stream) {
     if (!e || !params || !shadow) return QST_ERR_BAD_ARG;
-    bf16* sh = (bf16*)shadow;
-    for (const Seg& s : e->lay.segs) {
-        if (!s.gemm) continue;
-        QST_TRY(qst_shadow_matrix(params + s.off, s.rows, s.cols, sh + s.shadow_off,
-                                  sh + s.shadow_off + qst_align_up(s.numel, kAlign), stream));
-    }
-    return QST_OK;
+    return qst_shadow_all(params, shadow, e->shadow_tab, e->shadow_nseg, e->shadow_blocks, stream);
 }
 
 // Parity-precision forward (QST_PREC_BF16X3): same operator sequence as below on fp32 activations and the fp32

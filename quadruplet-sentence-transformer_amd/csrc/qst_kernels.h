@@ -93,6 +93,9 @@ int qst_gemm_nt_x3(const QstGemmArgs* a, int epi, void* stream);
 int qst_attention_fwd_x3(const float* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A, int d,
                          float* ctx, void* stream);
 
+/* All GEMM weights of the arena in one launch; table_dev = int64 [nseg][6] {src off, rows, cols, dst off, dstT off,
+ * first block} (built by qst_encoder_create). */
+int qst_shadow_all(const float* params, void* shadow, const int64_t* table_dev, int nseg, int nblocks, void* stream);
 /* bf16 shadow: dst[i] = bf16(src[i]) and dstT = transpose for a [rows, cols] matrix. */
 int qst_shadow_matrix(const float* src, int rows, int cols, void* dst_bf16, void* dstT_bf16, void* stream);
 

@@ -223,12 +223,14 @@ __global__ __launch_bounds__(256) void embed_bwd_word_type_kernel(const float* d
 //  first one in registers, atomics only for the irregular rest
 __global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const float* ds, const int32_t* pos_ids, int nseq, int L,
                                                             int H, float* dpos) {
+    // block = (position t, 64-column slab, sequence slice); 4 sequence slices per block run as 4 waves
     const int t = blockIdx.x;
-    const int c = blockIdx.y * 256 + threadIdx.x;
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+    const int slice = threadIdx.x >> 6, nslice = 4 * gridDim.z, sl = blockIdx.z * 4 + slice;
     if (c >= H) return;
     const int p0 = pos_ids[t];
     float acc = 0.f;
-    for (int s = 0; s < nseq; ++s) {
+    for (int s = sl; s < nseq; s += nslice) {
         const int row = s * L + t;
         const int p = pos_ids[row];
         const float v = ds[(size_t)row * H + c];
@@ -380,6 +382,39 @@ __global__ __launch_bounds__(256) void shadow_kernel(const float* src, int rows,
         }
 }
 
+// all GEMM weights in ONE launch: table entry = {src offset, rows, cols, dst offset, dstT offset, first block}
+__global__ __launch_bounds__(256) void shadow_all_kernel(const float* params, bf16* shadow, const int64_t* tab, int nseg) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) {                                   // last segment whose first block <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid * 6 + 5] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* e = tab + lo * 6;
+    const float* src = params + e[0];
+    const int rows = (int)e[1], cols = (int)e[2];
+    bf16* dst = shadow + e[3];
+    bf16* dstT = shadow + e[4];
+    const int b = blockIdx.x - (int)e[5];
+    const int tiles_x = (cols + 31) / 32;
+    const int c0 = (b % tiles_x) * 32, r0 = (b / tiles_x) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        float v = 0.f;
+        if (r < rows && c < cols) {
+            v = src[(size_t)r * cols + c];
+            dst[(size_t)r * cols + c] = f2bf(v);
+        }
+        tile[ty + 8 * k][tx] = v;
+    }
+    __syncthreads();
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (r < rows && c < cols) dstT[(size_t)c * rows + r] = f2bf(tile[tx][ty + 8 * k]);
+    }
+}
+
 #define QST_VPL_DISPATCH(H, CALL)                           \
     do {                                                    \
         const int _vpl = ((H) / 2 + 63) / 64;               \
@@ -454,7 +489,7 @@ extern "C" int qst_embed_bwd(const float* ds, const int64_t* ids, const int64_t*
     embed_bwd_word_type_kernel<<<(M + 63) / 64, 256, (size_t)2 * H * sizeof(float), st>>>(ds, ids, type_ids, M, H,
                                                                                            num_types, dword, dtype_);
     QST_LAUNCH_CHECK();
-    embed_bwd_pos_kernel<<<dim3(L, (H + 255) / 256), 256, 0, st>>>(ds, pos_ids, nseq, L, H, dpos);
+    embed_bwd_pos_kernel<<<dim3(L, (H + 63) / 64, nseq >= 64 ? 4 : 1), 256, 0, st>>>(ds, pos_ids, nseq, L, H, dpos);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
@@ -496,6 +531,13 @@ extern "C" int qst_rel_bias_bwd(const float* drel, const int32_t* lut, int bucke
                                 void* stream) {
     if (!drel || !lut || !dtable || A <= 0 || L <= 0 || L > 512 || buckets <= 0) return QST_ERR_BAD_ARG;
     rel_bias_bwd_kernel<<<buckets * A, 256, 0, (hipStream_t)stream>>>(drel, lut, buckets, A, L, dtable);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+extern "C" int qst_shadow_all(const float* params, void* shadow, const int64_t* table_dev, int nseg, int nblocks, void* stream) {
+    if (!params || !shadow || !table_dev || nseg <= 0 || nblocks <= 0) return QST_ERR_BAD_ARG;
+    shadow_all_kernel<<<nblocks, 256, 0, (hipStream_t)stream>>>(params, (bf16*)shadow, table_dev, nseg);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
