@@ -49,17 +49,31 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& acc, int s) {
 }
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// stage `rows` x D bf16 (global row stride ld elements) into an LDS image
-template <int D, bool TR>
-__device__ __forceinline__ void stage(char* img, const bf16* g, int ld, int rows, int tid) {
-    constexpr int CPR = D / 8;
-    for (int idx = tid; idx < rows * CPR; idx += 256) {
-        const int row = idx / CPR, c = idx % CPR;
-        const u32x4 v = *(const u32x4*)(g + (size_t)row * ld + c * 8);
-        const uint32_t off = TR ? tr_off<D>(row, c * 16) : rr_off<D>(row, c);
-        *(u32x4*)(img + off) = v;
+// Stage a 128-row chunk (rows valid) of up to three [rows, D] bf16 tensors into LDS images. ALL global loads of the
+// chunk are issued before the first LDS store (one round trip instead of one per image: the per-image version spent
+// two thirds of the wave's life waiting), and a tensor needed both row-wise and transposed is loaded once.
+template <int D>
+struct Stager {
+    static constexpr int CPR = D / 8;                 // 16-byte chunks per row
+    static constexpr int PER = 128 * CPR / 256;       // chunks per thread per tensor (2 for d=32, 4 for d=64)
+    u32x4 v[3][PER];
+    __device__ __forceinline__ void load(int t, const bf16* g, int ld, int rows, int tid) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int idx = tid + 256 * k, row = idx / CPR, c = idx % CPR;
+            const u32x4 z = {0, 0, 0, 0};
+            v[t][k] = row < rows ? *(const u32x4*)(g + (size_t)row * ld + c * 8) : z;
+        }
     }
-}
+    template <bool TR>
+    __device__ __forceinline__ void store(int t, char* img, int tid) const {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int idx = tid + 256 * k, row = idx / CPR, c = idx % CPR;
+            *(u32x4*)(img + (TR ? tr_off<D>(row, c * 16) : rr_off<D>(row, c))) = v[t][k];
+        }
+    }
+};
 
 struct AttnArgs {
     const bf16* qkv; const bf16* ctx; const bf16* dctx; const float* lse_in; const int64_t* mask;
@@ -102,8 +116,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     for (int c = 0; c < nchunk; ++c) {
         const int rows = min(128, a.L - c * 128);
         __syncthreads();
-        stage<D, false>(kimg, base + (size_t)c * 128 * ld + a.H, ld, rows, tid);
-        stage<D, true>(vimg, base + (size_t)c * 128 * ld + 2 * a.H, ld, rows, tid);
+        {
+            Stager<D> sg;
+            sg.load(0, base + (size_t)c * 128 * ld + a.H, ld, rows, tid);
+            sg.load(1, base + (size_t)c * 128 * ld + 2 * a.H, ld, rows, tid);
+            sg.template store<false>(0, kimg, tid);
+            sg.template store<true>(1, vimg, tid);
+        }
         __syncthreads();
         if (!active) continue;
         for (int jt = 0; jt < rows / 32; ++jt) {
@@ -126,13 +145,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 s[r] = v;
                 mx = fmaxf(mx, v);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = fmaxf(mx, swap32(mx));
             const float mn = fmaxf(m, mx);
             const float alpha = __expf(m - mn);
             float ps = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - mn); ps += s[r]; }
-            ps += __shfl_xor(ps, 32, 64);
+            ps += swap32(ps);
             l = l * alpha + ps;
             m = mn;
 #pragma unroll
@@ -198,7 +217,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) delta += (float)dof[s][e] * (float)of[e];
         }
-        delta += __shfl_xor(delta, 32, 64);
+        delta += swap32(delta);
         lse = a.lse_in[((size_t)seq * a.A + head) * a.L + qi];
     }
     f32x16 dq[DB];
@@ -211,9 +230,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     for (int c = 0; c < nchunk; ++c) {
         const int rows = min(128, a.L - c * 128);
         __syncthreads();
-        stage<D, false>(kimg, base + (size_t)c * 128 * ld + a.H, ld, rows, tid);
-        stage<D, true>(ktr, base + (size_t)c * 128 * ld + a.H, ld, rows, tid);
-        stage<D, false>(vimg, base + (size_t)c * 128 * ld + 2 * a.H, ld, rows, tid);
+        {
+            Stager<D> sg;
+            sg.load(0, base + (size_t)c * 128 * ld + a.H, ld, rows, tid);
+            sg.load(1, base + (size_t)c * 128 * ld + 2 * a.H, ld, rows, tid);
+            sg.template store<false>(0, kimg, tid);
+            sg.template store<true>(0, ktr, tid);
+            sg.template store<false>(1, vimg, tid);
+        }
         __syncthreads();
         if (!active) continue;
         for (int jt = 0; jt < rows / 32; ++jt) {
@@ -303,10 +327,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     for (int c = 0; c < nchunk; ++c) {
         const int rows = min(128, a.L - c * 128);
         __syncthreads();
-        stage<D, false>(qimg, base + (size_t)c * 128 * ld, ld, rows, tid);
-        stage<D, true>(qtr, base + (size_t)c * 128 * ld, ld, rows, tid);
-        stage<D, false>(dimg, dbase + (size_t)c * 128 * a.H, a.H, rows, tid);
-        stage<D, true>(dtr, dbase + (size_t)c * 128 * a.H, a.H, rows, tid);
+        Stager<D> sg;
+        sg.load(0, base + (size_t)c * 128 * ld, ld, rows, tid);
+        sg.load(1, dbase + (size_t)c * 128 * a.H, a.H, rows, tid);
         {   // delta_i = sum_dd dO[i][dd] * O[i][dd]; two threads per row
             const int row = tid >> 1, half = tid & 1;
             float dsum = 0.f;
@@ -326,6 +349,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
                 lse_s[row] = a.lse_in[((size_t)seq * a.A + head) * a.L + c * 128 + row];
             }
         }
+        sg.template store<false>(0, qimg, tid);
+        sg.template store<true>(0, qtr, tid);
+        sg.template store<false>(1, dimg, tid);
+        sg.template store<true>(1, dtr, tid);
         __syncthreads();
         if (!active) continue;
         for (int it = 0; it < rows / 32; ++it) {

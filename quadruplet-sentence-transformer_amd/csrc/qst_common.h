@@ -62,7 +62,10 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 // exchange with the lane 32 away (the other half of an MFMA 32x32 accumulator column)
 __device__ __forceinline__ float swap32(float v) {
-    return __shfl_xor(v, 32, 64);
+    // v_permlane32_swap: lanes 32-63 of the first operand trade places with lanes 0-31 of the second (VALU, no LDS)
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
 }
 
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
