@@ -143,9 +143,37 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void gemm_nt_kernel(QstGemmArgs g
     // lane holds 4 consecutive n per register group: stage 32 rows x 96 columns of the wave's sub-tile at a time
     // through LDS as [m][n] (conflict-free ds_write_b128) and read it back row-wise, so bias / residual / GELU and
     // the global stores run on 16-byte row-contiguous vectors (24 lanes = one 384-byte fp32 row segment).
+    // All global LOADS of a pass (residual / saved pre-activation) are issued before the pass touches LDS and before
+    // any store: with loads and stores interleaved per row the compiler must keep them in order (C may alias resid),
+    // and in-kernel stamps showed the epilogue then costing 2-4x the whole K loop in exposed load latency.
     float* stg = (float*)smem + wave * (32 * NT_STG_LD);
+    float* bias_s = (float*)smem + (2 * WAVES_M) * (32 * NT_STG_LD) + wave * 96;     // this wave's 96 bias values
+    if (g.bias) {
+        for (int c = lane; c < 96; c += 64) {
+            const int n = n0 + wn * 96 + c;
+            bias_s[c] = n < g.N ? g.bias[n] : 0.f;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+        f32x4 rv[12];
+        u32x2 av[12];
+#pragma unroll
+        for (int t = 0; t < 12; ++t) {
+            const int idx = t * 64 + lane;
+            const int row = idx / 24, c4 = idx % 24;
+            const int m = m0 + wm * 64 + i * 32 + row;
+            const int n = n0 + wn * 96 + c4 * 4;
+            const bool ok = m < g.M && n < g.N;
+            if (EPI == QST_EPI_F32_RESID || EPI == QST_EPI_F32_RESID_BF16) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                rv[t] = (ok && g.resid) ? *(const f32x4*)(g.resid + (size_t)m * g.ldr + n) : z;
+            }
+            if (EPI == QST_EPI_GELU_BWD) {
+                const u32x2 z = {0u, 0u};
+                av[t] = ok ? *(const u32x2*)((const bf16*)g.aux + (size_t)m * g.ldc + n) : z;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -156,7 +184,7 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void gemm_nt_kernel(QstGemmArgs g
                 *(f32x4*)(stg + fr * NT_STG_LD + j * 32 + 8 * g4 + 4 * fh) = v;
             }
         // the same wave reads back what it wrote (wave-private region): no workgroup barrier needed
-#pragma unroll 4
+#pragma unroll
         for (int t = 0; t < 12; ++t) {
             const int idx = t * 64 + lane;
             const int row = idx / 24, c4 = idx % 24;
@@ -164,28 +192,37 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void gemm_nt_kernel(QstGemmArgs g
             const int n = n0 + wn * 96 + c4 * 4;
             if (m >= g.M || n >= g.N) continue;
             f32x4 v = *(const f32x4*)(stg + row * NT_STG_LD + c4 * 4);
-            if (g.bias) v += *(const f32x4*)(g.bias + n);
+            if (g.bias) v += *(const f32x4*)(bias_s + c4 * 4);
             const size_t o = (size_t)m * g.ldc + n;
             if (EPI == QST_EPI_BF16) {
                 u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
                 *(u32x2*)((bf16*)g.C + o) = pk;
             } else if (EPI == QST_EPI_F32_RESID || EPI == QST_EPI_F32_RESID_BF16) {
-                if (g.resid) v += *(const f32x4*)(g.resid + (size_t)m * g.ldr + n);
+                v += rv[t];
                 *(f32x4*)((float*)g.C + o) = v;
                 if (EPI == QST_EPI_F32_RESID_BF16) {
                     u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
                     *(u32x2*)((bf16*)g.C2 + o) = pk;
                 }
             } else if (EPI == QST_EPI_GELU) {
-                u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
-                *(u32x2*)((bf16*)g.C + o) = pk;                                   // u (pre-activation), saved for backward
-                pk[0] = pack_bf16x2(gelu_erf(v[0]), gelu_erf(v[1])); pk[1] = pack_bf16x2(gelu_erf(v[2]), gelu_erf(v[3]));
+                // h = gelu(u) feeds FFN2; gelu'(u) (not u) is what backward needs: both share one exp and one rcp,
+                // so the dgrad epilogue is a single multiply instead of a second erf evaluation
+                float hh[4], gg[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float cdf, pdf;
+                    gelu_parts(v[e], cdf, pdf);
+                    hh[e] = v[e] * cdf;
+                    gg[e] = cdf + v[e] * pdf;
+                }
+                u32x2 pk; pk[0] = pack_bf16x2(gg[0], gg[1]); pk[1] = pack_bf16x2(gg[2], gg[3]);
+                *(u32x2*)((bf16*)g.C + o) = pk;                                   // gelu'(u), saved for backward
+                pk[0] = pack_bf16x2(hh[0], hh[1]); pk[1] = pack_bf16x2(hh[2], hh[3]);
                 *(u32x2*)((bf16*)g.C2 + o) = pk;                                  // h
             } else if (EPI == QST_EPI_GELU_BWD) {
-                const u32x2 ua = *(const u32x2*)((const bf16*)g.aux + o);
                 u32x2 pk;
-                pk[0] = pack_bf16x2(v[0] * gelu_erf_grad(bf16lo(ua[0])), v[1] * gelu_erf_grad(bf16hi(ua[0])));
-                pk[1] = pack_bf16x2(v[2] * gelu_erf_grad(bf16lo(ua[1])), v[3] * gelu_erf_grad(bf16hi(ua[1])));
+                pk[0] = pack_bf16x2(v[0] * bf16lo(av[t][0]), v[1] * bf16hi(av[t][0]));
+                pk[1] = pack_bf16x2(v[2] * bf16lo(av[t][1]), v[3] * bf16hi(av[t][1]));
                 *(u32x2*)((bf16*)g.C + o) = pk;
             }
         }
@@ -374,7 +411,8 @@ extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     // a->splits (unused by nt otherwise) can force the tile height: 1 = 128 rows, 2 = 256 rows
     const int64_t blocks256 = (int64_t)((a->M + 255) / 256) * ((a->N + NBN - 1) / NBN);
-    const bool small = a->splits == 1 || (a->splits != 2 && blocks256 < 512);
+    const int force = a->splits & 3;
+    const bool small = force == 1 || (force != 2 && blocks256 < 512);
 #define QST_NT_CASE(E) case E: return small ? launch_nt<E, 2>(a, st) : launch_nt<E, 4>(a, st);
     switch (epi) {
         QST_NT_CASE(QST_EPI_BF16)

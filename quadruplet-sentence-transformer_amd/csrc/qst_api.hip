@@ -472,7 +472,7 @@ extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, 
         // LN2 -> ds2 (fp32 for the residual path, bf16 for the GEMMs)
         QST_TRY(qst_ln_bwd(dxa, sv + a.xh2, (const float*)(sv + a.rs2), P(b + LN2_G), M, H, ds, dsb, G(b + LN2_G),
                            G(b + LN2_B), lnred, st));
-        // FFN2 dgrad through GELU': du = (ds2 . W2) * gelu'(u)
+        // FFN2 dgrad through GELU: du = (ds2 . W2) * gelu'(u)   (a.u holds gelu'(u), written by the forward epilogue)
         QST_TRY(nt(dsb, H, WT(b + W_2), H, du, I, nullptr, sv + a.u, nullptr, nullptr, 0, M, I, H, QST_EPI_GELU_BWD, st));
         // FFN1 dgrad + residual: dy1 = du . W1 + ds2
         QST_TRY(nt(du, I, WT(b + W_1), I, dxb, H, nullptr, nullptr, nullptr, ds, H, M, H, I, QST_EPI_F32_RESID, st));

@@ -12,8 +12,8 @@ extern "C" {
 enum {
     QST_EPI_BF16 = 0,            // C(bf16) = acc + bias
     QST_EPI_F32_RESID = 1,       // C(f32)  = acc + bias + resid
-    QST_EPI_GELU = 2,            // C(bf16) = u = acc + bias ; C2(bf16) = gelu(u)
-    QST_EPI_GELU_BWD = 3,        // C(bf16) = (acc) * gelu'(aux)
+    QST_EPI_GELU = 2,            // u = acc + bias ; C(bf16) = gelu'(u) (saved for backward) ; C2(bf16) = gelu(u)
+    QST_EPI_GELU_BWD = 3,        // C(bf16) = acc * aux   (aux = the gelu'(u) saved by QST_EPI_GELU)
     QST_EPI_F32_RESID_BF16 = 4   // C(f32) = acc + bias + resid ; C2(bf16) = same
 };
 

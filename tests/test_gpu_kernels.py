@@ -117,17 +117,17 @@ def test_gemm_nt_epilogues(lib, M, N, K):
     _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=Cf, bias=dev(bias), resid=dev(resid), M=M, N=N, K=K, lda=K, ldb=K,
                                          ldc=N, ldr=N), 1, stream()))
     torch.testing.assert_close(Cf.cpu(), ref + resid, rtol=1e-4, atol=1e-3)
-    # EPI_GELU
+    # EPI_GELU: C = gelu'(u) (saved for backward), C2 = gelu(u)
     C2 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=Cb, C2=C2, bias=dev(bias), M=M, N=N, K=K, lda=K, ldb=K, ldc=N), 2, stream()))
-    torch.testing.assert_close(Cb.float().cpu(), ref, rtol=8e-3, atol=2e-2)
-    torch.testing.assert_close(C2.float().cpu(), torch.nn.functional.gelu(ref), rtol=8e-3, atol=2e-2)
-    # EPI_GELU_BWD: C = acc * gelu'(aux)
-    u = bfr(torch.randn(M, N, generator=g))
-    ur = u.clone().requires_grad_(True)
+    ur = ref.clone().requires_grad_(True)
     torch.nn.functional.gelu(ur).sum().backward()
-    _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=Cb, aux=dev(u.to(torch.bfloat16)), M=M, N=N, K=K, lda=K, ldb=K, ldc=N), 3, stream()))
-    torch.testing.assert_close(Cb.float().cpu(), (A @ B.t()) * ur.grad, rtol=8e-3, atol=2e-2)
+    torch.testing.assert_close(Cb.float().cpu(), ur.grad, rtol=8e-3, atol=2e-2)
+    torch.testing.assert_close(C2.float().cpu(), torch.nn.functional.gelu(ref), rtol=8e-3, atol=2e-2)
+    # EPI_GELU_BWD: C = acc * aux
+    gp = bfr(torch.rand(M, N, generator=g) * 1.2 - 0.1)
+    _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=Cb, aux=dev(gp.to(torch.bfloat16)), M=M, N=N, K=K, lda=K, ldb=K, ldc=N), 3, stream()))
+    torch.testing.assert_close(Cb.float().cpu(), (A @ B.t()) * gp, rtol=8e-3, atol=2e-2)
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 128, 128), (512, 384, 384), (1000, 1152, 384), (300, 64, 256), (4096, 384, 1536),
