@@ -154,76 +154,121 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void gemm_nt_kernel(QstGemmArgs g
             bias_s[c] = n < g.N ? g.bias[n] : 0.f;
         }
     }
+    constexpr bool kF32Out = (EPI == QST_EPI_F32_RESID || EPI == QST_EPI_F32_RESID_BF16);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        f32x4 rv[12];
-        u32x2 av[12];
+        if (kF32Out) {
+            // fp32 outputs: 4 columns (16 B) per lane, 24 lanes per row, 12 items per lane
+            f32x4 rv[12];
 #pragma unroll
-        for (int t = 0; t < 12; ++t) {
-            const int idx = t * 64 + lane;
-            const int row = idx / 24, c4 = idx % 24;
-            const int m = m0 + wm * 64 + i * 32 + row;
-            const int n = n0 + wn * 96 + c4 * 4;
-            const bool ok = m < g.M && n < g.N;
-            if (EPI == QST_EPI_F32_RESID || EPI == QST_EPI_F32_RESID_BF16) {
+            for (int t = 0; t < 12; ++t) {
+                const int idx = t * 64 + lane;
+                const int row = idx / 24, c4 = idx % 24;
+                const int m = m0 + wm * 64 + i * 32 + row;
+                const int n = n0 + wn * 96 + c4 * 4;
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                rv[t] = (ok && g.resid) ? *(const f32x4*)(g.resid + (size_t)m * g.ldr + n) : z;
+                rv[t] = (m < g.M && n < g.N && g.resid) ? *(const f32x4*)(g.resid + (size_t)m * g.ldr + n) : z;
             }
-            if (EPI == QST_EPI_GELU_BWD) {
-                const u32x2 z = {0u, 0u};
-                av[t] = ok ? *(const u32x2*)((const bf16*)g.aux + (size_t)m * g.ldc + n) : z;
-            }
-        }
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+            for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                f32x4 v;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g4 + e];
-                *(f32x4*)(stg + fr * NT_STG_LD + j * 32 + 8 * g4 + 4 * fh) = v;
-            }
-        // the same wave reads back what it wrote (wave-private region): no workgroup barrier needed
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g4 + e];
+                    *(f32x4*)(stg + fr * NT_STG_LD + j * 32 + 8 * g4 + 4 * fh) = v;
+                }
+            // the same wave reads back what it wrote (wave-private region): no workgroup barrier needed
 #pragma unroll
-        for (int t = 0; t < 12; ++t) {
-            const int idx = t * 64 + lane;
-            const int row = idx / 24, c4 = idx % 24;
-            const int m = m0 + wm * 64 + i * 32 + row;
-            const int n = n0 + wn * 96 + c4 * 4;
-            if (m >= g.M || n >= g.N) continue;
-            f32x4 v = *(const f32x4*)(stg + row * NT_STG_LD + c4 * 4);
-            if (g.bias) v += *(const f32x4*)(bias_s + c4 * 4);
-            const size_t o = (size_t)m * g.ldc + n;
-            if (EPI == QST_EPI_BF16) {
-                u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
-                *(u32x2*)((bf16*)g.C + o) = pk;
-            } else if (EPI == QST_EPI_F32_RESID || EPI == QST_EPI_F32_RESID_BF16) {
+            for (int t = 0; t < 12; ++t) {
+                const int idx = t * 64 + lane;
+                const int row = idx / 24, c4 = idx % 24;
+                const int m = m0 + wm * 64 + i * 32 + row;
+                const int n = n0 + wn * 96 + c4 * 4;
+                if (m >= g.M || n >= g.N) continue;
+                f32x4 v = *(const f32x4*)(stg + row * NT_STG_LD + c4 * 4);
+                if (g.bias) v += *(const f32x4*)(bias_s + c4 * 4);
                 v += rv[t];
+                const size_t o = (size_t)m * g.ldc + n;
                 *(f32x4*)((float*)g.C + o) = v;
                 if (EPI == QST_EPI_F32_RESID_BF16) {
                     u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
                     *(u32x2*)((bf16*)g.C2 + o) = pk;
                 }
-            } else if (EPI == QST_EPI_GELU) {
-                // h = gelu(u) feeds FFN2; gelu'(u) (not u) is what backward needs: both share one exp and one rcp,
-                // so the dgrad epilogue is a single multiply instead of a second erf evaluation
-                float hh[4], gg[4];
+            }
+        } else {
+            // bf16 outputs: 8 columns (16 B) per lane, 12 lanes per row, 6 items per lane -- 16-byte stores issue
+            // at twice the byte rate of 8-byte ones, and the epilogue is VMEM-issue/HBM bound
+            u32x4 av[6];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float cdf, pdf;
-                    gelu_parts(v[e], cdf, pdf);
-                    hh[e] = v[e] * cdf;
-                    gg[e] = cdf + v[e] * pdf;
+            for (int t = 0; t < 6; ++t) {
+                const int idx = t * 64 + lane;
+                const int row = idx / 12, c8 = idx % 12;
+                const int m = m0 + wm * 64 + i * 32 + row;
+                const int n = n0 + wn * 96 + c8 * 8;
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                if (EPI == QST_EPI_GELU_BWD)
+                    av[t] = (m < g.M && n < g.N) ? *(const u32x4*)((const bf16*)g.aux + (size_t)m * g.ldc + n) : z;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g4 + e];
+                    *(f32x4*)(stg + fr * NT_STG_LD + j * 32 + 8 * g4 + 4 * fh) = v;
                 }
-                u32x2 pk; pk[0] = pack_bf16x2(gg[0], gg[1]); pk[1] = pack_bf16x2(gg[2], gg[3]);
-                *(u32x2*)((bf16*)g.C + o) = pk;                                   // gelu'(u), saved for backward
-                pk[0] = pack_bf16x2(hh[0], hh[1]); pk[1] = pack_bf16x2(hh[2], hh[3]);
-                *(u32x2*)((bf16*)g.C2 + o) = pk;                                  // h
-            } else if (EPI == QST_EPI_GELU_BWD) {
-                u32x2 pk;
-                pk[0] = pack_bf16x2(v[0] * bf16lo(av[t][0]), v[1] * bf16hi(av[t][0]));
-                pk[1] = pack_bf16x2(v[2] * bf16lo(av[t][1]), v[3] * bf16hi(av[t][1]));
-                *(u32x2*)((bf16*)g.C + o) = pk;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const int idx = t * 64 + lane;
+                const int row = idx / 12, c8 = idx % 12;
+                const int m = m0 + wm * 64 + i * 32 + row;
+                const int n = n0 + wn * 96 + c8 * 8;
+                if (m >= g.M || n >= g.N) continue;
+                float v[8];
+                {
+                    const f32x4 lo = *(const f32x4*)(stg + row * NT_STG_LD + c8 * 8);
+                    const f32x4 hi = *(const f32x4*)(stg + row * NT_STG_LD + c8 * 8 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+                }
+                if (g.bias) {
+                    const f32x4 lo = *(const f32x4*)(bias_s + c8 * 8), hi = *(const f32x4*)(bias_s + c8 * 8 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += lo[e]; v[4 + e] += hi[e]; }
+                }
+                const size_t o = (size_t)m * g.ldc + n;
+                // N % 8 != 0 tails fall back to two 8-byte halves (N % 4 == 0 is required)
+                const bool full = n + 8 <= g.N;
+                u32x4 pk;
+                if (EPI == QST_EPI_BF16) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                } else if (EPI == QST_EPI_GELU) {
+                    // h = gelu(u) feeds FFN2; gelu'(u) (not u) is what backward needs: both share one exp and one
+                    // rcp, so the dgrad epilogue is a single multiply instead of a second erf evaluation
+                    float gg[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float cdf, pdf;
+                        gelu_parts(v[e], cdf, pdf);
+                        gg[e] = cdf + v[e] * pdf;
+                        v[e] = v[e] * cdf;
+                    }
+                    u32x4 pg;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { pg[e] = pack_bf16x2(gg[2 * e], gg[2 * e + 1]); pk[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]); }
+                    if (full) *(u32x4*)((bf16*)g.C + o) = pg;                     // gelu'(u), saved for backward
+                    else { u32x2 h2; h2[0] = pg[0]; h2[1] = pg[1]; *(u32x2*)((bf16*)g.C + o) = h2; }
+                } else {   // QST_EPI_GELU_BWD: acc * gelu'(u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        pk[e] = pack_bf16x2(v[2 * e] * bf16lo(av[t][e]), v[2 * e + 1] * bf16hi(av[t][e]));
+                }
+                bf16* dst = (EPI == QST_EPI_GELU) ? (bf16*)g.C2 : (bf16*)g.C;
+                if (full) *(u32x4*)(dst + o) = pk;
+                else { u32x2 h2; h2[0] = pk[0]; h2[1] = pk[1]; *(u32x2*)(dst + o) = h2; }
             }
         }
     }
@@ -409,10 +454,9 @@ extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
     if (a->K % NBK != 0 || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->N % 4 != 0 || a->ldc % 4 != 0) return QST_ERR_UNSUPPORTED;
     if ((int64_t)256 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)NBN * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    // a->splits (unused by nt otherwise) can force the tile height: 1 = 128 rows, 2 = 256 rows
-    const int64_t blocks256 = (int64_t)((a->M + 255) / 256) * ((a->N + NBN - 1) / NBN);
-    const int force = a->splits & 3;
-    const bool small = force == 1 || (force != 2 && blocks256 < 512);
+    // Two 128-row workgroups per CU beat one 256-row workgroup on every shape of the step (their MFMA and
+    // store phases interleave); a->splits (unused by nt otherwise) can force the tile height: 1 = 128, 2 = 256 rows.
+    const bool small = (a->splits & 3) != 2;
 #define QST_NT_CASE(E) case E: return small ? launch_nt<E, 2>(a, st) : launch_nt<E, 4>(a, st);
     switch (epi) {
         QST_NT_CASE(QST_EPI_BF16)

@@ -15,7 +15,7 @@ for name,N,K,epi,force in [("FFN1 fwd epi2 256-row",1536,384,2,2),("FFN1 fwd epi
     torch.cuda.synchronize()
     rows = 256 if force==2 else 128
     nblk = ((M+rows-1)//rows)*((N+191)//192); nw = 8 if force==2 else 4
-    t = dbg.cpu().numpy().reshape(-1, 8)[:, :6].astype(np.float64)
-    t = t.reshape(8192, 8, 6)[:nblk, :nw].reshape(-1, 6)
+    t = dbg.cpu().numpy().reshape(-1, 8).astype(np.float64)
+    t = t.reshape(8192, 8, 8)[:nblk, :nw].reshape(-1, 8)
     med = np.median(t, axis=0)
-    print(f"{name:26s} prologue {med[0]:6.0f} wait {med[1]:6.0f} barrier {med[2]:6.0f} compute {med[3]:6.0f} epilogue {med[4]:6.0f} total {med[5]:6.0f}  (stages={K//64}, MFMA/wave={K//64*24})")
+    print(f"{name:26s} prologue {med[0]:6.0f} wait {med[1]:6.0f} barrier {med[2]:6.0f} compute {med[3]:6.0f} epilogue {med[4]:6.0f} [loads-issue {med[6]:5.0f} lds-write {med[7]:5.0f} rest {med[4]-med[6]-med[7]:6.0f}] total {med[5]:6.0f}  (stages={K//64}, MFMA/wave={K//64*24})")
