@@ -286,10 +286,10 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void gemm_nt_kernel(QstGemmArgs g
 // (8 adders per element). Operands are consumed straight from row-major [M, *] images with ds_read_b64_tr_b16.
 // LDS image per operand stage: [32 m-rows][192 bf16] = 384-byte rows (24 chunks of 16 B); chunk c of row r sits at
 // chunk position c ^ (((r >> 1) & 1) << 2): the 4 rows x 64 B that one half-wave reads land in 16 distinct 16-B slots.
-constexpr int TT = 192, TBK = 32, TSTAGES = 3;
+constexpr int TT = 192, TBK = 32, TSTAGES = 5;            // 5-slot ring: three stages in flight, one being read, one free
 constexpr int TT_TILE = TBK * TT * 2;                // 12 KB per operand per stage
 constexpr int TT_STAGE = 2 * TT_TILE;                // 24 KB
-constexpr int TT_LDS = TSTAGES * TT_STAGE;           // 72 KB -> two workgroups per CU
+constexpr int TT_LDS = TSTAGES * TT_STAGE;           // 120 KB: one workgroup (4 MFMA + 2 loader waves) per CU
 __device__ __forceinline__ int tn_swz(int row) { return ((row >> 1) & 1) << 2; }
 __device__ __forceinline__ uint32_t tn_off(int row, int chunk) {
     return (uint32_t)(row * 384 + ((chunk ^ tn_swz(row)) << 4));
@@ -299,14 +299,19 @@ __device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt_n() {
     if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(QstTnGroup grp) {
+// Wave roles: waves 0-3 run the MFMAs (one per SIMD, the whole register file to themselves), waves 4-5 are loaders
+// that issue every LDS-DMA (wave 4: the dY stage, wave 5: the X stage). In-kernel stamps on the earlier
+// all-waves-load version showed 2800 cycles per 32-row stage for 672 cycles of MFMA: an in-order wave pays the DMA
+// issue cost (60-185 cycles per instruction) and the LDS read latency in series with its MFMAs.
+__global__ __launch_bounds__(384, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = (wave >> 1) & 1, wn = wave & 1;
     // block -> (M-range = XCD-aligned split, problem, tile)
     const int xcd = blockIdx.x & 7, jloc = blockIdx.x >> 3;
     int tile = jloc % grp.total_tiles;
@@ -320,36 +325,46 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(QstTnGroup grp) {
     const int per = (((g.M + grp.splits - 1) / grp.splits) + TBK - 1) / TBK * TBK;
     const int mbeg = split * per, mend = min(g.M, mbeg + per);
     if (mbeg >= mend) return;
+    const int nm = (mend - mbeg + TBK - 1) / TBK;
 
-    const bf16* Ab = (const bf16*)g.A + (size_t)mbeg * g.lda + n0;
-    const bf16* Bb = (const bf16*)g.B + (size_t)mbeg * g.ldb + k0;
-    // range = rows [mbeg, mend); the last row's tail past the allocation reads as zero
-    const uint32_t bytes_a = (uint32_t)min((size_t)(mend - mbeg) * g.lda * 2u - (size_t)n0 * 2u, (size_t)0x7FFFFF00u);
-    const uint32_t bytes_b = (uint32_t)min((size_t)(mend - mbeg) * g.ldb * 2u - (size_t)k0 * 2u, (size_t)0x7FFFFF00u);
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc(Ab, bytes_a);
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc(Bb, bytes_b);
-
-    // DMA map: an operand stage is 768 chunks = 12 wave-instructions of 1 KB; wave w issues 3w .. 3w+2.
-    // LDS position p = q*64 + lane -> row p/24, chunk position p%24 -> logical chunk = pos ^ swz(row).
-    // Columns beyond the matrix width must not alias the next row: those lanes get an out-of-range offset (-> 0).
-    uint32_t va[3], vb[3];
+    if (wave >= 4) {
+        // ------------------------------------------------------------ loader wave: one operand, 12 DMA per stage
+        const bool isA = wave == 4;
+        const int ld = isA ? g.lda : g.ldb, c0 = isA ? n0 : k0, width = isA ? g.N : g.K;
+        const bf16* base = (const bf16*)(isA ? g.A : g.B) + (size_t)mbeg * ld + c0;
+        // range = rows [mbeg, mend); the last row's tail past the allocation reads as zero
+        const uint32_t bytes = (uint32_t)min((size_t)(mend - mbeg) * ld * 2u - (size_t)c0 * 2u, (size_t)0x7FFFFF00u);
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, bytes);
+        // an operand stage is 768 chunks = 12 wave-instructions of 1 KB. LDS position p = q*64 + lane -> row p/24,
+        // chunk position p%24 -> logical chunk = pos ^ swz(row). Columns beyond the matrix width must not alias the
+        // next row: those lanes get an out-of-range offset (-> zero fill).
+        uint32_t vo[12];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int p = (wave * 3 + t) * 64 + lane;
-        const int row = p / 24, chunk = (p % 24) ^ tn_swz(row);
-        va[t] = (n0 + chunk * 8 < g.N) ? (uint32_t)row * g.lda * 2u + chunk * 16u : kOOB;
-        vb[t] = (k0 + chunk * 8 < g.K) ? (uint32_t)row * g.ldb * 2u + chunk * 16u : kOOB;
-    }
-    auto issue = [&](int mt) {
-        char* st = smem + (mt % TSTAGES) * TT_STAGE + wave * 3072;
-        const uint32_t soa = (uint32_t)mt * TBK * g.lda * 2u, sob = (uint32_t)mt * TBK * g.ldb * 2u;
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            dma16(ra, st + t * 1024, va[t], soa);                  // kOOB + soa < 2^32: no wrap, still out of range
-            dma16(rb, st + TT_TILE + t * 1024, vb[t], sob);
+        for (int t = 0; t < 12; ++t) {
+            const int p = t * 64 + lane;
+            const int row = p / 24, chunk = (p % 24) ^ tn_swz(row);
+            vo[t] = (c0 + chunk * 8 < width) ? (uint32_t)row * ld * 2u + chunk * 16u : kOOB;
         }
-    };
+        auto issue = [&](int mt) {
+            char* st = smem + (mt % TSTAGES) * TT_STAGE + (isA ? 0 : TT_TILE);
+            const uint32_t so = (uint32_t)mt * TBK * ld * 2u;
+#pragma unroll
+            for (int t = 0; t < 12; ++t) dma16(rs, st + t * 1024, vo[t], so);      // kOOB + so < 2^32: no wrap
+        };
+#pragma unroll 1
+        for (int s = 0; s < 3 && s < nm; ++s) issue(s);
+#pragma unroll 1
+        for (int mt = 0; mt < nm; ++mt) {
+            // stage mt must have landed before this wave arrives at the barrier that releases it to the MFMA waves
+            const int younger = min(2, nm - 1 - mt);
+            if (younger == 2) wait_vmcnt_n<24>(); else if (younger == 1) wait_vmcnt_n<12>(); else wait_vmcnt_n<0>();
+            __builtin_amdgcn_s_barrier();                  // MFMA waves are done with stage mt-1: slot (mt+3)%5 != (mt-1)%5 ...
+            if (mt + 3 < nm) issue(mt + 3);                // ... and slot (mt+3)%5 was last read at stage mt-2
+        }
+        return;
+    }
 
+    // ---------------------------------------------------------------- MFMA waves
     f32x16 acc[3][3], bacc[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -365,15 +380,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(QstTnGroup grp) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
-    const int nm = (mend - mbeg + TBK - 1) / TBK;
     // transposed-read lane geometry (cdna guide T10): lane i = 4q+p of a 16-lane group supplies row q, cols 4p..4p+3
     const int li = lane & 15, q = li >> 2, p = li & 3, gsel = (lane >> 4) & 1, fh = lane >> 5;
-    issue(0);
-    if (nm > 1) issue(1);
     for (int mt = 0; mt < nm; ++mt) {
-        if (mt + 1 < nm) wait_vmcnt_n<6>(); else wait_vmcnt_n<0>();   // stage mt landed (one younger stage may be in flight)
-        __builtin_amdgcn_s_barrier();                                  // for everyone; and slot (mt-1)%3 is free
-        if (mt + 2 < nm) issue(mt + 2);
+        __builtin_amdgcn_s_barrier();                      // stage mt landed (the loaders waited for it before arriving)
         const char* pa = smem + (mt % TSTAGES) * TT_STAGE;
         const char* pb = pa + TT_TILE;
 #pragma unroll
@@ -495,7 +505,7 @@ extern "C" int qst_gemm_tn_group(const QstTnGroup* grp_in, void* stream) {
         QST_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TT_LDS));
         attr_set = true;
     }
-    gemm_tn_group_kernel<<<dim3(g.total_tiles * g.splits), dim3(256), TT_LDS, (hipStream_t)stream>>>(g);
+    gemm_tn_group_kernel<<<dim3(g.total_tiles * g.splits), dim3(384), TT_LDS, (hipStream_t)stream>>>(g);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }

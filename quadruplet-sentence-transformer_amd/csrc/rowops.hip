@@ -118,20 +118,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const bf16
         ag[i][0] = ag[i][1] = ab[i][0] = ab[i][1] = 0.f;
     }
     const int row0 = (blockIdx.x * 4 + wave) * LN_BWD_ROWS_PER_WAVE;
+    // software pipeline: the loads of row r+1 are in flight while row r is reduced and stored
+    f32x2 dn[VPL];
+    uint32_t xn[VPL];
+    float rsn = 0.f;
+    auto fetch = [&](int row) {
+        const size_t base = (size_t)row * H;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lane + 64 * i;
+            dn[i][0] = dn[i][1] = 0.f; xn[i] = 0u;
+            if (c < nv) {
+                dn[i] = *(const f32x2*)(dy + base + 2 * c);
+                xn[i] = *(const uint32_t*)(xh + base + 2 * c);
+            }
+        }
+        rsn = rstd[row];
+    };
+    if (row0 < M) fetch(row0);
     for (int rr = 0; rr < LN_BWD_ROWS_PER_WAVE; ++rr) {
         const int row = row0 + rr;
         if (row >= M) break;
         const size_t base = (size_t)row * H;
         f32x2 d[VPL], x[VPL];
+        const float rs = rsn;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) { d[i] = dn[i]; x[i][0] = bf16lo(xn[i]); x[i][1] = bf16hi(xn[i]); }
+        if (rr + 1 < LN_BWD_ROWS_PER_WAVE && row + 1 < M) fetch(row + 1);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int c = lane + 64 * i;
-            d[i][0] = d[i][1] = x[i][0] = x[i][1] = 0.f;
             if (c < nv) {
-                d[i] = *(const f32x2*)(dy + base + 2 * c);
-                const uint32_t u = *(const uint32_t*)(xh + base + 2 * c);
-                x[i][0] = bf16lo(u); x[i][1] = bf16hi(u);
                 ag[i][0] += d[i][0] * x[i][0]; ag[i][1] += d[i][1] * x[i][1];
                 ab[i][0] += d[i][0];           ab[i][1] += d[i][1];
                 d[i][0] *= g[i][0]; d[i][1] *= g[i][1];          // dxhat
@@ -140,7 +158,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const bf16
             }
         }
         const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
-        const float rs = rstd[row];
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int c = lane + 64 * i;

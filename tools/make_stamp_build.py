@@ -12,7 +12,7 @@ s = s.replace("        wait_vmcnt<0>();                              // stage kt
 s = s.replace("                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // D rows = n, col = m\n        }\n    }\n",
               "                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // D rows = n, col = m\n        }\n        STAMP(5);\n        tcomp += tstamp[5] - tstamp[4];\n    }\n")
 s = s.replace("    __builtin_amdgcn_s_barrier();                     // all waves done with the ring before the epilogue reuses it\n",
-              "    __builtin_amdgcn_s_barrier();\n    STAMP(6);\n", 1)
+              "    __builtin_amdgcn_s_barrier();\n    STAMP(6);\n    unsigned long long te0 = 0, te1 = 0;\n", 1)
 s = s.replace("#pragma unroll\n    for (int i = 0; i < 2; ++i) {\n        f32x4 rv[12];", "    unsigned long long te0 = 0, te1 = 0, te2 = 0;\n#pragma unroll\n    for (int i = 0; i < 2; ++i) {\n        STAMP(2);\n        f32x4 rv[12];")
 s = s.replace("#pragma unroll\n        for (int j = 0; j < 3; ++j)\n#pragma unroll\n            for (int g4 = 0; g4 < 4; ++g4) {\n                f32x4 v;\n#pragma unroll\n                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g4 + e];\n                *(f32x4*)(stg + fr * NT_STG_LD", "        STAMP(3);\n#pragma unroll\n        for (int j = 0; j < 3; ++j)\n#pragma unroll\n            for (int g4 = 0; g4 < 4; ++g4) {\n                f32x4 v;\n#pragma unroll\n                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g4 + e];\n                *(f32x4*)(stg + fr * NT_STG_LD")
 s = s.replace("        // the same wave reads back what it wrote (wave-private region): no workgroup barrier needed\n#pragma unroll\n        for (int t = 0; t < 12; ++t) {\n            const int idx = t * 64 + lane;", "        STAMP(4);\n        te0 += tstamp[3] - tstamp[2]; te1 += tstamp[4] - tstamp[3];\n#pragma unroll\n        for (int t = 0; t < 12; ++t) {\n            const int idx = t * 64 + lane;")
@@ -20,8 +20,16 @@ a = s.index("// ----------------------------------------------------------------
 b = s.rfind("}\n", 0, a)
 s = s[:b] + "    STAMP(7);\n    if (lane == 0 && g.colsum) { unsigned long long* dbg = (unsigned long long*)g.colsum + ((size_t)blockIdx.x * 8 + wave) * 8; dbg[0] = tstamp[1] - tstamp[0]; dbg[1] = twait; dbg[2] = tbar; dbg[3] = tcomp; dbg[4] = tstamp[7] - tstamp[6]; dbg[5] = tstamp[7] - tstamp[0]; dbg[6] = te0; dbg[7] = te1; }\n" + s[b:]
 open(os.path.join(CS, "_gemm_stamp.hip"), "w").write(s)
+# ---- grouped wgrad stamps
+s = s.replace("    // ---------------------------------------------------------------- MFMA waves\n", "    unsigned long long tstamp[8]; unsigned long long twait = 0, tbar = 0, tcomp = 0; STAMP(0);\n")
+s = s.replace("        __builtin_amdgcn_s_barrier();                      // stage mt landed (the loaders waited for it before arriving)\n",
+              "        STAMP(3);\n        __builtin_amdgcn_s_barrier();\n        STAMP(4);\n        tbar += tstamp[4] - tstamp[3];\n")
+s = s.replace("                    bacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], ones, bacc[i], 0, 0, 0);\n            }\n        }\n    }\n",
+              "                    bacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], ones, bacc[i], 0, 0, 0);\n            }\n        }\n        STAMP(5);\n        tcomp += tstamp[5] - tstamp[4];\n    }\n    STAMP(6);\n")
+s = s.replace("    if (do_bias && fr == 0) {\n#pragma unroll\n        for (int i = 0; i < 3; ++i)", "    STAMP(7);\n    if (lane == 0 && grp.prob[7].A) { unsigned long long* dbg = (unsigned long long*)grp.prob[7].A + ((size_t)blockIdx.x * 4 + wave) * 8; dbg[0] = nm; dbg[1] = twait; dbg[2] = tbar; dbg[3] = tcomp; dbg[4] = tstamp[7] - tstamp[6]; dbg[5] = tstamp[7] - tstamp[0]; }\n    if (do_bias && fr == 0) {\n#pragma unroll\n        for (int i = 0; i < 3; ++i)")
+open(os.path.join(CS, "_gemm_stamp.hip"), "w").write(s)
 objs = [os.path.join(CS, f) for f in ("qst_api.o", "loss.o", "attention.o", "rowops.o", "optim.o", "x3.o")]
 subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-c", os.path.join(CS, "_gemm_stamp.hip"), "-o", os.path.join(CS, "_gemm_stamp.o")], check=True)
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(ROOT, "quadruplet-sentence-transformer_amd", "libqst_stamp.so"), os.path.join(CS, "_gemm_stamp.o")] + objs, check=True)
-os.remove(os.path.join(CS, "_gemm_stamp.hip")); os.remove(os.path.join(CS, "_gemm_stamp.o"))
+os.remove(os.path.join(CS, "_gemm_stamp.o"))
 print("built libqst_stamp.so")
