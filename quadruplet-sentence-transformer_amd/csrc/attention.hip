@@ -77,7 +77,7 @@ struct Stager {
 
 struct AttnArgs {
     const bf16* qkv; const bf16* ctx; const bf16* dctx; const float* lse_in; const int64_t* mask;
-    const float* rel; bf16* out; bf16* dqkv; float* lse_out; float* drel;
+    const float* rel; bf16* out; bf16* dqkv; float* lse_out; float* drel; float* delta;
     int nseq, L, A, H; float scale;
 };
 
@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         }
         delta += swap32(delta);
         lse = a.lse_in[((size_t)seq * a.A + head) * a.L + qi];
+        if (h == 0) a.delta[((size_t)seq * a.A + head) * a.L + qi] = delta;     // reused by the dK/dV kernel
     }
     f32x16 dq[DB];
 #pragma unroll
@@ -301,7 +302,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     const int kb = blockIdx.x % nkb, head = (blockIdx.x / nkb) % a.A, seq = blockIdx.x / (nkb * a.A);
     const int ld = 3 * a.H;
     const bf16* base = a.qkv + (size_t)seq * a.L * ld + head * D;
-    const bf16* cbase = a.ctx + (size_t)seq * a.L * a.H + head * D;
     const bf16* dbase = a.dctx + (size_t)seq * a.L * a.H + head * D;
     const int j0 = kb * 128 + wave * 32;
     const bool active = j0 < a.L;
@@ -330,24 +330,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         Stager<D> sg;
         sg.load(0, base + (size_t)c * 128 * ld, ld, rows, tid);
         sg.load(1, dbase + (size_t)c * 128 * a.H, a.H, rows, tid);
-        {   // delta_i = sum_dd dO[i][dd] * O[i][dd]; two threads per row
-            const int row = tid >> 1, half = tid & 1;
-            float dsum = 0.f;
-            if (row < rows) {
-                const bf16* orow = cbase + (size_t)(c * 128 + row) * a.H + half * (D / 2);
-                const bf16* drow = dbase + (size_t)(c * 128 + row) * a.H + half * (D / 2);
-#pragma unroll
-                for (int e = 0; e < D / 2; e += 8) {
-                    const bf16x8 ov = *(const bf16x8*)(orow + e), dvv = *(const bf16x8*)(drow + e);
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) dsum += (float)ov[t] * (float)dvv[t];
-                }
-            }
-            dsum += __shfl_xor(dsum, 1, 64);
-            if (row < rows && half == 0) {
-                del_s[row] = dsum;
-                lse_s[row] = a.lse_in[((size_t)seq * a.A + head) * a.L + c * 128 + row];
-            }
+        if (tid < rows) {      // per-query constants: log-sum-exp from forward, delta_i = dO_i . O_i from the dQ kernel
+            const size_t o = ((size_t)seq * a.A + head) * a.L + c * 128 + tid;
+            lse_s[tid] = a.lse_in[o];
+            del_s[tid] = a.delta[o];
         }
         sg.template store<false>(0, qimg, tid);
         sg.template store<true>(0, qtr, tid);
@@ -369,17 +355,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
             const int i0 = c * 128 + it * 32;
             f32x16 p;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int il = it * 32 + acc_row(r, h);
-                const int i = i0 + acc_row(r, h);
-                float v = s[r] * a.scale;
-                if (a.rel) v += a.rel[((size_t)head * a.L + i) * a.L + kj];
-                v += madd;
-                const float pr = __expf(v - lse_s[il]);
-                const float dsr = pr * (dp[r] - del_s[il]);                // dS (unscaled) = d(score)
-                if (a.drel) atomicAdd(a.drel + ((size_t)head * a.L + i) * a.L + kj, dsr);
-                p[r] = pr;
-                s[r] = dsr * a.scale;
+            for (int g = 0; g < 4; ++g) {
+                // accumulator registers 4g..4g+3 are query rows 8g + 4h + (0..3): one 16-byte LDS read per constant
+                const int il = it * 32 + 8 * g + 4 * h;
+                const f32x4 l4 = *(const f32x4*)(lse_s + il), d4 = *(const f32x4*)(del_s + il);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const int i = i0 + 8 * g + 4 * h + e;
+                    float v = s[r] * a.scale;
+                    if (a.rel) v += a.rel[((size_t)head * a.L + i) * a.L + kj];
+                    v += madd;
+                    const float pr = __expf(v - l4[e]);
+                    const float dsr = pr * (dp[r] - d4[e]);                    // dS (unscaled) = d(score)
+                    if (a.drel) atomicAdd(a.drel + ((size_t)head * a.L + i) * a.L + kj, dsr);
+                    p[r] = pr;
+                    s[r] = dsr * a.scale;
+                }
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -444,13 +436,13 @@ extern "C" int qst_attention_fwd(const void* qkv, const int64_t* mask, const flo
 
 extern "C" int qst_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse,
                                  const int64_t* mask, const float* rel_bias, int nseq, int L, int A, int d,
-                                 void* dqkv, float* drel, void* stream) {
-    if (!qkv || !ctx || !dctx || !lse || !mask || !dqkv) return QST_ERR_BAD_ARG;
+                                 void* dqkv, float* drel, float* delta_scratch, void* stream) {
+    if (!qkv || !ctx || !dctx || !lse || !mask || !dqkv || !delta_scratch) return QST_ERR_BAD_ARG;
     int rc = check_attn(nseq, L, A, d);
     if (rc) return rc;
     AttnArgs a{};
     a.qkv = (const bf16*)qkv; a.ctx = (const bf16*)ctx; a.dctx = (const bf16*)dctx; a.lse_in = lse; a.mask = mask;
-    a.rel = rel_bias; a.dqkv = (bf16*)dqkv; a.drel = drel;
+    a.rel = rel_bias; a.dqkv = (bf16*)dqkv; a.drel = drel; a.delta = delta_scratch;
     a.nseq = nseq; a.L = L; a.A = A; a.H = A * d; a.scale = 1.0f / sqrtf((float)d);
     const int grid = nseq * A * ((L + 127) / 128);
     const size_t lds_q = (size_t)3 * 128 * d * 2 + (size_t)L * 4;

@@ -259,7 +259,7 @@ X3Plan plan_x3(const qst_config& c, int nseq, int L) {
     return p;
 }
 
-struct BwdPlan { size_t dxa, dxb, ds, dsb, dsb1, du, dctx, dqkv, drel, lnred, total; };
+struct BwdPlan { size_t dxa, dxb, ds, dsb, dsb1, du, dctx, dqkv, drel, lnred, delta, total; };
 BwdPlan plan_bwd(const qst_config& c, int nseq, int L) {
     BwdPlan p;
     const size_t M = (size_t)nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads;
@@ -270,6 +270,7 @@ BwdPlan plan_bwd(const qst_config& c, int nseq, int L) {
     p.du = take(M * I * 2); p.dctx = take(M * H * 2); p.dqkv = take(M * 3 * H * 2);
     p.drel = (c.arch == QST_ARCH_MPNET) ? take(A * (size_t)L * L * 4) : 0;
     p.lnred = take(qst_ln_bwd_scratch_bytes((int)M, (int)H));
+    p.delta = take((size_t)nseq * A * L * 4);
     p.total = off;
     return p;
 }
@@ -482,7 +483,7 @@ extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, 
         // attention output projection dgrad, attention core
         QST_TRY(nt(dsb1, H, WT(b + W_O), H, dctx, H, nullptr, nullptr, nullptr, nullptr, 0, M, H, H, QST_EPI_BF16, st));
         QST_TRY(qst_attention_bwd(sv + a.qkv, sv + a.ctx, dctx, (const float*)(sv + a.lse), mask, rel, nseq, L, A, d,
-                                  dqkv, drel, st));
+                                  dqkv, drel, (float*)(ws + w.delta), st));
         // all four weight gradients (+ bias gradients) of the layer in one grouped launch
         {
             QstTnGroup grp{};

@@ -77,9 +77,11 @@ int qst_pool_norm_bwd(const float* demb, const float* pooled, const int64_t* mas
  * mask int64 [nseq, L], rel_bias f32 [A, L, L] or NULL -> ctx bf16 [nseq*L, H], lse f32 [nseq, A, L]. */
 int qst_attention_fwd(const void* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A, int d,
                       void* ctx, float* lse, void* stream);
-/* Backward: dctx bf16 [nseq*L, H] -> dqkv bf16 [nseq*L, 3H]; drel f32 [A, L, L] += (or NULL). */
+/* Backward: dctx bf16 [nseq*L, H] -> dqkv bf16 [nseq*L, 3H]; drel f32 [A, L, L] += (or NULL).
+ * delta_scratch: f32 [nseq, A, L] (dO.O per query, written by the dQ kernel, read by the dK/dV kernel). */
 int qst_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, const int64_t* mask,
-                      const float* rel_bias, int nseq, int L, int A, int d, void* dqkv, float* drel, void* stream);
+                      const float* rel_bias, int nseq, int L, int A, int d, void* dqkv, float* drel,
+                      float* delta_scratch, void* stream);
 
 /* MPNet relative position bias: rel_bias[a, i, j] = table[lut[(j - i) + 511]][a]; lut = int32 [1023] device
  * table of qst_rel_bucket_host(j - i). Backward accumulates drel [A, L, L] into dtable [buckets, A]. */

@@ -255,8 +255,10 @@ def test_attention_fwd_bwd(lib, n, L, A, d, use_rel):
     dq = torch.empty(n * L, 3 * H, dtype=torch.bfloat16, device="cuda")
     drel = torch.zeros(A, L, L, device="cuda") if use_rel else None
     dcd = dev(dctx.to(torch.bfloat16))
+    delta = torch.empty(n, A, L, device="cuda")
     _lib.check(lib.qst_attention_bwd(qd.data_ptr(), ctx.data_ptr(), dcd.data_ptr(), lse.data_ptr(),
-                                     md.data_ptr(), _lib.ptr(reld), n, L, A, d, dq.data_ptr(), _lib.ptr(drel), stream()))
+                                     md.data_ptr(), _lib.ptr(reld), n, L, A, d, dq.data_ptr(), _lib.ptr(drel),
+                                     delta.data_ptr(), stream()))
     gref = qr.grad
     err = (dq.float().cpu() - gref).abs().max().item()
     assert err <= 3e-2 * max(1.0, gref.abs().max().item()), f"dqkv max err {err}"
