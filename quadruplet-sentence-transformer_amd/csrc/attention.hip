@@ -83,7 +83,7 @@ struct AttnArgs {
 
 // ------------------------------------------------------------------ forward
 template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = D / 16, DB = D / 32, IMG = 128 * D * 2;
     char* kimg = smem;                  // row-read image of the K chunk
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------ backward: dQ
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dq_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = D / 16, DB = D / 32, IMG = 128 * D * 2;
     char* kimg = smem;                  // K rows (S^T = K.Q^T)
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------ backward: dK, dV
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = D / 16, DB = D / 32, IMG = 128 * D * 2;
     char* qimg = smem;                  // Q rows   (S = Q.K^T)
@@ -463,4 +463,13 @@ extern "C" int qst_attention_bwd(const void* qkv, const void* ctx, const void* d
     }
     QST_LAUNCH_CHECK();
     return QST_OK;
+}
+
+// Diagnostic (not declared in the public headers): resident workgroups per CU the runtime reports for the d=32 kernels.
+extern "C" int qst_debug_attn_occupancy(int which, int lds_bytes) {
+    int n = -1;
+    if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<32>, 256, lds_bytes);
+    if (which == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dq_kernel<32>, 256, lds_bytes);
+    if (which == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dkv_kernel<32>, 256, lds_bytes);
+    return n;
 }
