@@ -259,7 +259,7 @@ X3Plan plan_x3(const qst_config& c, int nseq, int L) {
     return p;
 }
 
-struct BwdPlan { size_t dxa, dxb, ds, dsb, dsb1, du, dctx, dqkv, drel, lnred, delta, total; };
+struct BwdPlan { size_t dxa, dxb, ds, dsb, dsb1, du, dctx, dqkv, drel, lnred, lnred_stride, delta, total; };
 BwdPlan plan_bwd(const qst_config& c, int nseq, int L) {
     BwdPlan p;
     const size_t M = (size_t)nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads;
@@ -269,7 +269,8 @@ BwdPlan plan_bwd(const qst_config& c, int nseq, int L) {
     p.dsb1 = take(M * H * 2);
     p.du = take(M * I * 2); p.dctx = take(M * H * 2); p.dqkv = take(M * 3 * H * 2);
     p.drel = (c.arch == QST_ARCH_MPNET) ? take(A * (size_t)L * L * 4) : 0;
-    p.lnred = take(qst_ln_bwd_scratch_bytes((int)M, (int)H));
+    p.lnred_stride = (qst_ln_bwd_scratch_bytes((int)M, (int)H) + 255) / 256 * 256;
+    p.lnred = take(p.lnred_stride * (size_t)(2 * c.num_layers + 1));
     p.delta = take((size_t)nseq * A * L * 4);
     p.total = off;
     return p;
@@ -456,7 +457,16 @@ extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, 
     void* du = ws + w.du;
     void* dctx = ws + w.dctx;
     void* dqkv = ws + w.dqkv;
-    float* lnred = (float*)(ws + w.lnred);
+    // LayerNorm gamma/beta gradients: every ln_bwd of this call writes per-block partials into its own slot; one
+    // batched launch at the end reduces them all (13 small launches per step -> 1-7)
+    QstLnReduceBatch lnb{};
+    lnb.H = H;
+    lnb.nblocks = (int)(qst_ln_bwd_scratch_bytes(M, H) / ((size_t)2 * H * sizeof(float)));
+    auto ln_slot = [&](int slot, float* dg, float* db) {
+        float* sp = (float*)(ws + w.lnred + (size_t)slot * w.lnred_stride);
+        lnb.partials[lnb.count] = sp; lnb.dgamma[lnb.count] = dg; lnb.dbeta[lnb.count] = db; ++lnb.count;
+        return sp;
+    };
     float* drel = nullptr;
     const float* rel = nullptr;
     if (c.arch == QST_ARCH_MPNET) {
@@ -471,15 +481,15 @@ extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, 
         const int b = lay.layer0[l];
         const void* xin_b = (l == 0) ? (const void*)(sv + p.x0b) : (const void*)(sv + p.layers[l - 1].xb);
         // LN2 -> ds2 (fp32 for the residual path, bf16 for the GEMMs)
-        QST_TRY(qst_ln_bwd(dxa, sv + a.xh2, (const float*)(sv + a.rs2), P(b + LN2_G), M, H, ds, dsb, G(b + LN2_G),
-                           G(b + LN2_B), lnred, st));
+        QST_TRY(qst_ln_bwd(dxa, sv + a.xh2, (const float*)(sv + a.rs2), P(b + LN2_G), M, H, ds, dsb, nullptr, nullptr,
+                           ln_slot(2 * l + 1, G(b + LN2_G), G(b + LN2_B)), st));
         // FFN2 dgrad through GELU: du = (ds2 . W2) * gelu'(u)   (a.u holds gelu'(u), written by the forward epilogue)
         QST_TRY(nt(dsb, H, WT(b + W_2), H, du, I, nullptr, sv + a.u, nullptr, nullptr, 0, M, I, H, QST_EPI_GELU_BWD, st));
         // FFN1 dgrad + residual: dy1 = du . W1 + ds2
         QST_TRY(nt(du, I, WT(b + W_1), I, dxb, H, nullptr, nullptr, nullptr, ds, H, M, H, I, QST_EPI_F32_RESID, st));
         // LN1 -> ds1
-        QST_TRY(qst_ln_bwd(dxb, sv + a.xh1, (const float*)(sv + a.rs1), P(b + LN1_G), M, H, ds, dsb1, G(b + LN1_G),
-                           G(b + LN1_B), lnred, st));
+        QST_TRY(qst_ln_bwd(dxb, sv + a.xh1, (const float*)(sv + a.rs1), P(b + LN1_G), M, H, ds, dsb1, nullptr, nullptr,
+                           ln_slot(2 * l, G(b + LN1_G), G(b + LN1_B)), st));
         // attention output projection dgrad, attention core
         QST_TRY(nt(dsb1, H, WT(b + W_O), H, dctx, H, nullptr, nullptr, nullptr, nullptr, 0, M, H, H, QST_EPI_BF16, st));
         QST_TRY(qst_attention_bwd(sv + a.qkv, sv + a.ctx, dctx, (const float*)(sv + a.lse), mask, rel, nseq, L, A, d,
@@ -504,9 +514,15 @@ extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, 
         QST_TRY(nt(dqkv, 3 * H, WT(b + W_QKV), 3 * H, dxa, H, nullptr, nullptr, nullptr, ds, H, M, H, 3 * H,
                    QST_EPI_F32_RESID, st));
     }
+    if (do_embed)
+        QST_TRY(qst_ln_bwd(dxa, sv + p.xh0, (const float*)(sv + p.rs0), P(lay.eg), M, H, ds, nullptr, nullptr, nullptr,
+                           ln_slot(2 * c.num_layers, G(lay.eg), G(lay.eb)), st));
+    if (lnb.count > 0) {
+        if (lnb.count > QST_LN_BATCH_MAX) return QST_ERR_UNSUPPORTED;
+        QST_TRY(qst_ln_bwd_reduce_batch(&lnb, st));
+    }
     if (!do_embed) return QST_OK;
     // embeddings
-    QST_TRY(qst_ln_bwd(dxa, sv + p.xh0, (const float*)(sv + p.rs0), P(lay.eg), M, H, ds, nullptr, G(lay.eg), G(lay.eb), lnred, st));
     QST_TRY(qst_embed_bwd(ds, ids, type_ids, (const int32_t*)(sv + p.pos_ids), nseq, L, H, c.type_vocab_size,
                           G(lay.word), G(lay.pos), lay.type >= 0 ? G(lay.type) : nullptr, st));
     if (c.arch == QST_ARCH_MPNET) {

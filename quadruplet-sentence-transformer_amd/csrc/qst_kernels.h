@@ -61,6 +61,16 @@ int qst_ln_fwd(const float* s, const float* gamma, const float* beta, float eps,
 size_t qst_ln_bwd_scratch_bytes(int M, int H);
 int qst_ln_bwd(const float* dy, const void* xhat_bf16, const float* rstd, const float* gamma, int M, int H,
                float* ds, void* ds_bf16, float* dgamma, float* dbeta, float* scratch, void* stream);
+/* Deferred second stage: qst_ln_bwd called with dgamma = dbeta = NULL only writes its partials into `scratch`;
+ * this reduces up to QST_LN_BATCH_MAX such buffers (same M, H) into their dgamma/dbeta in one launch. */
+#define QST_LN_BATCH_MAX 32
+typedef struct {
+    int32_t count, H, nblocks;      /* nblocks = qst_ln_bwd_scratch_bytes(M, H) / (2 * H * 4) */
+    const float* partials[QST_LN_BATCH_MAX];
+    float* dgamma[QST_LN_BATCH_MAX];
+    float* dbeta[QST_LN_BATCH_MAX];
+} QstLnReduceBatch;
+int qst_ln_bwd_reduce_batch(const QstLnReduceBatch* b, void* stream);
 /* Embedding backward: scatter ds rows into word/pos/type gradient tables. */
 int qst_embed_bwd(const float* ds, const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
                   int nseq, int L, int H, int num_types, float* dword, float* dpos, float* dtype_, void* stream);

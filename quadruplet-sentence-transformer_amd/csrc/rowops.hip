@@ -472,6 +472,24 @@ extern "C" int qst_ln_fwd(const float* s, const float* gamma, const float* beta,
     return QST_OK;
 }
 
+// Batched second stage for several LayerNorms at once (one launch per backward call instead of one per LayerNorm)
+__global__ __launch_bounds__(256) void ln_bwd_reduce_batch_kernel(QstLnReduceBatch b) {
+    const int which = blockIdx.z;
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= 2 * b.H) return;
+    const float* partials = b.partials[which];
+    float acc = 0.f;
+    for (int r = blockIdx.y; r < b.nblocks; r += gridDim.y) acc += partials[(size_t)r * 2 * b.H + col];
+    atomicAdd(col < b.H ? b.dgamma[which] + col : b.dbeta[which] + (col - b.H), acc);
+}
+
+extern "C" int qst_ln_bwd_reduce_batch(const QstLnReduceBatch* b, void* stream) {
+    if (!b || b->count <= 0 || b->count > QST_LN_BATCH_MAX || b->H <= 0 || b->nblocks <= 0) return QST_ERR_BAD_ARG;
+    ln_bwd_reduce_batch_kernel<<<dim3((2 * b->H + 255) / 256, 16, b->count), 256, 0, (hipStream_t)stream>>>(*b);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
 extern "C" size_t qst_ln_bwd_scratch_bytes(int M, int H) {
     const int rows_per_block = 4 * LN_BWD_ROWS_PER_WAVE;
     return (size_t)((M + rows_per_block - 1) / rows_per_block) * 2 * H * sizeof(float);
@@ -479,7 +497,10 @@ extern "C" size_t qst_ln_bwd_scratch_bytes(int M, int H) {
 
 extern "C" int qst_ln_bwd(const float* dy, const void* xhat_bf16, const float* rstd, const float* gamma, int M, int H,
                           float* ds, void* ds_bf16, float* dgamma, float* dbeta, float* scratch, void* stream) {
-    if (!dy || !xhat_bf16 || !rstd || !gamma || !ds || !dgamma || !dbeta || M <= 0 || H <= 0 || (H & 1))
+    // dgamma == dbeta == NULL with a scratch buffer: only write the per-block partials; the caller reduces them later
+    // with qst_ln_bwd_reduce_batch (one launch for many LayerNorms)
+    const bool deferred = !dgamma && !dbeta && scratch;
+    if (!dy || !xhat_bf16 || !rstd || !gamma || !ds || (!deferred && (!dgamma || !dbeta)) || M <= 0 || H <= 0 || (H & 1))
         return QST_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int rows_per_block = 4 * LN_BWD_ROWS_PER_WAVE;
@@ -488,7 +509,7 @@ extern "C" int qst_ln_bwd(const float* dy, const void* xhat_bf16, const float* r
     QST_VPL_DISPATCH(H, (ln_bwd_kernel<VPL><<<grid, 256, lds, st>>>(dy, (const bf16*)xhat_bf16, rstd, gamma, M, H, ds,
                                                                    (bf16*)ds_bf16, dgamma, dbeta, scratch)));
     QST_LAUNCH_CHECK();
-    if (scratch) {
+    if (scratch && !deferred) {
         ln_bwd_reduce_kernel<<<dim3((2 * H + 255) / 256, 32), 256, 0, st>>>(scratch, grid, H, dgamma, dbeta);
         QST_LAUNCH_CHECK();
     }
