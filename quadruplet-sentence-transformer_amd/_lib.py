@@ -38,7 +38,8 @@ class QstGemmArgs(C.Structure):
 
 
 class QstTnGroup(C.Structure):
-    _fields_ = [("nprob", C.c_int32), ("splits", C.c_int32), ("total_tiles", C.c_int32), ("tiles", C.c_int32 * 8),
+    _fields_ = [("nprob", C.c_int32), ("splits", C.c_int32), ("total_tiles", C.c_int32), ("ranges_per_xcd", C.c_int32),
+                ("tiles", C.c_int32 * 8),
                 ("prob", QstGemmArgs * 8)]
 
 

@@ -306,138 +306,158 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_n() {
 // Wave roles: waves 0-3 run the MFMAs (one per SIMD, the whole register file to themselves), waves 4-5 are loaders
 // that issue every LDS-DMA (wave 4: the dY stage, wave 5: the X stage). In-kernel stamps on the earlier
 // all-waves-load version showed 2800 cycles per 32-row stage for 672 cycles of MFMA: an in-order wave pays the DMA
-// issue cost (60-185 cycles per instruction) and the LDS read latency in series with its MFMAs.
+// issue cost (60-185 cycles per instruction) and the LDS read latency in series with its MFMAs; with loaders it is 990.
+//
+// Work decomposition ("stream-K inside an XCD"): XCD x owns M-range x. Its work is the list of (tile, stage) pairs of
+// all T tiles x S stages, cut into 32 equal contiguous spans, one per workgroup (one workgroup per CU: 120 KB of LDS).
+// A span may cover the end of one tile and the start of the next; each piece is flushed with fp32 atomics, so a tile
+// shared by two workgroups simply receives two partial sums. This removes the 48-tiles-on-32-CUs round quantisation
+// (1.5 tiles per CU) that cost a third of the kernel.
 __global__ __launch_bounds__(384, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (wave >> 1) & 1, wn = wave & 1;
-    // block -> (M-range = XCD-aligned split, problem, tile)
-    const int xcd = blockIdx.x & 7, jloc = blockIdx.x >> 3;
-    int tile = jloc % grp.total_tiles;
-    const int split = xcd + 8 * (jloc / grp.total_tiles);
-    int pi = 0;
-#pragma unroll 1
-    while (pi + 1 < grp.nprob && tile >= grp.tiles[pi]) { tile -= grp.tiles[pi]; ++pi; }
-    const QstGemmArgs& g = grp.prob[pi];
-    const int ntk = (g.K + TT - 1) / TT;
-    const int n0 = (tile / ntk) * TT, k0 = (tile % ntk) * TT;
-    const int per = (((g.M + grp.splits - 1) / grp.splits) + TBK - 1) / TBK * TBK;
-    const int mbeg = split * per, mend = min(g.M, mbeg + per);
+    const int xcd = blockIdx.x & 7, jloc = blockIdx.x >> 3;        // blocks b and b+8 share an XCD (speed only)
+    const int wg_per_range = (int)(gridDim.x >> 3) / grp.ranges_per_xcd;
+    const int range = xcd + 8 * (jloc / wg_per_range);             // which M-range
+    const int jr = jloc % wg_per_range;                            // workgroup index inside the range
+    const int M = grp.prob[0].M;
+    const int per = (((M + grp.splits - 1) / grp.splits) + TBK - 1) / TBK * TBK;
+    const int mbeg = range * per, mend = min(M, mbeg + per);
     if (mbeg >= mend) return;
-    const int nm = (mend - mbeg + TBK - 1) / TBK;
-
-    if (wave >= 4) {
-        // ------------------------------------------------------------ loader wave: one operand, 12 DMA per stage
-        const bool isA = wave == 4;
-        const int ld = isA ? g.lda : g.ldb, c0 = isA ? n0 : k0, width = isA ? g.N : g.K;
-        const bf16* base = (const bf16*)(isA ? g.A : g.B) + (size_t)mbeg * ld + c0;
-        // range = rows [mbeg, mend); the last row's tail past the allocation reads as zero
-        const uint32_t bytes = (uint32_t)min((size_t)(mend - mbeg) * ld * 2u - (size_t)c0 * 2u, (size_t)0x7FFFFF00u);
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, bytes);
-        // an operand stage is 768 chunks = 12 wave-instructions of 1 KB. LDS position p = q*64 + lane -> row p/24,
-        // chunk position p%24 -> logical chunk = pos ^ swz(row). Columns beyond the matrix width must not alias the
-        // next row: those lanes get an out-of-range offset (-> zero fill).
-        uint32_t vo[12];
-#pragma unroll
-        for (int t = 0; t < 12; ++t) {
-            const int p = t * 64 + lane;
-            const int row = p / 24, chunk = (p % 24) ^ tn_swz(row);
-            vo[t] = (c0 + chunk * 8 < width) ? (uint32_t)row * ld * 2u + chunk * 16u : kOOB;
-        }
-        auto issue = [&](int mt) {
-            char* st = smem + (mt % TSTAGES) * TT_STAGE + (isA ? 0 : TT_TILE);
-            const uint32_t so = (uint32_t)mt * TBK * ld * 2u;
-#pragma unroll
-            for (int t = 0; t < 12; ++t) dma16(rs, st + t * 1024, vo[t], so);      // kOOB + so < 2^32: no wrap
-        };
-#pragma unroll 1
-        for (int s = 0; s < 3 && s < nm; ++s) issue(s);
-#pragma unroll 1
-        for (int mt = 0; mt < nm; ++mt) {
-            // stage mt must have landed before this wave arrives at the barrier that releases it to the MFMA waves
-            const int younger = min(2, nm - 1 - mt);
-            if (younger == 2) wait_vmcnt_n<24>(); else if (younger == 1) wait_vmcnt_n<12>(); else wait_vmcnt_n<0>();
-            __builtin_amdgcn_s_barrier();                  // MFMA waves are done with stage mt-1: slot (mt+3)%5 != (mt-1)%5 ...
-            if (mt + 3 < nm) issue(mt + 3);                // ... and slot (mt+3)%5 was last read at stage mt-2
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------- MFMA waves
-    f32x16 acc[3][3], bacc[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bacc[i][r] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    }
-    const bool do_bias = (g.colsum != nullptr) && (k0 == 0) && (wn == 0);
-    bf16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+    const int S = (mend - mbeg + TBK - 1) / TBK;                   // stages per tile in this range
+    const long long total = (long long)grp.total_tiles * S;
+    const long long span = (total + wg_per_range - 1) / wg_per_range;
+    long long pos = (long long)jr * span;
+    const long long span_end = min(total, pos + span);
 
     // transposed-read lane geometry (cdna guide T10): lane i = 4q+p of a 16-lane group supplies row q, cols 4p..4p+3
     const int li = lane & 15, q = li >> 2, p = li & 3, gsel = (lane >> 4) & 1, fh = lane >> 5;
-    for (int mt = 0; mt < nm; ++mt) {
-        __builtin_amdgcn_s_barrier();                      // stage mt landed (the loaders waited for it before arriving)
-        const char* pa = smem + (mt % TSTAGES) * TT_STAGE;
-        const char* pb = pa + TT_TILE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[3], fb[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const int row = ks * 16 + 8 * fh + 4 * jj + q;
-                    const int ca = wm * 12 + i * 4 + gsel * 2 + (p >> 1);
-                    const int cb = wn * 12 + i * 4 + gsel * 2 + (p >> 1);
-                    const bf16x4 ta = lds_tr16(pa + tn_off(row, ca) + 8 * (p & 1));
-                    const bf16x4 tb = lds_tr16(pb + tn_off(row, cb) + 8 * (p & 1));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { fa[i][jj * 4 + e] = ta[e]; fb[i][jj * 4 + e] = tb[e]; }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            if (do_bias) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-                    bacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], ones, bacc[i], 0, 0, 0);
-            }
-        }
-    }
-
     const int fr = lane & 31;
-    float* C = (float*)g.C;
+
+#pragma unroll 1
+    while (pos < span_end) {
+        int tile = (int)(pos / S);
+        const int s0 = (int)(pos % S);
+        const int s1 = (int)min((long long)S, (long long)s0 + (span_end - pos));
+        const int nm = s1 - s0;
+        pos += nm;
+        int pi = 0;
+#pragma unroll 1
+        while (pi + 1 < grp.nprob && tile >= grp.tiles[pi]) { tile -= grp.tiles[pi]; ++pi; }
+        const QstGemmArgs& g = grp.prob[pi];
+        const int ntk = (g.K + TT - 1) / TT;
+        const int n0 = (tile / ntk) * TT, k0 = (tile % ntk) * TT;
+        const int row0 = mbeg + s0 * TBK;                          // first reduction row of this piece
+
+        if (wave >= 4) {
+            // -------------------------------------------------------- loader wave: one operand, 12 DMA per stage
+            const bool isA = wave == 4;
+            const int ld = isA ? g.lda : g.ldb, c0 = isA ? n0 : k0, width = isA ? g.N : g.K;
+            const bf16* base = (const bf16*)(isA ? g.A : g.B) + (size_t)row0 * ld + c0;
+            // range = rows [row0, mend); the last row's tail past the allocation reads as zero
+            const uint32_t bytes = (uint32_t)min((size_t)(mend - row0) * ld * 2u - (size_t)c0 * 2u, (size_t)0x7FFFFF00u);
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, bytes);
+            // an operand stage is 768 chunks = 12 wave-instructions of 1 KB. LDS position p = q*64 + lane -> row p/24,
+            // chunk position p%24 -> logical chunk = pos ^ swz(row). Columns beyond the matrix width must not alias
+            // the next row: those lanes get an out-of-range offset (-> zero fill).
+            uint32_t vo[12];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int k = k0 + wn * 96 + j * 32 + fr;
-        if (k >= g.K) continue;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wm * 96 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (n < g.N) atomicAdd(&C[(size_t)n * g.ldc + k], acc[i][j][r]);
+            for (int t = 0; t < 12; ++t) {
+                const int pp = t * 64 + lane;
+                const int row = pp / 24, chunk = (pp % 24) ^ tn_swz(row);
+                vo[t] = (c0 + chunk * 8 < width) ? (uint32_t)row * ld * 2u + chunk * 16u : kOOB;
             }
+            auto issue = [&](int mt) {
+                char* st = smem + (mt % TSTAGES) * TT_STAGE + (isA ? 0 : TT_TILE);
+                const uint32_t so = (uint32_t)mt * TBK * ld * 2u;
+#pragma unroll
+                for (int t = 0; t < 12; ++t) dma16(rs, st + t * 1024, vo[t], so);  // kOOB + so < 2^32: no wrap
+            };
+#pragma unroll 1
+            for (int st = 0; st < 3 && st < nm; ++st) issue(st);
+#pragma unroll 1
+            for (int mt = 0; mt < nm; ++mt) {
+                // stage mt must have landed before this wave arrives at the barrier that releases it to the MFMA waves
+                const int younger = min(2, nm - 1 - mt);
+                if (younger == 2) wait_vmcnt_n<24>(); else if (younger == 1) wait_vmcnt_n<12>(); else wait_vmcnt_n<0>();
+                __builtin_amdgcn_s_barrier();              // MFMA waves are done with stage mt-1 (and older)
+                if (mt + 3 < nm) issue(mt + 3);            // slot (mt+3)%5 was last read at stage mt-2
+            }
+            __builtin_amdgcn_s_barrier();                  // end of piece: every MFMA wave has left the ring
+            continue;
         }
-    }
-    if (do_bias && fr == 0) {
+
+        // ------------------------------------------------------------ MFMA waves
+        f32x16 acc[3][3];
+        float bsum[3] = {0.f, 0.f, 0.f};       // bias gradient: per-lane partial column sums of the dY fragments
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wm * 96 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (n < g.N) atomicAdd(&g.colsum[n], bacc[i][r]);
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const bool do_bias = (g.colsum != nullptr) && (k0 == 0) && (wn == 0);
+
+        for (int mt = 0; mt < nm; ++mt) {
+            __builtin_amdgcn_s_barrier();                  // stage mt landed (the loaders waited for it before arriving)
+            const char* pa = smem + (mt % TSTAGES) * TT_STAGE;
+            const char* pb = pa + TT_TILE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[3], fb[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int row = ks * 16 + 8 * fh + 4 * jj + q;
+                        const int ca = wm * 12 + i * 4 + gsel * 2 + (p >> 1);
+                        const int cb = wn * 12 + i * 4 + gsel * 2 + (p >> 1);
+                        const bf16x4 ta = lds_tr16(pa + tn_off(row, ca) + 8 * (p & 1));
+                        const bf16x4 tb = lds_tr16(pb + tn_off(row, cb) + 8 * (p & 1));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { fa[i][jj * 4 + e] = ta[e]; fb[i][jj * 4 + e] = tb[e]; }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                if (do_bias) {
+                    // lane (n' = lane&31, half h) holds dY[m = 8h .. 8h+7][n']: 8 of the 16 rows of this k-step
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) bsum[i] += (float)fa[i][e];
+                }
             }
+        }
+        __builtin_amdgcn_s_barrier();                      // end of piece: the loaders may refill the ring while we flush
+
+        float* C = (float*)g.C;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int k = k0 + wn * 96 + j * 32 + fr;
+            if (k >= g.K) continue;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + wm * 96 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    if (n < g.N) atomicAdd(&C[(size_t)n * g.ldc + k], acc[i][j][r]);
+                }
+            }
+        }
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float t = bsum[i] + swap32(bsum[i]);             // both row halves of the k-steps
+                const int n = n0 + wm * 96 + i * 32 + fr;
+                if (fh == 0 && n < g.N) atomicAdd(&g.colsum[n], t);
+            }
+        }
     }
 }
 
@@ -491,21 +511,27 @@ extern "C" int qst_gemm_tn_group(const QstTnGroup* grp_in, void* stream) {
         g.tiles[i] = ((a.N + TT - 1) / TT) * ((a.K + TT - 1) / TT);
         g.total_tiles += g.tiles[i];
     }
+    const int M = g.prob[0].M;
     if (g.splits <= 0) {
-        // one M-range per XCD; more ranges only while the launch cannot fill two workgroups per CU and each range
-        // keeps >= 256 reduction rows (every extra range adds one more atomic pass over the outputs)
-        int q = (64 + g.total_tiles / 2) / g.total_tiles;
-        q = q < 1 ? 1 : (q > 4 ? 4 : q);
-        while (q > 1 && (int64_t)g.prob[0].M < (int64_t)8 * q * 256) --q;
-        g.splits = 8 * q;
+        // one M-range per XCD (every operand row leaves HBM once); a second range per XCD only when the ranges are
+        // long enough that 32 workgroups per range still get >= 8 stages of work each
+        g.splits = 8;
     }
     g.splits = (g.splits + 7) / 8 * 8;
+    g.ranges_per_xcd = g.splits / 8;
+    // 32 workgroups per XCD (one per CU) share each XCD's ranges; never more workgroups than (tile, stage) pairs
+    const int64_t stages = ((int64_t)(M + g.splits - 1) / g.splits + TBK - 1) / TBK;
+    int64_t wg_per_range = 32 / g.ranges_per_xcd;
+    if (wg_per_range < 1) wg_per_range = 1;
+    const int64_t work = (int64_t)g.total_tiles * stages;
+    if (wg_per_range > work) wg_per_range = work < 1 ? 1 : work;
+    const int grid = (int)(8 * g.ranges_per_xcd * wg_per_range);
     static bool attr_set = false;
     if (!attr_set) {
         QST_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TT_LDS));
         attr_set = true;
     }
-    gemm_tn_group_kernel<<<dim3(g.total_tiles * g.splits), dim3(384), TT_LDS, (hipStream_t)stream>>>(g);
+    gemm_tn_group_kernel<<<dim3(grid), dim3(384), TT_LDS, (hipStream_t)stream>>>(g);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }

@@ -498,7 +498,7 @@ extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, 
         {
             QstTnGroup grp{};
             grp.nprob = 4;
-            grp.splits = 16;
+            grp.splits = 0;
             auto set = [&](int i, const void* dY, int N, const void* X, int K, int wseg, int bseg) {
                 QstGemmArgs& q = grp.prob[i];
                 q.A = dY; q.B = X; q.C = G(wseg); q.colsum = G(bseg); q.M = M; q.N = N; q.K = K;

@@ -41,6 +41,7 @@ typedef struct {
     int32_t nprob;
     int32_t splits;               /* reduction ranges over M, rounded up to a multiple of 8; 0 = auto */
     int32_t total_tiles;          /* filled by the library */
+    int32_t ranges_per_xcd;       /* filled by the library */
     int32_t tiles[QST_TN_MAX_PROB];
     QstGemmArgs prob[QST_TN_MAX_PROB];
 } QstTnGroup;

@@ -9,7 +9,7 @@ def make_group(M=32768, H=384, I=1536, dev="cuda"):
     bf = torch.bfloat16
     keep = []
     grp = _lib.QstTnGroup()
-    grp.nprob, grp.splits = 4, 0
+    grp.nprob, grp.splits = 4, int(__import__("os").environ.get("QST_SPLITS", "0"))
     for i, (N, K) in enumerate([(H, I), (I, H), (H, H), (3 * H, H)]):
         A = torch.randn(M, N, device=dev).to(bf); B = torch.randn(M, K, device=dev).to(bf)
         C = torch.zeros(N, K, device=dev); cs = torch.zeros(N, device=dev)
