@@ -308,11 +308,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_n() {
 // all-waves-load version showed 2800 cycles per 32-row stage for 672 cycles of MFMA: an in-order wave pays the DMA
 // issue cost (60-185 cycles per instruction) and the LDS read latency in series with its MFMAs; with loaders it is 990.
 //
-// Work decomposition ("stream-K inside an XCD"): XCD x owns M-range x. Its work is the list of (tile, stage) pairs of
-// all T tiles x S stages, cut into 32 equal contiguous spans, one per workgroup (one workgroup per CU: 120 KB of LDS).
-// A span may cover the end of one tile and the start of the next; each piece is flushed with fp32 atomics, so a tile
-// shared by two workgroups simply receives two partial sums. This removes the 48-tiles-on-32-CUs round quantisation
-// (1.5 tiles per CU) that cost a third of the kernel.
+// Work decomposition: XCD x owns M-range x and runs W = 32 workgroups on it (one per CU: 120 KB of LDS). With T tiles
+// = a*W + b, every workgroup reduces `a` whole tiles and then one stage-piece of a leftover tile (task list in the
+// kernel), so all CUs finish together instead of 1.5 tiles per CU being rounded up to 2; split tiles simply receive
+// several partial sums through the fp32 atomics.
 __global__ __launch_bounds__(384, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -327,22 +326,32 @@ __global__ __launch_bounds__(384, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
     const int mbeg = range * per, mend = min(M, mbeg + per);
     if (mbeg >= mend) return;
     const int S = (mend - mbeg + TBK - 1) / TBK;                   // stages per tile in this range
-    const long long total = (long long)grp.total_tiles * S;
-    const long long span = (total + wg_per_range - 1) / wg_per_range;
-    long long pos = (long long)jr * span;
-    const long long span_end = min(total, pos + span);
+    // Task list of this workgroup (W = workgroups per range, T = tiles = a*W + b):
+    //   a full tiles (tile t*W + jr, all S stages), processed in lockstep with the other workgroups of the range, so
+    //   the rows being streamed are shared through the XCD's L2 (a tile-major "stream-K" split lost that: every
+    //   workgroup sat at a different stage and HBM traffic tripled);
+    //   then one piece of a leftover tile: the b leftover tiles are cut into floor(W/b) stage pieces each.
+    const int W = wg_per_range, T = grp.total_tiles;
+    const int a_full = T / W, b_left = T % W;
+    const int pieces = b_left > 0 ? max(1, W / b_left) : 1;
+    const int ntasks = a_full + ((b_left > 0 && jr / pieces < b_left) ? 1 : 0);
 
     // transposed-read lane geometry (cdna guide T10): lane i = 4q+p of a 16-lane group supplies row q, cols 4p..4p+3
     const int li = lane & 15, q = li >> 2, p = li & 3, gsel = (lane >> 4) & 1, fh = lane >> 5;
     const int fr = lane & 31;
 
 #pragma unroll 1
-    while (pos < span_end) {
-        int tile = (int)(pos / S);
-        const int s0 = (int)(pos % S);
-        const int s1 = (int)min((long long)S, (long long)s0 + (span_end - pos));
+    for (int task = 0; task < ntasks; ++task) {
+        int tile, s0, s1;
+        if (task < a_full) { tile = task * W + jr; s0 = 0; s1 = S; }
+        else {
+            tile = a_full * W + jr / pieces;
+            const int pc = jr % pieces;
+            const int per_piece = (S + pieces - 1) / pieces;
+            s0 = pc * per_piece; s1 = min(S, s0 + per_piece);
+        }
         const int nm = s1 - s0;
-        pos += nm;
+        if (nm <= 0) continue;                                     // uniform over the workgroup
         int pi = 0;
 #pragma unroll 1
         while (pi + 1 < grp.nprob && tile >= grp.tiles[pi]) { tile -= grp.tiles[pi]; ++pi; }
