@@ -20,13 +20,12 @@ a = s.index("// ----------------------------------------------------------------
 b = s.rfind("}\n", 0, a)
 s = s[:b] + "    STAMP(7);\n    if (lane == 0 && g.colsum) { unsigned long long* dbg = (unsigned long long*)g.colsum + ((size_t)blockIdx.x * 8 + wave) * 8; dbg[0] = tstamp[1] - tstamp[0]; dbg[1] = twait; dbg[2] = tbar; dbg[3] = tcomp; dbg[4] = tstamp[7] - tstamp[6]; dbg[5] = tstamp[7] - tstamp[0]; dbg[6] = te0; dbg[7] = te1; }\n" + s[b:]
 open(os.path.join(CS, "_gemm_stamp.hip"), "w").write(s)
-# ---- grouped wgrad stamps
-s = s.replace("    // ---------------------------------------------------------------- MFMA waves\n", "    unsigned long long tstamp[8]; unsigned long long twait = 0, tbar = 0, tcomp = 0; STAMP(0);\n")
-s = s.replace("        __builtin_amdgcn_s_barrier();                      // stage mt landed (the loaders waited for it before arriving)\n",
-              "        STAMP(3);\n        __builtin_amdgcn_s_barrier();\n        STAMP(4);\n        tbar += tstamp[4] - tstamp[3];\n")
-s = s.replace("                    bacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], ones, bacc[i], 0, 0, 0);\n            }\n        }\n    }\n",
-              "                    bacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], ones, bacc[i], 0, 0, 0);\n            }\n        }\n        STAMP(5);\n        tcomp += tstamp[5] - tstamp[4];\n    }\n    STAMP(6);\n")
-s = s.replace("    if (do_bias && fr == 0) {\n#pragma unroll\n        for (int i = 0; i < 3; ++i)", "    STAMP(7);\n    if (lane == 0 && grp.prob[7].A) { unsigned long long* dbg = (unsigned long long*)grp.prob[7].A + ((size_t)blockIdx.x * 4 + wave) * 8; dbg[0] = nm; dbg[1] = twait; dbg[2] = tbar; dbg[3] = tcomp; dbg[4] = tstamp[7] - tstamp[6]; dbg[5] = tstamp[7] - tstamp[0]; }\n    if (do_bias && fr == 0) {\n#pragma unroll\n        for (int i = 0; i < 3; ++i)")
+# ---- grouped wgrad stamps (task-list kernel): totals over all tasks of an MFMA wave
+s = s.replace("#pragma unroll 1\n    for (int task = 0; task < ntasks; ++task) {", "    unsigned long long tstamp[8]; unsigned long long tbar = 0, tcomp = 0, tepi = 0, nst = 0; STAMP(0);\n#pragma unroll 1\n    for (int task = 0; task < ntasks; ++task) {")
+s = s.replace("            __builtin_amdgcn_s_barrier();                  // stage mt landed (the loaders waited for it before arriving)\n", "            STAMP(3);\n            __builtin_amdgcn_s_barrier();\n            STAMP(4);\n            tbar += tstamp[4] - tstamp[3]; ++nst;\n")
+s = s.replace("                        for (int e = 0; e < 8; ++e) bsum[i] += (float)fa[i][e];\n                }\n            }\n        }\n", "                        for (int e = 0; e < 8; ++e) bsum[i] += (float)fa[i][e];\n                }\n            }\n            STAMP(5);\n            tcomp += tstamp[5] - tstamp[4];\n        }\n")
+s = s.replace("        __builtin_amdgcn_s_barrier();                      // end of piece: the loaders may refill the ring while we flush\n", "        __builtin_amdgcn_s_barrier();\n        STAMP(6);\n")
+s = s.replace("                if (fh == 0 && n < g.N) atomicAdd(&g.colsum[n], t);\n            }\n        }\n    }\n}", "                if (fh == 0 && n < g.N) atomicAdd(&g.colsum[n], t);\n            }\n        }\n        STAMP(7);\n        tepi += tstamp[7] - tstamp[6];\n    }\n    if (wave < 4 && lane == 0 && grp.prob[7].A) { STAMP(1); unsigned long long* dbg = (unsigned long long*)grp.prob[7].A + ((size_t)blockIdx.x * 4 + wave) * 8; dbg[0] = nst; dbg[1] = 0; dbg[2] = tbar; dbg[3] = tcomp; dbg[4] = tepi; dbg[5] = tstamp[1] - tstamp[0]; }\n}")
 open(os.path.join(CS, "_gemm_stamp.hip"), "w").write(s)
 objs = [os.path.join(CS, f) for f in ("qst_api.o", "loss.o", "attention.o", "rowops.o", "optim.o", "x3.o")]
 subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-c", os.path.join(CS, "_gemm_stamp.hip"), "-o", os.path.join(CS, "_gemm_stamp.o")], check=True)
