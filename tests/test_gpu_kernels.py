@@ -98,9 +98,12 @@ def gemm_args(**kw):
     return g
 
 
+@pytest.mark.parametrize("form", [0, 2], ids=["tiles128", "tiles256"])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 384), (200, 192, 128), (1000, 1152, 384), (64, 64, 64),
-                                   (4096, 384, 1536)])
-def test_gemm_nt_epilogues(lib, M, N, K):
+                                   (4096, 384, 1536), (5000, 1536, 384)])
+def test_gemm_nt_epilogues(lib, M, N, K, form):
+    """form: QstGemmArgs.splits selects the nt tile height (0 = 128-row tiles, two workgroups per CU; 2 = 256-row
+    tiles, one 8-wave workgroup per CU); both must give the same results."""
     g = torch.Generator().manual_seed(M + N + K)
     A = bfr(torch.randn(M, K, generator=g))
     B = bfr(torch.randn(N, K, generator=g) * 0.05)
@@ -110,23 +113,23 @@ def test_gemm_nt_epilogues(lib, M, N, K):
     Ad, Bd = dev(A.to(torch.bfloat16)), dev(B.to(torch.bfloat16))
     # EPI_BF16
     Cb = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-    _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=Cb, bias=dev(bias), M=M, N=N, K=K, lda=K, ldb=K, ldc=N), 0, stream()))
+    _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=Cb, bias=dev(bias), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, splits=form), 0, stream()))
     torch.testing.assert_close(Cb.float().cpu(), ref, rtol=8e-3, atol=2e-2)
     # EPI_F32_RESID
     Cf = torch.empty(M, N, dtype=torch.float32, device="cuda")
     _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=Cf, bias=dev(bias), resid=dev(resid), M=M, N=N, K=K, lda=K, ldb=K,
-                                         ldc=N, ldr=N), 1, stream()))
+                                         ldc=N, ldr=N, splits=form), 1, stream()))
     torch.testing.assert_close(Cf.cpu(), ref + resid, rtol=1e-4, atol=1e-3)
     # EPI_GELU: C = gelu'(u) (saved for backward), C2 = gelu(u)
     C2 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-    _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=Cb, C2=C2, bias=dev(bias), M=M, N=N, K=K, lda=K, ldb=K, ldc=N), 2, stream()))
+    _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=Cb, C2=C2, bias=dev(bias), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, splits=form), 2, stream()))
     ur = ref.clone().requires_grad_(True)
     torch.nn.functional.gelu(ur).sum().backward()
     torch.testing.assert_close(Cb.float().cpu(), ur.grad, rtol=8e-3, atol=2e-2)
     torch.testing.assert_close(C2.float().cpu(), torch.nn.functional.gelu(ref), rtol=8e-3, atol=2e-2)
     # EPI_GELU_BWD: C = acc * aux
     gp = bfr(torch.rand(M, N, generator=g) * 1.2 - 0.1)
-    _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=Cb, aux=dev(gp.to(torch.bfloat16)), M=M, N=N, K=K, lda=K, ldb=K, ldc=N), 3, stream()))
+    _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=Cb, aux=dev(gp.to(torch.bfloat16)), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, splits=form), 3, stream()))
     torch.testing.assert_close(Cb.float().cpu(), (A @ B.t()) * gp, rtol=8e-3, atol=2e-2)
 
 
