@@ -123,7 +123,7 @@ def time_kernels(trainer, n, L, reps, batches):
     wflops = 2.0 * M * (H * I + I * H + H * H + 3 * H * H)
     return ({"kernel": "gemm_tn_group_kernel (all 4 wgrads of one layer: dW2, dW1, dWo, dWqkv + bias grads)",
              "ms": t_wgrad / reps, "flops_per_launch": wflops, "shape": [M, H, I]},
-            {"kernel": "gemm_nt_kernel<2, 4> (FFN1 fwd, bias+GELU epilogue)", "ms": t_ffn1 / reps,
+            {"kernel": "gemm_nt_kernel<2, 2> (FFN1 fwd, bias+GELU epilogue)", "ms": t_ffn1 / reps,
              "flops_per_launch": 2.0 * M * I * H, "shape": [M, I, H]})
 
 
