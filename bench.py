@@ -127,6 +127,51 @@ def time_kernels(trainer, n, L, reps, batches):
              "flops_per_launch": 2.0 * M * I * H, "shape": [M, I, H]})
 
 
+def time_fwd_only(trainer, batches, steps):
+    """Forward-only throughput (inference forward of the 4 columns as one [4B, L] pass + fused loss, no saved
+    activations) -- SURVEY.md section 8d's second figure."""
+    import torch
+    for i in range(3):
+        trainer.forward_loss(*batches[i % len(batches)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        trainer.forward_loss(*batches[i % len(batches)])
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def time_loss_kernel(D, reps=10, rows=262144):
+    """HBM evidence for the fused loss kernel at a size where it is not launch-latency-bound:
+    rows x D fp32, forward + gradients = 8*rows*D*4 algorithmic bytes."""
+    import torch
+    from quadruplet_sentence_transformer_amd.encoder import quadruplet_loss_raw
+    x = [torch.nn.functional.normalize(torch.randn(rows, D, device="cuda"), dim=1) for _ in range(4)]
+    args = (0.6, 1.0, 0.5, 0.5, 2.0, False, 1)
+    for _ in range(2):
+        quadruplet_loss_raw(*x, *args, want_grads=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    out = grads = None
+    scratch = torch.empty(rows, dtype=torch.float32, device="cuda")
+    from quadruplet_sentence_transformer_amd import _lib
+    lib = _lib.load()
+    out = torch.empty(1, dtype=torch.float32, device="cuda")
+    grads = [torch.empty_like(x[0]) for _ in range(4)]
+    st = _lib.current_stream_ptr()
+    e0.record()
+    for _ in range(reps):
+        _lib.check(lib.qst_quadruplet_loss(x[0].data_ptr(), x[1].data_ptr(), x[2].data_ptr(), x[3].data_ptr(), rows, D,
+                                           *[float(a) for a in args[:5]], 0, 1, out.data_ptr(), None,
+                                           *[g_.data_ptr() for g_ in grads], scratch.data_ptr(), st))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = 8.0 * rows * D * 4
+    return {"bound": "hbm", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+            "kernel": "quad_loss_kernel fwd+grads", "avg_launch_ms": round(ms, 4), "rows": rows, "D": D}
+
+
 def main():
     args = parse()
     import torch
@@ -226,6 +271,12 @@ def main():
                                   "unit": "TFLOP/s", "frac": round(achieved2 / PEAK_BF16_TFLOPS, 4), "traffic": traffic2,
                                   "kernel": dk2["kernel"], "avg_launch_ms": round(dk2["ms"], 5), "shape_MNK": dk2["shape"]},
         }
+        if world == 1:
+            t_f = time_fwd_only(trainer, batches, max(5, args.steps // 2))
+            out["fwd_only"] = {"value": round(B / t_f, 1), "unit": "quadruplets/s", "ms_per_step": round(t_f * 1e3, 4),
+                               "what": "encode 4 columns + loss forward, no backward / saved activations",
+                               "mfma_frac": round(B / t_f * fwd_flops_q / 1e12 / PEAK_BF16_TFLOPS, 4)}
+            out["roofline_loss_kernel"] = time_loss_kernel(cfg.hidden_size)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, arena, L)
         print(json.dumps(out), flush=True)

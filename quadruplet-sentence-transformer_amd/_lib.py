@@ -37,6 +37,10 @@ class QstGemmArgs(C.Structure):
                 ("ldb", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32), ("splits", C.c_int32)]
 
 
+class QstLnEpi(C.Structure):
+    _fields_ = [("gamma", vp), ("beta", vp), ("eps", C.c_float), ("xhat", vp), ("rstd", vp), ("partials", vp)]
+
+
 class QstTnGroup(C.Structure):
     _fields_ = [("nprob", C.c_int32), ("splits", C.c_int32), ("total_tiles", C.c_int32), ("ranges_per_xcd", C.c_int32),
                 ("tiles", C.c_int32 * 8),
@@ -67,6 +71,8 @@ SIGNATURES = {
                                       C.c_float, C.c_float, C.c_int64, vp, vp, vp]),
     # kernel level (include/qst_kernels.h)
     "qst_gemm_nt": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int, vp]),
+    "qst_gemm_nt_ln_supported": (C.c_int, [C.c_int]),
+    "qst_gemm_nt_ln": (C.c_int, [C.POINTER(QstGemmArgs), C.POINTER(QstLnEpi), C.c_int, vp]),
     "qst_gemm_tn": (C.c_int, [C.POINTER(QstGemmArgs), vp]),
     "qst_gemm_tn_group": (C.c_int, [C.POINTER(QstTnGroup), vp]),
     "qst_embed_ln_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp]),

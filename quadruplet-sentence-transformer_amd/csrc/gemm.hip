@@ -21,6 +21,7 @@ namespace {
 constexpr uint32_t kOOB = 0x7FFFFFF0u;              // voffset that always fails the buffer range check -> zero fill
 
 typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* lds_wave_base, uint32_t voff, uint32_t soff) {
     // one wave-instruction writes 64 x 16 B = 1 KB at lds_wave_base + lane*16 (base must be wave-uniform)
@@ -54,8 +55,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 // (384/1152/1536, 768/2304/3072), so no tile is padded along N, and M = 32768 gives 1-4 whole tiles per CU.
 // LDS image per operand tile: [rows][64 bf16] = 128-byte rows (whole cache lines per DMA row); 16-byte chunk c of
 // row r sits at chunk position c ^ ((r >> 1) & 7)  (conflict-free for the MFMA fragment ds_read_b128).
-constexpr int NBN = 192, NBK = 64;
-constexpr int NT_B_BYTES = NBN * NBK * 2;            // 24 KB
+constexpr int NBK = 64;
 // WAVES_M = 4: 256 x 192 tile, 8 waves, 112 KB ring (one workgroup per CU)
 // WAVES_M = 2: 128 x 192 tile, 4 waves,  80 KB ring (two workgroups per CU: their phases interleave) -- used when the
 //              256-row tiling would give fewer than two workgroups per CU (N = 384 GEMMs at M = 32768)
@@ -64,19 +64,18 @@ __device__ __forceinline__ uint32_t nt_off(int row, int chunk) {
     return (uint32_t)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
 
-template <int EPI, int WAVES_M>
-__global__ __launch_bounds__(128 * WAVES_M, 2) void gemm_nt_kernel(QstGemmArgs g) {
-    constexpr int NBM = 64 * WAVES_M;
-    constexpr int NT_A_BYTES = NBM * NBK * 2;
+// Prologue + K loop shared by every NT kernel: leaves the wave's 64 x 96 sub-tile in acc (D rows = n, D column = m)
+// and returns after a workgroup barrier, so the caller may reuse the ring for its epilogue.
+template <int WAVES_M, int WAVES_N>
+__device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, int m0, int n0, f32x16 (&acc)[2][3]) {
+    constexpr int NBM = 64 * WAVES_M, NBN = 96 * WAVES_N, NW = WAVES_M * WAVES_N;
+    constexpr int NT_A_BYTES = NBM * NBK * 2, NT_B_BYTES = NBN * NBK * 2;
     constexpr int NT_STAGE = NT_A_BYTES + NT_B_BYTES;
-    constexpr int B_PER_WAVE = 24 / (2 * WAVES_M);       // B tile = 24 DMA instructions
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int A_PER_WAVE = (NBM / 8) / NW;           // one DMA instruction = 8 tile rows
+    constexpr int B_PER_WAVE = (NBN / 8) / NW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int ntn = (g.N + NBN - 1) / NBN, ntm = (g.M + NBM - 1) / NBM;
-    const int wg = xcd_remap(blockIdx.x, ntm * ntn);
-    const int m0 = (wg / ntn) * NBM, n0 = (wg % ntn) * NBN;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
     const int rows_a = min(NBM, g.M - m0), rows_b = min(NBN, g.N - n0);
     const bf16* Ab = (const bf16*)g.A + (size_t)m0 * g.lda;
@@ -84,12 +83,12 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void gemm_nt_kernel(QstGemmArgs g
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(Ab, (uint32_t)rows_a * g.lda * 2u);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(Bb, (uint32_t)rows_b * g.ldb * 2u);
 
-    // DMA map: one wave-instruction = 1 KB = 8 rows x 128 B. A tile = 32 instructions (4 per wave), B tile = 24 (3 per
-    // wave). LDS position p (16-B units) = q*64 + lane -> row p/8, chunk position p%8 -> logical chunk = pos ^ swz(row).
-    uint32_t va[4], vb[B_PER_WAVE];
+    // DMA map: one wave-instruction = 1 KB = 8 rows x 128 B. LDS position p (16-B units) = q*64 + lane -> row p/8,
+    // chunk position p%8 -> logical chunk = pos ^ swz(row).
+    uint32_t va[A_PER_WAVE], vb[B_PER_WAVE];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int row = (wave * 4 + t) * 8 + (lane >> 3);
+    for (int t = 0; t < A_PER_WAVE; ++t) {
+        const int row = (wave * A_PER_WAVE + t) * 8 + (lane >> 3);
         va[t] = (uint32_t)row * g.lda * 2u + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
     }
 #pragma unroll
@@ -101,12 +100,11 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void gemm_nt_kernel(QstGemmArgs g
         char* st = smem + (kt & 1) * NT_STAGE;
         const uint32_t ko = (uint32_t)kt * (NBK * 2);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) dma16(ra, st + (wave * 4 + t) * 1024, va[t], ko);
+        for (int t = 0; t < A_PER_WAVE; ++t) dma16(ra, st + (wave * A_PER_WAVE + t) * 1024, va[t], ko);
 #pragma unroll
         for (int t = 0; t < B_PER_WAVE; ++t) dma16(rb, st + NT_A_BYTES + (wave * B_PER_WAVE + t) * 1024, vb[t], ko);
     };
 
-    f32x16 acc[2][3];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -138,6 +136,21 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void gemm_nt_kernel(QstGemmArgs g
         }
     }
     __builtin_amdgcn_s_barrier();                     // all waves done with the ring before the epilogue reuses it
+}
+
+template <int EPI, int WAVES_M, int WAVES_N = 2>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 2 ? 2 : 1) void gemm_nt_kernel(QstGemmArgs g) {
+    constexpr int NBM = 64 * WAVES_M, NBN = 96 * WAVES_N, NW = WAVES_M * WAVES_N;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int ntn = (g.N + NBN - 1) / NBN, ntm = (g.M + NBM - 1) / NBM;
+    const int wg = xcd_remap(blockIdx.x, ntm * ntn);
+    const int m0 = (wg / ntn) * NBM, n0 = (wg % ntn) * NBN;
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x16 acc[2][3];
+    nt_mainloop<WAVES_M, WAVES_N>(g, smem, m0, n0, acc);
 
     // ---- epilogue. The MFMA operands were swapped (D rows = n in registers, D column = m on the lane), so each
     // lane holds 4 consecutive n per register group: stage 32 rows x 96 columns of the wave's sub-tile at a time
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void gemm_nt_kernel(QstGemmArgs g
     // any store: with loads and stores interleaved per row the compiler must keep them in order (C may alias resid),
     // and in-kernel stamps showed the epilogue then costing 2-4x the whole K loop in exposed load latency.
     float* stg = (float*)smem + wave * (32 * NT_STG_LD);
-    float* bias_s = (float*)smem + (2 * WAVES_M) * (32 * NT_STG_LD) + wave * 96;     // this wave's 96 bias values
+    float* bias_s = (float*)smem + NW * (32 * NT_STG_LD) + wave * 96;     // this wave's 96 bias values
     if (g.bias) {
         for (int c = lane; c < 96; c += 64) {
             const int n = n0 + wn * 96 + c;
@@ -270,6 +283,165 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void gemm_nt_kernel(QstGemmArgs g
                 if (full) *(u32x4*)(dst + o) = pk;
                 else { u32x2 h2; h2[0] = pk[0]; h2[1] = pk[1]; *(u32x2*)(dst + o) = h2; }
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- NT with a LayerNorm fused into the epilogue
+// For N = 384 (MiniLM's hidden size) one 128 x 384 tile spans whole rows, so the LayerNorm that always follows the
+// attention-output / FFN-2 projection (forward) and the LayerNorm backward that always follows the FFN-1 / QKV dgrad
+// (backward) run on the tile while it is still on the CU: the fp32 pre-norm tensor never goes to HBM (it used to be
+// written by the GEMM and read back by a row kernel, 100 MB per LayerNorm at M = 32768, with both kernels HBM-bound).
+// 8 waves as 2 (M) x 4 (N), the same 64 x 96 wave tile and K loop as gemm_nt_kernel. Epilogue per 32-row pass: the
+// four waves of a row panel stage their sub-tiles into one [32][384] fp32 slab, then each takes 8 complete rows
+// (6 columns per lane, as the row kernels in rowops.hip do).
+constexpr int LN_N = 384, LN_LD = 388;               // slab row stride 1552 B: ds_write_b128 conflict-free
+constexpr int LN_LDS = 2 * (128 + LN_N) * NBK * 2;   // the K-loop ring (128 KB); slabs + vectors need 104 KB of it
+
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLnEpi e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntm = (g.M + 127) / 128;
+    const int m0 = xcd_remap(blockIdx.x, ntm) * 128;
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x16 acc[2][3];
+    nt_mainloop<2, 4>(g, smem, m0, 0, acc);
+
+    float* slab = (float*)smem + wm * (32 * LN_LD);
+    float* vec_s = (float*)smem + 2 * (32 * LN_LD);          // [3][384]: bias, gamma, beta
+    for (int c = tid; c < 3 * LN_N; c += 512) {
+        const int which = c / LN_N, n = c - which * LN_N;
+        float v = 0.f;
+        if (which == 0) v = g.bias ? g.bias[n] : 0.f;
+        else if (which == 1) v = e.gamma[n];
+        else if (MODE == 0) v = e.beta[n];
+        vec_s[c] = v;
+    }
+    f32x2 ag[3], ab[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { ag[t][0] = ag[t][1] = ab[t][0] = ab[t][1] = 0.f; }
+    const float inv_n = 1.f / (float)LN_N;
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        // every global input of this wave's 8 rows is requested before the pass touches LDS or stores anything
+        f32x2 rv[8][3];
+        uint32_t xv[8][3];
+        float rs[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int m = m0 + wm * 64 + i * 32 + wn * 8 + k;
+            const bool ok = m < g.M;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int c = 2 * (lane + 64 * t);
+                rv[k][t][0] = rv[k][t][1] = 0.f;
+                xv[k][t] = 0u;
+                if (ok && g.resid) rv[k][t] = *(const f32x2*)(g.resid + (size_t)m * g.ldr + c);
+                if (MODE == 1 && ok) xv[k][t] = *(const uint32_t*)((const bf16*)e.xhat + (size_t)m * LN_N + c);
+            }
+            rs[k] = (MODE == 1 && ok) ? e.rstd[m] : 0.f;
+        }
+        if (i > 0) __builtin_amdgcn_s_barrier();             // everyone has finished reading pass 0's slab
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = acc[i][j][4 * g4 + q];
+                *(f32x4*)(slab + fr * LN_LD + wn * 96 + j * 32 + 8 * g4 + 4 * fh) = v;
+            }
+        __syncthreads();                                     // slab (and, in pass 0, the vectors) complete
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int row = wn * 8 + k;
+            const int m = m0 + wm * 64 + i * 32 + row;
+            f32x2 v[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) v[t] = *(const f32x2*)(slab + row * LN_LD + 2 * (lane + 64 * t));
+            if (MODE == 0) {
+                float s = 0.f;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const f32x2 b = *(const f32x2*)(vec_s + 2 * (lane + 64 * t));
+                    v[t][0] = (v[t][0] + b[0]) + rv[k][t][0];        // same association as the unfused epilogue
+                    v[t][1] = (v[t][1] + b[1]) + rv[k][t][1];
+                    s += v[t][0] + v[t][1];
+                }
+                const float mean = wave_sum(s) * inv_n;
+                float q = 0.f;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const float a0 = v[t][0] - mean, a1 = v[t][1] - mean;
+                    q += a0 * a0 + a1 * a1;
+                }
+                const float rstd = rsqrtf(wave_sum(q) * inv_n + e.eps);      // biased variance, as nn.LayerNorm
+                if (m < g.M) {
+                    if (lane == 0 && e.rstd) e.rstd[m] = rstd;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const int c = 2 * (lane + 64 * t);
+                        const f32x2 ga = *(const f32x2*)(vec_s + LN_N + c), be = *(const f32x2*)(vec_s + 2 * LN_N + c);
+                        const float h0 = (v[t][0] - mean) * rstd, h1 = (v[t][1] - mean) * rstd;
+                        f32x2 o;
+                        o[0] = h0 * ga[0] + be[0];
+                        o[1] = h1 * ga[1] + be[1];
+                        *(f32x2*)((float*)g.C + (size_t)m * g.ldc + c) = o;
+                        if (g.C2) *(uint32_t*)((bf16*)g.C2 + (size_t)m * g.ldc + c) = pack_bf16x2(o[0], o[1]);
+                        if (e.xhat) *(uint32_t*)((bf16*)e.xhat + (size_t)m * LN_N + c) = pack_bf16x2(h0, h1);
+                    }
+                }
+            } else {
+                float s1 = 0.f, s2 = 0.f;
+                f32x2 x[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const f32x2 ga = *(const f32x2*)(vec_s + LN_N + 2 * (lane + 64 * t));
+                    x[t][0] = bf16lo(xv[k][t]); x[t][1] = bf16hi(xv[k][t]);
+                    v[t][0] += rv[k][t][0];                        // dy = dgrad + residual-path gradient
+                    v[t][1] += rv[k][t][1];
+                    ag[t][0] += v[t][0] * x[t][0]; ag[t][1] += v[t][1] * x[t][1];
+                    ab[t][0] += v[t][0];           ab[t][1] += v[t][1];
+                    v[t][0] *= ga[0]; v[t][1] *= ga[1];            // dxhat
+                    s1 += v[t][0] + v[t][1];
+                    s2 += v[t][0] * x[t][0] + v[t][1] * x[t][1];
+                }
+                const float m1 = wave_sum(s1) * inv_n, m2 = wave_sum(s2) * inv_n;
+                if (m < g.M) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const int c = 2 * (lane + 64 * t);
+                        f32x2 o;
+                        o[0] = rs[k] * (v[t][0] - m1 - x[t][0] * m2);
+                        o[1] = rs[k] * (v[t][1] - m1 - x[t][1] * m2);
+                        *(f32x2*)((float*)g.C + (size_t)m * g.ldc + c) = o;
+                        if (g.C2) *(uint32_t*)((bf16*)g.C2 + (size_t)m * g.ldc + c) = pack_bf16x2(o[0], o[1]);
+                    }
+                }
+            }
+        }
+    }
+    if (MODE == 1 && e.partials) {
+        // dgamma / dbeta of this tile's 128 rows: 8 waves x 6 columns per lane -> LDS -> one [2][384] row per tile,
+        // reduced over tiles by ln_bwd_reduce_batch_kernel in a fixed order
+        __syncthreads();
+        float* red = (float*)smem;                               // [8 waves][2][384]
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            *(f32x2*)(red + (wave * 2 + 0) * LN_N + 2 * (lane + 64 * t)) = ag[t];
+            *(f32x2*)(red + (wave * 2 + 1) * LN_N + 2 * (lane + 64 * t)) = ab[t];
+        }
+        __syncthreads();
+        for (int c = tid; c < 2 * LN_N; c += 512) {
+            const int which = c / LN_N, n = c - which * LN_N;
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) a += red[(w * 2 + which) * LN_N + n];
+            e.partials[(size_t)blockIdx.x * 2 * LN_N + c] = a;
         }
     }
 }
@@ -472,18 +644,18 @@ __global__ __launch_bounds__(384, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
 
 }  // namespace
 
-template <int EPI, int WAVES_M>
+template <int EPI, int WAVES_M, int WAVES_N = 2>
 static int launch_nt(const QstGemmArgs* a, hipStream_t st) {
-    constexpr int NBM = 64 * WAVES_M;
-    constexpr int lds = 2 * (NBM * NBK * 2 + NT_B_BYTES);       // ring; the epilogue staging (WAVES x 12.8 KB) fits inside
+    constexpr int NBM = 64 * WAVES_M, NBN = 96 * WAVES_N;
+    constexpr int lds = 2 * (NBM + NBN) * NBK * 2;       // ring; the epilogue staging (WAVES x 12.8 KB) fits inside
     static bool attr_set = false;
     if (!attr_set) {
-        QST_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, WAVES_M>,
+        QST_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, WAVES_M, WAVES_N>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     const int ntm = (a->M + NBM - 1) / NBM, ntn = (a->N + NBN - 1) / NBN;
-    gemm_nt_kernel<EPI, WAVES_M><<<dim3(ntm * ntn), dim3(128 * WAVES_M), lds, st>>>(*a);
+    gemm_nt_kernel<EPI, WAVES_M, WAVES_N><<<dim3(ntm * ntn), dim3(64 * WAVES_M * WAVES_N), lds, st>>>(*a);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
@@ -491,11 +663,12 @@ static int launch_nt(const QstGemmArgs* a, hipStream_t st) {
 extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
     if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
     if (a->K % NBK != 0 || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->N % 4 != 0 || a->ldc % 4 != 0) return QST_ERR_UNSUPPORTED;
-    if ((int64_t)256 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)NBN * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
+    if ((int64_t)256 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)384 * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     // Two 128-row workgroups per CU beat one 256-row workgroup on every shape of the step (their MFMA and
     // store phases interleave); a->splits (unused by nt otherwise) can force the tile height: 1 = 128, 2 = 256 rows.
     const bool small = (a->splits & 3) != 2;
+    if ((a->splits & 3) == 3 && epi == QST_EPI_F32_RESID) return launch_nt<QST_EPI_F32_RESID, 2, 4>(a, st);   // experiment
 #define QST_NT_CASE(E) case E: return small ? launch_nt<E, 2>(a, st) : launch_nt<E, 4>(a, st);
     switch (epi) {
         QST_NT_CASE(QST_EPI_BF16)
@@ -506,6 +679,29 @@ extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
         default: return QST_ERR_BAD_ARG;
     }
 #undef QST_NT_CASE
+}
+
+extern "C" int qst_gemm_nt_ln_supported(int N) { return N == LN_N ? 1 : 0; }
+
+extern "C" int qst_gemm_nt_ln(const QstGemmArgs* a, const QstLnEpi* ln, int mode, void* stream) {
+    if (!a || !ln || !a->A || !a->B || !a->C || !ln->gamma || a->M <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
+    if (mode != 0 && mode != 1) return QST_ERR_BAD_ARG;
+    if (mode == 0 && !ln->beta) return QST_ERR_BAD_ARG;
+    if (mode == 1 && (!ln->xhat || !ln->rstd)) return QST_ERR_BAD_ARG;
+    if (a->N != LN_N || a->K % NBK != 0 || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->ldc % 2 != 0 || (a->resid && a->ldr % 2 != 0))
+        return QST_ERR_UNSUPPORTED;
+    if ((int64_t)128 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)LN_N * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        QST_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_ln_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS));
+        QST_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_ln_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS));
+        attr_set = true;
+    }
+    const int ntm = (a->M + 127) / 128;
+    if (mode == 0) gemm_nt_ln_kernel<0><<<dim3(ntm), dim3(512), LN_LDS, (hipStream_t)stream>>>(*a, *ln);
+    else gemm_nt_ln_kernel<1><<<dim3(ntm), dim3(512), LN_LDS, (hipStream_t)stream>>>(*a, *ln);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
 }
 
 extern "C" int qst_gemm_tn_group(const QstTnGroup* grp_in, void* stream) {

@@ -165,14 +165,14 @@ extern "C" int qst_encoder_create(const qst_config* cfg, qst_encoder** out) {
             for (int64_t ch = s.off / kAlign; ch < qst_align_up(s.off + s.numel, kAlign) / kAlign; ++ch) flags[(size_t)ch] = 1;
     if (hipMalloc((void**)&e->chunk_decay, (size_t)nchunks) != hipSuccess) { delete e; return QST_ERR_HIP; }
     if (hipMemcpy(e->chunk_decay, flags.data(), (size_t)nchunks, hipMemcpyHostToDevice) != hipSuccess) {
-        hipFree(e->chunk_decay); delete e; return QST_ERR_HIP;
+        (void)hipFree(e->chunk_decay); delete e; return QST_ERR_HIP;
     }
     if (cfg->arch == QST_ARCH_MPNET) {
         std::vector<int32_t> lut(1023);
         for (int r = -511; r <= 511; ++r) lut[(size_t)(r + 511)] = qst_rel_bucket_host(r, cfg->rel_buckets, cfg->rel_max_distance);
         if (hipMalloc((void**)&e->rel_lut, 1023 * sizeof(int32_t)) != hipSuccess ||
             hipMemcpy(e->rel_lut, lut.data(), 1023 * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
-            hipFree(e->chunk_decay); if (e->rel_lut) hipFree(e->rel_lut); delete e; return QST_ERR_HIP;
+            (void)hipFree(e->chunk_decay); if (e->rel_lut) (void)hipFree(e->rel_lut); delete e; return QST_ERR_HIP;
         }
     }
     {
@@ -198,9 +198,9 @@ extern "C" int qst_encoder_create(const qst_config* cfg, qst_encoder** out) {
 
 extern "C" void qst_encoder_destroy(qst_encoder* e) {
     if (!e) return;
-    if (e->chunk_decay) hipFree(e->chunk_decay);
-    if (e->rel_lut) hipFree(e->rel_lut);
-    if (e->shadow_tab) hipFree(e->shadow_tab);
+    if (e->chunk_decay) (void)hipFree(e->chunk_decay);
+    if (e->rel_lut) (void)hipFree(e->rel_lut);
+    if (e->shadow_tab) (void)hipFree(e->shadow_tab);
     delete e;
 }
 
@@ -298,6 +298,17 @@ int nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* C
     g.A = A; g.B = B; g.C = C; g.C2 = C2; g.aux = aux; g.bias = bias; g.resid = resid;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
     return qst_gemm_nt(&g, epi, st);
+}
+// GEMM with the following LayerNorm (mode 0) / LayerNorm backward (mode 1) fused into its epilogue (N = H = 384)
+int nt_ln(const void* A, int lda, const void* B, int ldb, float* C, void* C2, const float* bias, const float* resid,
+          int M, int H, int K, int mode, const float* gamma, const float* beta, float eps, void* xhat, float* rstd,
+          float* partials, hipStream_t st) {
+    QstGemmArgs g{};
+    g.A = A; g.B = B; g.C = C; g.C2 = C2; g.bias = bias; g.resid = resid;
+    g.M = M; g.N = H; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = H; g.ldr = H;
+    QstLnEpi e{};
+    e.gamma = gamma; e.beta = beta; e.eps = eps; e.xhat = xhat; e.rstd = rstd; e.partials = partials;
+    return qst_gemm_nt_ln(&g, &e, mode, st);
 }
 int tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, float* colsum, int M, int N, int K,
        hipStream_t st) {
@@ -399,21 +410,34 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     const float* x = (const float*)(sv + p.x0);
     const void* xb = sv + p.x0b;
     float* s = (float*)(sv + p.s_scratch);
+    // H = 384: the LayerNorm after each projection runs inside that GEMM's epilogue (full-row tiles)
+    const bool fuse_ln = qst_gemm_nt_ln_supported(H) != 0;
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerAct& a = p.layers[l];
         const int b = lay.layer0[l];
         QST_TRY(nt(xb, H, W(b + W_QKV), H, sv + a.qkv, 3 * H, nullptr, nullptr, P(b + B_QKV), nullptr, 0, M, 3 * H, H,
                    QST_EPI_BF16, st));
         QST_TRY(qst_attention_fwd(sv + a.qkv, mask, rel, nseq, L, A, d, sv + a.ctx, (float*)(sv + a.lse), st));
-        QST_TRY(nt(sv + a.ctx, H, W(b + W_O), H, s, H, nullptr, nullptr, P(b + B_O), x, H, M, H, H, QST_EPI_F32_RESID, st));
-        QST_TRY(qst_ln_fwd(s, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, (float*)(sv + a.y1), sv + a.y1b,
-                           sv + a.xh1, (float*)(sv + a.rs1), st));
+        if (fuse_ln) {
+            QST_TRY(nt_ln(sv + a.ctx, H, W(b + W_O), H, (float*)(sv + a.y1), sv + a.y1b, P(b + B_O), x, M, H, H, 0,
+                          P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, sv + a.xh1, (float*)(sv + a.rs1), nullptr, st));
+        } else {
+            QST_TRY(nt(sv + a.ctx, H, W(b + W_O), H, s, H, nullptr, nullptr, P(b + B_O), x, H, M, H, H, QST_EPI_F32_RESID, st));
+            QST_TRY(qst_ln_fwd(s, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, (float*)(sv + a.y1), sv + a.y1b,
+                               sv + a.xh1, (float*)(sv + a.rs1), st));
+        }
         QST_TRY(nt(sv + a.y1b, H, W(b + W_1), H, sv + a.u, I, sv + a.hact, nullptr, P(b + B_1), nullptr, 0, M, I, H,
                    QST_EPI_GELU, st));
-        QST_TRY(nt(sv + a.hact, I, W(b + W_2), I, s, H, nullptr, nullptr, P(b + B_2), (const float*)(sv + a.y1), H, M, H,
-                   I, QST_EPI_F32_RESID, st));
-        QST_TRY(qst_ln_fwd(s, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, M, H, (float*)(sv + a.x), sv + a.xb,
-                           sv + a.xh2, (float*)(sv + a.rs2), st));
+        if (fuse_ln) {
+            QST_TRY(nt_ln(sv + a.hact, I, W(b + W_2), I, (float*)(sv + a.x), sv + a.xb, P(b + B_2),
+                          (const float*)(sv + a.y1), M, H, I, 0, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, sv + a.xh2,
+                          (float*)(sv + a.rs2), nullptr, st));
+        } else {
+            QST_TRY(nt(sv + a.hact, I, W(b + W_2), I, s, H, nullptr, nullptr, P(b + B_2), (const float*)(sv + a.y1), H, M, H,
+                       I, QST_EPI_F32_RESID, st));
+            QST_TRY(qst_ln_fwd(s, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, M, H, (float*)(sv + a.x), sv + a.xb,
+                               sv + a.xh2, (float*)(sv + a.rs2), st));
+        }
         x = (const float*)(sv + a.x);
         xb = sv + a.xb;
     }
@@ -462,9 +486,15 @@ extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, 
     QstLnReduceBatch lnb{};
     lnb.H = H;
     lnb.nblocks = (int)(qst_ln_bwd_scratch_bytes(M, H) / ((size_t)2 * H * sizeof(float)));
-    auto ln_slot = [&](int slot, float* dg, float* db) {
+    // H = 384: every LayerNorm backward except the top one (whose input comes from the pooling head, not from a GEMM)
+    // runs inside the epilogue of the dgrad GEMM that produces its input; those write one partial row per 128-row tile
+    const bool fuse_ln = qst_gemm_nt_ln_supported(H) != 0;
+    const int fused_rows = (M + 127) / 128;
+    auto ln_slot = [&](int slot, float* dg, float* db, int nrows = 0) {
         float* sp = (float*)(ws + w.lnred + (size_t)slot * w.lnred_stride);
-        lnb.partials[lnb.count] = sp; lnb.dgamma[lnb.count] = dg; lnb.dbeta[lnb.count] = db; ++lnb.count;
+        lnb.partials[lnb.count] = sp; lnb.dgamma[lnb.count] = dg; lnb.dbeta[lnb.count] = db;
+        lnb.nblocks_each[lnb.count] = nrows;
+        ++lnb.count;
         return sp;
     };
     float* drel = nullptr;
@@ -480,16 +510,24 @@ extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, 
         const LayerAct& a = p.layers[l];
         const int b = lay.layer0[l];
         const void* xin_b = (l == 0) ? (const void*)(sv + p.x0b) : (const void*)(sv + p.layers[l - 1].xb);
-        // LN2 -> ds2 (fp32 for the residual path, bf16 for the GEMMs)
-        QST_TRY(qst_ln_bwd(dxa, sv + a.xh2, (const float*)(sv + a.rs2), P(b + LN2_G), M, H, ds, dsb, nullptr, nullptr,
-                           ln_slot(2 * l + 1, G(b + LN2_G), G(b + LN2_B)), st));
+        // LN2 -> ds2 (fp32 for the residual path, bf16 for the GEMMs). Fused mode: only the top layer runs it as a
+        // row kernel; below, (ds, dsb) were written by the QKV dgrad of layer l+1.
+        if (!fuse_ln || l == c.num_layers - 1)
+            QST_TRY(qst_ln_bwd(dxa, sv + a.xh2, (const float*)(sv + a.rs2), P(b + LN2_G), M, H, ds, dsb, nullptr, nullptr,
+                               ln_slot(2 * l + 1, G(b + LN2_G), G(b + LN2_B)), st));
         // FFN2 dgrad through GELU: du = (ds2 . W2) * gelu'(u)   (a.u holds gelu'(u), written by the forward epilogue)
         QST_TRY(nt(dsb, H, WT(b + W_2), H, du, I, nullptr, sv + a.u, nullptr, nullptr, 0, M, I, H, QST_EPI_GELU_BWD, st));
-        // FFN1 dgrad + residual: dy1 = du . W1 + ds2
-        QST_TRY(nt(du, I, WT(b + W_1), I, dxb, H, nullptr, nullptr, nullptr, ds, H, M, H, I, QST_EPI_F32_RESID, st));
-        // LN1 -> ds1
-        QST_TRY(qst_ln_bwd(dxb, sv + a.xh1, (const float*)(sv + a.rs1), P(b + LN1_G), M, H, ds, dsb1, nullptr, nullptr,
-                           ln_slot(2 * l, G(b + LN1_G), G(b + LN1_B)), st));
+        // FFN1 dgrad + residual: dy1 = du . W1 + ds2 ; LN1 backward -> ds1 (fp32 in `ds1`, bf16 in dsb1)
+        const float* ds1 = ds;
+        if (fuse_ln) {
+            QST_TRY(nt_ln(du, I, WT(b + W_1), I, dxb, dsb1, nullptr, ds, M, H, I, 1, P(b + LN1_G), nullptr, 0.f, sv + a.xh1,
+                          (float*)(sv + a.rs1), ln_slot(2 * l, G(b + LN1_G), G(b + LN1_B), fused_rows), st));
+            ds1 = dxb;
+        } else {
+            QST_TRY(nt(du, I, WT(b + W_1), I, dxb, H, nullptr, nullptr, nullptr, ds, H, M, H, I, QST_EPI_F32_RESID, st));
+            QST_TRY(qst_ln_bwd(dxb, sv + a.xh1, (const float*)(sv + a.rs1), P(b + LN1_G), M, H, ds, dsb1, nullptr, nullptr,
+                               ln_slot(2 * l, G(b + LN1_G), G(b + LN1_B)), st));
+        }
         // attention output projection dgrad, attention core
         QST_TRY(nt(dsb1, H, WT(b + W_O), H, dctx, H, nullptr, nullptr, nullptr, nullptr, 0, M, H, H, QST_EPI_BF16, st));
         QST_TRY(qst_attention_bwd(sv + a.qkv, sv + a.ctx, dctx, (const float*)(sv + a.lse), mask, rel, nseq, L, A, d,
@@ -510,11 +548,23 @@ extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, 
             set(3, dqkv, 3 * H, xin_b, H, b + W_QKV, b + B_QKV);       // dWqkv [3H, H]
             QST_TRY(qst_gemm_tn_group(&grp, st));
         }
-        // QKV projection dgrad + residual: dx_in = dqkv . Wqkv + ds1
-        QST_TRY(nt(dqkv, 3 * H, WT(b + W_QKV), 3 * H, dxa, H, nullptr, nullptr, nullptr, ds, H, M, H, 3 * H,
-                   QST_EPI_F32_RESID, st));
+        // QKV projection dgrad + residual: dx_in = dqkv . Wqkv + ds1. Fused mode: followed in the same kernel by the
+        // backward of the LayerNorm that produced this layer's input (LN2 of layer l-1, or the embedding LayerNorm)
+        if (fuse_ln && l > 0) {
+            const LayerAct& lo = p.layers[l - 1];
+            const int bl = lay.layer0[l - 1];
+            QST_TRY(nt_ln(dqkv, 3 * H, WT(b + W_QKV), 3 * H, ds, dsb, nullptr, ds1, M, H, 3 * H, 1, P(bl + LN2_G), nullptr, 0.f,
+                          sv + lo.xh2, (float*)(sv + lo.rs2),
+                          ln_slot(2 * (l - 1) + 1, G(bl + LN2_G), G(bl + LN2_B), fused_rows), st));
+        } else if (fuse_ln) {
+            QST_TRY(nt_ln(dqkv, 3 * H, WT(b + W_QKV), 3 * H, ds, nullptr, nullptr, ds1, M, H, 3 * H, 1, P(lay.eg), nullptr, 0.f,
+                          sv + p.xh0, (float*)(sv + p.rs0), ln_slot(2 * c.num_layers, G(lay.eg), G(lay.eb), fused_rows), st));
+        } else {
+            QST_TRY(nt(dqkv, 3 * H, WT(b + W_QKV), 3 * H, dxa, H, nullptr, nullptr, nullptr, ds1, H, M, H, 3 * H,
+                       QST_EPI_F32_RESID, st));
+        }
     }
-    if (do_embed)
+    if (do_embed && !fuse_ln)
         QST_TRY(qst_ln_bwd(dxa, sv + p.xh0, (const float*)(sv + p.rs0), P(lay.eg), M, H, ds, nullptr, nullptr, nullptr,
                            ln_slot(2 * c.num_layers, G(lay.eg), G(lay.eb)), st));
     if (lnb.count > 0) {

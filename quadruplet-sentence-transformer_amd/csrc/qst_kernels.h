@@ -33,6 +33,23 @@ typedef struct {
 
 /* C[M,N] = A[M,K] . B[N,K]^T with epilogue `epi`. K % 64 == 0, lda/ldb % 8 == 0. */
 int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream);
+/* NT GEMM with a LayerNorm fused into the epilogue (one 128 x 384 tile spans whole rows: N must be 384;
+ * qst_gemm_nt_ln_supported(N) tells). xhat is bf16 [M, 384] contiguous, rstd f32 [M].
+ *  mode 0 (forward):  v = A.B^T + bias + resid ; y = LayerNorm(v) -> C (f32), C2 (bf16, nullable);
+ *                     xhat, rstd (nullable) are written for the backward pass.
+ *  mode 1 (backward): dy = A.B^T + resid ; ds = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)) -> C (f32),
+ *                     C2 (bf16, nullable); partials (nullable) f32 [ceil(M/128)][2][384] receives each tile's
+ *                     sum(dy*xhat) and sum(dy) rows (reduce with qst_ln_bwd_reduce_batch). */
+typedef struct {
+    const float* gamma;
+    const float* beta;
+    float eps;
+    void* xhat;
+    float* rstd;
+    float* partials;
+} QstLnEpi;
+int qst_gemm_nt_ln_supported(int N);
+int qst_gemm_nt_ln(const QstGemmArgs* a, const QstLnEpi* ln, int mode, void* stream);
 /* C[N,K] (f32, atomically accumulated) += A[M,N]^T . B[M,K]; colsum[N] += sum_m A[m,:]. */
 int qst_gemm_tn(const QstGemmArgs* a, void* stream);
 /* Several such products over the same M in ONE launch (all weight gradients of a layer). */
@@ -70,6 +87,7 @@ typedef struct {
     const float* partials[QST_LN_BATCH_MAX];
     float* dgamma[QST_LN_BATCH_MAX];
     float* dbeta[QST_LN_BATCH_MAX];
+    int32_t nblocks_each[QST_LN_BATCH_MAX];   /* per-entry row count of partials; 0 = nblocks */
 } QstLnReduceBatch;
 int qst_ln_bwd_reduce_batch(const QstLnReduceBatch* b, void* stream);
 /* Embedding backward: scatter ds rows into word/pos/type gradient tables. */

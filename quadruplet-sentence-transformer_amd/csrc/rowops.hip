@@ -479,7 +479,8 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_batch_kernel(QstLnReduceBat
     if (col >= 2 * b.H) return;
     const float* partials = b.partials[which];
     float acc = 0.f;
-    for (int r = blockIdx.y; r < b.nblocks; r += gridDim.y) acc += partials[(size_t)r * 2 * b.H + col];
+    const int nb = b.nblocks_each[which] > 0 ? b.nblocks_each[which] : b.nblocks;
+    for (int r = blockIdx.y; r < nb; r += gridDim.y) acc += partials[(size_t)r * 2 * b.H + col];
     atomicAdd(col < b.H ? b.dgamma[which] + col : b.dbeta[which] + (col - b.H), acc);
 }
 

@@ -219,6 +219,80 @@ def test_layernorm_fwd_bwd(lib, M, H):
     torch.testing.assert_close(dg.cpu(), gr.grad, rtol=1e-2, atol=1e-2 * math.sqrt(M))
 
 
+@pytest.mark.parametrize("M,K", [(128, 64), (300, 384), (1000, 1536), (4096, 1152)])
+def test_gemm_nt_fused_layernorm(lib, M, K):
+    """qst_gemm_nt_ln (N = 384 full-row tiles) against the unfused pair it replaces: qst_gemm_nt(F32_RESID) followed
+    by qst_ln_fwd / qst_ln_bwd -- same arithmetic, so fp32 outputs agree to accumulation-order noise."""
+    N = 384
+    assert lib.qst_gemm_nt_ln_supported(N) == 1 and lib.qst_gemm_nt_ln_supported(768) == 0
+    g = torch.Generator().manual_seed(M + K)
+    Ad = dev(bfr(torch.randn(M, K, generator=g)).to(torch.bfloat16))
+    Bd = dev(bfr(torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16))
+    bias, resid = dev(torch.randn(N, generator=g)), dev(torch.randn(M, N, generator=g))
+    gamma, beta = dev(1 + 0.1 * torch.randn(N, generator=g)), dev(0.1 * torch.randn(N, generator=g))
+    eps = 1e-12
+
+    def ln_epi(**kw):
+        e = _lib.QstLnEpi()
+        e._keep = [v for v in kw.values() if torch.is_tensor(v)]
+        for k, v in kw.items():
+            setattr(e, k, v.data_ptr() if torch.is_tensor(v) else v)
+        return e
+
+    def f32(*shape):
+        return torch.empty(*shape, dtype=torch.float32, device="cuda")
+
+    def b16(*shape):
+        return torch.empty(*shape, dtype=torch.bfloat16, device="cuda")
+
+    # ---- forward: y = LN(A.B^T + bias + resid)
+    s = f32(M, N)
+    _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=s, bias=bias, resid=resid, M=M, N=N, K=K, lda=K, ldb=K, ldc=N,
+                                         ldr=N), 1, stream()))
+    y0, yb0, xh0, rs0 = f32(M, N), b16(M, N), b16(M, N), f32(M)
+    _lib.check(lib.qst_ln_fwd(s.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, M, N, y0.data_ptr(), yb0.data_ptr(),
+                              xh0.data_ptr(), rs0.data_ptr(), stream()))
+    y1, yb1, xh1, rs1 = f32(M, N), b16(M, N), b16(M, N), f32(M)
+    _lib.check(lib.qst_gemm_nt_ln(gemm_args(A=Ad, B=Bd, C=y1, C2=yb1, bias=bias, resid=resid, M=M, N=N, K=K, lda=K, ldb=K,
+                                            ldc=N, ldr=N),
+                                  ln_epi(gamma=gamma, beta=beta, eps=eps, xhat=xh1, rstd=rs1), 0, stream()))
+    torch.testing.assert_close(y1, y0, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(rs1, rs0, rtol=1e-5, atol=0)
+    torch.testing.assert_close(yb1.float(), yb0.float(), rtol=8e-3, atol=1e-2)
+    torch.testing.assert_close(xh1.float(), xh0.float(), rtol=8e-3, atol=1e-2)
+    ref = torch.nn.functional.layer_norm(Ad.float() @ Bd.float().t() + bias + resid, (N,), gamma, beta, eps)
+    torch.testing.assert_close(y1, ref, rtol=1e-4, atol=2e-4)
+    # outputs that the caller does not want may be NULL (inference)
+    y2 = f32(M, N)
+    _lib.check(lib.qst_gemm_nt_ln(gemm_args(A=Ad, B=Bd, C=y2, bias=bias, resid=resid, M=M, N=N, K=K, lda=K, ldb=K, ldc=N,
+                                            ldr=N), ln_epi(gamma=gamma, beta=beta, eps=eps), 0, stream()))
+    torch.testing.assert_close(y2, y1, rtol=0, atol=0)
+
+    # ---- backward: ds = LN_bwd(A.B^T + resid), dgamma/dbeta through per-tile partial sums
+    dy = f32(M, N)
+    _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=dy, resid=resid, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, ldr=N), 1,
+                               stream()))
+    ds0, dsb0 = f32(M, N), b16(M, N)
+    dg0, db0 = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+    scratch = torch.empty(lib.qst_ln_bwd_scratch_bytes(M, N) // 4, device="cuda")
+    _lib.check(lib.qst_ln_bwd(dy.data_ptr(), xh0.data_ptr(), rs0.data_ptr(), gamma.data_ptr(), M, N, ds0.data_ptr(),
+                              dsb0.data_ptr(), dg0.data_ptr(), db0.data_ptr(), scratch.data_ptr(), stream()))
+    ds1, dsb1 = f32(M, N), b16(M, N)
+    ntile = (M + 127) // 128
+    part = torch.full((ntile, 2, N), float("nan"), device="cuda")
+    _lib.check(lib.qst_gemm_nt_ln(gemm_args(A=Ad, B=Bd, C=ds1, C2=dsb1, resid=resid, M=M, N=N, K=K, lda=K, ldb=K, ldc=N,
+                                            ldr=N),
+                                  ln_epi(gamma=gamma, xhat=xh0, rstd=rs0, partials=part), 1, stream()))
+    scale = ds0.abs().max().item()
+    torch.testing.assert_close(ds1, ds0, rtol=1e-4, atol=1e-4 * scale)
+    torch.testing.assert_close(dsb1.float(), dsb0.float(), rtol=8e-3, atol=1e-2 * scale)
+    torch.testing.assert_close(part[:, 0].sum(0), dg0, rtol=1e-4, atol=1e-4 * math.sqrt(M) * dy.abs().max().item())
+    torch.testing.assert_close(part[:, 1].sum(0), db0, rtol=1e-4, atol=1e-4 * math.sqrt(M) * dy.abs().max().item())
+    # bad shapes are refused, not mis-computed
+    assert lib.qst_gemm_nt_ln(gemm_args(A=Ad, B=Bd, C=ds1, M=M, N=192, K=K, lda=K, ldb=K, ldc=192),
+                              ln_epi(gamma=gamma, xhat=xh0, rstd=rs0), 1, stream()) == -2
+
+
 # ------------------------------------------------------------------ attention
 def attn_ref(qkv, mask, rel, n, L, A, d):
     H = A * d

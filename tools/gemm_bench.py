@@ -46,13 +46,45 @@ def main():
         g.A, g.B, g.C, g.C2, g.aux, g.bias, g.resid = A.data_ptr(), B.data_ptr(), C.data_ptr(), C2.data_ptr(), aux.data_ptr(), bias.data_ptr(), resid.data_ptr()
         g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.ldr = M, N, K, K, K, N, N
         res = []
-        for force in (1, 2):
+        for force in (1, 2, 3):
             g.splits = force
             res.append(timeit(lambda: _lib.check(lib.qst_gemm_nt(g, epi, st))))
         g.splits = 0
         us = timeit(lambda: _lib.check(lib.qst_gemm_nt(g, epi, st)))
         tot += us
-        print(f"nt {name:31s} {us:8.1f} {2.0 * M * N * K / us / 1e6:8.1f}   (128-row tile {res[0]:.1f} us, 256-row tile {res[1]:.1f} us)")
+        print(f"nt {name:31s} {us:8.1f} {2.0 * M * N * K / us / 1e6:8.1f}   (128-row tile {res[0]:.1f} us, 256-row tile {res[1]:.1f} us, 128x384 tile {res[2]:.1f} us)")
+    # fused GEMM + LayerNorm (N = 384 full-row tiles) against the unfused pair
+    if lib.qst_gemm_nt_ln_supported(H):
+        for name, K, mode in [("out+LN1 fwd", H, 0), ("FFN2+LN2 fwd", I, 0), ("FFN1 dgrad+LN1 bwd", I, 1), ("QKV dgrad+LN2 bwd", 3 * H, 1)]:
+            A = torch.randn(M, K, device=dev).to(bf)
+            B = (torch.randn(H, K, device=dev) * 0.02).to(bf)
+            bias = torch.zeros(H, device=dev); gamma = torch.ones(H, device=dev); beta = torch.zeros(H, device=dev)
+            resid = torch.randn(M, H, device=dev)
+            s_ = torch.empty(M, H, device=dev); y = torch.empty(M, H, device=dev)
+            yb = torch.empty(M, H, device=dev, dtype=bf); xh = torch.randn(M, H, device=dev).to(bf)
+            rs = torch.rand(M, device=dev) + 0.5
+            part = torch.empty((M + 127) // 128, 2, H, device=dev)
+            scratch = torch.empty(lib.qst_ln_bwd_scratch_bytes(M, H) // 4, device=dev)
+            g = _lib.QstGemmArgs()
+            g.A, g.B, g.C, g.C2, g.bias, g.resid = A.data_ptr(), B.data_ptr(), y.data_ptr(), yb.data_ptr(), bias.data_ptr(), resid.data_ptr()
+            g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.ldr = M, H, K, K, K, H, H
+            e = _lib.QstLnEpi()
+            e.gamma, e.beta, e.eps, e.xhat, e.rstd, e.partials = gamma.data_ptr(), beta.data_ptr(), 1e-12, xh.data_ptr(), rs.data_ptr(), part.data_ptr()
+            g0 = _lib.QstGemmArgs()
+            g0.A, g0.B, g0.C, g0.bias, g0.resid = A.data_ptr(), B.data_ptr(), s_.data_ptr(), bias.data_ptr(), resid.data_ptr()
+            g0.M, g0.N, g0.K, g0.lda, g0.ldb, g0.ldc, g0.ldr = M, H, K, K, K, H, H
+
+            def pair():
+                _lib.check(lib.qst_gemm_nt(g0, 1, st))
+                if mode == 0:
+                    _lib.check(lib.qst_ln_fwd(s_.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-12, M, H, y.data_ptr(),
+                                              yb.data_ptr(), xh.data_ptr(), rs.data_ptr(), st))
+                else:
+                    _lib.check(lib.qst_ln_bwd(s_.data_ptr(), xh.data_ptr(), rs.data_ptr(), gamma.data_ptr(), M, H, y.data_ptr(),
+                                              yb.data_ptr(), None, None, scratch.data_ptr(), st))
+            t_pair = timeit(pair)
+            t_fused = timeit(lambda: _lib.check(lib.qst_gemm_nt_ln(g, e, mode, st)))
+            print(f"ln {name:31s} fused {t_fused:7.1f} us   unfused pair {t_pair:7.1f} us")
     for name, N, K in [("dW2 [H,I]", H, I), ("dW1 [I,H]", I, H), ("dWo [H,H]", H, H), ("dWqkv [3H,H]", 3 * H, H)]:
         A = torch.randn(M, N, device=dev).to(bf)
         B = torch.randn(M, K, device=dev).to(bf)
