@@ -403,6 +403,281 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dkv_kernel(Attn
         }
 }
 
+// ------------------------------------------------------------------ backward, whole (sequence, head) in one workgroup
+// L <= 128: the score matrix of one (sequence, head) is a single 128 x 128 tile, so dQ, dK and dV come out of ONE
+// evaluation of S, P, dP and dS (the two-kernel path above evaluates them twice and reads q/k/v/dO twice).
+// Orientation as in the dK/dV kernel (S = Q.K^T: rows = queries in registers, column = key on the lane; wave w owns
+// keys 32w..32w+31 and accumulates dK^T, dV^T over the query tiles). dQ needs the contraction over keys, i.e. dS^T as
+// an operand: every wave drops its dS tiles (bf16, already scaled) into a [key][query] image, and after one barrier
+// wave w computes dQ^T = K^T.dS^T for ITS query tile from that image with transposing LDS reads. delta_i = dO_i.O_i is
+// computed while dO is being staged.
+constexpr int DS_IMG = 128 * 128 * 2;
+constexpr float kLog2e = 1.4426950408889634f;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ uint32_t ds_off(int row, int byte) { return (uint32_t)(row * 256 + (byte ^ ((row & 3) << 6))); }
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = D / 16, DB = D / 32, IMG = 128 * D * 2, CPR = D / 8, PER = 128 * CPR / 256;
+    char* qimg = smem;                  // Q rows   (S = Q.K^T)
+    char* qtr = smem + IMG;             // Q^T      (dK^T = Q^T.dS)
+    char* dimg = smem + 2 * IMG;        // dO rows  (dP = dO.V^T)
+    char* dtr = smem + 3 * IMG;         // dO^T     (dV^T = dO^T.P)
+    char* ktr = smem + 4 * IMG;         // K^T      (dQ^T = K^T.dS^T)
+    char* dsimg = smem + 5 * IMG;       // dS [key][query] bf16
+    float* lse_s = (float*)(smem + 5 * IMG + DS_IMG);   // [128]
+    float* del_s = lse_s + 128;                          // [128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, fr = lane & 31;
+    const int ld = 3 * a.H, rows = a.L;
+    const int j0 = wave * 32;
+    const bool active = j0 < rows;
+    const int kj = j0 + fr;
+    const int nitems = a.nseq * a.A;
+    const float sc2 = a.scale * kLog2e;
+
+    // Persistent over (sequence, head) items: the global loads of item n+1 are in flight (in registers) while item n
+    // is computed -- a workgroup per item spent most of its life waiting for its own loads at two workgroups per CU.
+    u32x4 pq[PER], pd[PER], po[PER], pk[PER], pv[PER];
+    float nmadd = 0.f, nlse = 0.f;
+    // part 0..3: a quarter of the next item's loads each. Issued between the score tiles so that the CU's address
+    // unit sees them spread over the compute phase (issued as one burst, with all eight waves of the CU doing the same,
+    // the ten loads took 3700 cycles to get through it while nothing else ran); part < 0 issues everything.
+    auto prefetch = [&](int item, int part) {
+        const int head = item % a.A, seq = item / a.A;
+        const bf16* base = a.qkv + (size_t)seq * a.L * ld + head * D;
+        const bf16* dbase = a.dctx + (size_t)seq * a.L * a.H + head * D;
+        const bf16* obase = a.ctx + (size_t)seq * a.L * a.H + head * D;
+        const u32x4 z = {0, 0, 0, 0};
+        if (part < 0 || part == 0) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int idx = tid + 256 * k, row = idx / CPR, c = idx % CPR;
+                pq[k] = row < rows ? *(const u32x4*)(base + (size_t)row * ld + c * 8) : z;
+            }
+            if (active) nmadd = a.mask[(size_t)seq * a.L + kj] ? 0.f : kMaskMin;
+        }
+        if (part < 0 || part == 1) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int idx = tid + 256 * k, row = idx / CPR, c = idx % CPR;
+                pk[k] = row < rows ? *(const u32x4*)(base + (size_t)row * ld + a.H + c * 8) : z;
+            }
+            if (tid < rows) nlse = a.lse_in[((size_t)seq * a.A + head) * a.L + tid];
+        }
+        if (part < 0 || part == 2) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int idx = tid + 256 * k, row = idx / CPR, c = idx % CPR;
+                pv[k] = row < rows ? *(const u32x4*)(base + (size_t)row * ld + 2 * a.H + c * 8) : z;
+            }
+        }
+        if (part < 0 || part == 3) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int idx = tid + 256 * k, row = idx / CPR, c = idx % CPR;
+                pd[k] = row < rows ? *(const u32x4*)(dbase + (size_t)row * a.H + c * 8) : z;
+                po[k] = row < rows ? *(const u32x4*)(obase + (size_t)row * a.H + c * 8) : z;
+            }
+        }
+    };
+
+#ifdef QST_STAMP_ATTN
+    // diagnostic build: s_memtime at the phase boundaries of the third item, wave 0 -> a.delta as uint64 [block][8]
+#define QST_STAMP(k) do { if (iter == 2 && tid == 0) ((unsigned long long*)a.delta)[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define QST_STAMP(k) do {} while (0)
+#endif
+    // Item order: d = 32 head slices are 64 bytes, so heads 2k and 2k+1 of a token share every 128-byte line.
+    // Workgroups b and b + grid/2 sit on the same XCD (grid/2 is a multiple of 8) and walk the two heads of the same
+    // pair in step, so each line leaves HBM once and the partner finds it in that XCD's L2.
+    const int half = gridDim.x >> 1;
+    const bool paired = (a.A % 2 == 0) && (gridDim.x % 16 == 0);
+    const int bsub = paired ? ((int)blockIdx.x >= half) : 0;
+    const int bp = paired ? (int)blockIdx.x - bsub * half : (int)blockIdx.x;
+    const int stride = paired ? half : (int)gridDim.x;
+    const int nunits = paired ? nitems / 2 : nitems;
+    auto item_of = [&](int unit) { return paired ? 2 * unit + bsub : unit; };
+    int unit = bp, iter = 0;
+    if (unit < nunits) prefetch(item_of(unit), -1);
+    for (; unit < nunits; unit += stride, ++iter) {
+        const int item = item_of(unit);
+        const int head = item % a.A, seq = item / a.A;
+        __syncthreads();                                 // the previous item's readers of the images are done
+        QST_STAMP(0);
+        const float madd2 = nmadd * kLog2e;              // 0 or -inf
+        if (tid < rows) lse_s[tid] = -nlse * kLog2e;
+        // delta_i = sum_dd dO[i][dd] * O[i][dd]: 8 elements per thread, CPR adjacent threads per row
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            float part = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                part += bf16lo(pd[k][e]) * bf16lo(po[k][e]) + bf16hi(pd[k][e]) * bf16hi(po[k][e]);
+#pragma unroll
+            for (int o = 1; o < CPR; o <<= 1) part += __shfl_xor(part, o);
+            const int idx = tid + 256 * k, row = idx / CPR, c = idx % CPR;
+            if (c == 0) del_s[row] = part;
+            *(u32x4*)(qimg + rr_off<D>(row, c)) = pq[k];
+            *(u32x4*)(qtr + tr_off<D>(row, c * 16)) = pq[k];
+            *(u32x4*)(dimg + rr_off<D>(row, c)) = pd[k];
+            *(u32x4*)(dtr + tr_off<D>(row, c * 16)) = pd[k];
+            *(u32x4*)(ktr + tr_off<D>(row, c * 16)) = pk[k];
+            *(u32x4*)(dsimg + ds_off(row, c * 16)) = pv[k];          // V rows borrow the head of the dS image rows
+        }
+        QST_STAMP(7);
+        const bool more = unit + stride < nunits;
+        const int next_item = more ? item_of(unit + stride) : 0;
+        QST_STAMP(1);
+        __syncthreads();
+        QST_STAMP(2);
+
+        f32x16 dk[DB], dv[DB];
+#pragma unroll
+        for (int b = 0; b < DB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[b][r] = 0.f; dv[b][r] = 0.f; }
+        if (active) {
+            // this wave's K / V operand fragments (lane = key row). Image rows of a wave's own keys are touched by no
+            // other wave before the next barrier, so the V rows parked in the dS image are read before this wave's
+            // first dS tile overwrites them (program order).
+            bf16x8 kf[KS], vf[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                kf[s] = *(const bf16x8*)(ktr + tr_off<D>(kj, (16 * s + 8 * h) * 2));
+                vf[s] = *(const bf16x8*)(dsimg + ds_off(kj, (16 * s + 8 * h) * 2));
+            }
+            for (int it = 0; it < rows / 32; ++it) {
+                if (more) prefetch(next_item, it);
+                f32x16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 qf = *(const bf16x8*)(qimg + rr_off<D>(it * 32 + fr, 2 * ks + h));
+                    const bf16x8 df = *(const bf16x8*)(dimg + rr_off<D>(it * 32 + fr, 2 * ks + h));
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], s, 0, 0, 0);      // rows i, col j
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], dp, 0, 0, 0);
+                }
+                // Elementwise part, trimmed because it (not the MFMAs) bounds this kernel: log2(e), the softmax scale,
+                // the key mask and -lse are folded into one packed fma feeding v_exp_f32 directly; dS stays unscaled
+                // (dK and dQ are scaled once at the end); P and dS are rounded to bf16 once and the packed words serve
+                // both as MFMA fragments and as the dS image rows.
+                uint32_t pw[4][2], sw[4][2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int il = it * 32 + 8 * g + 4 * h;     // accumulator registers 4g..4g+3 = query rows il..il+3
+                    const f32x4 l4 = *(const f32x4*)(lse_s + il), d4 = *(const f32x4*)(del_s + il);
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        const int r = 4 * g + e;
+                        f32x2 sv, cv, dpv, dv2;
+                        sv[0] = s[r]; sv[1] = s[r + 1];
+                        cv[0] = l4[e] + madd2; cv[1] = l4[e + 1] + madd2;
+                        dpv[0] = dp[r]; dpv[1] = dp[r + 1];
+                        dv2[0] = d4[e]; dv2[1] = d4[e + 1];
+                        f32x2 v = sv * sc2 + cv;                                  // log2 of the probability
+                        if (a.rel) {
+                            v[0] += kLog2e * a.rel[((size_t)head * a.L + il + e) * a.L + kj];
+                            v[1] += kLog2e * a.rel[((size_t)head * a.L + il + e + 1) * a.L + kj];
+                        }
+                        f32x2 pr;
+                        pr[0] = __builtin_amdgcn_exp2f(v[0]);
+                        pr[1] = __builtin_amdgcn_exp2f(v[1]);
+                        const f32x2 dsr = pr * (dpv - dv2);                       // dS (unscaled) = d(score)
+                        if (a.drel) {
+                            atomicAdd(a.drel + ((size_t)head * a.L + il + e) * a.L + kj, dsr[0]);
+                            atomicAdd(a.drel + ((size_t)head * a.L + il + e + 1) * a.L + kj, dsr[1]);
+                        }
+                        pw[g][e >> 1] = pack_bf16x2(pr[0], pr[1]);
+                        sw[g][e >> 1] = pack_bf16x2(dsr[0], dsr[1]);
+                    }
+                    u32x2 pkd;
+                    pkd[0] = sw[g][0]; pkd[1] = sw[g][1];
+                    *(u32x2*)(dsimg + ds_off(kj, il * 2)) = pkd;
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    u32x4 pu, su;
+                    pu[0] = pw[2 * ks][0]; pu[1] = pw[2 * ks][1]; pu[2] = pw[2 * ks + 1][0]; pu[3] = pw[2 * ks + 1][1];
+                    su[0] = sw[2 * ks][0]; su[1] = sw[2 * ks][1]; su[2] = sw[2 * ks + 1][0]; su[3] = sw[2 * ks + 1][1];
+                    const bf16x8 pf = __builtin_bit_cast(bf16x8, pu), sf = __builtin_bit_cast(bf16x8, su);
+#pragma unroll
+                    for (int b = 0; b < DB; ++b) {
+                        const bf16x8 dt = tr_frag<D>(dtr, it * 32 + 16 * ks, b, lane);
+                        const bf16x8 qt = tr_frag<D>(qtr, it * 32 + 16 * ks, b, lane);
+                        dv[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt, pf, dv[b], 0, 0, 0);
+                        dk[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, sf, dk[b], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < DB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dk[b][r] *= a.scale;
+        }
+        if (more)
+            for (int part = active ? rows / 32 : 0; part < 4; ++part) prefetch(next_item, part);
+        QST_STAMP(3);
+        __syncthreads();                                 // every wave's dS tiles are in the image
+        QST_STAMP(4);
+        if (active) {
+            // dQ^T[dd][i] for this wave's query tile i = 32*wave + (lane & 31): contraction over all keys
+            f32x16 dq[DB];
+#pragma unroll
+            for (int b = 0; b < DB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dq[b][r] = 0.f;
+            const int li = lane & 15, q = li >> 2, pp = li & 3, gsel = (lane >> 4) & 1;
+            const int byte = wave * 64 + gsel * 32 + 8 * pp;
+            for (int ks = 0; ks < rows / 16; ++ks) {
+                const bf16x4 lo = lds_tr(dsimg + ds_off(16 * ks + 4 * h + q, byte));
+                const bf16x4 hi = lds_tr(dsimg + ds_off(16 * ks + 8 + 4 * h + q, byte));
+                bf16x8 df;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { df[e] = lo[e]; df[4 + e] = hi[e]; }
+#pragma unroll
+                for (int b = 0; b < DB; ++b) {
+                    const bf16x8 kt = tr_frag<D>(ktr, 16 * ks, b, lane);
+                    dq[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, df, dq[b], 0, 0, 0);
+                }
+            }
+            QST_STAMP(5);
+            // Outputs leave through LDS so that every global store is 16 bytes and four lanes cover a row's whole
+            // 64-byte head slice (stamps showed ~200 cycles per 8-byte-per-lane store instruction: 12 of them cost as
+            // much as the dQ product). The Q / dO images are dead after the barrier above; wave w stages in its 8 KB.
+            char* stg = smem + wave * (4 * IMG / 4);
+#pragma unroll
+            for (int b = 0; b < DB; ++b)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 o2;
+                    const uint32_t off = rr_off<D>(fr, (b * 64 + 16 * g) >> 4) + 8 * h;
+                    o2[0] = pack_bf16x2(dq[b][4 * g] * a.scale, dq[b][4 * g + 1] * a.scale);
+                    o2[1] = pack_bf16x2(dq[b][4 * g + 2] * a.scale, dq[b][4 * g + 3] * a.scale);
+                    *(u32x2*)(stg + off) = o2;
+                    o2[0] = pack_bf16x2(dk[b][4 * g], dk[b][4 * g + 1]);
+                    o2[1] = pack_bf16x2(dk[b][4 * g + 2], dk[b][4 * g + 3]);
+                    *(u32x2*)(stg + 32 * D * 2 + off) = o2;
+                    o2[0] = pack_bf16x2(dv[b][4 * g], dv[b][4 * g + 1]);
+                    o2[1] = pack_bf16x2(dv[b][4 * g + 2], dv[b][4 * g + 3]);
+                    *(u32x2*)(stg + 2 * 32 * D * 2 + off) = o2;
+                }
+            // wave-private staging: no workgroup barrier, the LDS queue is in order within a wave
+            bf16* obase2 = a.dqkv + ((size_t)seq * a.L + j0) * ld + head * D;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int k = 0; k < 32 * CPR / 64; ++k) {
+                    const int idx = lane + 64 * k, row = idx / CPR, c = idx % CPR;
+                    const u32x4 v = *(const u32x4*)(stg + t * 32 * D * 2 + rr_off<D>(row, c));
+                    *(u32x4*)(obase2 + (size_t)row * ld + t * a.H + c * 8) = v;
+                }
+            QST_STAMP(6);
+        }
+    }
+}
+
 template <typename K>
 int set_lds(K kern, size_t bytes) {
     QST_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -411,6 +686,7 @@ int set_lds(K kern, size_t bytes) {
 
 }  // namespace
 
+static int g_attn_force_split = 0;      // diagnostic switch (qst_debug_attn_force_split): always use the two-kernel path
 static int check_attn(int nseq, int L, int A, int d) {
     if (nseq <= 0 || L <= 0 || A <= 0) return QST_ERR_BAD_ARG;
     if ((d != 32 && d != 64) || (L % 32) != 0 || L > 512) return QST_ERR_UNSUPPORTED;
@@ -448,6 +724,14 @@ extern "C" int qst_attention_bwd(const void* qkv, const void* ctx, const void* d
     const size_t lds_q = (size_t)3 * 128 * d * 2 + (size_t)L * 4;
     const size_t lds_kv = (size_t)4 * 128 * d * 2 + 256 * 4;
     hipStream_t st = (hipStream_t)stream;
+    if (L <= 128 && d == 32 && !g_attn_force_split) {
+        // one workgroup per (sequence, head) computes dQ, dK and dV from a single evaluation of the score tile
+        const size_t lds_f = (size_t)5 * 128 * d * 2 + DS_IMG + 256 * 4;
+        if ((rc = set_lds(attn_bwd_fused_kernel<32>, lds_f))) return rc;
+        attn_bwd_fused_kernel<32><<<min(nseq * A, 512), 256, lds_f, st>>>(a);      // two per CU, persistent
+        QST_LAUNCH_CHECK();
+        return QST_OK;
+    }
     if (d == 32) {
         if ((rc = set_lds(attn_bwd_dq_kernel<32>, lds_q))) return rc;
         attn_bwd_dq_kernel<32><<<grid, 256, lds_q, st>>>(a);
@@ -464,6 +748,8 @@ extern "C" int qst_attention_bwd(const void* qkv, const void* ctx, const void* d
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
+
+extern "C" void qst_debug_attn_force_split(int on) { g_attn_force_split = on; }
 
 // Diagnostic (not declared in the public headers): resident workgroups per CU the runtime reports for the d=32 kernels.
 extern "C" int qst_debug_attn_occupancy(int which, int lds_bytes) {

@@ -306,7 +306,8 @@ def attn_ref(qkv, mask, rel, n, L, A, d):
 
 
 @pytest.mark.parametrize("n,L,A,d,use_rel", [(2, 32, 2, 32, False), (3, 128, 12, 32, False), (2, 160, 2, 64, True),
-                                              (2, 256, 3, 64, False), (1, 384, 2, 64, True), (2, 64, 2, 32, True)])
+                                              (2, 256, 3, 64, False), (1, 384, 2, 64, True), (2, 64, 2, 32, True),
+                                              (5, 96, 3, 32, False), (2, 160, 2, 32, True)])
 def test_attention_fwd_bwd(lib, n, L, A, d, use_rel):
     H = A * d
     g = torch.Generator().manual_seed(n * L + A + d)
@@ -344,6 +345,21 @@ def test_attention_fwd_bwd(lib, n, L, A, d, use_rel):
     if use_rel:
         rel_l2 = ((drel.cpu() - relr.grad).norm() / relr.grad.norm()).item()
         assert rel_l2 < 1e-2, f"drel relative L2 error {rel_l2}"
+    if L <= 128 and d == 32:
+        # this shape ran the single-workgroup backward; the two-kernel path must agree with it
+        dq2 = torch.empty_like(dq)
+        drel2 = torch.zeros(A, L, L, device="cuda") if use_rel else None
+        lib.qst_debug_attn_force_split(1)
+        try:
+            _lib.check(lib.qst_attention_bwd(qd.data_ptr(), ctx.data_ptr(), dcd.data_ptr(), lse.data_ptr(),
+                                             md.data_ptr(), _lib.ptr(reld), n, L, A, d, dq2.data_ptr(), _lib.ptr(drel2),
+                                             delta.data_ptr(), stream()))
+            torch.cuda.synchronize()
+        finally:
+            lib.qst_debug_attn_force_split(0)
+        torch.testing.assert_close(dq.float(), dq2.float(), rtol=2e-2, atol=2e-2 * max(1.0, gref.abs().max().item()))
+        if use_rel:
+            torch.testing.assert_close(drel, drel2, rtol=1e-3, atol=1e-3 * max(1.0, drel2.abs().max().item()))
 
 
 # ------------------------------------------------------------------ AdamW
