@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=10)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the forward-only and loss-kernel side measurements (profiled runs: keeps per-step kernel counts clean)")
     return ap.parse_args()
 
 
@@ -123,7 +125,7 @@ def time_kernels(trainer, n, L, reps, batches):
     wflops = 2.0 * M * (H * I + I * H + H * H + 3 * H * H)
     return ({"kernel": "gemm_tn_group_kernel (all 4 wgrads of one layer: dW2, dW1, dWo, dWqkv + bias grads)",
              "ms": t_wgrad / reps, "flops_per_launch": wflops, "shape": [M, H, I]},
-            {"kernel": "gemm_nt_kernel<2, 2> (FFN1 fwd, bias+GELU epilogue)", "ms": t_ffn1 / reps,
+            {"kernel": "gemm_nt_kernel<2, 2, 2> (FFN1 fwd, bias+GELU epilogue)", "ms": t_ffn1 / reps,
              "flops_per_launch": 2.0 * M * I * H, "shape": [M, I, H]})
 
 
@@ -271,7 +273,7 @@ def main():
                                   "unit": "TFLOP/s", "frac": round(achieved2 / PEAK_BF16_TFLOPS, 4), "traffic": traffic2,
                                   "kernel": dk2["kernel"], "avg_launch_ms": round(dk2["ms"], 5), "shape_MNK": dk2["shape"]},
         }
-        if world == 1:
+        if world == 1 and not args.no_extras:
             t_f = time_fwd_only(trainer, batches, max(5, args.steps // 2))
             out["fwd_only"] = {"value": round(B / t_f, 1), "unit": "quadruplets/s", "ms_per_step": round(t_f * 1e3, 4),
                                "what": "encode 4 columns + loss forward, no backward / saved activations",

@@ -471,12 +471,13 @@ __device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt_n() {
     if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
 }
 
-// Wave roles: waves 0-3 run the MFMAs (one per SIMD, the whole register file to themselves), waves 4-5 are loaders
-// that issue every LDS-DMA (wave 4: the dY stage, wave 5: the X stage). In-kernel stamps on the earlier
+// Wave roles: waves 0-3 run the MFMAs (one per SIMD, the whole register file to themselves), waves 4-7 are loaders
+// that issue every LDS-DMA (waves 4,5: the two halves of the dY stage, waves 6,7: of the X stage). In-kernel stamps on the earlier
 // all-waves-load version showed 2800 cycles per 32-row stage for 672 cycles of MFMA: an in-order wave pays the DMA
 // issue cost (60-185 cycles per instruction) and the LDS read latency in series with its MFMAs; with loaders it is 990.
 //
@@ -484,7 +485,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_n() {
 // = a*W + b, every workgroup reduces `a` whole tiles and then one stage-piece of a leftover tile (task list in the
 // kernel), so all CUs finish together instead of 1.5 tiles per CU being rounded up to 2; split tiles simply receive
 // several partial sums through the fp32 atomics.
-__global__ __launch_bounds__(384, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
+__global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -533,8 +534,10 @@ __global__ __launch_bounds__(384, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
         const int row0 = mbeg + s0 * TBK;                          // first reduction row of this piece
 
         if (wave >= 4) {
-            // -------------------------------------------------------- loader wave: one operand, 12 DMA per stage
-            const bool isA = wave == 4;
+            // -------------------------------------------------------- loader wave: half an operand, 6 DMA per stage
+            // (four loaders instead of two: -1.6% on the MiniLM and mpnet layer shapes, same-process A/B)
+            const bool isA = wave < 6;
+            const int half = wave & 1;
             const int ld = isA ? g.lda : g.ldb, c0 = isA ? n0 : k0, width = isA ? g.N : g.K;
             const bf16* base = (const bf16*)(isA ? g.A : g.B) + (size_t)row0 * ld + c0;
             // range = rows [row0, mend); the last row's tail past the allocation reads as zero
@@ -543,10 +546,10 @@ __global__ __launch_bounds__(384, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
             // an operand stage is 768 chunks = 12 wave-instructions of 1 KB. LDS position p = q*64 + lane -> row p/24,
             // chunk position p%24 -> logical chunk = pos ^ swz(row). Columns beyond the matrix width must not alias
             // the next row: those lanes get an out-of-range offset (-> zero fill).
-            uint32_t vo[12];
+            uint32_t vo[6];
 #pragma unroll
-            for (int t = 0; t < 12; ++t) {
-                const int pp = t * 64 + lane;
+            for (int t = 0; t < 6; ++t) {
+                const int pp = (half * 6 + t) * 64 + lane;
                 const int row = pp / 24, chunk = (pp % 24) ^ tn_swz(row);
                 vo[t] = (c0 + chunk * 8 < width) ? (uint32_t)row * ld * 2u + chunk * 16u : kOOB;
             }
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(384, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
                 char* st = smem + (mt % TSTAGES) * TT_STAGE + (isA ? 0 : TT_TILE);
                 const uint32_t so = (uint32_t)mt * TBK * ld * 2u;
 #pragma unroll
-                for (int t = 0; t < 12; ++t) dma16(rs, st + t * 1024, vo[t], so);  // kOOB + so < 2^32: no wrap
+                for (int t = 0; t < 6; ++t) dma16(rs, st + (half * 6 + t) * 1024, vo[t], so);  // kOOB + so < 2^32: no wrap
             };
 #pragma unroll 1
             for (int st = 0; st < 3 && st < nm; ++st) issue(st);
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(384, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
             for (int mt = 0; mt < nm; ++mt) {
                 // stage mt must have landed before this wave arrives at the barrier that releases it to the MFMA waves
                 const int younger = min(2, nm - 1 - mt);
-                if (younger == 2) wait_vmcnt_n<24>(); else if (younger == 1) wait_vmcnt_n<12>(); else wait_vmcnt_n<0>();
+                if (younger == 2) wait_vmcnt_n<12>(); else if (younger == 1) wait_vmcnt_n<6>(); else wait_vmcnt_n<0>();
                 __builtin_amdgcn_s_barrier();              // MFMA waves are done with stage mt-1 (and older)
                 if (mt + 3 < nm) issue(mt + 3);            // slot (mt+3)%5 was last read at stage mt-2
             }
@@ -736,7 +739,7 @@ extern "C" int qst_gemm_tn_group(const QstTnGroup* grp_in, void* stream) {
         QST_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TT_LDS));
         attr_set = true;
     }
-    gemm_tn_group_kernel<<<dim3(grid), dim3(384), TT_LDS, (hipStream_t)stream>>>(g);
+    gemm_tn_group_kernel<<<dim3(grid), dim3(512), TT_LDS, (hipStream_t)stream>>>(g);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
