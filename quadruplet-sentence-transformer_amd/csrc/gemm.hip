@@ -458,10 +458,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
 // (8 adders per element). Operands are consumed straight from row-major [M, *] images with ds_read_b64_tr_b16.
 // LDS image per operand stage: [32 m-rows][192 bf16] = 384-byte rows (24 chunks of 16 B); chunk c of row r sits at
 // chunk position c ^ (((r >> 1) & 1) << 2): the 4 rows x 64 B that one half-wave reads land in 16 distinct 16-B slots.
-constexpr int TT = 192, TBK = 32, TSTAGES = 5;            // 5-slot ring: three stages in flight, one being read, one free
+constexpr int TT = 192, TBK = 32, TSTAGES = 6;            // 6-slot ring: one stage being read, up to five in flight
 constexpr int TT_TILE = TBK * TT * 2;                // 12 KB per operand per stage
 constexpr int TT_STAGE = 2 * TT_TILE;                // 24 KB
-constexpr int TT_LDS = TSTAGES * TT_STAGE;           // 120 KB: one workgroup (4 MFMA + 2 loader waves) per CU
+constexpr int TT_LDS = TSTAGES * TT_STAGE;           // 144 KB: one workgroup (4 MFMA + 4 loader waves) per CU
 __device__ __forceinline__ int tn_swz(int row) { return ((row >> 1) & 1) << 2; }
 __device__ __forceinline__ uint32_t tn_off(int row, int chunk) {
     return (uint32_t)(row * 384 + ((chunk ^ tn_swz(row)) << 4));
@@ -473,6 +473,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_n() {
     if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
 }
 
@@ -559,15 +560,21 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
 #pragma unroll
                 for (int t = 0; t < 6; ++t) dma16(rs, st + (half * 6 + t) * 1024, vo[t], so);  // kOOB + so < 2^32: no wrap
             };
+            // All TSTAGES-1 slots that are not being read are kept in flight (120 KB per CU). Timing experiments on this
+            // kernel (same-process A/B): MFMAs compiled out -17%, atomic flush compiled out -16%, constant LDS slot
+            // (no per-stage address arithmetic) -8%, two -> four loaders and 72 -> 120 KB in flight -1.7% together:
+            // no single resource bounds it; the skeleton of barriers + L2->LDS streaming is 70% of the time.
+            constexpr int AHEAD = TSTAGES - 1;
 #pragma unroll 1
-            for (int st = 0; st < 3 && st < nm; ++st) issue(st);
+            for (int st = 0; st < AHEAD && st < nm; ++st) issue(st);
 #pragma unroll 1
             for (int mt = 0; mt < nm; ++mt) {
                 // stage mt must have landed before this wave arrives at the barrier that releases it to the MFMA waves
-                const int younger = min(2, nm - 1 - mt);
-                if (younger == 2) wait_vmcnt_n<12>(); else if (younger == 1) wait_vmcnt_n<6>(); else wait_vmcnt_n<0>();
+                const int younger = min(AHEAD - 1, nm - 1 - mt);
+                if (younger >= 4) wait_vmcnt_n<24>(); else if (younger == 3) wait_vmcnt_n<18>();
+                else if (younger == 2) wait_vmcnt_n<12>(); else if (younger == 1) wait_vmcnt_n<6>(); else wait_vmcnt_n<0>();
                 __builtin_amdgcn_s_barrier();              // MFMA waves are done with stage mt-1 (and older)
-                if (mt + 3 < nm) issue(mt + 3);            // slot (mt+3)%5 was last read at stage mt-2
+                if (mt + AHEAD < nm) issue(mt + AHEAD);    // into the slot of stage mt-1
             }
             __builtin_amdgcn_s_barrier();                  // end of piece: every MFMA wave has left the ring
             continue;
