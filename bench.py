@@ -237,11 +237,12 @@ def main():
     final_loss = float(loss.item())
 
     out = None
+    # every rank runs the kernel timing: its interleaved training steps are collective (gradient all-reduce)
+    dk, dk2 = time_kernels(trainer, 4 * B, L, args.kernel_reps, batches)
     if rank == 0:
         fwd_flops_q = 4.0 * forward_flops_per_sequence(cfg, L)
         train_flops_q = 3.0 * fwd_flops_q
         step_tflops = value * train_flops_q / 1e12
-        dk, dk2 = time_kernels(trainer, 4 * B, L, args.kernel_reps, batches)
         achieved = dk["flops_per_launch"] / (dk["ms"] * 1e-3) / 1e12
         achieved2 = dk2["flops_per_launch"] / (dk2["ms"] * 1e-3) / 1e12
         traffic = traffic2 = None
