@@ -480,13 +480,24 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_batch_kernel(QstLnReduceBat
     const float* partials = b.partials[which];
     float acc = 0.f;
     const int nb = b.nblocks_each[which] > 0 ? b.nblocks_each[which] : b.nblocks;
-    for (int r = blockIdx.y; r < nb; r += gridDim.y) acc += partials[(size_t)r * 2 * b.H + col];
+    // four independent loads in flight per thread: the loop is latency-bound (a row of partials is 3 KB)
+    const size_t rs = (size_t)2 * b.H, gs = gridDim.y;
+    int r = blockIdx.y;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (; r + 3 * (int)gs < nb; r += 4 * (int)gs) {
+        a0 += partials[(size_t)r * rs + col];
+        a1 += partials[((size_t)r + gs) * rs + col];
+        a2 += partials[((size_t)r + 2 * gs) * rs + col];
+        a3 += partials[((size_t)r + 3 * gs) * rs + col];
+    }
+    for (; r < nb; r += (int)gs) acc += partials[(size_t)r * rs + col];
+    acc += (a0 + a1) + (a2 + a3);
     atomicAdd(col < b.H ? b.dgamma[which] + col : b.dbeta[which] + (col - b.H), acc);
 }
 
 extern "C" int qst_ln_bwd_reduce_batch(const QstLnReduceBatch* b, void* stream) {
     if (!b || b->count <= 0 || b->count > QST_LN_BATCH_MAX || b->H <= 0 || b->nblocks <= 0) return QST_ERR_BAD_ARG;
-    ln_bwd_reduce_batch_kernel<<<dim3((2 * b->H + 255) / 256, 16, b->count), 256, 0, (hipStream_t)stream>>>(*b);
+    ln_bwd_reduce_batch_kernel<<<dim3((2 * b->H + 255) / 256, 32, b->count), 256, 0, (hipStream_t)stream>>>(*b);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }

@@ -98,12 +98,13 @@ def gemm_args(**kw):
     return g
 
 
-@pytest.mark.parametrize("form", [0, 2], ids=["tiles128", "tiles256"])
+@pytest.mark.parametrize("form", [0, 2, 4], ids=["tiles128", "tiles256", "tall256"])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 384), (200, 192, 128), (1000, 1152, 384), (64, 64, 64),
                                    (4096, 384, 1536), (5000, 1536, 384)])
 def test_gemm_nt_epilogues(lib, M, N, K, form):
-    """form: QstGemmArgs.splits selects the nt tile height (0 = 128-row tiles, two workgroups per CU; 2 = 256-row
-    tiles, one 8-wave workgroup per CU); both must give the same results."""
+    """form: QstGemmArgs.splits selects the nt tiling (0 = 128-row tiles, two workgroups per CU; 2 = 256-row tiles, one
+    8-wave workgroup per CU; 4 = 256-row tiles of four waves owning 128 x 96 each, bf16-output epilogues only -- the
+    fp32 one falls back to form 0); all must give the same results."""
     g = torch.Generator().manual_seed(M + N + K)
     A = bfr(torch.randn(M, K, generator=g))
     B = bfr(torch.randn(N, K, generator=g) * 0.05)

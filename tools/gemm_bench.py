@@ -27,7 +27,8 @@ def main():
     lib = _lib.load()
     st = _lib.current_stream_ptr()
     dev = "cuda"
-    H, I = 384, 1536
+    H = int(sys.argv[2]) if len(sys.argv) > 2 else 384
+    I = 4 * H
     bf = torch.bfloat16
     tot = 0.0
     print(f"{'launch':34s} {'us':>8s} {'TFLOP/s':>8s}")
@@ -46,13 +47,13 @@ def main():
         g.A, g.B, g.C, g.C2, g.aux, g.bias, g.resid = A.data_ptr(), B.data_ptr(), C.data_ptr(), C2.data_ptr(), aux.data_ptr(), bias.data_ptr(), resid.data_ptr()
         g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.ldr = M, N, K, K, K, N, N
         res = []
-        for force in (1, 2, 3):
+        for force in (1, 2, 3, 4):
             g.splits = force
             res.append(timeit(lambda: _lib.check(lib.qst_gemm_nt(g, epi, st))))
         g.splits = 0
         us = timeit(lambda: _lib.check(lib.qst_gemm_nt(g, epi, st)))
         tot += us
-        print(f"nt {name:31s} {us:8.1f} {2.0 * M * N * K / us / 1e6:8.1f}   (128-row tile {res[0]:.1f} us, 256-row tile {res[1]:.1f} us, 128x384 tile {res[2]:.1f} us)")
+        print(f"nt {name:31s} {us:8.1f} {2.0 * M * N * K / us / 1e6:8.1f}   (128-row tile {res[0]:.1f} us, 256-row tile {res[1]:.1f} us, 128x384 tile {res[2]:.1f} us, tall 256x192 {res[3]:.1f} us)")
     # fused GEMM + LayerNorm (N = 384 full-row tiles) against the unfused pair
     if lib.qst_gemm_nt_ln_supported(H):
         for name, K, mode in [("out+LN1 fwd", H, 0), ("FFN2+LN2 fwd", I, 0), ("FFN1 dgrad+LN1 bwd", I, 1), ("QKV dgrad+LN2 bwd", 3 * H, 1)]:
