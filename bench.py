@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=10)
+    ap.add_argument("--graph", action="store_true",
+                    help="single GPU: replay the step from a captured HIP graph (device-side LR schedule)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the forward-only and loss-kernel side measurements (profiled runs: keeps per-step kernel counts clean)")
     return ap.parse_args()
@@ -206,7 +208,8 @@ def main():
     arena = synthetic_params(cfg, seed=14)          # same replica on every rank
     trainer = QuadrupletTrainer(cfg, arena=arena, device=f"cuda:{dev_index}", lr=2e-5, weight_decay=0.01,
                                 max_grad_norm=1.0, warmup_steps=10000, total_steps=1000000,
-                                process_group=None, world_size=world, overlap=not args.no_overlap)
+                                process_group=None, world_size=world, overlap=not args.no_overlap,
+                                use_graph=args.graph and world == 1)
     # a few distinct synthetic batches, resident in HBM before the timed region (rank-offset streams)
     nb = 4
     batches = []
@@ -263,7 +266,8 @@ def main():
                                    "fwd + gamma-quadruplet loss + bwd + clip + AdamW (BASELINE.json configs[1]"
                                    + ("/[3]" if world > 1 else "") + ")",
                        "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}",
-                       "precision": "bf16 MFMA operands, fp32 accumulate/residual/LN/softmax/loss/optimizer"},
+                       "precision": "bf16 MFMA operands, fp32 accumulate/residual/LN/softmax/loss/optimizer",
+                       "launch": "hip graph replay" if (args.graph and world == 1) else "eager"},
             "loss": round(final_loss, 6),
             "step_tflops": round(step_tflops, 2),
             "step_mfma_frac": round(step_tflops / (PEAK_BF16_TFLOPS * world), 4),

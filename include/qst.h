@@ -155,6 +155,17 @@ int qst_clip_adamw_step(const qst_encoder* enc, float* params, float* grads, flo
                         float max_grad_norm, float grad_scale, int64_t step,
                         float* norm_out, float* scratch, void* stream);
 
+/* The same step with the schedule on the device, so that a whole training step can be captured in a HIP graph and
+ * replayed: no per-step host value is a kernel argument. step_dev (int64 [1], device) holds the number of optimiser
+ * steps taken so far and is incremented by the call; the learning rate of step t is
+ * transformers.get_linear_schedule_with_warmup(base_lr, warmup_steps, total_steps) at t-1 (constant base_lr when
+ * total_steps <= 0), as SentenceTransformer.fit's 'WarmupLinear' (reference call site training/main.py:133-134).
+ * scratch: fp32 [1024 + 3]. */
+int qst_clip_adamw_step_sched(const qst_encoder* enc, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                              float base_lr, float beta1, float beta2, float eps, float weight_decay,
+                              float max_grad_norm, float grad_scale, int64_t warmup_steps, int64_t total_steps,
+                              int64_t* step_dev, float* norm_out, float* scratch, void* stream);
+
 /* Data parallelism has no entry point here: the gradient arena is one contiguous fp32 buffer, and
  * the host side all-reduces slices of it with torch.distributed (backend "nccl" = RCCL over xGMI) on a side stream,
  * between qst_encoder_backward_partial stages; qst_clip_adamw_step's grad_scale applies the 1/world_size. */

@@ -69,6 +69,8 @@ SIGNATURES = {
                                       C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "qst_clip_adamw_step": (C.c_int, [vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                       C.c_float, C.c_float, C.c_int64, vp, vp, vp]),
+    "qst_clip_adamw_step_sched": (C.c_int, [vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                            C.c_float, C.c_float, C.c_int64, C.c_int64, vp, vp, vp, vp]),
     # kernel level (include/qst_kernels.h)
     "qst_gemm_nt": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int, vp]),
     "qst_gemm_nt_ln_supported": (C.c_int, [C.c_int]),

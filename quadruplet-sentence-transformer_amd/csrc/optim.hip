@@ -39,15 +39,53 @@ __global__ __launch_bounds__(1024) void norm_finish_kernel(const float* partial,
     }
 }
 
+// Device-side schedule (graph-capturable step: no per-step host value reaches a kernel argument). One thread advances
+// the step counter and derives this step's learning rate (transformers.get_linear_schedule_with_warmup, as
+// trainer.warmup_linear_lr) and Adam bias corrections into dyn[0..2] = {lr, 1-beta1^t, sqrt(1-beta2^t)}.
+struct SchedArgs { int64_t* step; float base_lr, beta1, beta2; int64_t warmup, total; float* dyn; };
+
+__global__ __launch_bounds__(1024) void norm_finish_sched_kernel(const float* partial, int n, float grad_scale,
+                                                                 float* norm_out, SchedArgs sc) {
+    __shared__ float red[16];
+    float s = threadIdx.x < n ? partial[threadIdx.x] : 0.f;
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float v = threadIdx.x < 16 ? red[threadIdx.x] : 0.f;
+        v = wave_sum(v);
+        if (threadIdx.x == 0) {
+            norm_out[0] = sqrtf(v) * fabsf(grad_scale);
+            const int64_t t = sc.step[0] + 1;                   // 1-based optimiser step
+            sc.step[0] = t;
+            const int64_t k = t - 1;                            // scheduler steps already taken
+            float lr = sc.base_lr;
+            if (sc.total > 0) {
+                if (k < sc.warmup) lr = sc.base_lr * (float)((double)k / (double)(sc.warmup > 1 ? sc.warmup : 1));
+                else {
+                    const int64_t den = sc.total - sc.warmup > 1 ? sc.total - sc.warmup : 1;
+                    const double f = (double)(sc.total - k) / (double)den;
+                    lr = sc.base_lr * (float)(f > 0.0 ? f : 0.0);
+                }
+            }
+            sc.dyn[0] = lr;
+            sc.dyn[1] = (float)(1.0 - pow((double)sc.beta1, (double)t));
+            sc.dyn[2] = (float)sqrt(1.0 - pow((double)sc.beta2, (double)t));
+        }
+    }
+}
+
 struct AdamArgs {
     float* p; float* g; float* m; float* v;
     const uint8_t* chunk_decay;     // one flag per 256-element chunk of the arena
     const float* norm;              // device scalar (pre-clip global norm), or null
+    const float* dyn;               // device {lr, bc1, bc2_sqrt} (device-side schedule), or null: the by-value fields
     int64_t n4;
     float lr, beta1, beta2, eps, wd, max_norm, grad_scale, bc1, bc2_sqrt;
 };
 
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
+    if (a.dyn) { a.lr = a.dyn[0]; a.bc1 = a.dyn[1]; a.bc2_sqrt = a.dyn[2]; }
     float coef = a.grad_scale;
     if (a.norm && a.max_norm > 0.f) {
         const float c = a.max_norm / (a.norm[0] + 1e-6f);      // clip_grad_norm_: clamp(max_norm/(norm+1e-6), max=1)
@@ -89,12 +127,40 @@ extern "C" int qst_adamw_launch(float* params, float* grads, float* exp_avg, flo
     }
     AdamArgs a;
     a.p = params; a.g = grads; a.m = exp_avg; a.v = exp_avg_sq; a.chunk_decay = chunk_decay;
+    a.dyn = nullptr;
     a.norm = (max_grad_norm > 0.f) ? norm_out : nullptr;
     a.n4 = n / 4;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.max_norm = max_grad_norm;
     a.grad_scale = grad_scale;
     a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    adamw_kernel<<<2048, 256, 0, st>>>(a);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+extern "C" int qst_adamw_launch_sched(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                                      const uint8_t* chunk_decay, int64_t n, float base_lr, float beta1, float beta2,
+                                      float eps, float weight_decay, float max_grad_norm, float grad_scale,
+                                      int64_t warmup_steps, int64_t total_steps, int64_t* step_dev, float* norm_out,
+                                      float* scratch, hipStream_t st) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !chunk_decay || n <= 0 || (n & 255) || !step_dev || !norm_out ||
+        !scratch)
+        return QST_ERR_BAD_ARG;
+    sumsq_kernel<<<kNormBlocks, 256, 0, st>>>(grads, n / 4, scratch);
+    QST_LAUNCH_CHECK();
+    SchedArgs sc;
+    sc.step = step_dev; sc.base_lr = base_lr; sc.beta1 = beta1; sc.beta2 = beta2; sc.warmup = warmup_steps;
+    sc.total = total_steps; sc.dyn = scratch + kNormBlocks;
+    norm_finish_sched_kernel<<<1, 1024, 0, st>>>(scratch, kNormBlocks, grad_scale, norm_out, sc);
+    QST_LAUNCH_CHECK();
+    AdamArgs a;
+    a.p = params; a.g = grads; a.m = exp_avg; a.v = exp_avg_sq; a.chunk_decay = chunk_decay;
+    a.dyn = sc.dyn;
+    a.norm = (max_grad_norm > 0.f) ? norm_out : nullptr;
+    a.n4 = n / 4;
+    a.lr = 0.f; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.max_norm = max_grad_norm;
+    a.grad_scale = grad_scale; a.bc1 = 1.f; a.bc2_sqrt = 1.f;
     adamw_kernel<<<2048, 256, 0, st>>>(a);
     QST_LAUNCH_CHECK();
     return QST_OK;

@@ -590,6 +590,23 @@ extern "C" int qst_encoder_backward(qst_encoder* e, const int64_t* ids, const in
                                         saved_bytes, workspace, workspace_bytes, 1, e->cfg.num_layers, 0, 1, stream);
 }
 
+extern "C" int qst_adamw_launch_sched(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                                      const uint8_t* chunk_decay, int64_t n, float base_lr, float beta1, float beta2,
+                                      float eps, float weight_decay, float max_grad_norm, float grad_scale,
+                                      int64_t warmup_steps, int64_t total_steps, int64_t* step_dev, float* norm_out,
+                                      float* scratch, hipStream_t st);
+
+extern "C" int qst_clip_adamw_step_sched(const qst_encoder* e, float* params, float* grads, float* exp_avg,
+                                         float* exp_avg_sq, float base_lr, float beta1, float beta2, float eps,
+                                         float weight_decay, float max_grad_norm, float grad_scale,
+                                         int64_t warmup_steps, int64_t total_steps, int64_t* step_dev,
+                                         float* norm_out, float* scratch, void* stream) {
+    if (!e) return QST_ERR_BAD_ARG;
+    return qst_adamw_launch_sched(params, grads, exp_avg, exp_avg_sq, e->chunk_decay, e->lay.total, base_lr, beta1, beta2,
+                                  eps, weight_decay, max_grad_norm, grad_scale, warmup_steps, total_steps, step_dev,
+                                  norm_out, scratch, (hipStream_t)stream);
+}
+
 extern "C" int qst_clip_adamw_step(const qst_encoder* e, float* params, float* grads, float* exp_avg,
                                    float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
                                    float weight_decay, float max_grad_norm, float grad_scale, int64_t step,

@@ -46,6 +46,7 @@ class HipEncoder:
         self._saved: Optional[torch.Tensor] = None
         self._ws: Optional[torch.Tensor] = None
         self._scratch = torch.zeros(2048, dtype=torch.float32, device=self.device)
+        self._step_dev: Optional[torch.Tensor] = None    # device-side optimiser step counter (graph-captured steps)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.opt_step = 0
 
@@ -177,6 +178,23 @@ class HipEncoder:
             self.exp_avg_sq.data_ptr(), lr, betas[0], betas[1], eps, weight_decay, max_grad_norm, grad_scale,
             self.opt_step, self.grad_norm.data_ptr(), self._scratch.data_ptr(), _lib.current_stream_ptr()),
             "qst_clip_adamw_step")
+        self.shadow_stale = True
+
+
+    def adamw_step_sched(self, base_lr: float, warmup_steps: int, total_steps: int, betas=(0.9, 0.999),
+                         eps: float = 1e-8, weight_decay: float = 0.01, max_grad_norm: float = 1.0,
+                         grad_scale: float = 1.0) -> None:
+        """adamw_step with the WarmupLinear schedule and the step counter on the device (no per-step host value is a
+        kernel argument, so the call can sit inside a captured HIP graph). The counter starts from self.opt_step."""
+        self.ensure_train_state()
+        if self._step_dev is None:
+            self._step_dev = torch.tensor([self.opt_step], dtype=torch.int64, device=self.device)
+        self.opt_step += 1               # host mirror (bookkeeping only; the device counter is authoritative)
+        _lib.check(self.lib.qst_clip_adamw_step_sched(
+            self.handle, self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
+            self.exp_avg_sq.data_ptr(), base_lr, betas[0], betas[1], eps, weight_decay, max_grad_norm, grad_scale,
+            int(warmup_steps), int(total_steps), self._step_dev.data_ptr(), self.grad_norm.data_ptr(),
+            self._scratch.data_ptr(), _lib.current_stream_ptr()), "qst_clip_adamw_step_sched")
         self.shadow_stale = True
 
 
