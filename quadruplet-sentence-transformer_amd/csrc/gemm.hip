@@ -32,6 +32,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
+template <int N> __device__ __forceinline__ void wait_vmcnt_n() {
+    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+}
 // wait until all but the `stages_behind` most recently issued stages (4 DMA per thread each) have landed
 __device__ __forceinline__ void wait_stage(int stages_behind) {
     if (stages_behind >= 2) wait_vmcnt<8>();
@@ -210,36 +217,18 @@ __device__ __forceinline__ void nt_mainloop_tall(const QstGemmArgs& g, char* sme
     __builtin_amdgcn_s_barrier();
 }
 
-template <int EPI, int WAVES_M, int WAVES_N = 2, int TI = 2>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 2 ? 2 : 1) void gemm_nt_kernel(QstGemmArgs g) {
-    constexpr int NBM = 32 * TI * WAVES_M, NBN = 96 * WAVES_N, NW = WAVES_M * WAVES_N;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int ntn = (g.N + NBN - 1) / NBN, ntm = (g.M + NBM - 1) / NBM;
-    const int wg = xcd_remap(blockIdx.x, ntm * ntn);
-    const int m0 = (wg / ntn) * NBM, n0 = (wg % ntn) * NBN;
+// Epilogue of one wave's (32*TI) x 96 sub-tile whose first element is C[m_base][n_base]. The MFMA operands were
+// swapped (D rows = n in registers, D column = m on the lane), so each lane holds 4 consecutive n per register group:
+// 32 rows x 96 columns at a time go through the wave-private LDS region `stg` as [m][n] (conflict-free ds_write_b128)
+// and are read back row-wise, so bias / residual / GELU and the global accesses run on 16-byte row-contiguous vectors.
+// All global LOADS of a pass (residual / saved gelu') are issued before the pass touches LDS and before any store:
+// with loads and stores interleaved per row the compiler must keep them in order (C may alias resid), and in-kernel
+// stamps showed the epilogue then costing 2-4x the whole K loop in exposed load latency.
+// bias_s: this wave's 96 bias values in LDS (written by the caller, same wave).
+template <int EPI, int TI>
+__device__ __forceinline__ void nt_epilogue(const QstGemmArgs& g, f32x16 (&acc)[TI][3], float* stg, const float* bias_s,
+                                            int m_base, int n_base, int lane) {
     const int fr = lane & 31, fh = lane >> 5;
-    f32x16 acc[TI][3];
-    if constexpr (TI == 4) nt_mainloop_tall<WAVES_M, WAVES_N>(g, smem, m0, n0, acc);
-    else nt_mainloop<WAVES_M, WAVES_N>(g, smem, m0, n0, acc);
-
-    // ---- epilogue. The MFMA operands were swapped (D rows = n in registers, D column = m on the lane), so each
-    // lane holds 4 consecutive n per register group: stage 32 rows x 96 columns of the wave's sub-tile at a time
-    // through LDS as [m][n] (conflict-free ds_write_b128) and read it back row-wise, so bias / residual / GELU and
-    // the global stores run on 16-byte row-contiguous vectors (24 lanes = one 384-byte fp32 row segment).
-    // All global LOADS of a pass (residual / saved pre-activation) are issued before the pass touches LDS and before
-    // any store: with loads and stores interleaved per row the compiler must keep them in order (C may alias resid),
-    // and in-kernel stamps showed the epilogue then costing 2-4x the whole K loop in exposed load latency.
-    float* stg = (float*)smem + wave * (32 * NT_STG_LD);
-    float* bias_s = (float*)smem + NW * (32 * NT_STG_LD) + wave * 96;     // this wave's 96 bias values
-    if (g.bias) {
-        for (int c = lane; c < 96; c += 64) {
-            const int n = n0 + wn * 96 + c;
-            bias_s[c] = n < g.N ? g.bias[n] : 0.f;
-        }
-    }
     constexpr bool kF32Out = (EPI == QST_EPI_F32_RESID || EPI == QST_EPI_F32_RESID_BF16);
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
@@ -250,8 +239,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 2 ? 2 : 1) void 
             for (int t = 0; t < 12; ++t) {
                 const int idx = t * 64 + lane;
                 const int row = idx / 24, c4 = idx % 24;
-                const int m = m0 + wm * (32 * TI) + i * 32 + row;
-                const int n = n0 + wn * 96 + c4 * 4;
+                const int m = m_base + i * 32 + row;
+                const int n = n_base + c4 * 4;
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                 rv[t] = (m < g.M && n < g.N && g.resid) ? *(const f32x4*)(g.resid + (size_t)m * g.ldr + n) : z;
             }
@@ -269,8 +258,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 2 ? 2 : 1) void 
             for (int t = 0; t < 12; ++t) {
                 const int idx = t * 64 + lane;
                 const int row = idx / 24, c4 = idx % 24;
-                const int m = m0 + wm * (32 * TI) + i * 32 + row;
-                const int n = n0 + wn * 96 + c4 * 4;
+                const int m = m_base + i * 32 + row;
+                const int n = n_base + c4 * 4;
                 if (m >= g.M || n >= g.N) continue;
                 f32x4 v = *(const f32x4*)(stg + row * NT_STG_LD + c4 * 4);
                 if (g.bias) v += *(const f32x4*)(bias_s + c4 * 4);
@@ -290,8 +279,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 2 ? 2 : 1) void 
             for (int t = 0; t < 6; ++t) {
                 const int idx = t * 64 + lane;
                 const int row = idx / 12, c8 = idx % 12;
-                const int m = m0 + wm * (32 * TI) + i * 32 + row;
-                const int n = n0 + wn * 96 + c8 * 8;
+                const int m = m_base + i * 32 + row;
+                const int n = n_base + c8 * 8;
                 const u32x4 z = {0u, 0u, 0u, 0u};
                 if (EPI == QST_EPI_GELU_BWD)
                     av[t] = (m < g.M && n < g.N) ? *(const u32x4*)((const bf16*)g.aux + (size_t)m * g.ldc + n) : z;
@@ -309,8 +298,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 2 ? 2 : 1) void 
             for (int t = 0; t < 6; ++t) {
                 const int idx = t * 64 + lane;
                 const int row = idx / 12, c8 = idx % 12;
-                const int m = m0 + wm * (32 * TI) + i * 32 + row;
-                const int n = n0 + wn * 96 + c8 * 8;
+                const int m = m_base + i * 32 + row;
+                const int n = n_base + c8 * 8;
                 if (m >= g.M || n >= g.N) continue;
                 float v[8];
                 {
@@ -358,6 +347,32 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 2 ? 2 : 1) void 
             }
         }
     }
+}
+
+template <int EPI, int WAVES_M, int WAVES_N = 2, int TI = 2>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 2 ? 2 : 1) void gemm_nt_kernel(QstGemmArgs g) {
+    constexpr int NBM = 32 * TI * WAVES_M, NBN = 96 * WAVES_N, NW = WAVES_M * WAVES_N;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int ntn = (g.N + NBN - 1) / NBN, ntm = (g.M + NBM - 1) / NBM;
+    const int wg = xcd_remap(blockIdx.x, ntm * ntn);
+    const int m0 = (wg / ntn) * NBM, n0 = (wg % ntn) * NBN;
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x16 acc[TI][3];
+    if constexpr (TI == 4) nt_mainloop_tall<WAVES_M, WAVES_N>(g, smem, m0, n0, acc);
+    else nt_mainloop<WAVES_M, WAVES_N>(g, smem, m0, n0, acc);
+
+    float* stg = (float*)smem + wave * (32 * NT_STG_LD);
+    float* bias_s = (float*)smem + NW * (32 * NT_STG_LD) + wave * 96;     // this wave's 96 bias values
+    if (g.bias) {
+        for (int c = lane; c < 96; c += 64) {
+            const int n = n0 + wn * 96 + c;
+            bias_s[c] = n < g.N ? g.bias[n] : 0.f;
+        }
+    }
+    nt_epilogue<EPI, TI>(g, acc, stg, bias_s, m0 + wm * (32 * TI), n0 + wn * 96, lane);
 }
 
 // ---------------------------------------------------------------- NT with a LayerNorm fused into the epilogue
@@ -541,13 +556,6 @@ __device__ __forceinline__ uint32_t tn_off(int row, int chunk) {
 }
 __device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
-}
-template <int N> __device__ __forceinline__ void wait_vmcnt_n() {
-    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
 }
 
 // Wave roles: waves 0-3 run the MFMAs (one per SIMD, the whole register file to themselves), waves 4-7 are loaders
