@@ -323,17 +323,16 @@ __device__ __forceinline__ void nt_epilogue(const QstGemmArgs& g, f32x16 (&acc)[
                 } else if (EPI == QST_EPI_GELU) {
                     // h = gelu(u) feeds FFN2; gelu'(u) (not u) is what backward needs: both share one exp and one
                     // rcp, so the dgrad epilogue is a single multiply instead of a second erf evaluation
-                    float gg[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float cdf, pdf;
-                        gelu_parts(v[e], cdf, pdf);
-                        gg[e] = cdf + v[e] * pdf;
-                        v[e] = v[e] * cdf;
-                    }
                     u32x4 pg;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { pg[e] = pack_bf16x2(gg[2 * e], gg[2 * e + 1]); pk[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]); }
+                    for (int e = 0; e < 4; ++e) {
+                        qst_f32x2 x2, cdf, pdf;
+                        x2[0] = v[2 * e]; x2[1] = v[2 * e + 1];
+                        gelu_parts2(x2, cdf, pdf);
+                        const qst_f32x2 gg = x2 * pdf + cdf, hh = x2 * cdf;
+                        pg[e] = pack_bf16x2(gg[0], gg[1]);
+                        pk[e] = pack_bf16x2(hh[0], hh[1]);
+                    }
                     if (full) *(u32x4*)((bf16*)g.C + o) = pg;                     // gelu'(u), saved for backward
                     else { u32x2 h2; h2[0] = pg[0]; h2[1] = pg[1]; *(u32x2*)((bf16*)g.C + o) = h2; }
                 } else {   // QST_EPI_GELU_BWD: acc * gelu'(u)

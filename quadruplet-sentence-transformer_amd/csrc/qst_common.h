@@ -91,6 +91,31 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float bf16lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
 
+typedef __attribute__((ext_vector_type(2))) float qst_f32x2;
+// Two elements at a time, written on 2-vectors so that the compiler emits v_pk_fma_f32 / v_pk_mul_f32 /
+// v_pk_add_f32 (one issue slot per pair): the GELU epilogue of FFN-1 is VALU-bound (the whole [M, I] tensor goes
+// through ~22 VALU issue slots per element in the scalar form, more SIMD time than the GEMM's MFMAs).
+__device__ __forceinline__ void gelu_parts2(qst_f32x2 x, qst_f32x2& cdf, qst_f32x2& pdf) {
+    qst_f32x2 ax;
+    ax[0] = fabsf(x[0]); ax[1] = fabsf(x[1]);
+    ax = ax * 0.70710678118654752f;
+    const qst_f32x2 den = ax * 0.3275911f + 1.0f;
+    qst_f32x2 t, e;
+    t[0] = __builtin_amdgcn_rcpf(den[0]); t[1] = __builtin_amdgcn_rcpf(den[1]);
+    const qst_f32x2 arg = (ax * ax) * -1.4426950408889634f;          // exp(-ax^2) = exp2(-ax^2 log2 e)
+    e[0] = __builtin_amdgcn_exp2f(arg[0]); e[1] = __builtin_amdgcn_exp2f(arg[1]);
+    qst_f32x2 poly = t * 1.061405429f + -1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t + -0.284496736f;
+    poly = poly * t + 0.254829592f;
+    poly = poly * t;
+    const qst_f32x2 half_erf = (poly * e) * -0.5f + 0.5f;              // 0.5 * erf(|x|/sqrt2)
+    qst_f32x2 sh;
+    sh[0] = __builtin_copysignf(half_erf[0], x[0]); sh[1] = __builtin_copysignf(half_erf[1], x[1]);
+    cdf = sh + 0.5f;
+    pdf = e * 0.39894228040143268f;
+}
+
 // erf GELU (HF "gelu": modeling_bert.py:325-337 via ACT2FN) and its derivative.
 // erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32-level) on v_exp_f32 / v_rcp_f32: ~14 VALU ops
 // instead of libm erff's ~50, which made the GELU epilogue cost more than the GEMM's MFMAs.
