@@ -1,2 +1,3 @@
-from quadruplet_sentence_transformer_amd.evaluation import (SentenceEvaluator, SequentialEvaluator,  # noqa: F401
+from quadruplet_sentence_transformer_amd.evaluation import (InformationRetrievalEvaluator,  # noqa: F401
+                                                            SentenceEvaluator, SequentialEvaluator,
                                                             SimilarityFunction, TripletEvaluator)

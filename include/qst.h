@@ -166,6 +166,16 @@ int qst_clip_adamw_step_sched(const qst_encoder* enc, float* params, float* grad
                               float max_grad_norm, float grad_scale, int64_t warmup_steps, int64_t total_steps,
                               int64_t* step_dev, float* norm_out, float* scratch, void* stream);
 
+/* Retrieval scoring for the encode()-driven evaluators: what sentence-transformers'
+ * InformationRetrievalEvaluator does per corpus chunk -- util.cos_sim / util.dot_score of the query embeddings
+ * against the chunk, then torch.topk(k) (reference call sites models/evaluators.py:572-588,
+ * ir_evauation_script.py:107-131). queries f32 [nq, dim], corpus f32 [nc, dim] (device, contiguous), dim % 32 == 0,
+ * k <= min(nc, 1024). cosine != 0 normalises both sides first (eps 1e-12). Outputs: the k best per query, sorted by
+ * descending score (ties: ascending corpus index): out_scores f32 [nq, k], out_index int64 [nq, k]. */
+size_t qst_topk_workspace_bytes(int nq, int nc, int dim);
+int qst_topk_scores(const float* queries, const float* corpus, int nq, int nc, int dim, int k, int cosine,
+                    float* out_scores, int64_t* out_index, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Data parallelism has no entry point here: the gradient arena is one contiguous fp32 buffer, and
  * the host side all-reduces slices of it with torch.distributed (backend "nccl" = RCCL over xGMI) on a side stream,
  * between qst_encoder_backward_partial stages; qst_clip_adamw_step's grad_scale applies the 1/world_size. */

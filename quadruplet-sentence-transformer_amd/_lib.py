@@ -71,6 +71,8 @@ SIGNATURES = {
                                       C.c_float, C.c_float, C.c_int64, vp, vp, vp]),
     "qst_clip_adamw_step_sched": (C.c_int, [vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                             C.c_float, C.c_float, C.c_int64, C.c_int64, vp, vp, vp, vp]),
+    "qst_topk_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "qst_topk_scores": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
     # kernel level (include/qst_kernels.h)
     "qst_gemm_nt": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int, vp]),
     "qst_gemm_nt_ln_supported": (C.c_int, [C.c_int]),
@@ -91,6 +93,7 @@ SIGNATURES = {
     "qst_rel_bucket_host": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "qst_rel_bias_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
     "qst_rel_bias_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "qst_topk_rows": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "qst_shadow_matrix": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
     "qst_shadow_all": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     "qst_gemm_nt_x3": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int, vp]),

@@ -124,6 +124,12 @@ int qst_gemm_nt_x3(const QstGemmArgs* a, int epi, void* stream);
 int qst_attention_fwd_x3(const float* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A, int d,
                          float* ctx, void* stream);
 
+/* k best entries of every row of scores f32 [nrows, ld] (first n columns), sorted by descending score (ties: ascending
+ * index). index_map (nullable, int64, same ld) translates column numbers into caller ids -- used to merge the
+ * per-chunk results of qst_topk_scores. k <= min(n, 1024). */
+int qst_topk_rows(const float* scores, int64_t ld, const int64_t* index_map, int nrows, int n, int k,
+                  float* out_scores, int64_t* out_index, void* stream);
+
 /* All GEMM weights of the arena in one launch; table_dev = int64 [nseg][6] {src off, rows, cols, dst off, dstT off,
  * first block} (built by qst_encoder_create). */
 int qst_shadow_all(const float* params, void* shadow, const int64_t* table_dev, int nseg, int nblocks, void* stream);

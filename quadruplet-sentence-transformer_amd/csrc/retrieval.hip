@@ -1,0 +1,172 @@
+// retrieval.hip -- similarity scoring + top-k for the encode()-driven evaluators.
+//
+// Replaces the device part of sentence-transformers' InformationRetrievalEvaluator.compute_metrices (2.2.2,
+// third-party; reference call sites /root/reference/models/evaluators.py:572-588 and
+// /root/reference/ir_evauation_script.py:107-131): for every corpus chunk, score_function(query_emb, chunk_emb)
+// (util.cos_sim = normalise both sides, then a matmul; util.dot_score = matmul) followed by torch.topk(k, dim=1,
+// largest=True, sorted=False) and a host-side merge of the per-chunk results.
+//
+// Here: rows are normalised (cosine) or copied into a 4-row-padded workspace, the [nq, nc] score matrix comes from the
+// split-bf16 x3 GEMM (fp32-class products: near-ties keep the order an fp32 matmul would give them), and one
+// workgroup per query selects the k best by a 4-pass radix select on order-preserving integer keys, then sorts them.
+#include "qst_common.h"
+#include "qst_kernels.h"
+
+namespace {
+
+// L2-normalise rows (torch.nn.functional.normalize(p=2, dim=1, eps=1e-12)) or copy them; rows >= n are zero-filled.
+__global__ __launch_bounds__(256) void prep_rows_kernel(const float* x, int n, int n_pad, int dim, int normalize, float* y) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_pad) return;
+    float* dst = y + (size_t)row * dim;
+    if (row >= n) {
+        for (int c = lane; c < dim; c += 64) dst[c] = 0.f;
+        return;
+    }
+    const float* src = x + (size_t)row * dim;
+    float inv = 1.f;
+    if (normalize) {
+        float s = 0.f;
+        for (int c = lane; c < dim; c += 64) { const float v = src[c]; s += v * v; }
+        inv = 1.f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+    }
+    for (int c = lane; c < dim; c += 64) dst[c] = src[c] * inv;
+}
+
+// order-preserving map float -> uint32 (larger float <=> larger key); NaNs sort above +inf, as torch.topk ranks them
+__device__ __forceinline__ uint32_t fkey(float v) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+constexpr int TOPK_MAX = 1024;
+
+// One workgroup per row. Pass p fixes 8 more bits of the k-th largest key: histogram the digit of every element that
+// still matches the prefix, walk the 256 bins from the top. After 4 passes `prefix` IS the k-th largest key, `need`
+// the number of elements equal to it that belong to the result. Then collect (> prefix: all, == prefix: the first
+// `need` in index order of arrival), sort by (score desc, index asc) with a bitonic network in LDS, write.
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* scores, int64_t ld, const int64_t* index_map, int n,
+                                                        int k, float* out_scores, int64_t* out_index) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sh_prefix, sh_need, sh_cnt, sh_cnt_eq;
+    __shared__ float sv[TOPK_MAX];
+    __shared__ int64_t si[TOPK_MAX];
+    const int tid = threadIdx.x;
+    const float* row = scores + (size_t)blockIdx.x * ld;
+    const int64_t* imap = index_map ? index_map + (size_t)blockIdx.x * ld : nullptr;
+
+    uint32_t prefix = 0, mask = 0, need = (uint32_t)k;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            const uint32_t key = fkey(row[i]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t acc = 0;
+            int d = 255;
+            for (; d > 0; --d) {
+                if (acc + hist[d] >= need) break;
+                acc += hist[d];
+            }
+            sh_prefix = prefix | ((uint32_t)d << shift);
+            sh_need = need - acc;                      // still to take among the elements with this digit
+        }
+        __syncthreads();
+        prefix = sh_prefix;
+        need = sh_need;
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    // collect
+    if (tid == 0) { sh_cnt = 0; sh_cnt_eq = 0; }
+    __syncthreads();
+    const int kp = k <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(k - 1)));     // next power of two
+    for (int i = tid; i < kp; i += 256) { sv[i] = -INFINITY; si[i] = INT64_MAX; }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const float v = row[i];
+        const uint32_t key = fkey(v);
+        bool take = key > prefix;
+        if (key == prefix) take = atomicAdd(&sh_cnt_eq, 1u) < need;
+        if (take) {
+            const uint32_t pos = atomicAdd(&sh_cnt, 1u);
+            if (pos < (uint32_t)k) { sv[pos] = v; si[pos] = imap ? imap[i] : (int64_t)i; }
+        }
+    }
+    __syncthreads();
+    // bitonic sort of kp entries: descending score, ascending index among equal scores
+    for (int size = 2; size <= kp; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (kp >> 1); t += 256) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const float a = sv[lo], b = sv[hi];
+                const int64_t ia = si[lo], ib = si[hi];
+                const bool a_first = (a > b) || (a == b && ia < ib);       // a ranks before b
+                if (desc ? !a_first : a_first) { sv[lo] = b; sv[hi] = a; si[lo] = ib; si[hi] = ia; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < k; i += 256) {
+        out_scores[(size_t)blockIdx.x * k + i] = sv[i];
+        out_index[(size_t)blockIdx.x * k + i] = si[i];
+    }
+}
+
+constexpr int kQueryBlock = 2048;        // score matrix rows per GEMM launch (keeps byte offsets inside 32 bits)
+
+inline size_t pad4(size_t n) { return (n + 3) / 4 * 4; }
+
+}  // namespace
+
+extern "C" int qst_topk_rows(const float* scores, int64_t ld, const int64_t* index_map, int nrows, int n, int k,
+                             float* out_scores, int64_t* out_index, void* stream) {
+    if (!scores || !out_scores || !out_index || nrows <= 0 || n <= 0 || k <= 0 || ld < n) return QST_ERR_BAD_ARG;
+    if (k > n || k > TOPK_MAX) return QST_ERR_UNSUPPORTED;
+    topk_rows_kernel<<<nrows, 256, 0, (hipStream_t)stream>>>(scores, ld, index_map, n, k, out_scores, out_index);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+extern "C" size_t qst_topk_workspace_bytes(int nq, int nc, int dim) {
+    if (nq <= 0 || nc <= 0 || dim <= 0) return 0;
+    const size_t qrows = pad4((size_t)(nq < kQueryBlock ? nq : kQueryBlock));
+    return (pad4((size_t)nq) + pad4((size_t)nc)) * dim * sizeof(float) + qrows * pad4((size_t)nc) * sizeof(float) + 1024;
+}
+
+extern "C" int qst_topk_scores(const float* queries, const float* corpus, int nq, int nc, int dim, int k, int cosine,
+                               float* out_scores, int64_t* out_index, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    if (!queries || !corpus || !out_scores || !out_index || !workspace || nq <= 0 || nc <= 0 || dim <= 0 || k <= 0)
+        return QST_ERR_BAD_ARG;
+    if (k > nc || k > TOPK_MAX || dim % 32 != 0) return QST_ERR_UNSUPPORTED;
+    if (workspace_bytes < qst_topk_workspace_bytes(nq, nc, dim)) return QST_ERR_WORKSPACE;
+    if ((int64_t)pad4(nc) * dim * 4 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int nqp = (int)pad4(nq), ncp = (int)pad4(nc);
+    float* qn = (float*)workspace;
+    float* cn = qn + (size_t)nqp * dim;
+    float* sc = cn + (size_t)ncp * dim;
+    prep_rows_kernel<<<(nqp + 3) / 4, 256, 0, st>>>(queries, nq, nqp, dim, cosine, qn);
+    QST_LAUNCH_CHECK();
+    prep_rows_kernel<<<(ncp + 3) / 4, 256, 0, st>>>(corpus, nc, ncp, dim, cosine, cn);
+    QST_LAUNCH_CHECK();
+    for (int q0 = 0; q0 < nq; q0 += kQueryBlock) {
+        const int rows = nq - q0 < kQueryBlock ? nq - q0 : kQueryBlock;
+        QstGemmArgs g{};
+        g.A = qn + (size_t)q0 * dim; g.B = cn; g.C = sc;
+        g.M = rows; g.N = ncp; g.K = dim; g.lda = dim; g.ldb = dim; g.ldc = ncp;
+        int rc = qst_gemm_nt_x3(&g, 0, st);
+        if (rc != QST_OK) return rc;
+        rc = qst_topk_rows(sc, ncp, nullptr, rows, nc, k, out_scores + (size_t)q0 * k, out_index + (size_t)q0 * k, st);
+        if (rc != QST_OK) return rc;
+    }
+    return QST_OK;
+}

@@ -1,12 +1,13 @@
-"""Minimal sentence_transformers.evaluation surface used by the reference's evaluators
-(models/evaluators.py:9-12,187-216,602-612): the base class, SimilarityFunction, SequentialEvaluator and an
-encode()-driven TripletEvaluator. IR metrics / CSV plumbing stay out of scope."""
+"""sentence_transformers.evaluation surface used by the reference's evaluators (models/evaluators.py:9-12,187-216,
+572-612; ir_evauation_script.py:107-131): the base class, SimilarityFunction, SequentialEvaluator, an encode()-driven
+TripletEvaluator and InformationRetrievalEvaluator, whose scoring + top-k run on the GPU
+through libqst (util.topk_scores)."""
 from __future__ import annotations
 
 import csv
 import os
 from enum import Enum
-from typing import Iterable, List
+from typing import Callable, Dict, Iterable, List, Optional, Set
 
 import numpy as np
 
@@ -73,3 +74,159 @@ class TripletEvaluator(SentenceEvaluator):
         if self.main_distance_function == SimilarityFunction.EUCLIDEAN:
             return acc_euc
         return max(acc_cos, acc_man, acc_euc)
+
+
+def ir_metrics(queries_result_list: List[List[dict]], queries_ids: List[str], relevant_docs: Dict[str, Set[str]],
+               mrr_at_k: List[int], ndcg_at_k: List[int], accuracy_at_k: List[int], precision_recall_at_k: List[int],
+               map_at_k: List[int]) -> dict:
+    """Accuracy@k, Precision@k, Recall@k, MRR@k, NDCG@k (binary gains, log2 discount), MAP@k over ranked hit lists
+    [{'corpus_id', 'score'}] (best first), with the definitions InformationRetrievalEvaluator.compute_metrics uses:
+    MAP@k divides by min(k, |relevant|); a query with no hit in the top k contributes 0."""
+    n = len(queries_ids)
+    acc = {k: 0 for k in accuracy_at_k}
+    prec = {k: [] for k in precision_recall_at_k}
+    rec = {k: [] for k in precision_recall_at_k}
+    mrr = {k: 0.0 for k in mrr_at_k}
+    ndcg = {k: [] for k in ndcg_at_k}
+    ap = {k: [] for k in map_at_k}
+    for qi, qid in enumerate(queries_ids):
+        hits = sorted(queries_result_list[qi], key=lambda h: h["score"], reverse=True)
+        rel = relevant_docs[qid]
+        flags = [h["corpus_id"] in rel for h in hits]
+        for k in accuracy_at_k:
+            acc[k] += int(any(flags[:k]))
+        for k in precision_recall_at_k:
+            c = sum(flags[:k])
+            prec[k].append(c / k)
+            rec[k].append(c / len(rel))
+        for k in mrr_at_k:
+            for rank, f in enumerate(flags[:k]):
+                if f:
+                    mrr[k] += 1.0 / (rank + 1)
+                    break
+        for k in ndcg_at_k:
+            dcg = sum(1.0 / np.log2(r + 2) for r, f in enumerate(flags[:k]) if f)
+            idcg = sum(1.0 / np.log2(r + 2) for r in range(min(k, len(rel))))
+            ndcg[k].append(dcg / idcg if idcg > 0 else 0.0)
+        for k in map_at_k:
+            good, s_prec = 0, 0.0
+            for rank, f in enumerate(flags[:k]):
+                if f:
+                    good += 1
+                    s_prec += good / (rank + 1)
+            ap[k].append(s_prec / min(k, len(rel)))
+    return {"accuracy@k": {k: acc[k] / n for k in acc}, "precision@k": {k: float(np.mean(v)) for k, v in prec.items()},
+            "recall@k": {k: float(np.mean(v)) for k, v in rec.items()}, "ndcg@k": {k: float(np.mean(v)) for k, v in ndcg.items()},
+            "mrr@k": {k: mrr[k] / n for k in mrr}, "map@k": {k: float(np.mean(v)) for k, v in ap.items()}}
+
+
+class InformationRetrievalEvaluator(SentenceEvaluator):
+    """Queries against a corpus: encode both, score (cos_sim / dot_score), keep the top max(k) hits per query across
+    corpus chunks, report Accuracy/Precision/Recall/MRR/NDCG/MAP @k. Constructor, CSV layout and return value follow
+    sentence-transformers 2.2.2 as the reference drives it (models/evaluators.py:572-588,
+    ir_evauation_script.py:107-131): the main score is max over score functions of MAP@max(map_at_k) unless
+    main_score_function names one. Scoring and top-k selection run in libqst (one fused call per corpus chunk, the
+    per-chunk results merged by a second top-k over the candidates); only the metric arithmetic is host Python."""
+
+    def __init__(self, queries: Dict[str, str], corpus: Dict[str, str], relevant_docs: Dict[str, Set[str]],
+                 corpus_chunk_size: int = 50000, mrr_at_k: List[int] = [10], ndcg_at_k: List[int] = [10],
+                 accuracy_at_k: List[int] = [1, 3, 5, 10], precision_recall_at_k: List[int] = [1, 3, 5, 10],
+                 map_at_k: List[int] = [100], show_progress_bar: bool = False, batch_size: int = 32, name: str = "",
+                 write_csv: bool = True, score_functions: Optional[Dict[str, Callable]] = None,
+                 main_score_function: Optional[str] = None):
+        self.queries_ids = [qid for qid in queries if qid in relevant_docs and len(relevant_docs[qid]) > 0]
+        self.queries = [queries[qid] for qid in self.queries_ids]
+        self.corpus_ids = list(corpus.keys())
+        self.corpus = [corpus[cid] for cid in self.corpus_ids]
+        self.relevant_docs = relevant_docs
+        self.corpus_chunk_size = corpus_chunk_size
+        self.mrr_at_k, self.ndcg_at_k, self.accuracy_at_k = mrr_at_k, ndcg_at_k, accuracy_at_k
+        self.precision_recall_at_k, self.map_at_k = precision_recall_at_k, map_at_k
+        self.show_progress_bar, self.batch_size, self.name, self.write_csv = show_progress_bar, batch_size, name, write_csv
+        # score functions by name; callables are accepted for signature compatibility, but the names decide the
+        # arithmetic: anything called 'cos_sim' / 'dot_score' (the reference passes exactly these two) runs natively
+        if score_functions is None:
+            score_functions = {"cos_sim": None, "dot_score": None}
+        self.score_functions = score_functions
+        self.score_function_names = sorted(score_functions.keys())
+        for nm in self.score_function_names:
+            if nm not in ("cos_sim", "dot_score"):
+                raise ValueError(f"score function {nm!r}: this evaluator scores with 'cos_sim' and/or 'dot_score'")
+        self.main_score_function = main_score_function
+        self.csv_file = "Information-Retrieval_evaluation" + ("_" + name if name else "") + "_results.csv"
+        self.csv_headers = ["epoch", "steps"]
+        for nm in self.score_function_names:
+            for k in accuracy_at_k:
+                self.csv_headers.append(f"{nm}-Accuracy@{k}")
+            for k in precision_recall_at_k:
+                self.csv_headers.append(f"{nm}-Precision@{k}")
+                self.csv_headers.append(f"{nm}-Recall@{k}")
+            for k in mrr_at_k:
+                self.csv_headers.append(f"{nm}-MRR@{k}")
+            for k in ndcg_at_k:
+                self.csv_headers.append(f"{nm}-NDCG@{k}")
+            for k in map_at_k:
+                self.csv_headers.append(f"{nm}-MAP@{k}")
+
+    def __call__(self, model, output_path: str = None, epoch: int = -1, steps: int = -1, *args, **kwargs) -> float:
+        scores = self.compute_metrices(model, *args, **kwargs)
+        if output_path is not None and self.write_csv:
+            path = os.path.join(output_path, self.csv_file)
+            new = not os.path.isfile(path)
+            with open(path, "a", newline="", encoding="utf-8") as f:
+                w = csv.writer(f)
+                if new:
+                    w.writerow(self.csv_headers)
+                row = [epoch, steps]
+                for nm in self.score_function_names:
+                    for k in self.accuracy_at_k:
+                        row.append(scores[nm]["accuracy@k"][k])
+                    for k in self.precision_recall_at_k:
+                        row.append(scores[nm]["precision@k"][k])
+                        row.append(scores[nm]["recall@k"][k])
+                    for k in self.mrr_at_k:
+                        row.append(scores[nm]["mrr@k"][k])
+                    for k in self.ndcg_at_k:
+                        row.append(scores[nm]["ndcg@k"][k])
+                    for k in self.map_at_k:
+                        row.append(scores[nm]["map@k"][k])
+                w.writerow(row)
+        if self.main_score_function is None:
+            return max(scores[nm]["map@k"][max(self.map_at_k)] for nm in self.score_function_names)
+        return scores[self.main_score_function]["map@k"][max(self.map_at_k)]
+
+    def _embed(self, model, texts):
+        return model.encode(texts, batch_size=self.batch_size, show_progress_bar=self.show_progress_bar,
+                            convert_to_tensor=True)
+
+    def compute_metrices(self, model, corpus_model=None, corpus_embeddings=None) -> Dict[str, dict]:
+        import torch
+        from . import util
+        if corpus_model is None:
+            corpus_model = model
+        max_k = max(max(self.mrr_at_k), max(self.ndcg_at_k), max(self.accuracy_at_k), max(self.precision_recall_at_k),
+                    max(self.map_at_k))
+        q_emb = self._embed(model, self.queries)
+        best = {nm: None for nm in self.score_function_names}        # name -> (scores [nq, <=max_k], corpus rows)
+        for start in range(0, len(self.corpus), self.corpus_chunk_size):
+            end = min(start + self.corpus_chunk_size, len(self.corpus))
+            c_emb = corpus_embeddings[start:end] if corpus_embeddings is not None else \
+                self._embed(corpus_model, self.corpus[start:end])
+            c_emb = torch.as_tensor(c_emb).to(q_emb.device)
+            k = min(max_k, end - start)
+            for nm in self.score_function_names:
+                sc, idx = util.topk_scores(q_emb, c_emb, k, cosine=(nm == "cos_sim"))
+                idx = idx + start
+                if best[nm] is not None:                             # merge with the hits of earlier chunks
+                    sc = torch.cat([best[nm][0], sc], dim=1)
+                    idx = torch.cat([best[nm][1], idx], dim=1)
+                    sc, idx = util.topk_rows(sc, min(max_k, sc.shape[1]), index_map=idx)
+                best[nm] = (sc, idx)
+        out = {}
+        for nm in self.score_function_names:
+            sc, idx = best[nm][0].cpu().numpy(), best[nm][1].cpu().numpy()
+            results = [[{"corpus_id": self.corpus_ids[int(c)], "score": float(s)} for s, c in zip(sc[qi], idx[qi])]
+                       for qi in range(len(self.queries_ids))]
+            out[nm] = ir_metrics(results, self.queries_ids, self.relevant_docs, self.mrr_at_k, self.ndcg_at_k,
+                                 self.accuracy_at_k, self.precision_recall_at_k, self.map_at_k)
+        return out
