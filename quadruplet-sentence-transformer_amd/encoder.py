@@ -181,6 +181,24 @@ class HipEncoder:
         self.shadow_stale = True
 
 
+    # ------------------------------------------------------------------ optimiser state (true resume)
+    def optimizer_state(self) -> Dict[str, torch.Tensor]:
+        """The Adam moments as flat arenas (same layout as the parameters) + the step counter."""
+        self.ensure_train_state()
+        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "opt_step": torch.tensor([self.opt_step], dtype=torch.int64)}
+
+    def load_optimizer_state(self, state: Dict[str, torch.Tensor]) -> None:
+        self.ensure_train_state()
+        for k in ("exp_avg", "exp_avg_sq"):
+            t = state[k]
+            if t.numel() != self.total:
+                raise ValueError(f"optimizer state '{k}' has {t.numel()} elements, expected {self.total}")
+            getattr(self, k).copy_(t.to(self.device, dtype=torch.float32).view(-1))
+        self.opt_step = int(state["opt_step"].view(-1)[0])
+        if self._step_dev is not None:
+            self._step_dev.fill_(self.opt_step)
+
     def adamw_step_sched(self, base_lr: float, warmup_steps: int, total_steps: int, betas=(0.9, 0.999),
                          eps: float = 1e-8, weight_decay: float = 0.01, max_grad_norm: float = 1.0,
                          grad_scale: float = 1.0) -> None:

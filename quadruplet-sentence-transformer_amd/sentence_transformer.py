@@ -300,7 +300,12 @@ class SentenceTransformer(nn.Module):
             weight_decay: float = 0.01, evaluation_steps: int = 0, output_path: str = None,
             save_best_model: bool = True, max_grad_norm: float = 1, use_amp: bool = False,
             callback: Callable[[float, int, int], None] = None, show_progress_bar: bool = True,
-            checkpoint_path: str = None, checkpoint_save_steps: int = 500, checkpoint_save_total_limit: int = 0):
+            checkpoint_path: str = None, checkpoint_save_steps: int = 500, checkpoint_save_total_limit: int = 0,
+            resume_from_checkpoint: str = None):
+        """Same keyword set as sentence-transformers 2.2.2 `fit` (the reference passes all of them,
+        training/main.py:128-148) plus `resume_from_checkpoint`: a checkpoint directory written by this method
+        (weights + Adam moments + step counters; the reference's checkpoints hold weights only)
+        from which training continues with the schedule where it stopped."""
         optimizer_params = dict(optimizer_params or {"lr": 2e-5})
         if optimizer_class not in (torch.optim.AdamW,):
             raise NotImplementedError(f"fit() drives the fused HIP AdamW; optimizer_class={optimizer_class} is not supported")
@@ -334,13 +339,22 @@ class SentenceTransformer(nn.Module):
         enc.ensure_train_state()
         enc.grads.zero_()
         global_step = 0
+        if resume_from_checkpoint is not None:
+            global_step = self._load_training_state(resume_from_checkpoint)
+        self._fit_meta = {"scheduler": sched, "lr": lr, "warmup_steps": int(warmup_steps), "t_total": t_total}
         iters = [iter(dl) for dl in dataloaders]
-        for epoch in range(epochs):
-            training_steps = 0
+        if global_step > 0:
+            # resumed run: consume the batches the interrupted run already trained on (exact for unshuffled loaders)
+            for i, dl in enumerate(dataloaders):
+                for _ in range(global_step % max(1, len(dl))):
+                    next(iters[i])
+        first_epoch, skip_steps = divmod(global_step, steps_per_epoch)
+        for epoch in range(first_epoch, epochs):
+            training_steps = skip_steps if epoch == first_epoch else 0
             for lm in loss_models:
                 lm.train()
             self._rebind_grads()
-            for _ in range(steps_per_epoch):
+            for _ in range(steps_per_epoch - training_steps):
                 for idx, lm in enumerate(loss_models):
                     try:
                         data = next(iters[idx])
@@ -392,11 +406,41 @@ class SentenceTransformer(nn.Module):
                     self.save(output_path)
 
     def _save_checkpoint(self, checkpoint_path, checkpoint_save_total_limit, step):
-        self.save(os.path.join(checkpoint_path, str(step)))
+        path = os.path.join(checkpoint_path, str(step))
+        self.save(path)
+        # training state next to the ST model files: Adam moments (flat arenas) + counters, so a run can resume
+        from safetensors.torch import save_file
+        st = self._enc.optimizer_state()
+        save_file({"exp_avg": st["exp_avg"].detach().cpu().contiguous(),
+                   "exp_avg_sq": st["exp_avg_sq"].detach().cpu().contiguous()},
+                  os.path.join(path, "training_state.safetensors"))
+        meta = dict(getattr(self, "_fit_meta", {}))
+        meta.update({"global_step": int(step), "opt_step": int(self._enc.opt_step), "best_score": float(self.best_score)})
+        with open(os.path.join(path, "training_state.json"), "w") as f:
+            json.dump(meta, f, indent=2)
         if checkpoint_save_total_limit is not None and checkpoint_save_total_limit > 0:
             old = sorted(int(d) for d in os.listdir(checkpoint_path) if d.isdigit())
             for s in old[:-checkpoint_save_total_limit]:
                 shutil.rmtree(os.path.join(checkpoint_path, str(s)), ignore_errors=True)
+
+    def _load_training_state(self, path: str) -> int:
+        """Weights, Adam moments and counters from a checkpoint directory written by fit(); returns its global step."""
+        from safetensors.torch import load_file
+        state_file = os.path.join(path, "training_state.safetensors")
+        if not os.path.isfile(state_file):
+            raise FileNotFoundError(f"{path} holds no training_state.safetensors (weights-only checkpoint: cannot resume)")
+        with open(os.path.join(path, "training_state.json")) as f:
+            meta = json.load(f)
+        cfg, arena, _ = _load_model_dir(path)
+        if (cfg.hidden_size, cfg.num_layers, cfg.vocab_size, cfg.arch) != (self.cfg.hidden_size, self.cfg.num_layers,
+                                                                            self.cfg.vocab_size, self.cfg.arch):
+            raise ValueError(f"{path}: checkpoint architecture differs from this model")
+        self._enc.load_arena(arena)
+        st = load_file(state_file)
+        st["opt_step"] = torch.tensor([int(meta["opt_step"])], dtype=torch.int64)
+        self._enc.load_optimizer_state(st)
+        self.best_score = float(meta.get("best_score", self.best_score))
+        return int(meta["global_step"])
 
     # ---- save / load: ST model-directory layout (modules.json, config.json, model.safetensors, 1_Pooling/...)
     def save(self, path: str, model_name: Optional[str] = None, create_model_card: bool = False, **kwargs):

@@ -137,3 +137,52 @@ def test_named_parameters_are_views_with_hf_names(model):
     w = names["0.auto_model.encoder.layer.0.output.LayerNorm.weight"]
     assert w.data_ptr() >= model._enc.params.data_ptr()
     assert w.data_ptr() < model._enc.params.data_ptr() + model._enc.params.numel() * 4
+
+
+def test_fit_checkpoints_carry_optimizer_state_and_resume(tmp_path):
+    """fit() checkpoints hold the Adam moments and step counters next to the ST model files, and
+    fit(resume_from_checkpoint=...) continues the interrupted run: 6 uninterrupted steps == 3 steps, checkpoint, a NEW
+    model object resumed from it, 3 more steps (same data order), up to the float-atomics noise of two identical runs."""
+    examples = [to_input_example(quad(i)) for i in range(24)]
+
+    def run(model, **kw):
+        loader = DataLoader(examples, batch_size=4, shuffle=False)
+        lm = QuadrupletSentenceTransformerLossModel(model, GammaQuadrupletLoss(gamma=0.6, margin_pos_neg=1.0,
+                                                                               margin_pos_part=0.5, margin_part_neg=0.5))
+        model.fit(train_objectives=[(loader, lm)], epochs=1, steps_per_epoch=6, warmup_steps=2,
+                  optimizer_params={"lr": 1e-3}, show_progress_bar=False, **kw)
+
+    full = SentenceTransformer("tiny-bert", device="cuda")
+    w0 = full._enc.params.clone()
+    run(full)
+    part = SentenceTransformer("tiny-bert", device="cuda")
+    ck = str(tmp_path / "ck")
+    # stop during step 4: an evaluator callback that raises is how the reference stops early (callbacks.py:47)
+    class Stop(BaseException):
+        pass
+
+    class Ev(SentenceEvaluator):
+        def __call__(self, model, output_path=None, epoch=-1, steps=-1):
+            return 0.0
+
+    def cb(score, epoch, steps):
+        if steps == 4:                   # the step-3 checkpoint has been written by then
+            raise Stop()
+
+    with pytest.raises(Stop):
+        run(part, checkpoint_path=ck, checkpoint_save_steps=3, evaluator=Ev(), evaluation_steps=1, callback=cb)
+    assert sorted(os.listdir(ck)) == ["3"]
+    assert {"model.safetensors", "training_state.safetensors", "training_state.json"} <= set(os.listdir(os.path.join(ck, "3")))
+    resumed = SentenceTransformer(os.path.join(ck, "3"), device="cuda")        # the checkpoint is a loadable ST directory
+    run(resumed, resume_from_checkpoint=os.path.join(ck, "3"))
+    assert resumed._enc.opt_step == 6
+    moved = (full._enc.params - w0).abs().mean().item()
+    assert moved > 0
+    assert (resumed._enc.params - full._enc.params).abs().mean().item() < 0.05 * moved
+    # and the moments really were restored: resuming WITHOUT them lands measurably elsewhere
+    cold = SentenceTransformer(os.path.join(ck, "3"), device="cuda")
+    run(cold)            # 6 fresh steps from the step-3 weights: different trajectory
+    assert (cold._enc.params - full._enc.params).abs().mean().item() > 0.2 * moved
+    with pytest.raises(FileNotFoundError):
+        full.save(str(tmp_path / "plain"))
+        run(SentenceTransformer("tiny-bert", device="cuda"), resume_from_checkpoint=str(tmp_path / "plain"))
