@@ -17,6 +17,7 @@
 namespace {
 
 constexpr float kMaskMin = -3.4028234663852886e38f;   // torch.finfo(float32).min, HF's additive mask value
+constexpr float kLog2e = 1.4426950408889634f;
 
 template <int D> __device__ __forceinline__ uint32_t rr_off(int row, int chunk) {   // image for ds_read_b128 row reads
     if (D == 32) return (uint32_t)(row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4));
@@ -88,17 +89,27 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs
     constexpr int KS = D / 16, DB = D / 32, IMG = 128 * D * 2;
     char* kimg = smem;                  // row-read image of the K chunk
     char* vimg = smem + IMG;            // transposed-read image of the V chunk
-    float* madd = (float*)(smem + 2 * IMG);   // additive key mask for the whole sequence [L]
+    float* madd = (float*)(smem + 2 * IMG);   // additive key mask for the whole sequence [L], in log2 units
+    char* ostg = smem + 2 * IMG + ((a.L * 4 + 15) & ~15);   // output staging, 32 rows x D bf16 per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, fr = lane & 31;
     const int nqb = (a.L + 127) / 128;
-    const int qb = blockIdx.x % nqb, head = (blockIdx.x / nqb) % a.A, seq = blockIdx.x / (nqb * a.A);
+    // d = 32: heads 2k and 2k+1 of a token share every 128-byte line of q/k/v. Workgroups b and b+8 run on the same
+    // XCD, so give them the two heads of a pair: the line then leaves HBM once and the partner finds it in that L2
+    // (consecutive workgroup ids go to different XCDs: both would fetch it).
+    int bid = blockIdx.x;
+    if (D == 32 && nqb == 1 && (a.A & 1) == 0 && (gridDim.x & 15) == 0)
+        bid = 2 * ((bid >> 4) * 8 + (bid & 7)) + ((bid >> 3) & 1);
+    const int qb = bid % nqb, head = (bid / nqb) % a.A, seq = bid / (nqb * a.A);
     const int ld = 3 * a.H;
     const bf16* base = a.qkv + (size_t)seq * a.L * ld + head * D;
     const int i0 = qb * 128 + wave * 32;
     const bool active = i0 < a.L;
     const int qi = i0 + fr;
 
-    for (int t = tid; t < a.L; t += 256) madd[t] = a.mask[(size_t)seq * a.L + t] ? 0.f : kMaskMin;
+    // softmax in base 2: scores are scaled by scale*log2(e) and fed to v_exp_f32 directly (one multiply and one
+    // exp per element instead of scale, subtract, multiply-by-log2e, exp); kMaskMin * log2(e) overflows to -inf -> p = 0
+    for (int t = tid; t < a.L; t += 256) madd[t] = a.mask[(size_t)seq * a.L + t] ? 0.f : -INFINITY;
+    const float sc2 = a.scale * kLog2e;
 
     bf16x8 qf[KS];
     if (active) {
@@ -139,18 +150,17 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = j0 + acc_row(r, h);
-                float v = s[r] * a.scale;
-                if (a.rel) v += a.rel[((size_t)head * a.L + qi) * a.L + j];
-                v += madd[j];
+                float v = s[r] * sc2 + madd[j];
+                if (a.rel) v += kLog2e * a.rel[((size_t)head * a.L + qi) * a.L + j];
                 s[r] = v;
                 mx = fmaxf(mx, v);
             }
             mx = fmaxf(mx, swap32(mx));
             const float mn = fmaxf(m, mx);
-            const float alpha = __expf(m - mn);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
             float ps = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - mn); ps += s[r]; }
+            for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - mn); ps += s[r]; }
             ps += swap32(ps);
             l = l * alpha + ps;
             m = mn;
@@ -171,7 +181,9 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs
     }
     if (!active) return;
     const float inv = 1.0f / l;
-    bf16* orow = a.out + ((size_t)seq * a.L + qi) * a.H + head * D;
+    // the wave's 32 x D output rows leave through a wave-private LDS staging area as 16-byte stores (four lanes cover
+    // a row's 64-byte head slice); 8-byte-per-lane stores cost ~200 cycles each when every wave of the CU issues them
+    char* stg = ostg + wave * (32 * D * 2);
 #pragma unroll
     for (int b = 0; b < DB; ++b)
 #pragma unroll
@@ -179,9 +191,17 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs
             u32x2 pk;
             pk[0] = pack_bf16x2(o[b][4 * g] * inv, o[b][4 * g + 1] * inv);
             pk[1] = pack_bf16x2(o[b][4 * g + 2] * inv, o[b][4 * g + 3] * inv);
-            *(u32x2*)(orow + b * 32 + 8 * g + 4 * h) = pk;
+            *(u32x2*)(stg + rr_off<D>(fr, (b * 64 + 16 * g) >> 4) + 8 * h) = pk;
         }
-    if (h == 0 && a.lse_out) a.lse_out[((size_t)seq * a.A + head) * a.L + qi] = m + __logf(l);
+    constexpr int CPR = D / 8;
+    bf16* obase = a.out + ((size_t)seq * a.L + i0) * a.H + head * D;
+#pragma unroll
+    for (int kk = 0; kk < 32 * CPR / 64; ++kk) {
+        const int idx = lane + 64 * kk, row = idx / CPR, c = idx % CPR;
+        const u32x4 v = *(const u32x4*)(stg + rr_off<D>(row, c));
+        *(u32x4*)(obase + (size_t)row * a.H + c * 8) = v;
+    }
+    if (h == 0 && a.lse_out) a.lse_out[((size_t)seq * a.A + head) * a.L + qi] = (m + __log2f(l)) * 0.6931471805599453f;
 }
 
 // ------------------------------------------------------------------ backward: dQ
@@ -412,7 +432,6 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dkv_kernel(Attn
 // wave w computes dQ^T = K^T.dS^T for ITS query tile from that image with transposing LDS reads. delta_i = dO_i.O_i is
 // computed while dO is being staged.
 constexpr int DS_IMG = 128 * 128 * 2;
-constexpr float kLog2e = 1.4426950408889634f;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ uint32_t ds_off(int row, int byte) { return (uint32_t)(row * 256 + (byte ^ ((row & 3) << 6))); }
 
@@ -702,7 +721,7 @@ extern "C" int qst_attention_fwd(const void* qkv, const int64_t* mask, const flo
     a.qkv = (const bf16*)qkv; a.mask = mask; a.rel = rel_bias; a.out = (bf16*)ctx; a.lse_out = lse;
     a.nseq = nseq; a.L = L; a.A = A; a.H = A * d; a.scale = 1.0f / sqrtf((float)d);
     const int grid = nseq * A * ((L + 127) / 128);
-    const size_t lds = (size_t)2 * 128 * d * 2 + (size_t)L * 4;
+    const size_t lds = (size_t)2 * 128 * d * 2 + (((size_t)L * 4 + 15) & ~(size_t)15) + (size_t)4 * 32 * d * 2;
     hipStream_t st = (hipStream_t)stream;
     if (d == 32) { if ((rc = set_lds(attn_fwd_kernel<32>, lds))) return rc; attn_fwd_kernel<32><<<grid, 256, lds, st>>>(a); }
     else         { if ((rc = set_lds(attn_fwd_kernel<64>, lds))) return rc; attn_fwd_kernel<64><<<grid, 256, lds, st>>>(a); }
