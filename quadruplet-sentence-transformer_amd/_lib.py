@@ -93,6 +93,8 @@ SIGNATURES = {
     "qst_rel_bucket_host": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "qst_rel_bias_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
     "qst_rel_bias_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "qst_rel_pos_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
+    "qst_rel_pos_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "qst_topk_rows": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "qst_shadow_matrix": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
     "qst_shadow_all": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),

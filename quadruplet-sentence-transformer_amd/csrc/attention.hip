@@ -50,6 +50,35 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& acc, int s) {
 }
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// Relative-position gradient of one 32 x 32 dS tile (rows = queries in registers, column = key on the lane; rows of
+// half h are (r&3) + 8(r>>2) + 4h): the bias gradient only needs the sums along the tile's 63 diagonals j - i. Rotating
+// row i by 31 - i lanes lines every diagonal up on one lane: lane t then holds slot t (diagonal t - 31) if t >= 31 - i,
+// slot 32 + t (diagonal t + 1) otherwise. 16 ds_bpermute + selects per tile; the first version added every element to an
+// LDS array with ds_add_f32, 16 per lane per tile, which more than doubled the kernel (269 -> 656 us at L = 256).
+// Returns the sums of both half-waves combined: lo = slots 0..31, hi = slots 32..62 (lane 31: 0).
+__device__ __forceinline__ void diag_sums(const float (&ds)[16], int lane, float& lo, float& hi) {
+    const int t = lane & 31, h = lane >> 5;
+    lo = 0.f; hi = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = 31 - ((r & 3) + 8 * (r >> 2) + 4 * h);
+        const int src = ((t - k) & 31) + 32 * h;
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src * 4, __builtin_bit_cast(int, ds[r])));
+        lo += (t >= k) ? v : 0.f;
+        hi += (t < k) ? v : 0.f;
+    }
+    lo += swap32(lo);
+    hi += swap32(hi);
+}
+// add a tile's diagonal sums into this wave's private [2L] array: slot s <-> relative position (j0 - i0) + s - 31
+__device__ __forceinline__ void diag_store(float* drel_w, int L, int j0, int i0, int lane, float lo, float hi) {
+    if (lane < 32) {
+        const int base = (j0 - i0) - 31 + L + lane;
+        drel_w[base] += lo;
+        if (lane < 31) drel_w[base + 32] += hi;
+    }
+}
+
 // Stage a 128-row chunk (rows valid) of up to three [rows, D] bf16 tensors into LDS images. ALL global loads of the
 // chunk are issued before the first LDS store (one round trip instead of one per image: the per-image version spent
 // two thirds of the wave's life waiting), and a tensor needed both row-wise and transposed is loaded once.
@@ -76,6 +105,10 @@ struct Stager {
     }
 };
 
+// rel / drel: MPNet's position bias and its gradient as RELATIVE-POSITION vectors [A][2L] (entry j - i + L; the bias
+// depends on j - i only, modeling_mpnet.py:312-348). A workgroup keeps its head's vector in LDS: the earlier [A, L, L]
+// table cost one uncoalesced 4-byte gather per score element (lanes 1 KB apart) and one global float atomic per
+// element for the gradient -- forward 227 vs 70 us and backward 677 vs 251 us at L = 256, d = 64.
 struct AttnArgs {
     const bf16* qkv; const bf16* ctx; const bf16* dctx; const float* lse_in; const int64_t* mask;
     const float* rel; bf16* out; bf16* dqkv; float* lse_out; float* drel; float* delta;
@@ -91,6 +124,7 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs
     char* vimg = smem + IMG;            // transposed-read image of the V chunk
     float* madd = (float*)(smem + 2 * IMG);   // additive key mask for the whole sequence [L], in log2 units
     char* ostg = smem + 2 * IMG + ((a.L * 4 + 15) & ~15);   // output staging, 32 rows x D bf16 per wave
+    float* relv = (float*)(ostg + 4 * 32 * D * 2);           // this head's relative-position bias [2L], log2 units
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, fr = lane & 31;
     const int nqb = (a.L + 127) / 128;
     // d = 32: heads 2k and 2k+1 of a token share every 128-byte line of q/k/v. Workgroups b and b+8 run on the same
@@ -110,6 +144,8 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs
     // exp per element instead of scale, subtract, multiply-by-log2e, exp); kMaskMin * log2(e) overflows to -inf -> p = 0
     for (int t = tid; t < a.L; t += 256) madd[t] = a.mask[(size_t)seq * a.L + t] ? 0.f : -INFINITY;
     const float sc2 = a.scale * kLog2e;
+    if (a.rel)
+        for (int t = tid; t < 2 * a.L; t += 256) relv[t] = kLog2e * a.rel[(size_t)head * 2 * a.L + t];
 
     bf16x8 qf[KS];
     if (active) {
@@ -151,7 +187,7 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs
             for (int r = 0; r < 16; ++r) {
                 const int j = j0 + acc_row(r, h);
                 float v = s[r] * sc2 + madd[j];
-                if (a.rel) v += kLog2e * a.rel[((size_t)head * a.L + qi) * a.L + j];
+                if (a.rel) v += relv[j - qi + a.L];
                 s[r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -213,6 +249,7 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dq_kernel(AttnA
     char* ktr = smem + IMG;             // K transposed reads (dQ^T = K^T.dS^T)
     char* vimg = smem + 2 * IMG;        // V rows (dP^T = V.dO^T)
     float* madd = (float*)(smem + 3 * IMG);
+    float* relv = madd + ((a.L + 3) & ~3);      // this head's relative-position bias [2L]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, fr = lane & 31;
     const int nqb = (a.L + 127) / 128;
     const int qb = blockIdx.x % nqb, head = (blockIdx.x / nqb) % a.A, seq = blockIdx.x / (nqb * a.A);
@@ -223,6 +260,8 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dq_kernel(AttnA
     const int qi = i0 + fr;
 
     for (int t = tid; t < a.L; t += 256) madd[t] = a.mask[(size_t)seq * a.L + t] ? 0.f : kMaskMin;
+    if (a.rel)
+        for (int t = tid; t < 2 * a.L; t += 256) relv[t] = a.rel[(size_t)head * 2 * a.L + t];
 
     bf16x8 qf[KS], dof[KS];
     float lse = 0.f, delta = 0.f;
@@ -277,7 +316,7 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dq_kernel(AttnA
             for (int r = 0; r < 16; ++r) {
                 const int j = j0 + acc_row(r, h);
                 float v = s[r] * a.scale;
-                if (a.rel) v += a.rel[((size_t)head * a.L + qi) * a.L + j];
+                if (a.rel) v += relv[j - qi + a.L];
                 v += madd[j];
                 const float p = __expf(v - lse);
                 s[r] = p * (dp[r] - delta) * a.scale;          // dS^T * scale
@@ -317,6 +356,8 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dkv_kernel(Attn
     char* dtr = smem + 3 * IMG;         // dO^T     (dV^T = dO^T.P)
     float* lse_s = (float*)(smem + 4 * IMG);   // [128]
     float* del_s = lse_s + 128;                // [128]
+    float* relv = del_s + 128;                 // this head's relative-position bias [2L]
+    float* drel_s = relv + 2 * a.L;            // its gradient: one private [2L] array per wave (no atomics)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, fr = lane & 31;
     const int nkb = (a.L + 127) / 128;
     const int kb = blockIdx.x % nkb, head = (blockIdx.x / nkb) % a.A, seq = blockIdx.x / (nkb * a.A);
@@ -327,6 +368,11 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dkv_kernel(Attn
     const bool active = j0 < a.L;
     const int kj = j0 + fr;
 
+    if (a.rel)
+        for (int t = tid; t < 2 * a.L; t += 256) {
+            relv[t] = a.rel[(size_t)head * 2 * a.L + t];
+            drel_s[t] = drel_s[2 * a.L + t] = drel_s[4 * a.L + t] = drel_s[6 * a.L + t] = 0.f;
+        }
     bf16x8 kf[KS], vf[KS];
     float madd = 0.f;
     if (active) {
@@ -384,15 +430,23 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dkv_kernel(Attn
                     const int r = 4 * g + e;
                     const int i = i0 + 8 * g + 4 * h + e;
                     float v = s[r] * a.scale;
-                    if (a.rel) v += a.rel[((size_t)head * a.L + i) * a.L + kj];
+                    if (a.rel) v += relv[kj - i + a.L];
                     v += madd;
                     const float pr = __expf(v - l4[e]);
                     const float dsr = pr * (dp[r] - d4[e]);                    // dS (unscaled) = d(score)
-                    if (a.drel) atomicAdd(a.drel + ((size_t)head * a.L + i) * a.L + kj, dsr);
                     p[r] = pr;
-                    s[r] = dsr * a.scale;
+                    s[r] = dsr;                                                // unscaled until the bias gradient is taken
                 }
             }
+            if (a.drel) {
+                float dsl[16], lo, hi;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dsl[r] = s[r];
+                diag_sums(dsl, lane, lo, hi);
+                diag_store(drel_s + wave * 2 * a.L, a.L, j0, i0, lane, lo, hi);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] *= a.scale;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8 pf = acc_frag(p, ks), sf = acc_frag(s, ks);
@@ -406,21 +460,29 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dkv_kernel(Attn
             }
         }
     }
-    if (!active) return;
-    bf16* krow = a.dqkv + ((size_t)seq * a.L + kj) * ld + a.H + head * D;
-    bf16* vrow = krow + a.H;
+    if (active) {
+        bf16* krow = a.dqkv + ((size_t)seq * a.L + kj) * ld + a.H + head * D;
+        bf16* vrow = krow + a.H;
 #pragma unroll
-    for (int b = 0; b < DB; ++b)
+        for (int b = 0; b < DB; ++b)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            u32x2 pk;
-            pk[0] = pack_bf16x2(dk[b][4 * g], dk[b][4 * g + 1]);
-            pk[1] = pack_bf16x2(dk[b][4 * g + 2], dk[b][4 * g + 3]);
-            *(u32x2*)(krow + b * 32 + 8 * g + 4 * h) = pk;
-            pk[0] = pack_bf16x2(dv[b][4 * g], dv[b][4 * g + 1]);
-            pk[1] = pack_bf16x2(dv[b][4 * g + 2], dv[b][4 * g + 3]);
-            *(u32x2*)(vrow + b * 32 + 8 * g + 4 * h) = pk;
+            for (int g = 0; g < 4; ++g) {
+                u32x2 pk;
+                pk[0] = pack_bf16x2(dk[b][4 * g], dk[b][4 * g + 1]);
+                pk[1] = pack_bf16x2(dk[b][4 * g + 2], dk[b][4 * g + 3]);
+                *(u32x2*)(krow + b * 32 + 8 * g + 4 * h) = pk;
+                pk[0] = pack_bf16x2(dv[b][4 * g], dv[b][4 * g + 1]);
+                pk[1] = pack_bf16x2(dv[b][4 * g + 2], dv[b][4 * g + 3]);
+                *(u32x2*)(vrow + b * 32 + 8 * g + 4 * h) = pk;
+            }
+    }
+    if (a.drel) {
+        __syncthreads();                                 // every wave's LDS adds are done (uniform branch)
+        for (int t = tid; t < 2 * a.L; t += 256) {
+            const float v = (drel_s[t] + drel_s[2 * a.L + t]) + (drel_s[4 * a.L + t] + drel_s[6 * a.L + t]);
+            if (v != 0.f) atomicAdd(a.drel + (size_t)head * 2 * a.L + t, v);
         }
+    }
 }
 
 // ------------------------------------------------------------------ backward, whole (sequence, head) in one workgroup
@@ -447,6 +509,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
     char* dsimg = smem + 5 * IMG;       // dS [key][query] bf16
     float* lse_s = (float*)(smem + 5 * IMG + DS_IMG);   // [128]
     float* del_s = lse_s + 128;                          // [128]
+    float* relv = del_s + 128;                           // this head's relative-position bias [2L], log2 units
+    float* drel_s = relv + 2 * a.L;                      // its gradient: one private [2L] array per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, fr = lane & 31;
     const int ld = 3 * a.H, rows = a.L;
     const int j0 = wave * 32;
@@ -526,6 +590,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
         QST_STAMP(0);
         const float madd2 = nmadd * kLog2e;              // 0 or -inf
         if (tid < rows) lse_s[tid] = -nlse * kLog2e;
+        if (a.rel)
+            for (int t = tid; t < 2 * a.L; t += 256) {
+                relv[t] = kLog2e * a.rel[(size_t)head * 2 * a.L + t];
+                drel_s[t] = drel_s[2 * a.L + t] = drel_s[4 * a.L + t] = drel_s[6 * a.L + t] = 0.f;
+            }
         // delta_i = sum_dd dO[i][dd] * O[i][dd]: 8 elements per thread, CPR adjacent threads per row
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
@@ -583,6 +652,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
                 // (dK and dQ are scaled once at the end); P and dS are rounded to bf16 once and the packed words serve
                 // both as MFMA fragments and as the dS image rows.
                 uint32_t pw[4][2], sw[4][2];
+                float dsl[16];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int il = it * 32 + 8 * g + 4 * h;     // accumulator registers 4g..4g+3 = query rows il..il+3
@@ -597,23 +667,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
                         dv2[0] = d4[e]; dv2[1] = d4[e + 1];
                         f32x2 v = sv * sc2 + cv;                                  // log2 of the probability
                         if (a.rel) {
-                            v[0] += kLog2e * a.rel[((size_t)head * a.L + il + e) * a.L + kj];
-                            v[1] += kLog2e * a.rel[((size_t)head * a.L + il + e + 1) * a.L + kj];
+                            v[0] += relv[kj - (il + e) + a.L];
+                            v[1] += relv[kj - (il + e + 1) + a.L];
                         }
                         f32x2 pr;
                         pr[0] = __builtin_amdgcn_exp2f(v[0]);
                         pr[1] = __builtin_amdgcn_exp2f(v[1]);
                         const f32x2 dsr = pr * (dpv - dv2);                       // dS (unscaled) = d(score)
-                        if (a.drel) {
-                            atomicAdd(a.drel + ((size_t)head * a.L + il + e) * a.L + kj, dsr[0]);
-                            atomicAdd(a.drel + ((size_t)head * a.L + il + e + 1) * a.L + kj, dsr[1]);
-                        }
+                        if (a.drel) { dsl[r] = dsr[0]; dsl[r + 1] = dsr[1]; }
                         pw[g][e >> 1] = pack_bf16x2(pr[0], pr[1]);
                         sw[g][e >> 1] = pack_bf16x2(dsr[0], dsr[1]);
                     }
                     u32x2 pkd;
                     pkd[0] = sw[g][0]; pkd[1] = sw[g][1];
                     *(u32x2*)(dsimg + ds_off(kj, il * 2)) = pkd;
+                }
+                if (a.drel) {
+                    float lo, hi;
+                    diag_sums(dsl, lane, lo, hi);
+                    diag_store(drel_s + wave * 2 * a.L, a.L, j0, it * 32, lane, lo, hi);
                 }
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -640,6 +712,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
         QST_STAMP(3);
         __syncthreads();                                 // every wave's dS tiles are in the image
         QST_STAMP(4);
+        if (a.drel)
+            for (int t = tid; t < 2 * a.L; t += 256) {
+                const float v = (drel_s[t] + drel_s[2 * a.L + t]) + (drel_s[4 * a.L + t] + drel_s[6 * a.L + t]);
+                if (v != 0.f) atomicAdd(a.drel + (size_t)head * 2 * a.L + t, v);
+            }
         if (active) {
             // dQ^T[dd][i] for this wave's query tile i = 32*wave + (lane & 31): contraction over all keys
             f32x16 dq[DB];
@@ -721,7 +798,8 @@ extern "C" int qst_attention_fwd(const void* qkv, const int64_t* mask, const flo
     a.qkv = (const bf16*)qkv; a.mask = mask; a.rel = rel_bias; a.out = (bf16*)ctx; a.lse_out = lse;
     a.nseq = nseq; a.L = L; a.A = A; a.H = A * d; a.scale = 1.0f / sqrtf((float)d);
     const int grid = nseq * A * ((L + 127) / 128);
-    const size_t lds = (size_t)2 * 128 * d * 2 + (((size_t)L * 4 + 15) & ~(size_t)15) + (size_t)4 * 32 * d * 2;
+    const size_t lds = (size_t)2 * 128 * d * 2 + (((size_t)L * 4 + 15) & ~(size_t)15) + (size_t)4 * 32 * d * 2 +
+                       (rel_bias ? (size_t)2 * L * 4 : 0);
     hipStream_t st = (hipStream_t)stream;
     if (d == 32) { if ((rc = set_lds(attn_fwd_kernel<32>, lds))) return rc; attn_fwd_kernel<32><<<grid, 256, lds, st>>>(a); }
     else         { if ((rc = set_lds(attn_fwd_kernel<64>, lds))) return rc; attn_fwd_kernel<64><<<grid, 256, lds, st>>>(a); }
@@ -733,6 +811,7 @@ extern "C" int qst_attention_bwd(const void* qkv, const void* ctx, const void* d
                                  const int64_t* mask, const float* rel_bias, int nseq, int L, int A, int d,
                                  void* dqkv, float* drel, float* delta_scratch, void* stream) {
     if (!qkv || !ctx || !dctx || !lse || !mask || !dqkv || !delta_scratch) return QST_ERR_BAD_ARG;
+    if (drel && !rel_bias) return QST_ERR_BAD_ARG;
     int rc = check_attn(nseq, L, A, d);
     if (rc) return rc;
     AttnArgs a{};
@@ -740,12 +819,12 @@ extern "C" int qst_attention_bwd(const void* qkv, const void* ctx, const void* d
     a.rel = rel_bias; a.dqkv = (bf16*)dqkv; a.drel = drel; a.delta = delta_scratch;
     a.nseq = nseq; a.L = L; a.A = A; a.H = A * d; a.scale = 1.0f / sqrtf((float)d);
     const int grid = nseq * A * ((L + 127) / 128);
-    const size_t lds_q = (size_t)3 * 128 * d * 2 + (size_t)L * 4;
-    const size_t lds_kv = (size_t)4 * 128 * d * 2 + 256 * 4;
+    const size_t lds_q = (size_t)3 * 128 * d * 2 + (((size_t)L + 3) & ~(size_t)3) * 4 + (rel_bias ? (size_t)2 * L * 4 : 0);
+    const size_t lds_kv = (size_t)4 * 128 * d * 2 + 256 * 4 + (rel_bias ? (size_t)10 * L * 4 : 0);
     hipStream_t st = (hipStream_t)stream;
     if (L <= 128 && d == 32 && !g_attn_force_split) {
         // one workgroup per (sequence, head) computes dQ, dK and dV from a single evaluation of the score tile
-        const size_t lds_f = (size_t)5 * 128 * d * 2 + DS_IMG + 256 * 4;
+        const size_t lds_f = (size_t)5 * 128 * d * 2 + DS_IMG + 256 * 4 + (rel_bias ? (size_t)10 * L * 4 : 0);
         if ((rc = set_lds(attn_bwd_fused_kernel<32>, lds_f))) return rc;
         attn_bwd_fused_kernel<32><<<min(nseq * A, 512), 256, lds_f, st>>>(a);      // two per CU, persistent
         QST_LAUNCH_CHECK();

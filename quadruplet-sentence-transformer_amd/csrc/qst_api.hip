@@ -225,7 +225,7 @@ ActPlan plan_acts(const qst_config& c, int nseq, int L, bool training) {
     p.x0 = take(M * H * 4); p.x0b = take(M * H * 2); p.xh0 = take(M * H * 2); p.rs0 = take(M * 4);
     p.s_scratch = take(M * H * 4);
     p.pooled = take((size_t)nseq * H * 4);
-    p.rel = (c.arch == QST_ARCH_MPNET) ? take(A * (size_t)L * L * 4) : 0;
+    p.rel = (c.arch == QST_ARCH_MPNET) ? take(A * (size_t)2 * L * 4) : 0;      // relative-position vectors [A][2L]
     p.layers.resize(c.num_layers);
     for (int l = 0; l < c.num_layers; ++l) {
         LayerAct& a = p.layers[l];
@@ -268,7 +268,7 @@ BwdPlan plan_bwd(const qst_config& c, int nseq, int L) {
     p.dxa = take(M * H * 4); p.dxb = take(M * H * 4); p.ds = take(M * H * 4); p.dsb = take(M * H * 2);
     p.dsb1 = take(M * H * 2);
     p.du = take(M * I * 2); p.dctx = take(M * H * 2); p.dqkv = take(M * 3 * H * 2);
-    p.drel = (c.arch == QST_ARCH_MPNET) ? take(A * (size_t)L * L * 4) : 0;
+    p.drel = (c.arch == QST_ARCH_MPNET) ? take(A * (size_t)2 * L * 4) : 0;
     p.lnred_stride = (qst_ln_bwd_scratch_bytes((int)M, (int)H) + 255) / 256 * 256;
     p.lnred = take(p.lnred_stride * (size_t)(2 * c.num_layers + 1));
     p.delta = take((size_t)nseq * A * L * 4);
@@ -404,7 +404,7 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
                              sv + p.xh0, (float*)(sv + p.rs0), st));
     const float* rel = nullptr;
     if (c.arch == QST_ARCH_MPNET) {
-        QST_TRY(qst_rel_bias_fwd(P(lay.rel), e->rel_lut, A, L, (float*)(sv + p.rel), st));
+        QST_TRY(qst_rel_pos_fwd(P(lay.rel), e->rel_lut, A, L, (float*)(sv + p.rel), st));
         rel = (const float*)(sv + p.rel);
     }
     const float* x = (const float*)(sv + p.x0);
@@ -502,7 +502,7 @@ extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, 
     if (c.arch == QST_ARCH_MPNET) {
         drel = (float*)(ws + w.drel);
         rel = (const float*)(sv + p.rel);
-        if (do_head) QST_HIP_CHECK(hipMemsetAsync(drel, 0, (size_t)A * L * L * 4, st));
+        if (do_head) QST_HIP_CHECK(hipMemsetAsync(drel, 0, (size_t)A * 2 * L * 4, st));
     }
     if (do_head)
         QST_TRY(qst_pool_norm_bwd(grad_emb, (const float*)(sv + p.pooled), mask, nseq, L, H, c.normalize, dxa, st));
@@ -576,7 +576,7 @@ extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, 
     QST_TRY(qst_embed_bwd(ds, ids, type_ids, (const int32_t*)(sv + p.pos_ids), nseq, L, H, c.type_vocab_size,
                           G(lay.word), G(lay.pos), lay.type >= 0 ? G(lay.type) : nullptr, st));
     if (c.arch == QST_ARCH_MPNET) {
-        QST_TRY(qst_rel_bias_bwd(drel, e->rel_lut, c.rel_buckets, A, L, G(lay.rel), st));
+        QST_TRY(qst_rel_pos_bwd(drel, e->rel_lut, c.rel_buckets, A, L, G(lay.rel), st));
     }
     return QST_OK;
 }

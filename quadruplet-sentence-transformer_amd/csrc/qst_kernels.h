@@ -103,10 +103,11 @@ int qst_pool_norm_bwd(const float* demb, const float* pooled, const int64_t* mas
                       int normalize, float* dtok, void* stream);
 
 /* Self-attention forward: qkv bf16 [nseq*L, 3H] token-major (q | k | v, heads concatenated),
- * mask int64 [nseq, L], rel_bias f32 [A, L, L] or NULL -> ctx bf16 [nseq*L, H], lse f32 [nseq, A, L]. */
-int qst_attention_fwd(const void* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A, int d,
+ * mask int64 [nseq, L], rel_pos f32 [A, 2L] (qst_rel_pos_fwd: bias of relative position j - i at entry j - i + L)
+ * or NULL -> ctx bf16 [nseq*L, H], lse f32 [nseq, A, L]. */
+int qst_attention_fwd(const void* qkv, const int64_t* mask, const float* rel_pos, int nseq, int L, int A, int d,
                       void* ctx, float* lse, void* stream);
-/* Backward: dctx bf16 [nseq*L, H] -> dqkv bf16 [nseq*L, 3H]; drel f32 [A, L, L] += (or NULL).
+/* Backward: dctx bf16 [nseq*L, H] -> dqkv bf16 [nseq*L, 3H]; drel_pos f32 [A, 2L] += (or NULL; needs rel_pos).
  * delta_scratch: f32 [nseq, A, L] (dO.O per query, written by the dQ kernel, read by the dK/dV kernel). */
 int qst_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, const int64_t* mask,
                       const float* rel_bias, int nseq, int L, int A, int d, void* dqkv, float* drel,
@@ -117,6 +118,11 @@ int qst_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const 
 int qst_rel_bucket_host(int rel, int num_buckets, int max_distance);
 int qst_rel_bias_fwd(const float* table, const int32_t* lut, int A, int L, float* rel_bias, void* stream);
 int qst_rel_bias_bwd(const float* drel, const int32_t* lut, int buckets, int A, int L, float* dtable, void* stream);
+/* The same bias as relative-position vectors [A][2L] (entry j - i + L; entry 0 unused): the form the bf16 attention
+ * kernels take (each workgroup keeps its head's 2L values in LDS instead of gathering from an [A, L, L] table), and
+ * the reduction of their gradient back onto the bucket table. */
+int qst_rel_pos_fwd(const float* table, const int32_t* lut, int A, int L, float* rel_pos, void* stream);
+int qst_rel_pos_bwd(const float* drel_pos, const int32_t* lut, int buckets, int A, int L, float* dtable, void* stream);
 
 /* Parity-precision (QST_PREC_BF16X3) forward kernels: fp32 operands split into hi+lo bf16 on the fly, three MFMAs
  * per product, fp32 out. epi: 0 = +bias, 1 = +bias +resid, 2 = gelu(+bias). K % 32 == 0. */

@@ -377,6 +377,28 @@ __global__ void rel_bias_bwd_kernel(const float* drel, const int32_t* lut, int b
     if (threadIdx.x == 0) dtable[b * A + a] += red[0] + red[1] + red[2] + red[3];
 }
 
+// The same bias as relative-position vectors, the form the bf16 attention kernels consume:
+// relpos[a][rp + L] = table[bucket(rp)][a] for rp = j - i in (-L, L); entry 0 is unused (zero).
+__global__ void rel_pos_fwd_kernel(const float* table, const int32_t* lut, int A, int L, float* out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= A * 2 * L) return;
+    const int t = idx % (2 * L), a = idx / (2 * L);
+    out[idx] = t == 0 ? 0.f : table[lut[(t - L) + 511] * A + a];
+}
+// dtable[b][a] += sum over the relative positions of bucket b of drelpos[a][rp + L]; block per (bucket, head),
+// fixed summation order (deterministic)
+__global__ void rel_pos_bwd_kernel(const float* drelpos, const int32_t* lut, int buckets, int A, int L, float* dtable) {
+    const int b = blockIdx.x % buckets, a = blockIdx.x / buckets;
+    float acc = 0.f;
+    for (int t = 1 + threadIdx.x; t < 2 * L; t += blockDim.x)
+        if (lut[(t - L) + 511] == b) acc += drelpos[(size_t)a * 2 * L + t];
+    __shared__ float red[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) dtable[b * A + a] += red[0] + red[1] + red[2] + red[3];
+}
+
 // bf16 shadow of a [rows, cols] fp32 matrix and its transpose, via a 32x32 LDS tile
 __global__ __launch_bounds__(256) void shadow_kernel(const float* src, int rows, int cols, bf16* dst, bf16* dstT) {
     __shared__ float tile[32][33];
@@ -581,6 +603,21 @@ extern "C" int qst_rel_bias_bwd(const float* drel, const int32_t* lut, int bucke
                                 void* stream) {
     if (!drel || !lut || !dtable || A <= 0 || L <= 0 || L > 512 || buckets <= 0) return QST_ERR_BAD_ARG;
     rel_bias_bwd_kernel<<<buckets * A, 256, 0, (hipStream_t)stream>>>(drel, lut, buckets, A, L, dtable);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+extern "C" int qst_rel_pos_fwd(const float* table, const int32_t* lut, int A, int L, float* rel_pos, void* stream) {
+    if (!table || !lut || !rel_pos || A <= 0 || L <= 0 || L > 512) return QST_ERR_BAD_ARG;
+    const int n = A * 2 * L;
+    rel_pos_fwd_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(table, lut, A, L, rel_pos);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+extern "C" int qst_rel_pos_bwd(const float* drel_pos, const int32_t* lut, int buckets, int A, int L, float* dtable,
+                               void* stream) {
+    if (!drel_pos || !lut || !dtable || A <= 0 || L <= 0 || L > 512 || buckets <= 0) return QST_ERR_BAD_ARG;
+    rel_pos_bwd_kernel<<<buckets * A, 256, 0, (hipStream_t)stream>>>(drel_pos, lut, buckets, A, L, dtable);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }

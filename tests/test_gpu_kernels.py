@@ -316,23 +316,25 @@ def test_attention_fwd_bwd(lib, n, L, A, d, use_rel):
     lens = torch.randint(max(1, L // 8), L + 1, (n,), generator=g)
     lens[0] = L
     mask = (torch.arange(L)[None, :] < lens[:, None]).long()
-    rel = (0.5 * torch.randn(A, L, L, generator=g)) if use_rel else None
+    # MPNet's bias depends on j - i only: the kernels take it as relative-position vectors [A, 2L] (entry j - i + L)
+    relpos = (0.5 * torch.randn(A, 2 * L, generator=g)) if use_rel else None
+    ridx = (torch.arange(L)[None, :] - torch.arange(L)[:, None]) + L          # [i, j] -> j - i + L
     dctx = bfr(torch.randn(n * L, H, generator=g))
     qr = qkv.clone().requires_grad_(True)
-    relr = rel.clone().requires_grad_(True) if use_rel else None
-    ref = attn_ref(qr, mask, relr, n, L, A, d)
+    relr = relpos.clone().requires_grad_(True) if use_rel else None
+    ref = attn_ref(qr, mask, relr[:, ridx] if use_rel else None, n, L, A, d)
     (ref * dctx).sum().backward()
 
     qd = dev(qkv.to(torch.bfloat16))
     md = dev(mask)
-    reld = dev(rel) if use_rel else None
+    reld = dev(relpos) if use_rel else None
     ctx = torch.empty(n * L, H, dtype=torch.bfloat16, device="cuda")
     lse = torch.empty(n, A, L, device="cuda")
     _lib.check(lib.qst_attention_fwd(qd.data_ptr(), md.data_ptr(), _lib.ptr(reld), n, L, A, d, ctx.data_ptr(), lse.data_ptr(), stream()))
     torch.testing.assert_close(ctx.float().cpu(), ref.detach(), rtol=2e-2, atol=2e-2)
 
     dq = torch.empty(n * L, 3 * H, dtype=torch.bfloat16, device="cuda")
-    drel = torch.zeros(A, L, L, device="cuda") if use_rel else None
+    drel = torch.zeros(A, 2 * L, device="cuda") if use_rel else None
     dcd = dev(dctx.to(torch.bfloat16))
     delta = torch.empty(n, A, L, device="cuda")
     _lib.check(lib.qst_attention_bwd(qd.data_ptr(), ctx.data_ptr(), dcd.data_ptr(), lse.data_ptr(),
@@ -349,7 +351,7 @@ def test_attention_fwd_bwd(lib, n, L, A, d, use_rel):
     if L <= 128 and d == 32:
         # this shape ran the single-workgroup backward; the two-kernel path must agree with it
         dq2 = torch.empty_like(dq)
-        drel2 = torch.zeros(A, L, L, device="cuda") if use_rel else None
+        drel2 = torch.zeros(A, 2 * L, device="cuda") if use_rel else None
         lib.qst_debug_attn_force_split(1)
         try:
             _lib.check(lib.qst_attention_bwd(qd.data_ptr(), ctx.data_ptr(), dcd.data_ptr(), lse.data_ptr(),
@@ -361,6 +363,30 @@ def test_attention_fwd_bwd(lib, n, L, A, d, use_rel):
         torch.testing.assert_close(dq.float(), dq2.float(), rtol=2e-2, atol=2e-2 * max(1.0, gref.abs().max().item()))
         if use_rel:
             torch.testing.assert_close(drel, drel2, rtol=1e-3, atol=1e-3 * max(1.0, drel2.abs().max().item()))
+
+
+def test_rel_pos_vectors_match_the_full_bias_table(lib):
+    """qst_rel_pos_fwd / qst_rel_pos_bwd (relative-position form used by the bf16 attention kernels) against
+    qst_rel_bias_fwd / qst_rel_bias_bwd (the [A, L, L] table of the parity path): same bias, same table gradient."""
+    A, L, buckets, maxd = 12, 96, 32, 128
+    lut = torch.tensor([lib.qst_rel_bucket_host(r, buckets, maxd) for r in range(-511, 512)], dtype=torch.int32).cuda()
+    table = torch.randn(buckets, A).cuda()
+    full = torch.empty(A, L, L, device="cuda")
+    vec = torch.empty(A, 2 * L, device="cuda")
+    _lib.check(lib.qst_rel_bias_fwd(table.data_ptr(), lut.data_ptr(), A, L, full.data_ptr(), stream()))
+    _lib.check(lib.qst_rel_pos_fwd(table.data_ptr(), lut.data_ptr(), A, L, vec.data_ptr(), stream()))
+    ridx = ((torch.arange(L)[None, :] - torch.arange(L)[:, None]) + L).cuda()
+    torch.testing.assert_close(vec[:, ridx], full, rtol=0, atol=0)
+    assert float(vec[:, 0].abs().max()) == 0.0
+    # gradient: a random d(full); its relative-position sums must reduce to the same table gradient
+    dfull = torch.randn(A, L, L, device="cuda")
+    dvec = torch.zeros(A, 2 * L, device="cuda")
+    dvec.index_put_((torch.arange(A, device="cuda")[:, None, None].expand(A, L, L), ridx[None].expand(A, L, L)), dfull,
+                    accumulate=True)
+    dt_full, dt_vec = torch.zeros(buckets, A, device="cuda"), torch.zeros(buckets, A, device="cuda")
+    _lib.check(lib.qst_rel_bias_bwd(dfull.data_ptr(), lut.data_ptr(), buckets, A, L, dt_full.data_ptr(), stream()))
+    _lib.check(lib.qst_rel_pos_bwd(dvec.data_ptr(), lut.data_ptr(), buckets, A, L, dt_vec.data_ptr(), stream()))
+    torch.testing.assert_close(dt_vec, dt_full, rtol=1e-4, atol=1e-3)
 
 
 # ------------------------------------------------------------------ AdamW
