@@ -55,23 +55,19 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 // row i by 31 - i lanes lines every diagonal up on one lane: lane t then holds slot t (diagonal t - 31) if t >= 31 - i,
 // slot 32 + t (diagonal t + 1) otherwise. 16 ds_bpermute + selects per tile; the first version added every element to an
 // LDS array with ds_add_f32, 16 per lane per tile, which more than doubled the kernel (269 -> 656 us at L = 256).
-// Returns the sums of both half-waves combined: lo = slots 0..31, hi = slots 32..62 (lane 31: 0).
-__device__ __forceinline__ void diag_sums(const float (&ds)[16], int lane, float& lo, float& hi) {
+// lo = slots 0..31, hi = slots 32..62 (lane 31: 0); diag_store combines the two half-waves.
+__device__ __forceinline__ void diag_add(float v_in, int r, int lane, float& lo, float& hi) {      // one tile element
     const int t = lane & 31, h = lane >> 5;
-    lo = 0.f; hi = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int k = 31 - ((r & 3) + 8 * (r >> 2) + 4 * h);
-        const int src = ((t - k) & 31) + 32 * h;
-        const float v = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src * 4, __builtin_bit_cast(int, ds[r])));
-        lo += (t >= k) ? v : 0.f;
-        hi += (t < k) ? v : 0.f;
-    }
-    lo += swap32(lo);
-    hi += swap32(hi);
+    const int k = 31 - ((r & 3) + 8 * (r >> 2) + 4 * h);
+    const int src = ((t - k) & 31) + 32 * h;
+    const float v = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src * 4, __builtin_bit_cast(int, v_in)));
+    lo += (t >= k) ? v : 0.f;
+    hi += (t < k) ? v : 0.f;
 }
 // add a tile's diagonal sums into this wave's private [2L] array: slot s <-> relative position (j0 - i0) + s - 31
 __device__ __forceinline__ void diag_store(float* drel_w, int L, int j0, int i0, int lane, float lo, float hi) {
+    lo += swap32(lo);
+    hi += swap32(hi);
     if (lane < 32) {
         const int base = (j0 - i0) - 31 + L + lane;
         drel_w[base] += lo;
@@ -346,7 +342,7 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dq_kernel(AttnA
 }
 
 // ------------------------------------------------------------------ backward: dK, dV
-template <int D>
+template <int D, bool REL>
 __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = D / 16, DB = D / 32, IMG = 128 * D * 2;
@@ -368,7 +364,7 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dkv_kernel(Attn
     const bool active = j0 < a.L;
     const int kj = j0 + fr;
 
-    if (a.rel)
+    if (REL)
         for (int t = tid; t < 2 * a.L; t += 256) {
             relv[t] = a.rel[(size_t)head * 2 * a.L + t];
             drel_s[t] = drel_s[2 * a.L + t] = drel_s[4 * a.L + t] = drel_s[6 * a.L + t] = 0.f;
@@ -430,23 +426,24 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dkv_kernel(Attn
                     const int r = 4 * g + e;
                     const int i = i0 + 8 * g + 4 * h + e;
                     float v = s[r] * a.scale;
-                    if (a.rel) v += relv[kj - i + a.L];
+                    if (REL) v += relv[kj - i + a.L];
                     v += madd;
                     const float pr = __expf(v - l4[e]);
                     const float dsr = pr * (dp[r] - d4[e]);                    // dS (unscaled) = d(score)
                     p[r] = pr;
-                    s[r] = dsr;                                                // unscaled until the bias gradient is taken
+                    s[r] = REL ? dsr : dsr * a.scale;                          // REL: unscaled until the bias gradient is taken
                 }
             }
-            if (a.drel) {
-                float dsl[16], lo, hi;
+            if (REL && a.drel) {
+                float lo = 0.f, hi = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dsl[r] = s[r];
-                diag_sums(dsl, lane, lo, hi);
+                for (int r = 0; r < 16; ++r) diag_add(s[r], r, lane, lo, hi);
                 diag_store(drel_s + wave * 2 * a.L, a.L, j0, i0, lane, lo, hi);
             }
+            if (REL) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] *= a.scale;
+                for (int r = 0; r < 16; ++r) s[r] *= a.scale;
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8 pf = acc_frag(p, ks), sf = acc_frag(s, ks);
@@ -476,7 +473,7 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dkv_kernel(Attn
                 *(u32x2*)(vrow + b * 32 + 8 * g + 4 * h) = pk;
             }
     }
-    if (a.drel) {
+    if (REL && a.drel) {
         __syncthreads();                                 // every wave's LDS adds are done (uniform branch)
         for (int t = tid; t < 2 * a.L; t += 256) {
             const float v = (drel_s[t] + drel_s[2 * a.L + t]) + (drel_s[4 * a.L + t] + drel_s[6 * a.L + t]);
@@ -497,7 +494,7 @@ constexpr int DS_IMG = 128 * 128 * 2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ uint32_t ds_off(int row, int byte) { return (uint32_t)(row * 256 + (byte ^ ((row & 3) << 6))); }
 
-template <int D>
+template <int D, bool REL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = D / 16, DB = D / 32, IMG = 128 * D * 2, CPR = D / 8, PER = 128 * CPR / 256;
@@ -590,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
         QST_STAMP(0);
         const float madd2 = nmadd * kLog2e;              // 0 or -inf
         if (tid < rows) lse_s[tid] = -nlse * kLog2e;
-        if (a.rel)
+        if (REL)
             for (int t = tid; t < 2 * a.L; t += 256) {
                 relv[t] = kLog2e * a.rel[(size_t)head * 2 * a.L + t];
                 drel_s[t] = drel_s[2 * a.L + t] = drel_s[4 * a.L + t] = drel_s[6 * a.L + t] = 0.f;
@@ -652,7 +649,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
                 // (dK and dQ are scaled once at the end); P and dS are rounded to bf16 once and the packed words serve
                 // both as MFMA fragments and as the dS image rows.
                 uint32_t pw[4][2], sw[4][2];
-                float dsl[16];
+                float dlo = 0.f, dhi = 0.f;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int il = it * 32 + 8 * g + 4 * h;     // accumulator registers 4g..4g+3 = query rows il..il+3
@@ -666,7 +663,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
                         dpv[0] = dp[r]; dpv[1] = dp[r + 1];
                         dv2[0] = d4[e]; dv2[1] = d4[e + 1];
                         f32x2 v = sv * sc2 + cv;                                  // log2 of the probability
-                        if (a.rel) {
+                        if (REL) {
                             v[0] += relv[kj - (il + e) + a.L];
                             v[1] += relv[kj - (il + e + 1) + a.L];
                         }
@@ -674,7 +671,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
                         pr[0] = __builtin_amdgcn_exp2f(v[0]);
                         pr[1] = __builtin_amdgcn_exp2f(v[1]);
                         const f32x2 dsr = pr * (dpv - dv2);                       // dS (unscaled) = d(score)
-                        if (a.drel) { dsl[r] = dsr[0]; dsl[r + 1] = dsr[1]; }
+                        if (REL && a.drel) { diag_add(dsr[0], r, lane, dlo, dhi); diag_add(dsr[1], r + 1, lane, dlo, dhi); }
                         pw[g][e >> 1] = pack_bf16x2(pr[0], pr[1]);
                         sw[g][e >> 1] = pack_bf16x2(dsr[0], dsr[1]);
                     }
@@ -682,11 +679,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
                     pkd[0] = sw[g][0]; pkd[1] = sw[g][1];
                     *(u32x2*)(dsimg + ds_off(kj, il * 2)) = pkd;
                 }
-                if (a.drel) {
-                    float lo, hi;
-                    diag_sums(dsl, lane, lo, hi);
-                    diag_store(drel_s + wave * 2 * a.L, a.L, j0, it * 32, lane, lo, hi);
-                }
+                if (REL && a.drel) diag_store(drel_s + wave * 2 * a.L, a.L, j0, it * 32, lane, dlo, dhi);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     u32x4 pu, su;
@@ -712,7 +705,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
         QST_STAMP(3);
         __syncthreads();                                 // every wave's dS tiles are in the image
         QST_STAMP(4);
-        if (a.drel)
+        if (REL && a.drel)
             for (int t = tid; t < 2 * a.L; t += 256) {
                 const float v = (drel_s[t] + drel_s[2 * a.L + t]) + (drel_s[4 * a.L + t] + drel_s[6 * a.L + t]);
                 if (v != 0.f) atomicAdd(a.drel + (size_t)head * 2 * a.L + t, v);
@@ -825,8 +818,13 @@ extern "C" int qst_attention_bwd(const void* qkv, const void* ctx, const void* d
     if (L <= 128 && d == 32 && !g_attn_force_split) {
         // one workgroup per (sequence, head) computes dQ, dK and dV from a single evaluation of the score tile
         const size_t lds_f = (size_t)5 * 128 * d * 2 + DS_IMG + 256 * 4 + (rel_bias ? (size_t)10 * L * 4 : 0);
-        if ((rc = set_lds(attn_bwd_fused_kernel<32>, lds_f))) return rc;
-        attn_bwd_fused_kernel<32><<<min(nseq * A, 512), 256, lds_f, st>>>(a);      // two per CU, persistent
+        if (rel_bias) {
+            if ((rc = set_lds(attn_bwd_fused_kernel<32, true>, lds_f))) return rc;
+            attn_bwd_fused_kernel<32, true><<<min(nseq * A, 512), 256, lds_f, st>>>(a);
+        } else {
+            if ((rc = set_lds(attn_bwd_fused_kernel<32, false>, lds_f))) return rc;
+            attn_bwd_fused_kernel<32, false><<<min(nseq * A, 512), 256, lds_f, st>>>(a);      // two per CU, persistent
+        }
         QST_LAUNCH_CHECK();
         return QST_OK;
     }
@@ -834,14 +832,24 @@ extern "C" int qst_attention_bwd(const void* qkv, const void* ctx, const void* d
         if ((rc = set_lds(attn_bwd_dq_kernel<32>, lds_q))) return rc;
         attn_bwd_dq_kernel<32><<<grid, 256, lds_q, st>>>(a);
         QST_LAUNCH_CHECK();
-        if ((rc = set_lds(attn_bwd_dkv_kernel<32>, lds_kv))) return rc;
-        attn_bwd_dkv_kernel<32><<<grid, 256, lds_kv, st>>>(a);
+        if (rel_bias) {
+            if ((rc = set_lds(attn_bwd_dkv_kernel<32, true>, lds_kv))) return rc;
+            attn_bwd_dkv_kernel<32, true><<<grid, 256, lds_kv, st>>>(a);
+        } else {
+            if ((rc = set_lds(attn_bwd_dkv_kernel<32, false>, lds_kv))) return rc;
+            attn_bwd_dkv_kernel<32, false><<<grid, 256, lds_kv, st>>>(a);
+        }
     } else {
         if ((rc = set_lds(attn_bwd_dq_kernel<64>, lds_q))) return rc;
         attn_bwd_dq_kernel<64><<<grid, 256, lds_q, st>>>(a);
         QST_LAUNCH_CHECK();
-        if ((rc = set_lds(attn_bwd_dkv_kernel<64>, lds_kv))) return rc;
-        attn_bwd_dkv_kernel<64><<<grid, 256, lds_kv, st>>>(a);
+        if (rel_bias) {
+            if ((rc = set_lds(attn_bwd_dkv_kernel<64, true>, lds_kv))) return rc;
+            attn_bwd_dkv_kernel<64, true><<<grid, 256, lds_kv, st>>>(a);
+        } else {
+            if ((rc = set_lds(attn_bwd_dkv_kernel<64, false>, lds_kv))) return rc;
+            attn_bwd_dkv_kernel<64, false><<<grid, 256, lds_kv, st>>>(a);
+        }
     }
     QST_LAUNCH_CHECK();
     return QST_OK;
@@ -854,6 +862,6 @@ extern "C" int qst_debug_attn_occupancy(int which, int lds_bytes) {
     int n = -1;
     if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<32>, 256, lds_bytes);
     if (which == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dq_kernel<32>, 256, lds_bytes);
-    if (which == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dkv_kernel<32>, 256, lds_bytes);
+    if (which == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dkv_kernel<32, false>, 256, lds_bytes);
     return n;
 }
