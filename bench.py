@@ -131,16 +131,16 @@ def time_kernels(trainer, n, L, reps, batches):
              "flops_per_launch": 2.0 * M * I * H, "shape": [M, I, H]})
 
 
-def time_fwd_only(trainer, batches, steps):
+def time_fwd_only(trainer, batches, steps, precision="bf16"):
     """Forward-only throughput (inference forward of the 4 columns as one [4B, L] pass + fused loss, no saved
     activations) -- SURVEY.md section 8d's second figure."""
     import torch
     for i in range(3):
-        trainer.forward_loss(*batches[i % len(batches)])
+        trainer.forward_loss(*batches[i % len(batches)], precision=precision)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        trainer.forward_loss(*batches[i % len(batches)])
+        trainer.forward_loss(*batches[i % len(batches)], precision=precision)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps
 
@@ -283,6 +283,9 @@ def main():
             out["fwd_only"] = {"value": round(B / t_f, 1), "unit": "quadruplets/s", "ms_per_step": round(t_f * 1e3, 4),
                                "what": "encode 4 columns + loss forward, no backward / saved activations",
                                "mfma_frac": round(B / t_f * fwd_flops_q / 1e12 / PEAK_BF16_TFLOPS, 4)}
+            t_8 = time_fwd_only(trainer, batches, max(5, args.steps // 2), precision="fp8w")
+            out["fwd_only_fp8w"] = {"value": round(B / t_8, 1), "unit": "quadruplets/s", "ms_per_step": round(t_8 * 1e3, 4),
+                                    "what": "same, Linear weights as fp8 e4m3 + per-row scales (QST_PREC_FP8W, inference)"}
             out["roofline_loss_kernel"] = time_loss_kernel(cfg.hidden_size)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, arena, L)

@@ -14,7 +14,10 @@
  * softmax / pooling / loss; GEMM and attention contractions take bf16 MFMA
  * operands with fp32 accumulation. precision = QST_PREC_BF16X3 splits every
  * fp32 operand into hi+lo bf16 and issues three MFMAs (fp32-class accuracy,
- * the parity mode); QST_PREC_BF16 rounds operands once (the throughput mode).
+ * the parity mode); QST_PREC_BF16 rounds operands once (the throughput mode);
+ * QST_PREC_FP8W (inference only; BASELINE configs[4] "fp8 weights") keeps every
+ * Linear weight as fp8 e4m3 (OCP) with one fp32 scale per output row
+ * (qst_refresh_shadow8), bf16 activations, fp32 accumulation.
  */
 #ifndef QST_H
 #define QST_H
@@ -36,7 +39,7 @@ typedef enum {
 } qst_status;
 
 enum { QST_ARCH_BERT = 0, QST_ARCH_MPNET = 1 };
-enum { QST_PREC_BF16 = 0, QST_PREC_BF16X3 = 1 };
+enum { QST_PREC_BF16 = 0, QST_PREC_BF16X3 = 1, QST_PREC_FP8W = 2 };
 enum { QST_REDUCE_NONE = 0, QST_REDUCE_SUM = 1, QST_REDUCE_MEAN = 2 };
 
 /* Encoder architecture. Mirrors HF BertConfig / MPNetConfig fields that the
@@ -74,6 +77,9 @@ int     qst_arena_segment(const qst_config* cfg, int idx, const char** name_out,
 /* Elements of the bf16 shadow arena: [W | W^T] copies of every GEMM weight. */
 int64_t qst_shadow_elems(const qst_config* cfg);
 
+/* Bytes of the fp8 weight shadow of QST_PREC_FP8W: per GEMM weight the e4m3 matrix and its fp32 row scales. */
+int64_t qst_shadow8_bytes(const qst_config* cfg);
+
 /* ---- encoder handle ---- */
 int  qst_encoder_create(const qst_config* cfg, qst_encoder** out);
 void qst_encoder_destroy(qst_encoder* enc);
@@ -87,6 +93,9 @@ size_t qst_encoder_bwd_workspace_bytes(const qst_encoder* enc, int nseq, int L);
 /* Refresh the bf16 shadows (W and W^T of every GEMM weight) from the fp32 arena.
  * Must be called after any parameter update and before forward/backward. */
 int qst_refresh_shadow(const qst_encoder* enc, const float* params, void* shadow_bf16, void* stream);
+/* QST_PREC_FP8W: quantise every GEMM weight of the fp32 arena into the fp8 shadow (per output row: scale = max|w| / 448,
+ * round to nearest even). qst_encoder_forward on a QST_PREC_FP8W handle takes this buffer as its `shadow` argument. */
+int qst_refresh_shadow8(const qst_encoder* enc, const float* params, void* shadow_fp8, void* stream);
 
 /*
  * Replaces SentenceTransformer.forward = Sequential(Transformer, Pooling(mean)[, Normalize])

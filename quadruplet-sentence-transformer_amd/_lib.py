@@ -34,7 +34,7 @@ class QstConfig(C.Structure):
 class QstGemmArgs(C.Structure):
     _fields_ = [("A", vp), ("B", vp), ("C", vp), ("C2", vp), ("aux", vp), ("bias", vp), ("resid", vp),
                 ("colsum", vp), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32),
-                ("ldb", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32), ("splits", C.c_int32)]
+                ("ldb", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32), ("splits", C.c_int32), ("bscale", vp)]
 
 
 class QstLnEpi(C.Structure):
@@ -69,12 +69,16 @@ SIGNATURES = {
                                       C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "qst_clip_adamw_step": (C.c_int, [vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                       C.c_float, C.c_float, C.c_int64, vp, vp, vp]),
+    "qst_shadow8_bytes": (C.c_int64, [C.POINTER(QstConfig)]),
+    "qst_refresh_shadow8": (C.c_int, [vp, vp, vp, vp]),
     "qst_clip_adamw_step_sched": (C.c_int, [vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                             C.c_float, C.c_float, C.c_int64, C.c_int64, vp, vp, vp, vp]),
     "qst_topk_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "qst_topk_scores": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
     # kernel level (include/qst_kernels.h)
     "qst_gemm_nt": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int, vp]),
+    "qst_gemm_nt_w8": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int, vp]),
+    "qst_quant_rows_fp8": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
     "qst_gemm_nt_ln_supported": (C.c_int, [C.c_int]),
     "qst_gemm_nt_ln": (C.c_int, [C.POINTER(QstGemmArgs), C.POINTER(QstLnEpi), C.c_int, vp]),
     "qst_gemm_tn": (C.c_int, [C.POINTER(QstGemmArgs), vp]),

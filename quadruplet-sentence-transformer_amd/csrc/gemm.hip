@@ -225,9 +225,11 @@ __device__ __forceinline__ void nt_mainloop_tall(const QstGemmArgs& g, char* sme
 // with loads and stores interleaved per row the compiler must keep them in order (C may alias resid), and in-kernel
 // stamps showed the epilogue then costing 2-4x the whole K loop in exposed load latency.
 // bias_s: this wave's 96 bias values in LDS (written by the caller, same wave).
+// scale_s: optional per-column factors applied to the accumulator before the bias (fp8-weight GEMM: the weight row's
+// quantisation scale), 96 values in LDS like bias_s, or nullptr.
 template <int EPI, int TI>
 __device__ __forceinline__ void nt_epilogue(const QstGemmArgs& g, f32x16 (&acc)[TI][3], float* stg, const float* bias_s,
-                                            int m_base, int n_base, int lane) {
+                                            int m_base, int n_base, int lane, const float* scale_s = nullptr) {
     const int fr = lane & 31, fh = lane >> 5;
     constexpr bool kF32Out = (EPI == QST_EPI_F32_RESID || EPI == QST_EPI_F32_RESID_BF16);
 #pragma unroll
@@ -262,6 +264,7 @@ __device__ __forceinline__ void nt_epilogue(const QstGemmArgs& g, f32x16 (&acc)[
                 const int n = n_base + c4 * 4;
                 if (m >= g.M || n >= g.N) continue;
                 f32x4 v = *(const f32x4*)(stg + row * NT_STG_LD + c4 * 4);
+                if (scale_s) v *= *(const f32x4*)(scale_s + c4 * 4);
                 if (g.bias) v += *(const f32x4*)(bias_s + c4 * 4);
                 v += rv[t];
                 const size_t o = (size_t)m * g.ldc + n;
@@ -307,6 +310,11 @@ __device__ __forceinline__ void nt_epilogue(const QstGemmArgs& g, f32x16 (&acc)[
                     const f32x4 hi = *(const f32x4*)(stg + row * NT_STG_LD + c8 * 8 + 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+                }
+                if (scale_s) {
+                    const f32x4 lo = *(const f32x4*)(scale_s + c8 * 8), hi = *(const f32x4*)(scale_s + c8 * 8 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] *= lo[e]; v[4 + e] *= hi[e]; }
                 }
                 if (g.bias) {
                     const f32x4 lo = *(const f32x4*)(bias_s + c8 * 8), hi = *(const f32x4*)(bias_s + c8 * 8 + 4);
@@ -372,6 +380,98 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 2 ? 2 : 1) void 
         }
     }
     nt_epilogue<EPI, TI>(g, acc, stg, bias_s, m0 + wm * (32 * TI), n0 + wn * 96, lane);
+}
+
+// ---------------------------------------------------------------- NT with fp8 (e4m3) weights (inference)
+// C = (A . Q^T) * scale[n] + epilogue: A bf16 activations, Q = fp8 weights quantised per output row (scale = row amax /
+// 448, qst_quant_rows_fp8). The K loop is the 128 x 192 one with the weight tile at half the bytes (12 instead of 24 KB
+// per 64-deep stage: 28 KB per stage against 40 -- the loop runs at the rate operands arrive, DESIGN.md finding 4);
+// fragments are widened to bf16 in registers (e4m3 values are exact in bf16) and go through the same bf16 MFMA, the row
+// scale is applied to the fp32 accumulator in the epilogue. BASELINE configs[4] "fp8 weights"; SURVEY.md 7 step 9.
+__device__ __forceinline__ bf16x8 fp8x8_to_bf16(u32x2 w) {
+    const auto a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[0], false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[0], true);
+    const auto c = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[1], false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[1], true);
+    bf16x8 f;
+    f[0] = (bf16)a[0]; f[1] = (bf16)a[1]; f[2] = (bf16)b[0]; f[3] = (bf16)b[1];
+    f[4] = (bf16)c[0]; f[5] = (bf16)c[1]; f[6] = (bf16)d[0]; f[7] = (bf16)d[1];
+    return f;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_w8_kernel(QstGemmArgs g) {
+    constexpr int NBM = 128, NBN = 192;
+    constexpr int A_BYTES = NBM * NBK * 2, B_BYTES = NBN * NBK, STAGE = A_BYTES + B_BYTES;      // 16 + 12 KB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (g.N + NBN - 1) / NBN, ntm = (g.M + NBM - 1) / NBM;
+    const int wg = xcd_remap(blockIdx.x, ntm * ntn);
+    const int m0 = (wg / ntn) * NBM, n0 = (wg % ntn) * NBN;
+    const int fr = lane & 31, fh = lane >> 5;
+
+    const int rows_a = min(NBM, g.M - m0), rows_b = min(NBN, g.N - n0);
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc((const bf16*)g.A + (size_t)m0 * g.lda, (uint32_t)rows_a * g.lda * 2u);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc((const uint8_t*)g.B + (size_t)n0 * g.ldb, (uint32_t)rows_b * g.ldb);
+    uint32_t va[4], vb[3];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {                     // A: 8 rows of 128 B per DMA instruction
+        const int row = (wave * 4 + t) * 8 + (lane >> 3);
+        va[t] = (uint32_t)row * g.lda * 2u + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {                     // B: 16 rows of 64 B (64 fp8) per DMA instruction
+        const int row = (wave * 3 + t) * 16 + (lane >> 2);
+        vb[t] = (uint32_t)row * g.ldb + (uint32_t)(((lane & 3) ^ ((row >> 2) & 3)) * 16);
+    }
+    auto issue = [&](int kt) {
+        char* st = smem + (kt & 1) * STAGE;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dma16(ra, st + (wave * 4 + t) * 1024, va[t], (uint32_t)kt * (NBK * 2));
+#pragma unroll
+        for (int t = 0; t < 3; ++t) dma16(rb, st + A_BYTES + (wave * 3 + t) * 1024, vb[t], (uint32_t)kt * NBK);
+    };
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nk = g.K / NBK;
+    issue(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) issue(kt + 1);
+        const char* pa = smem + (kt & 1) * STAGE;
+        const char* pb = pa + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 fa[2], fb[3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *(const bf16x8*)(pa + nt_off(wm * 64 + i * 32 + fr, ks * 2 + fh));
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                fb[j] = fp8x8_to_bf16(*(const u32x2*)(pb + nt_off32(wn * 96 + j * 32 + fr, ks) + 8 * fh));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+
+    float* stg = (float*)smem + wave * (32 * NT_STG_LD);
+    float* bias_s = (float*)smem + 4 * (32 * NT_STG_LD) + wave * 96;
+    float* scale_s = bias_s + 4 * 96;
+    for (int c = lane; c < 96; c += 64) {
+        const int n = n0 + wn * 96 + c;
+        bias_s[c] = (g.bias && n < g.N) ? g.bias[n] : 0.f;
+        scale_s[c] = n < g.N ? g.bscale[n] : 0.f;
+    }
+    nt_epilogue<EPI, 2>(g, acc, stg, bias_s, m0 + wm * 64, n0 + wn * 96, lane, scale_s);
 }
 
 // ---------------------------------------------------------------- NT with a LayerNorm fused into the epilogue
@@ -783,6 +883,33 @@ extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
         default: return QST_ERR_BAD_ARG;
     }
 #undef QST_NT_CASE
+}
+
+template <int EPI>
+static int launch_nt_w8(const QstGemmArgs* a, hipStream_t st) {
+    constexpr int lds = 2 * (128 * NBK * 2 + 192 * NBK);        // 56 KB ring; staging + bias + scales (54.3 KB) fit inside
+    static bool attr_set = false;
+    if (!attr_set) {
+        QST_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int ntm = (a->M + 127) / 128, ntn = (a->N + 191) / 192;
+    gemm_nt_w8_kernel<EPI><<<dim3(ntm * ntn), dim3(256), lds, st>>>(*a);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+extern "C" int qst_gemm_nt_w8(const QstGemmArgs* a, int epi, void* stream) {
+    if (!a || !a->A || !a->B || !a->C || !a->bscale || a->M <= 0 || a->N <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
+    if (a->K % NBK != 0 || a->lda % 8 != 0 || a->ldb % 16 != 0 || a->N % 4 != 0 || a->ldc % 4 != 0) return QST_ERR_UNSUPPORTED;
+    if ((int64_t)128 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)192 * a->ldb >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    switch (epi) {
+        case QST_EPI_BF16: return launch_nt_w8<QST_EPI_BF16>(a, st);
+        case QST_EPI_F32_RESID: return launch_nt_w8<QST_EPI_F32_RESID>(a, st);
+        case QST_EPI_GELU: return launch_nt_w8<QST_EPI_GELU>(a, st);
+        default: return QST_ERR_BAD_ARG;
+    }
 }
 
 extern "C" int qst_gemm_nt_ln_supported(int N) { return N == LN_N ? 1 : 0; }

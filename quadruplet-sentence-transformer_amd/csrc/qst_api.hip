@@ -111,6 +111,9 @@ struct qst_encoder {
 
 extern "C" int64_t qst_arena_elems(const qst_config* cfg) { return cfg_ok(cfg) ? build_layout(cfg).total : QST_ERR_BAD_ARG; }
 extern "C" int64_t qst_shadow_elems(const qst_config* cfg) { return cfg_ok(cfg) ? build_layout(cfg).shadow_total : QST_ERR_BAD_ARG; }
+// fp8 shadow: the weight bytes of segment s sit at byte offset s.shadow_off (inside the first half of what is the [W | W^T]
+// region in bf16-element units), its fp32 row scales at byte offset s.shadow_off + align(numel): same total, in bytes.
+extern "C" int64_t qst_shadow8_bytes(const qst_config* cfg) { return cfg_ok(cfg) ? build_layout(cfg).shadow_total : QST_ERR_BAD_ARG; }
 extern "C" int qst_arena_num_segments(const qst_config* cfg) { return cfg_ok(cfg) ? (int)build_layout(cfg).segs.size() : QST_ERR_BAD_ARG; }
 extern "C" int qst_arena_segment(const qst_config* cfg, int idx, const char** name_out, int64_t* offset_out,
                                  int64_t* numel_out, int32_t* decay_out, int32_t* gemm_out) {
@@ -152,7 +155,8 @@ extern "C" int qst_encoder_create(const qst_config* cfg, qst_encoder** out) {
     if (cfg->hidden_size % cfg->num_heads != 0 || (d != 32 && d != 64)) return QST_ERR_UNSUPPORTED;
     if (cfg->hidden_size % 64 != 0 || cfg->intermediate_size % 64 != 0 || cfg->hidden_size > 1024) return QST_ERR_UNSUPPORTED;
     if (cfg->type_vocab_size > 2) return QST_ERR_UNSUPPORTED;
-    if (cfg->precision != QST_PREC_BF16 && cfg->precision != QST_PREC_BF16X3) return QST_ERR_UNSUPPORTED;
+    if (cfg->precision != QST_PREC_BF16 && cfg->precision != QST_PREC_BF16X3 && cfg->precision != QST_PREC_FP8W)
+        return QST_ERR_UNSUPPORTED;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return QST_ERR_NO_DEVICE;
     qst_encoder* e = new qst_encoder();
@@ -299,6 +303,13 @@ int nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* C
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
     return qst_gemm_nt(&g, epi, st);
 }
+int nt_w8(const void* A, int lda, const void* B8, const float* bscale, int ldb, void* C, int ldc, void* C2, const float* bias,
+          const float* resid, int ldr, int M, int N, int K, int epi, hipStream_t st) {
+    QstGemmArgs g{};
+    g.A = A; g.B = B8; g.C = C; g.C2 = C2; g.bias = bias; g.resid = resid; g.bscale = bscale;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
+    return qst_gemm_nt_w8(&g, epi, st);
+}
 // GEMM with the following LayerNorm (mode 0) / LayerNorm backward (mode 1) fused into its epilogue (N = H = 384)
 int nt_ln(const void* A, int lda, const void* B, int ldb, float* C, void* C2, const float* bias, const float* resid,
           int M, int H, int K, int mode, const float* gamma, const float* beta, float eps, void* xhat, float* rstd,
@@ -335,6 +346,18 @@ extern "C" size_t qst_encoder_bwd_workspace_bytes(const qst_encoder* e, int nseq
 extern "C" int qst_refresh_shadow(const qst_encoder* e, const float* params, void* shadow, void* stream) {
     if (!e || !params || !shadow) return QST_ERR_BAD_ARG;
     return qst_shadow_all(params, shadow, e->shadow_tab, e->shadow_nseg, e->shadow_blocks, stream);
+}
+
+extern "C" int qst_refresh_shadow8(const qst_encoder* e, const float* params, void* shadow8, void* stream) {
+    if (!e || !params || !shadow8) return QST_ERR_BAD_ARG;
+    for (const Seg& s : e->lay.segs) {
+        if (!s.gemm) continue;
+        uint8_t* w8 = (uint8_t*)shadow8 + s.shadow_off;
+        float* sc = (float*)((uint8_t*)shadow8 + s.shadow_off + qst_align_up(s.numel, kAlign));
+        int rc = qst_quant_rows_fp8(params + s.off, s.rows, s.cols, w8, sc, stream);
+        if (rc != QST_OK) return rc;
+    }
+    return QST_OK;
 }
 
 // Parity-precision forward (QST_PREC_BF16X3): same operator sequence as below on fp32 activations and the fp32
@@ -387,6 +410,8 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
         return training ? QST_ERR_UNSUPPORTED
                         : forward_x3(e, ids, mask, type_ids, nseq, L, params, out_emb, out_tok, saved, saved_bytes, (hipStream_t)stream);
     if (!shadow) return QST_ERR_BAD_ARG;
+    const bool w8 = c.precision == QST_PREC_FP8W;       // fp8 weights (shadow = qst_refresh_shadow8's buffer): inference only
+    if (w8 && training) return QST_ERR_UNSUPPORTED;
     const ActPlan p = plan_acts(c, nseq, L, training != 0);
     if (saved_bytes < p.total) return QST_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -396,6 +421,15 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     const Layout& lay = e->lay;
     auto P = [&](int seg) { return params + lay.segs[seg].off; };
     auto W = [&](int seg) { return sh + lay.segs[seg].shadow_off; };
+    auto W8 = [&](int seg) { return (const uint8_t*)shadow + lay.segs[seg].shadow_off; };
+    auto S8 = [&](int seg) {
+        return (const float*)((const uint8_t*)shadow + lay.segs[seg].shadow_off + qst_align_up(lay.segs[seg].numel, kAlign));
+    };
+    // one Linear: bf16 shadow weights, or fp8 weights + row scales (same epilogues)
+    auto linear = [&](const void* Ain, int K, int wseg, void* Cout, int N, void* C2, int bseg, const float* resid, int epi) {
+        if (w8) return nt_w8(Ain, K, W8(wseg), S8(wseg), K, Cout, N, C2, P(bseg), resid, N, M, N, K, epi, st);
+        return nt(Ain, K, W(wseg), K, Cout, N, C2, nullptr, P(bseg), resid, N, M, N, K, epi, st);
+    };
 
     int32_t* pos_ids = (int32_t*)(sv + p.pos_ids);
     QST_TRY(qst_position_ids(ids, nseq, L, c.arch, c.pad_token_id, pos_ids, st));
@@ -411,30 +445,27 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     const void* xb = sv + p.x0b;
     float* s = (float*)(sv + p.s_scratch);
     // H = 384: the LayerNorm after each projection runs inside that GEMM's epilogue (full-row tiles)
-    const bool fuse_ln = qst_gemm_nt_ln_supported(H) != 0;
+    const bool fuse_ln = !w8 && qst_gemm_nt_ln_supported(H) != 0;
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerAct& a = p.layers[l];
         const int b = lay.layer0[l];
-        QST_TRY(nt(xb, H, W(b + W_QKV), H, sv + a.qkv, 3 * H, nullptr, nullptr, P(b + B_QKV), nullptr, 0, M, 3 * H, H,
-                   QST_EPI_BF16, st));
+        QST_TRY(linear(xb, H, b + W_QKV, sv + a.qkv, 3 * H, nullptr, b + B_QKV, nullptr, QST_EPI_BF16));
         QST_TRY(qst_attention_fwd(sv + a.qkv, mask, rel, nseq, L, A, d, sv + a.ctx, (float*)(sv + a.lse), st));
         if (fuse_ln) {
             QST_TRY(nt_ln(sv + a.ctx, H, W(b + W_O), H, (float*)(sv + a.y1), sv + a.y1b, P(b + B_O), x, M, H, H, 0,
                           P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, sv + a.xh1, (float*)(sv + a.rs1), nullptr, st));
         } else {
-            QST_TRY(nt(sv + a.ctx, H, W(b + W_O), H, s, H, nullptr, nullptr, P(b + B_O), x, H, M, H, H, QST_EPI_F32_RESID, st));
+            QST_TRY(linear(sv + a.ctx, H, b + W_O, s, H, nullptr, b + B_O, x, QST_EPI_F32_RESID));
             QST_TRY(qst_ln_fwd(s, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, (float*)(sv + a.y1), sv + a.y1b,
                                sv + a.xh1, (float*)(sv + a.rs1), st));
         }
-        QST_TRY(nt(sv + a.y1b, H, W(b + W_1), H, sv + a.u, I, sv + a.hact, nullptr, P(b + B_1), nullptr, 0, M, I, H,
-                   QST_EPI_GELU, st));
+        QST_TRY(linear(sv + a.y1b, H, b + W_1, sv + a.u, I, sv + a.hact, b + B_1, nullptr, QST_EPI_GELU));
         if (fuse_ln) {
             QST_TRY(nt_ln(sv + a.hact, I, W(b + W_2), I, (float*)(sv + a.x), sv + a.xb, P(b + B_2),
                           (const float*)(sv + a.y1), M, H, I, 0, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, sv + a.xh2,
                           (float*)(sv + a.rs2), nullptr, st));
         } else {
-            QST_TRY(nt(sv + a.hact, I, W(b + W_2), I, s, H, nullptr, nullptr, P(b + B_2), (const float*)(sv + a.y1), H, M, H,
-                       I, QST_EPI_F32_RESID, st));
+            QST_TRY(linear(sv + a.hact, I, b + W_2, s, H, nullptr, b + B_2, (const float*)(sv + a.y1), QST_EPI_F32_RESID));
             QST_TRY(qst_ln_fwd(s, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, M, H, (float*)(sv + a.x), sv + a.xb,
                                sv + a.xh2, (float*)(sv + a.rs2), st));
         }

@@ -28,11 +28,18 @@ typedef struct {
     float* colsum;        // tn only: f32 [N] += column sums of A (bias gradient), or NULL
     int32_t M, N, K;
     int32_t lda, ldb, ldc, ldr;
-    int32_t splits;       // tn only: reduction splits over M (0 = auto)
+    int32_t splits;       // tn only: reduction splits over M (0 = auto); nt: tile-variant selector (tests / tuning)
+    const float* bscale;  // qst_gemm_nt_w8 only: f32 [N] quantisation scale of each fp8 weight row
 } QstGemmArgs;
 
 /* C[M,N] = A[M,K] . B[N,K]^T with epilogue `epi`. K % 64 == 0, lda/ldb % 8 == 0. */
 int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream);
+/* NT GEMM with fp8 (e4m3, OCP) weights: C = (A . Q^T) * bscale[n] (+ epilogue). B = Q: fp8 [N, K] (ldb in bytes,
+ * % 16 == 0), bscale f32 [N]. epi: QST_EPI_BF16, QST_EPI_F32_RESID, QST_EPI_GELU. Inference path (QST_PREC_FP8W). */
+int qst_gemm_nt_w8(const QstGemmArgs* a, int epi, void* stream);
+/* Per-row symmetric quantisation of a [rows, cols] f32 matrix to fp8 e4m3: scale[r] = max|row| / 448 (1 for an
+ * all-zero row), dst = round-to-nearest-even(src / scale). cols % 4 == 0. */
+int qst_quant_rows_fp8(const float* src, int rows, int cols, void* dst_fp8, float* scales, void* stream);
 /* NT GEMM with a LayerNorm fused into the epilogue (one 128 x 384 tile spans whole rows: N must be 384;
  * qst_gemm_nt_ln_supported(N) tells). xhat is bf16 [M, 384] contiguous, rstd f32 [M].
  *  mode 0 (forward):  v = A.B^T + bias + resid ; y = LayerNorm(v) -> C (f32), C2 (bf16, nullable);

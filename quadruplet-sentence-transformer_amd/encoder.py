@@ -37,12 +37,15 @@ class HipEncoder:
         _lib.check(self.lib.qst_encoder_create(self.ccfg, h), "qst_encoder_create")
         self.handle = h
         self.handle_x3 = None         # QST_PREC_BF16X3 handle over the SAME arenas, created on first use
+        self.handle_fp8 = None        # QST_PREC_FP8W handle (fp8 e4m3 weights + row scales, inference), on first use
+        self.shadow8: Optional[torch.Tensor] = None
         self.params = torch.zeros(self.total, dtype=torch.float32, device=self.device)
         self.grads: Optional[torch.Tensor] = None
         self.exp_avg: Optional[torch.Tensor] = None
         self.exp_avg_sq: Optional[torch.Tensor] = None
         self.shadow = torch.zeros(self.lib.qst_shadow_elems(self.ccfg), dtype=torch.bfloat16, device=self.device)
         self.shadow_stale = True
+        self.shadow8_stale = True
         self._saved: Optional[torch.Tensor] = None
         self._ws: Optional[torch.Tensor] = None
         self._scratch = torch.zeros(2048, dtype=torch.float32, device=self.device)
@@ -52,7 +55,7 @@ class HipEncoder:
 
     def __del__(self):
         try:
-            for attr in ("handle", "handle_x3"):
+            for attr in ("handle", "handle_x3", "handle_fp8"):
                 if getattr(self, attr, None):
                     self.lib.qst_encoder_destroy(getattr(self, attr))
                     setattr(self, attr, None)
@@ -66,6 +69,7 @@ class HipEncoder:
             raise ValueError(f"arena has {t.numel()} elements, expected {self.total}")
         self.params.copy_(t.to(self.device))
         self.shadow_stale = True
+        self.shadow8_stale = True
 
     def named_views(self) -> Dict[str, torch.Tensor]:
         """HF-named views into the parameter arena (no copies)."""
@@ -93,6 +97,12 @@ class HipEncoder:
         if self.exp_avg is None:
             self.exp_avg = torch.zeros_like(self.params)
             self.exp_avg_sq = torch.zeros_like(self.params)
+
+    def refresh_shadow8(self) -> None:
+        """Quantise every Linear weight to fp8 e4m3 with one fp32 scale per output row (QST_PREC_FP8W)."""
+        _lib.check(self.lib.qst_refresh_shadow8(self.handle_fp8, self.params.data_ptr(), self.shadow8.data_ptr(),
+                                                _lib.current_stream_ptr()), "qst_refresh_shadow8")
+        self.shadow8_stale = False
 
     def refresh_shadow(self) -> None:
         _lib.check(self.lib.qst_refresh_shadow(self.handle, self.params.data_ptr(), self.shadow.data_ptr(),
@@ -124,8 +134,16 @@ class HipEncoder:
     def _handle_for(self, precision: str):
         if precision in ("bf16", 0, None):
             return self.handle
+        if precision in ("fp8w", 2):
+            if self.handle_fp8 is None:
+                h = _lib.vp()
+                _lib.check(self.lib.qst_encoder_create(_lib.make_config(self.cfg, 2), h), "qst_encoder_create(fp8w)")
+                self.handle_fp8 = h
+                self.shadow8 = torch.zeros(self.lib.qst_shadow8_bytes(self.ccfg), dtype=torch.uint8, device=self.device)
+                self.shadow8_stale = True
+            return self.handle_fp8
         if precision not in ("bf16x3", 1):
-            raise ValueError(f"unknown precision {precision!r} (bf16 | bf16x3)")
+            raise ValueError(f"unknown precision {precision!r} (bf16 | bf16x3 | fp8w)")
         if self.handle_x3 is None:
             h = _lib.vp()
             _lib.check(self.lib.qst_encoder_create(_lib.make_config(self.cfg, 1), h), "qst_encoder_create(x3)")
@@ -136,14 +154,19 @@ class HipEncoder:
                 training: bool = False, want_tokens: bool = False, saved: Optional[torch.Tensor] = None,
                 precision: str = "bf16"):
         """ids/mask int64 [n, L] on this device, L % 32 == 0. Returns (emb [n,H], tok [n,L,H] or None, saved).
-        precision="bf16x3" runs the fp32-class parity path (forward only)."""
+        precision="bf16x3" runs the fp32-class parity path, "fp8w" the fp8-weight path (both forward only)."""
         assert ids.dtype == torch.int64 and mask.dtype == torch.int64 and ids.is_cuda and ids.is_contiguous()
         n, L = ids.shape
         handle = self._handle_for(precision)
         if handle is self.handle and self.shadow_stale:
             self.refresh_shadow()
         if handle is not self.handle and training:
-            raise _lib.QstError("precision='bf16x3' is forward-only; training runs the bf16 path")
+            raise _lib.QstError(f"precision={precision!r} is forward-only; training runs the bf16 path")
+        shadow = self.shadow
+        if handle is self.handle_fp8 and handle is not None:
+            if self.shadow8_stale:
+                self.refresh_shadow8()
+            shadow = self.shadow8
         nbytes = self.lib.qst_encoder_saved_bytes(handle, n, L, int(training))
         if nbytes == 0:
             raise _lib.QstError(f"unsupported shape nseq={n} L={L} for this encoder (L % 32 == 0, L <= 512)")
@@ -153,7 +176,7 @@ class HipEncoder:
         tok = torch.empty(n, L, self.cfg.hidden_size, dtype=torch.float32, device=self.device) if want_tokens else None
         _lib.check(self.lib.qst_encoder_forward(
             handle, ids.data_ptr(), mask.data_ptr(), _lib.ptr(type_ids), n, L, self.params.data_ptr(),
-            self.shadow.data_ptr(), emb.data_ptr(), _lib.ptr(tok), saved.data_ptr(), saved.numel(), int(training),
+            shadow.data_ptr(), emb.data_ptr(), _lib.ptr(tok), saved.data_ptr(), saved.numel(), int(training),
             _lib.current_stream_ptr()), "qst_encoder_forward")
         return emb, tok, saved
 
@@ -179,6 +202,7 @@ class HipEncoder:
             self.opt_step, self.grad_norm.data_ptr(), self._scratch.data_ptr(), _lib.current_stream_ptr()),
             "qst_clip_adamw_step")
         self.shadow_stale = True
+        self.shadow8_stale = True
 
 
     # ------------------------------------------------------------------ optimiser state (true resume)
@@ -214,6 +238,7 @@ class HipEncoder:
             int(warmup_steps), int(total_steps), self._step_dev.data_ptr(), self.grad_norm.data_ptr(),
             self._scratch.data_ptr(), _lib.current_stream_ptr()), "qst_clip_adamw_step_sched")
         self.shadow_stale = True
+        self.shadow8_stale = True
 
 
 def quadruplet_loss_raw(xa, xp, xq, xn, gamma, m_pn, m_pq, m_qn, p, swap, reduction: int,

@@ -92,14 +92,15 @@ class QuadrupletTrainer:
         return warmup_linear_lr(self.lr, self.sched_step, self.warmup_steps, self.total_steps)
 
     def forward_loss(self, ids4: torch.Tensor, mask4: torch.Tensor, types4: Optional[torch.Tensor] = None,
-                     training: bool = False, want_grads: bool = False, saved: Optional[torch.Tensor] = None):
+                     training: bool = False, want_grads: bool = False, saved: Optional[torch.Tensor] = None,
+                     precision: str = "bf16"):
         """ids4/mask4 int64 [4, B, L] on the encoder's device. Returns (loss [1], emb [4,B,H], grads, saved, flat inputs)."""
         four, B, L = ids4.shape
         assert four == 4
         ids = ids4.reshape(4 * B, L)
         mask = mask4.reshape(4 * B, L)
         types = types4.reshape(4 * B, L) if (types4 is not None and self.cfg.type_vocab_size > 0) else None
-        emb, _, saved = self.enc.forward(ids, mask, types, training=training, saved=saved)
+        emb, _, saved = self.enc.forward(ids, mask, types, training=training, saved=saved, precision=precision)
         e4 = emb.view(4, B, -1)
         loss, g = quadruplet_loss_raw(e4[0], e4[1], e4[2], e4[3], *self.loss_args, _REDUCTION["mean"],
                                       want_grads=want_grads)
