@@ -1,2 +1,2 @@
 from quadruplet_sentence_transformer_amd.util import (batch_to_device, cos_sim, dot_score,  # noqa: F401
-                                                      pytorch_cos_sim, topk_rows, topk_scores)
+                                                      mine_hard_negatives, pytorch_cos_sim, topk_rows, topk_scores)

@@ -185,6 +185,14 @@ size_t qst_topk_workspace_bytes(int nq, int nc, int dim);
 int qst_topk_scores(const float* queries, const float* corpus, int nq, int nc, int dim, int k, int cosine,
                     float* out_scores, int64_t* out_index, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same with a ceiling: corpus rows scoring above max_score do not take part. This is the reference's negative
+ * selection (dataset/quadruplet_dataset.py:185-270: candidates with SBERT cosine <= 0.2 to the reference caption, then
+ * hard_contrastive_sampling = the k highest remaining scores, :31-47), for all reference captions at once
+ * (SURVEY.md 8f rank 4). Where fewer than k rows qualify the tail of a result row is score -inf, index -1. */
+int qst_topk_scores_capped(const float* queries, const float* corpus, int nq, int nc, int dim, int k, int cosine,
+                           float max_score, float* out_scores, int64_t* out_index, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 /* Data parallelism has no entry point here: the gradient arena is one contiguous fp32 buffer, and
  * the host side all-reduces slices of it with torch.distributed (backend "nccl" = RCCL over xGMI) on a side stream,
  * between qst_encoder_backward_partial stages; qst_clip_adamw_step's grad_scale applies the 1/world_size. */

@@ -75,6 +75,8 @@ SIGNATURES = {
                                             C.c_float, C.c_float, C.c_int64, C.c_int64, vp, vp, vp, vp]),
     "qst_topk_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "qst_topk_scores": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
+    "qst_topk_scores_capped": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp,
+                                         C.c_size_t, vp]),
     # kernel level (include/qst_kernels.h)
     "qst_gemm_nt": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int, vp]),
     "qst_gemm_nt_w8": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int, vp]),

@@ -46,8 +46,10 @@ constexpr int TOPK_MAX = 1024;
 // still matches the prefix, walk the 256 bins from the top. After 4 passes `prefix` IS the k-th largest key, `need`
 // the number of elements equal to it that belong to the result. Then collect (> prefix: all, == prefix: the first
 // `need` in index order of arrival), sort by (score desc, index asc) with a bitonic network in LDS, write.
+// cap: entries above it do not take part (they rank below everything and come out as -inf / index -1): the
+// "not too similar" filter of negative mining. +inf = plain top-k.
 __global__ __launch_bounds__(256) void topk_rows_kernel(const float* scores, int64_t ld, const int64_t* index_map, int n,
-                                                        int k, float* out_scores, int64_t* out_index) {
+                                                        int k, float cap, float* out_scores, int64_t* out_index) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t sh_prefix, sh_need, sh_cnt, sh_cnt_eq;
     __shared__ float sv[TOPK_MAX];
@@ -62,7 +64,8 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* scores, int
         hist[tid] = 0;
         __syncthreads();
         for (int i = tid; i < n; i += 256) {
-            const uint32_t key = fkey(row[i]);
+            const float v = row[i];
+            const uint32_t key = v > cap ? 0u : fkey(v);
             if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
         __syncthreads();
@@ -89,13 +92,15 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* scores, int
     for (int i = tid; i < kp; i += 256) { sv[i] = -INFINITY; si[i] = INT64_MAX; }
     __syncthreads();
     for (int i = tid; i < n; i += 256) {
-        const float v = row[i];
-        const uint32_t key = fkey(v);
+        const float v0 = row[i];
+        const bool over = v0 > cap;
+        const float v = over ? -INFINITY : v0;
+        const uint32_t key = over ? 0u : fkey(v0);
         bool take = key > prefix;
         if (key == prefix) take = atomicAdd(&sh_cnt_eq, 1u) < need;
         if (take) {
             const uint32_t pos = atomicAdd(&sh_cnt, 1u);
-            if (pos < (uint32_t)k) { sv[pos] = v; si[pos] = imap ? imap[i] : (int64_t)i; }
+            if (pos < (uint32_t)k) { sv[pos] = v; si[pos] = over ? INT64_MAX : (imap ? imap[i] : (int64_t)i); }
         }
     }
     __syncthreads();
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* scores, int
     }
     for (int i = tid; i < k; i += 256) {
         out_scores[(size_t)blockIdx.x * k + i] = sv[i];
-        out_index[(size_t)blockIdx.x * k + i] = si[i];
+        out_index[(size_t)blockIdx.x * k + i] = si[i] == INT64_MAX ? -1 : si[i];
     }
 }
 
@@ -130,7 +135,7 @@ extern "C" int qst_topk_rows(const float* scores, int64_t ld, const int64_t* ind
                              float* out_scores, int64_t* out_index, void* stream) {
     if (!scores || !out_scores || !out_index || nrows <= 0 || n <= 0 || k <= 0 || ld < n) return QST_ERR_BAD_ARG;
     if (k > n || k > TOPK_MAX) return QST_ERR_UNSUPPORTED;
-    topk_rows_kernel<<<nrows, 256, 0, (hipStream_t)stream>>>(scores, ld, index_map, n, k, out_scores, out_index);
+    topk_rows_kernel<<<nrows, 256, 0, (hipStream_t)stream>>>(scores, ld, index_map, n, k, INFINITY, out_scores, out_index);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
@@ -141,9 +146,26 @@ extern "C" size_t qst_topk_workspace_bytes(int nq, int nc, int dim) {
     return (pad4((size_t)nq) + pad4((size_t)nc)) * dim * sizeof(float) + qrows * pad4((size_t)nc) * sizeof(float) + 1024;
 }
 
+static int topk_scores_impl(const float* queries, const float* corpus, int nq, int nc, int dim, int k, int cosine, float cap,
+                            float* out_scores, int64_t* out_index, void* workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int qst_topk_scores(const float* queries, const float* corpus, int nq, int nc, int dim, int k, int cosine,
                                float* out_scores, int64_t* out_index, void* workspace, size_t workspace_bytes,
                                void* stream) {
+    return topk_scores_impl(queries, corpus, nq, nc, dim, k, cosine, INFINITY, out_scores, out_index, workspace,
+                            workspace_bytes, stream);
+}
+
+extern "C" int qst_topk_scores_capped(const float* queries, const float* corpus, int nq, int nc, int dim, int k, int cosine,
+                                      float max_score, float* out_scores, int64_t* out_index, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+    if (max_score != max_score) return QST_ERR_BAD_ARG;
+    return topk_scores_impl(queries, corpus, nq, nc, dim, k, cosine, max_score, out_scores, out_index, workspace,
+                            workspace_bytes, stream);
+}
+
+static int topk_scores_impl(const float* queries, const float* corpus, int nq, int nc, int dim, int k, int cosine, float cap,
+                            float* out_scores, int64_t* out_index, void* workspace, size_t workspace_bytes, void* stream) {
     if (!queries || !corpus || !out_scores || !out_index || !workspace || nq <= 0 || nc <= 0 || dim <= 0 || k <= 0)
         return QST_ERR_BAD_ARG;
     if (k > nc || k > TOPK_MAX || dim % 32 != 0) return QST_ERR_UNSUPPORTED;
@@ -165,8 +187,9 @@ extern "C" int qst_topk_scores(const float* queries, const float* corpus, int nq
         g.M = rows; g.N = ncp; g.K = dim; g.lda = dim; g.ldb = dim; g.ldc = ncp;
         int rc = qst_gemm_nt_x3(&g, 0, st);
         if (rc != QST_OK) return rc;
-        rc = qst_topk_rows(sc, ncp, nullptr, rows, nc, k, out_scores + (size_t)q0 * k, out_index + (size_t)q0 * k, st);
-        if (rc != QST_OK) return rc;
+        topk_rows_kernel<<<rows, 256, 0, st>>>(sc, ncp, nullptr, nc, k, cap, out_scores + (size_t)q0 * k,
+                                               out_index + (size_t)q0 * k);
+        QST_LAUNCH_CHECK();
     }
     return QST_OK;
 }

@@ -64,3 +64,41 @@ def topk_rows(scores: torch.Tensor, k: int, index_map: torch.Tensor = None):
     _lib.check(lib.qst_topk_rows(s.data_ptr(), n, _lib.ptr(im), n_rows, n, k, out_s.data_ptr(), out_i.data_ptr(),
                                  _lib.current_stream_ptr()), "qst_topk_rows")
     return out_s, out_i
+
+
+def mine_hard_negatives(references, candidates, k: int, threshold: float = 0.2, embedder=None, batch_size: int = 64):
+    """Negative selection of the reference's dataset (dataset/quadruplet_dataset.py:185-270) for MANY reference
+    captions in one GPU pass: among `candidates`, those whose cosine similarity to a reference is <= threshold
+    (NEG_EXAMPLE_SIM_TRESHOLD = 0.2, the "not a paraphrase" filter), and of those the k most similar
+    (hard_contrastive_sampling(max_mode=True), :31-47). The reference does this per item with two encode() calls on
+    the training thread; here both sides are encoded in batches and scored by libqst (qst_topk_scores_capped).
+
+    references / candidates: lists of str (then `embedder` -- a SentenceTransformer -- encodes them) or CUDA tensors of
+    embeddings [R, D] / [C, D]. Returns (index int64 [R, k] into candidates, -1 where fewer than k qualify;
+    score f32 [R, k], -inf there)."""
+    from . import _lib
+    lib = _lib.load()
+
+    def emb(x):
+        if torch.is_tensor(x):
+            return x
+        if embedder is None:
+            raise ValueError("pass embeddings, or sentences together with an embedder")
+        return embedder.encode(list(x), batch_size=batch_size, convert_to_tensor=True)
+    q, c = emb(references), emb(candidates)
+    if not (q.is_cuda and c.is_cuda):
+        raise _lib.QstError("mine_hard_negatives runs on the HIP device: embeddings must be CUDA tensors")
+    q, c = q.to(torch.float32).contiguous(), c.to(torch.float32).contiguous()
+    nq, dim = q.shape
+    nc = c.shape[0]
+    kk = min(k, nc)
+    ws = torch.empty(lib.qst_topk_workspace_bytes(nq, nc, dim), dtype=torch.uint8, device=q.device)
+    out_s = torch.full((nq, k), float("-inf"), dtype=torch.float32, device=q.device)
+    out_i = torch.full((nq, k), -1, dtype=torch.int64, device=q.device)
+    ts = torch.empty(nq, kk, dtype=torch.float32, device=q.device)
+    ti = torch.empty(nq, kk, dtype=torch.int64, device=q.device)
+    _lib.check(lib.qst_topk_scores_capped(q.data_ptr(), c.data_ptr(), nq, nc, dim, kk, 1, float(threshold), ts.data_ptr(),
+                                          ti.data_ptr(), ws.data_ptr(), ws.numel(), _lib.current_stream_ptr()),
+               "qst_topk_scores_capped")
+    out_s[:, :kk], out_i[:, :kk] = ts, ti
+    return out_i, out_s

@@ -118,3 +118,38 @@ def test_ir_evaluator_end_to_end(tmp_path, preset, chunk):
     assert score == pytest.approx(max(got[n]["map@k"][30] for n in ("cos_sim", "dot_score")), abs=1e-12)
     rows = open(os.path.join(str(tmp_path), ev.csv_file)).read().strip().splitlines()
     assert len(rows) == 2 and rows[0].split(",") == ev.csv_headers and rows[1].startswith("1,2,")
+
+
+def test_hard_negative_mining_matches_brute_force():
+    """for every reference the k most similar candidates among those with cosine <= threshold
+    (the reference's NEG_EXAMPLE_SIM_TRESHOLD filter + hard_contrastive_sampling), all references in one pass."""
+    g = torch.Generator().manual_seed(11)
+    R_, C_, D, k, thr = 37, 500, 128, 6, 0.05
+    q = torch.randn(R_, D, generator=g)
+    c = torch.randn(C_, D, generator=g)
+    c[:40] = q[:1] + 0.3 * torch.randn(40, D, generator=g)          # near-duplicates of reference 0: must be filtered
+    idx, sc = util.mine_hard_negatives(q.cuda(), c.cuda(), k, threshold=thr)
+    qn = (q / q.norm(dim=1, keepdim=True)).double()
+    cn = (c / c.norm(dim=1, keepdim=True)).double()
+    s = (qn @ cn.T).numpy()
+    for r in range(R_):
+        ok = np.where(s[r] <= thr)[0]
+        want = ok[np.argsort(-s[r][ok], kind="stable")][:k]
+        got = idx[r].cpu().numpy()
+        np.testing.assert_allclose(sc[r].cpu().numpy()[:len(want)], s[r][want], rtol=0, atol=2e-5)
+        assert float(sc[r].max()) <= thr + 1e-6
+        assert set(got[:len(want)].tolist()) == set(want.tolist()) or np.allclose(s[r][got[:len(want)]], s[r][want], atol=4e-5)
+    assert not (set(idx[0].cpu().tolist()) & set(range(40)))       # the paraphrase-like candidates never come back
+    # fewer qualifying candidates than k -> padded with (-1, -inf)
+    idx2, sc2 = util.mine_hard_negatives(q[:2].cuda(), c[:3].cuda(), 5, threshold=-0.99)
+    assert (idx2 == -1).all() and torch.isinf(sc2).all()
+    # sentences + embedder
+    model = SentenceTransformer("tiny-bert", device="cuda")
+    refs = [_HashTexts.make(i, 7) for i in range(5)]
+    cands = [_HashTexts.make(100 + i, 6) for i in range(30)]
+    i3, s3 = util.mine_hard_negatives(refs, cands, 4, threshold=0.9, embedder=model)
+    e_r, e_c = model.encode(refs, convert_to_tensor=True), model.encode(cands, convert_to_tensor=True)
+    i4, s4 = util.mine_hard_negatives(e_r, e_c, 4, threshold=0.9)
+    assert torch.equal(i3, i4) and torch.allclose(s3, s4)
+    with pytest.raises(ValueError):
+        util.mine_hard_negatives(refs, cands, 4)
