@@ -134,6 +134,122 @@ static void run_depth(const char* A, const char* B, int ld, int nk, int src, flo
            NSLOT - 1, ns_stage, 40960.0 / (ns_stage * 2.4));
 }
 
+// The full loop with 32-deep stages (20 KB) in an NSLOT-slot ring, two workgroups per CU: same LDS as the 2 x 40 KB ring
+// when NSLOT = 4, NSLOT - 1 stages in flight, twice the barriers per K.
+__device__ __forceinline__ uint32_t nt_off32(int row, int chunk) { return (uint32_t)(row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4)); }
+template <int NSLOT>
+__global__ __launch_bounds__(256, 2) void probe32(const char* A, const char* B, int lda_bytes, int ldb_bytes, int nk64, int src,
+                                                  float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int A_BYTES = 128 * 64, B_BYTES = 192 * 64, STAGE = A_BYTES + B_BYTES;      // 20 KB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
+    const size_t blk = src ? 0 : blockIdx.x;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(A + blk * 128 * (size_t)lda_bytes, 128u * lda_bytes);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(B + (blk % 8) * 192 * (size_t)ldb_bytes, 192u * ldb_bytes);
+    uint32_t va[2], vb[3];
+    for (int t = 0; t < 2; ++t) { const int row = (wave * 2 + t) * 16 + (lane >> 2); va[t] = row * lda_bytes + (((lane & 3) ^ ((row >> 2) & 3)) * 16); }
+    for (int t = 0; t < 3; ++t) { const int row = (wave * 3 + t) * 16 + (lane >> 2); vb[t] = row * ldb_bytes + (((lane & 3) ^ ((row >> 2) & 3)) * 16); }
+    const int nk = nk64 * 2;
+    auto issue = [&](int kt) {
+        char* st = smem + (kt % NSLOT) * STAGE;
+        const uint32_t ko = src ? 0u : (uint32_t)kt * 64u;
+        for (int t = 0; t < 2; ++t) dma16(ra, st + (wave * 2 + t) * 1024, va[t], ko);
+        for (int t = 0; t < 3; ++t) dma16(rb, st + A_BYTES + (wave * 3 + t) * 1024, vb[t], ko);
+    };
+    f32x16 acc[2][3];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int kt = 0; kt < NSLOT - 1 && kt < nk; ++kt) issue(kt);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int ahead = min(NSLOT - 2, nk - 1 - kt);          // 5 DMA instructions per stage per wave
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + NSLOT - 1 < nk) issue(kt + NSLOT - 1);
+        const char* pa = smem + (kt % NSLOT) * STAGE;
+        const char* pb = pa + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[2], fb[3];
+            for (int i = 0; i < 2; ++i) fa[i] = *(const bf16x8*)(pa + nt_off32(wm * 64 + i * 32 + fr, ks * 2 + fh));
+            for (int j = 0; j < 3; ++j) fb[j] = *(const bf16x8*)(pb + nt_off32(wn * 96 + j * 32 + fr, ks * 2 + fh));
+            for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    if (s == 12345.678f) sink[0] = s;
+}
+template <int NSLOT>
+static void run32(const char* A, const char* B, int ld, int nk64, int src, int blocks, float* sink) {
+    const int lds = NSLOT * (128 * 64 + 192 * 64);
+    CHECK(hipFuncSetAttribute((const void*)probe32<NSLOT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int w = 0; w < 2; ++w) probe32<NSLOT><<<blocks, 256, lds>>>(A, B, ld, ld, nk64, src, sink);
+    CHECK(hipEventRecord(e0));
+    const int reps = 5;
+    for (int r = 0; r < reps; ++r) probe32<NSLOT><<<blocks, 256, lds>>>(A, B, ld, ld, nk64, src, sink);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    const double rounds = (double)blocks / 512.0;
+    const double ns_stage = ms * 1e6 / (nk64 * (rounds < 1 ? 1 : rounds));
+    printf("everything, 32-deep stages, %d-slot ring, blocks %4d: %7.0f ns per 64 of K  MFMA %4.0f%%\n", NSLOT, blocks, ns_stage,
+           100.0 * 2.0 * 768.0 / (ns_stage * 2.4));
+}
+
+// DMA rate against the contiguous run per row: a 40 KB stage made of rows of ROWB bytes (40960 / ROWB rows, each at its own
+// leading-dimension stride), two workgroups per CU, 2-slot ring, no compute.
+template <int ROWB>
+__global__ __launch_bounds__(256, 2) void probe_row(const char* A, int ld_bytes, int nk, int src, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = 40960, ROWS = STAGE / ROWB, LPR = ROWB / 16, RPI = 64 / LPR;      // lanes per row, rows per instruction
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the A buffer holds 131072 rows of ld_bytes: keep every workgroup's ROWS rows inside it
+    const size_t blk = src ? 0 : (blockIdx.x % (131072 / ROWS - 1));
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(A + blk * ROWS * (size_t)ld_bytes, (uint32_t)ROWS * ld_bytes);
+    uint32_t vo[10];
+    for (int t = 0; t < 10; ++t) { const int row = (wave * 10 + t) * RPI + lane / LPR; vo[t] = row * ld_bytes + (lane % LPR) * 16; }
+    auto issue = [&](int kt) {
+        char* st = smem + (kt & 1) * STAGE;
+        const uint32_t ko = src ? 0u : (uint32_t)kt * ROWB;
+        for (int t = 0; t < 10; ++t) dma16(ra, st + (wave * 10 + t) * 1024, vo[t], ko);
+    };
+    issue(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) issue(kt + 1);
+    }
+    if (smem[tid] == 123 && sink) sink[1] = 1.f;
+}
+template <int ROWB>
+static void run_row(const char* A, int ld, int nk, int src, float* sink) {
+    const int lds = 2 * 40960;
+    CHECK(hipFuncSetAttribute((const void*)probe_row<ROWB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int w = 0; w < 2; ++w) probe_row<ROWB><<<512, 256, lds>>>(A, ld, nk, src, sink);
+    CHECK(hipEventRecord(e0));
+    const int reps = 5;
+    for (int r = 0; r < reps; ++r) probe_row<ROWB><<<512, 256, lds>>>(A, ld, nk, src, sink);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    const double ns_stage = ms * 1e6 / nk;
+    printf("DMA only, 40 KB stages of %3d-byte rows, two workgroups per CU: %7.0f ns/stage  ingest %5.1f B/clk/CU\n", ROWB, ns_stage,
+           2.0 * 40960.0 / (ns_stage * 2.4));
+}
+
 template <int MODE>
 static void run(const char* A, const char* B, int ld, int nk, int src, int blocks, float* sink, const char* what) {
     const int lds = 2 * (128 * 128 + 192 * 128);
@@ -172,6 +288,14 @@ int main() {
             run<2>(A, B, ld, nk, src, blocks, sink, "DMA + barrier + MFMA (operands in registers)");
             run<3>(A, B, ld, nk, src, blocks, sink, "everything");
         }
+        run_row<64>(A, ld, 12, src, sink);
+        run_row<128>(A, ld, 12, src, sink);
+        run_row<256>(A, ld, 12, src, sink);
+        run_row<512>(A, ld, 6, src, sink);
+        run32<2>(A, B, ld, nk, src, 512, sink);
+        run32<3>(A, B, ld, nk, src, 512, sink);
+        run32<4>(A, B, ld, nk, src, 512, sink);
+        run32<4>(A, B, ld, nk, src, 1024, sink);
         run_depth<2>(A, B, ld, nk, src, sink);
         run_depth<3>(A, B, ld, nk, src, sink);
         run_depth<4>(A, B, ld, nk, src, sink);
