@@ -329,6 +329,8 @@ int tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, float*
     return qst_gemm_tn(&g, st);
 }
 
+constexpr int kFuseLnMinRows = 16384;      // token rows from which the fused GEMM+LayerNorm kernels win (see forward)
+
 #define QST_TRY(expr) do { int _rc = (expr); if (_rc != QST_OK) return _rc; } while (0)
 
 }  // namespace
@@ -444,8 +446,10 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     const float* x = (const float*)(sv + p.x0);
     const void* xb = sv + p.x0b;
     float* s = (float*)(sv + p.s_scratch);
-    // H = 384: the LayerNorm after each projection runs inside that GEMM's epilogue (full-row tiles)
-    const bool fuse_ln = !w8 && qst_gemm_nt_ln_supported(H) != 0;
+    // H = 384: the LayerNorm after each projection runs inside that GEMM's epilogue (full-row tiles) -- from M = 16384
+    // token rows on: one 128-row tile per workgroup gives a small batch too few workgroups (measured: the unfused pair
+    // is 5-25% faster up to M = 8192, equal at 16384, 25% slower at 32768)
+    const bool fuse_ln = !w8 && qst_gemm_nt_ln_supported(H) != 0 && M >= kFuseLnMinRows;
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerAct& a = p.layers[l];
         const int b = lay.layer0[l];
@@ -519,7 +523,7 @@ extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, 
     lnb.nblocks = (int)(qst_ln_bwd_scratch_bytes(M, H) / ((size_t)2 * H * sizeof(float)));
     // H = 384: every LayerNorm backward except the top one (whose input comes from the pooling head, not from a GEMM)
     // runs inside the epilogue of the dgrad GEMM that produces its input; those write one partial row per 128-row tile
-    const bool fuse_ln = qst_gemm_nt_ln_supported(H) != 0;
+    const bool fuse_ln = qst_gemm_nt_ln_supported(H) != 0 && M >= kFuseLnMinRows;
     const int fused_rows = (M + 127) / 128;
     auto ln_slot = [&](int slot, float* dg, float* db, int nrows = 0) {
         float* sp = (float*)(ws + w.lnred + (size_t)slot * w.lnred_stride);

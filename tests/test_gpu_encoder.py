@@ -95,6 +95,18 @@ def test_tiny_models_trained_like(name):
     run_case(name, 3, 64, True, dict(std=0.08, bias_std=0.05, ln_jitter=0.1), emb_atol_vs_bf16_oracle=1.5e-3)
 
 
+def test_minilm_dims_at_the_fused_layernorm_size():
+    """M = 4*32*128 = 16384 token rows: from this size on the H = 384 forward/backward run the GEMM kernels with the
+    LayerNorm (forward and backward) fused into their epilogues; smaller batches take the unfused pair. Two MiniLM
+    layers and a small vocabulary keep the CPU oracle to a few seconds."""
+    from dataclasses import replace
+    PRESETS["minilm-2l"] = replace(PRESETS["all-MiniLM-L6-v2"], num_layers=2, vocab_size=4096)
+    try:
+        run_case("minilm-2l", 32, 128, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), emb_atol_vs_bf16_oracle=1.5e-3)
+    finally:
+        del PRESETS["minilm-2l"]
+
+
 def test_minilm_full_dims_ragged():
     run_case("all-MiniLM-L6-v2", 2, 128, True, dict(std=0.02))
 
