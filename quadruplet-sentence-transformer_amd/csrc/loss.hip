@@ -12,7 +12,7 @@
 namespace {
 
 constexpr float kEps = 1e-6f;       // torch pairwise_distance default eps
-constexpr int kMaxVec = 8;          // float4 per lane kept in registers -> D <= 64*4*8 = 2048
+constexpr int kMaxVecAll = 8;       // float4 per lane kept in registers -> D <= 64*4*8 = 2048
 
 struct LossArgs {
     const float* x[4];              // A, P, Q, N
@@ -50,8 +50,13 @@ __device__ __forceinline__ float dnorm(float v, float d, float p) {
 }
 
 // pair indices: 0 AP, 1 AN, 2 AQ, 3 PN, 4 QN, 5 PQ  (x1 - x2 + eps, in torch's argument order)
-template <int PMODE, bool VEC>
+// NV: float4 per lane kept in registers (rows of up to 256*NV floats); 0 = scalar path for odd shapes. Sizing the
+// arrays for the row at hand instead of the 2048-float maximum takes the D = 384 kernel from 194 to ~70 VGPRs:
+// the kernel is latency-bound, waves per SIMD is what feeds HBM.
+template <int PMODE, int NV>
 __global__ __launch_bounds__(256) void quad_loss_kernel(LossArgs a) {
+    constexpr bool VEC = NV > 0;
+    constexpr int kMaxVec = NV > 0 ? NV : 1;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.B) return;
@@ -209,8 +214,13 @@ __global__ __launch_bounds__(1024) void quad_loss_reduce_kernel(const float* row
 template <int PMODE>
 void launch_loss(const LossArgs& a, bool vec, hipStream_t st) {
     const int grid = (a.B + 3) / 4;
-    if (vec) quad_loss_kernel<PMODE, true><<<grid, 256, 0, st>>>(a);
-    else     quad_loss_kernel<PMODE, false><<<grid, 256, 0, st>>>(a);
+    const int nv = (a.D + 255) / 256;
+    if (!vec) quad_loss_kernel<PMODE, 0><<<grid, 256, 0, st>>>(a);
+    else if (nv <= 1) quad_loss_kernel<PMODE, 1><<<grid, 256, 0, st>>>(a);
+    else if (nv <= 2) quad_loss_kernel<PMODE, 2><<<grid, 256, 0, st>>>(a);
+    else if (nv <= 3) quad_loss_kernel<PMODE, 3><<<grid, 256, 0, st>>>(a);
+    else if (nv <= 4) quad_loss_kernel<PMODE, 4><<<grid, 256, 0, st>>>(a);
+    else quad_loss_kernel<PMODE, 8><<<grid, 256, 0, st>>>(a);
 }
 
 }  // namespace
@@ -239,7 +249,7 @@ extern "C" int qst_quadruplet_loss(const float* xa, const float* xp, const float
     a.B = B; a.D = D; a.gamma = gamma; a.m_pn = margin_pos_neg; a.m_pq = margin_pos_part; a.m_qn = margin_part_neg;
     a.p = p; a.swap = swap; a.reduction = reduction;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-    bool vec = (D % 4 == 0) && D <= 64 * 4 * kMaxVec && al16(xa) && al16(xp) && al16(xq) && al16(xn);
+    bool vec = (D % 4 == 0) && D <= 64 * 4 * kMaxVecAll && al16(xa) && al16(xp) && al16(xq) && al16(xn);
     if (any_g) vec = vec && al16(grad_a) && al16(grad_p) && al16(grad_q) && al16(grad_n);
     if (p == 2.0f) launch_loss<2>(a, vec, st);
     else if (p == 1.0f) launch_loss<1>(a, vec, st);
