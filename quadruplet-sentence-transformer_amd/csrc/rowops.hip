@@ -210,11 +210,16 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* partial
 __global__ __launch_bounds__(256) void embed_bwd_word_type_kernel(const float* ds, const int64_t* ids,
                                                                   const int64_t* type_ids, int M, int H, int num_types,
                                                                   float* dword, float* dtype_) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 types][H] floats
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [4 waves][2 types][H] floats
     float* sh = (float*)smem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = threadIdx.x; c < 2 * H; c += 256) sh[c] = 0.f;
-    __syncthreads();
+    // token-type sums: a row's type is wave-uniform, so each lane keeps its columns' partial sums for both types in
+    // registers (the first version added every element to an LDS array with ds_add_f32, which cost more than the
+    // global scatter itself: 83 us for the whole kernel at M = 32768)
+    constexpr int KMAX = 16;                                      // H <= 1024
+    float acc0[KMAX], acc1[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { acc0[k] = 0.f; acc1[k] = 0.f; }
     const int rows_per_wave = 16;
     const int row0 = (blockIdx.x * 4 + wave) * rows_per_wave;
     for (int rr = 0; rr < rows_per_wave; ++rr) {
@@ -222,19 +227,29 @@ __global__ __launch_bounds__(256) void embed_bwd_word_type_kernel(const float* d
         if (row >= M) break;
         const size_t base = (size_t)row * H;
         const size_t wrow = (size_t)ids[row] * H;
-        const int t = (num_types > 0 && type_ids) ? (int)type_ids[row] : 0;
-        for (int c = lane; c < H; c += 64) {
-            const float v = ds[base + c];
-            atomicAdd(dword + wrow + c, v);
-            if (num_types > 0) atomicAdd(sh + (t & 1) * H + c, v);     // LDS atomic
+        const int t = (num_types > 0 && type_ids) ? ((int)type_ids[row] & 1) : 0;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int c = lane + 64 * k;
+            if (c < H) {
+                const float v = ds[base + c];
+                atomicAdd(dword + wrow + c, v);
+                if (t == 0) acc0[k] += v; else acc1[k] += v;       // uniform branch
+            }
         }
     }
+    if (num_types <= 0) return;                                  // uniform
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int c = lane + 64 * k;
+        if (c < H) { sh[(wave * 2 + 0) * H + c] = acc0[k]; sh[(wave * 2 + 1) * H + c] = acc1[k]; }
+    }
     __syncthreads();
-    if (num_types > 0)
-        for (int c = threadIdx.x; c < min(num_types, 2) * H; c += 256) {
-            const float v = sh[c];
-            if (v != 0.f) atomicAdd(dtype_ + c, v);
-        }
+    for (int c = threadIdx.x; c < min(num_types, 2) * H; c += 256) {
+        const int t = c / H, cc = c - t * H;
+        const float v = (sh[(0 * 2 + t) * H + cc] + sh[(1 * 2 + t) * H + cc]) + (sh[(2 * 2 + t) * H + cc] + sh[(3 * 2 + t) * H + cc]);
+        if (v != 0.f) atomicAdd(dtype_ + c, v);
+    }
 }
 //  position: block per (t, column chunk); sum over sequences whose position id equals the block's
 //  first one in registers, atomics only for the irregular rest
@@ -584,7 +599,8 @@ extern "C" int qst_embed_bwd(const float* ds, const int64_t* ids, const int64_t*
     if (num_types > 0 && !dtype_) return QST_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int M = nseq * L;
-    embed_bwd_word_type_kernel<<<(M + 63) / 64, 256, (size_t)2 * H * sizeof(float), st>>>(ds, ids, type_ids, M, H,
+    if (H > 1024) return QST_ERR_UNSUPPORTED;
+    embed_bwd_word_type_kernel<<<(M + 63) / 64, 256, (size_t)8 * H * sizeof(float), st>>>(ds, ids, type_ids, M, H,
                                                                                            num_types, dword, dtype_);
     QST_LAUNCH_CHECK();
     embed_bwd_pos_kernel<<<dim3(L, (H + 63) / 64, nseq >= 64 ? 4 : 1), 256, 0, st>>>(ds, pos_ids, nseq, L, H, dpos);
