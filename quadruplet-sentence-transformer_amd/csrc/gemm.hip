@@ -662,7 +662,7 @@ __device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
 // all-waves-load version showed 2800 cycles per 32-row stage for 672 cycles of MFMA: an in-order wave pays the DMA
 // issue cost (60-185 cycles per instruction) and the LDS read latency in series with its MFMAs; with loaders it is 990.
 //
-// Work decomposition: XCD x owns M-range x and runs W = 32 workgroups on it (one per CU: 120 KB of LDS). With T tiles
+// Work decomposition: XCD x owns M-range x and runs W = 32 workgroups on it (one per CU: 144 KB of LDS). With T tiles
 // = a*W + b, every workgroup reduces `a` whole tiles and then one stage-piece of a leftover tile (task list in the
 // kernel), so all CUs finish together instead of 1.5 tiles per CU being rounded up to 2; split tiles simply receive
 // several partial sums through the fp32 atomics.
