@@ -134,6 +134,18 @@ int qst_encoder_backward_partial(qst_encoder* enc, const int64_t* ids, const int
                                  void* workspace, size_t workspace_bytes,
                                  int do_head, int layer_hi, int layer_lo, int do_embed, void* stream);
 
+/* The staged backward with flags. QST_BWD_HEAD / QST_BWD_EMBED = do_head / do_embed above. For ONE layer
+ * (layer_hi == layer_lo + 1): QST_BWD_SKIP_WGRAD leaves out that layer's weight-gradient launch (its operands stay in
+ * the workspace) and a later call with QST_BWD_WGRAD_ONLY for the same layer runs just that launch -- a data-parallel
+ * step does {layer 0 | SKIP_WGRAD | EMBED}, starts the all-reduce of the embedding gradients (the largest bucket),
+ * and runs layer 0's weight gradients underneath it. No other stage may run between the two calls. */
+enum { QST_BWD_HEAD = 1, QST_BWD_EMBED = 2, QST_BWD_SKIP_WGRAD = 4, QST_BWD_WGRAD_ONLY = 8 };
+int qst_encoder_backward_stage(qst_encoder* enc, const int64_t* ids, const int64_t* mask, const int64_t* type_ids,
+                               int nseq, int L, const float* params, const void* shadow_bf16,
+                               const float* grad_emb, float* grads, void* saved, size_t saved_bytes,
+                               void* workspace, size_t workspace_bytes,
+                               int flags, int layer_hi, int layer_lo, void* stream);
+
 /*
  * Replaces gamma_quadruplet_loss (/root/reference/models/losses/losses.py:9-69) and its autograd:
  * three triplet_margin_loss terms with pairwise_distance eps=1e-6 inside the norm.
@@ -179,17 +191,27 @@ int qst_clip_adamw_step_sched(const qst_encoder* enc, float* params, float* grad
  * InformationRetrievalEvaluator does per corpus chunk -- util.cos_sim / util.dot_score of the query embeddings
  * against the chunk, then torch.topk(k) (reference call sites models/evaluators.py:572-588,
  * ir_evauation_script.py:107-131). queries f32 [nq, dim], corpus f32 [nc, dim] (device, contiguous), dim % 32 == 0,
- * k <= min(nc, 1024). cosine != 0 normalises both sides first (eps 1e-12). Outputs: the k best per query, sorted by
- * descending score (ties: ascending corpus index): out_scores f32 [nq, k], out_index int64 [nq, k]. */
+ * k <= min(nc, 1024). mode: QST_SCORE_DOT (util.dot_score), QST_SCORE_COS (util.cos_sim: both sides normalised first,
+ * eps 1e-12) or QST_SCORE_EUCLID (the reference's own euclidean_score, models/evaluators.py:392-405:
+ * 1 / (1 + ||q - c||_2), which training/main.py:57 and ir_evauation_script.py:71 pass as 'euclid_score'). Outputs: the
+ * k best per query, sorted by descending score (ties: ascending corpus index): out_scores f32 [nq, k], out_index
+ * int64 [nq, k]. */
+enum { QST_SCORE_DOT = 0, QST_SCORE_COS = 1, QST_SCORE_EUCLID = 2 };
 size_t qst_topk_workspace_bytes(int nq, int nc, int dim);
-int qst_topk_scores(const float* queries, const float* corpus, int nq, int nc, int dim, int k, int cosine,
+int qst_topk_scores(const float* queries, const float* corpus, int nq, int nc, int dim, int k, int mode,
                     float* out_scores, int64_t* out_index, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The full score matrix of one of those functions (what util.cos_sim / util.dot_score / euclidean_score return):
+ * out f32 [nq, ld_out] with ld_out = nc rounded up to a multiple of 4. */
+size_t qst_score_workspace_bytes(int nq, int nc, int dim);
+int qst_score_matrix(const float* queries, const float* corpus, int nq, int nc, int dim, int mode, float* out,
+                     int64_t ld_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same with a ceiling: corpus rows scoring above max_score do not take part. This is the reference's negative
  * selection (dataset/quadruplet_dataset.py:185-270: candidates with SBERT cosine <= 0.2 to the reference caption, then
  * hard_contrastive_sampling = the k highest remaining scores, :31-47), for all reference captions at once
  * (SURVEY.md 8f rank 4). Where fewer than k rows qualify the tail of a result row is score -inf, index -1. */
-int qst_topk_scores_capped(const float* queries, const float* corpus, int nq, int nc, int dim, int k, int cosine,
+int qst_topk_scores_capped(const float* queries, const float* corpus, int nq, int nc, int dim, int k, int mode,
                            float max_score, float* out_scores, int64_t* out_index, void* workspace,
                            size_t workspace_bytes, void* stream);
 

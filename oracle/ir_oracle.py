@@ -11,13 +11,23 @@ import math
 import numpy as np
 
 
-def rank(queries: np.ndarray, corpus: np.ndarray, k: int, cosine: bool):
+def scores(queries: np.ndarray, corpus: np.ndarray, mode) -> np.ndarray:
+    """float64 score matrix. mode: True / 'cos' = util.cos_sim, False / 'dot' = util.dot_score, 'euclid' = the
+    reference's euclidean_score (/root/reference/models/evaluators.py:392-405): 1 / (1 + cdist(a, b, p=2))."""
     q = np.asarray(queries, dtype=np.float64)
     c = np.asarray(corpus, dtype=np.float64)
-    if cosine:
+    if mode == "euclid":
+        d2 = ((q[:, None, :] - c[None, :, :]) ** 2).sum(-1) if q.shape[0] * c.shape[0] * q.shape[1] < 4e7 else \
+            np.stack([((qi[None, :] - c) ** 2).sum(-1) for qi in q])
+        return 1.0 / (1.0 + np.sqrt(d2))
+    if mode is True or mode == "cos":
         q = q / np.maximum(np.linalg.norm(q, axis=1, keepdims=True), 1e-12)
         c = c / np.maximum(np.linalg.norm(c, axis=1, keepdims=True), 1e-12)
-    s = q @ c.T
+    return q @ c.T
+
+
+def rank(queries: np.ndarray, corpus: np.ndarray, k: int, cosine):
+    s = scores(queries, corpus, cosine)
     order = np.lexsort((np.broadcast_to(np.arange(s.shape[1]), s.shape), -s), axis=1)[:, :k]
     return np.take_along_axis(s, order, axis=1), order
 

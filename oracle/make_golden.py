@@ -28,8 +28,8 @@ from models.losses.losses import GammaQuadrupletLoss, gamma_quadruplet_loss  # n
 from transformers import BertConfig, BertModel, MPNetConfig, MPNetModel  # noqa: E402
 
 from quadruplet_sentence_transformer_amd.config import PRESETS, build_layout, hf_param_views  # noqa: E402
-from quadruplet_sentence_transformer_amd.synthetic import (approx_normal, synthetic_params,  # noqa: E402
-                                                           synthetic_quadruplets)
+from quadruplet_sentence_transformer_amd.synthetic import (approx_normal, mask_edge_cases,  # noqa: E402
+                                                           synthetic_params, synthetic_quadruplets)
 
 OUT = os.path.join(ROOT, "tests", "golden")
 CLI = dict(gamma=0.6, margin_pos_neg=1.0, margin_pos_part=0.5, margin_part_neg=0.5)   # training/main.py:211-218
@@ -157,11 +157,16 @@ def gen_encoder():
         ("tinympnet_trained", "tiny-mpnet", 2, 64, True, dict(std=0.08, bias_std=0.05, ln_jitter=0.1), "full"),
         ("minilm_c1", "all-MiniLM-L6-v2", 8, 32, True, dict(std=0.04, bias_std=0.02, ln_jitter=0.05), "norms"),
         ("minilm_l128", "all-MiniLM-L6-v2", 2, 128, True, dict(std=0.02), "norms"),
+        # an all-padding sequence and two left-padded ones (synthetic.mask_edge_cases): HF's finfo.min mask + ST's clamp
+        ("tinybert_maskedge", "tiny-bert", 3, 64, "edge", dict(std=0.08, bias_std=0.05, ln_jitter=0.1), "full"),
+        ("tinympnet_maskedge", "tiny-mpnet", 3, 64, "edge", dict(std=0.08, bias_std=0.05, ln_jitter=0.1), "full"),
     ]
     for key, preset, B, L, ragged, wkw, store in cases:
         cfg = PRESETS[preset]
         arena = synthetic_params(cfg, seed=14, **wkw)
-        ids, mask, types = synthetic_quadruplets(cfg, B, L, seed=14, ragged=ragged)
+        ids, mask, types = synthetic_quadruplets(cfg, B, L, seed=14, ragged=bool(ragged))
+        if ragged == "edge":
+            ids, mask = mask_edge_cases(ids, mask, cfg.pad_token_id)
         loss, emb, tok, g = hf_step(cfg, arena, ids, mask, types, CLI)
         out[key + "_loss"] = np.float32(loss)
         out[key + "_emb"] = emb.astype(np.float32)

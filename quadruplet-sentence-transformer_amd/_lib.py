@@ -65,6 +65,8 @@ SIGNATURES = {
     "qst_encoder_backward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp]),
     "qst_encoder_backward_partial": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t,
                                                C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "qst_encoder_backward_stage": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t,
+                                             C.c_int, C.c_int, C.c_int, vp]),
     "qst_quadruplet_loss": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                       C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "qst_clip_adamw_step": (C.c_int, [vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
@@ -77,6 +79,8 @@ SIGNATURES = {
     "qst_topk_scores": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
     "qst_topk_scores_capped": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp,
                                          C.c_size_t, vp]),
+    "qst_score_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "qst_score_matrix": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, C.c_size_t, vp]),
     # kernel level (include/qst_kernels.h)
     "qst_gemm_nt": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int, vp]),
     "qst_gemm_nt_w8": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int, vp]),

@@ -18,6 +18,11 @@ namespace {
 
 constexpr float kMaskMin = -3.4028234663852886e38f;   // torch.finfo(float32).min, HF's additive mask value
 constexpr float kLog2e = 1.4426950408889634f;
+// The forward works in log2 units, where kMaskMin * log2(e) would overflow to -inf, and -inf - (-inf) is NaN as soon as
+// a whole 32-key tile is masked before any unmasked key has been seen (left padding, an all-padding row). A finite
+// constant that absorbs every real score gives what HF's finfo.min gives: masked keys weigh exactly 0 next to any
+// unmasked key, and a row with no unmasked key attends uniformly (its pooled embedding is 0 either way: mask sum 0).
+constexpr float kMaskLog2 = -3.0e38f;
 
 template <int D> __device__ __forceinline__ uint32_t rr_off(int row, int chunk) {   // image for ds_read_b128 row reads
     if (D == 32) return (uint32_t)(row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4));
@@ -137,8 +142,8 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs
     const int qi = i0 + fr;
 
     // softmax in base 2: scores are scaled by scale*log2(e) and fed to v_exp_f32 directly (one multiply and one
-    // exp per element instead of scale, subtract, multiply-by-log2e, exp); kMaskMin * log2(e) overflows to -inf -> p = 0
-    for (int t = tid; t < a.L; t += 256) madd[t] = a.mask[(size_t)seq * a.L + t] ? 0.f : -INFINITY;
+    // exp per element instead of scale, subtract, multiply-by-log2e, exp); masked keys: kMaskLog2 (finite, see above)
+    for (int t = tid; t < a.L; t += 256) madd[t] = a.mask[(size_t)seq * a.L + t] ? 0.f : kMaskLog2;
     const float sc2 = a.scale * kLog2e;
     if (a.rel)
         for (int t = tid; t < 2 * a.L; t += 256) relv[t] = kLog2e * a.rel[(size_t)head * 2 * a.L + t];

@@ -839,12 +839,8 @@ static int launch_nt(const QstGemmArgs* a, hipStream_t st) {
     constexpr int NBM = 32 * TI * WAVES_M, NBN = 96 * WAVES_N;
     // ring (64-deep stages; 32-deep for the tall wave tile); the epilogue staging (WAVES x 12.8 KB) fits inside
     constexpr int lds = 2 * (NBM + NBN) * (TI == 4 ? 32 : NBK) * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        QST_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, WAVES_M, WAVES_N, TI>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    static QstLdsAttr attr;
+    if (int rc = qst_ensure_lds(attr, (const void*)gemm_nt_kernel<EPI, WAVES_M, WAVES_N, TI>, lds)) return rc;
     const int ntm = (a->M + NBM - 1) / NBM, ntn = (a->N + NBN - 1) / NBN;
     gemm_nt_kernel<EPI, WAVES_M, WAVES_N, TI><<<dim3(ntm * ntn), dim3(64 * WAVES_M * WAVES_N), lds, st>>>(*a);
     QST_LAUNCH_CHECK();
@@ -888,11 +884,8 @@ extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
 template <int EPI>
 static int launch_nt_w8(const QstGemmArgs* a, hipStream_t st) {
     constexpr int lds = 2 * (128 * NBK * 2 + 192 * NBK);        // 56 KB ring; staging + bias + scales (54.3 KB) fit inside
-    static bool attr_set = false;
-    if (!attr_set) {
-        QST_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    static QstLdsAttr attr;
+    if (int rc = qst_ensure_lds(attr, (const void*)gemm_nt_w8_kernel<EPI>, lds)) return rc;
     const int ntm = (a->M + 127) / 128, ntn = (a->N + 191) / 192;
     gemm_nt_w8_kernel<EPI><<<dim3(ntm * ntn), dim3(256), lds, st>>>(*a);
     QST_LAUNCH_CHECK();
@@ -922,12 +915,9 @@ extern "C" int qst_gemm_nt_ln(const QstGemmArgs* a, const QstLnEpi* ln, int mode
     if (a->N != LN_N || a->K % NBK != 0 || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->ldc % 2 != 0 || (a->resid && a->ldr % 2 != 0))
         return QST_ERR_UNSUPPORTED;
     if ((int64_t)128 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)LN_N * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
-        QST_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_ln_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS));
-        QST_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_ln_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS));
-        attr_set = true;
-    }
+    static QstLdsAttr attr0, attr1;
+    if (int rc = qst_ensure_lds(attr0, (const void*)gemm_nt_ln_kernel<0>, LN_LDS)) return rc;
+    if (int rc = qst_ensure_lds(attr1, (const void*)gemm_nt_ln_kernel<1>, LN_LDS)) return rc;
     const int ntm = (a->M + 127) / 128;
     if (mode == 0) gemm_nt_ln_kernel<0><<<dim3(ntm), dim3(512), LN_LDS, (hipStream_t)stream>>>(*a, *ln);
     else gemm_nt_ln_kernel<1><<<dim3(ntm), dim3(512), LN_LDS, (hipStream_t)stream>>>(*a, *ln);
@@ -962,11 +952,8 @@ extern "C" int qst_gemm_tn_group(const QstTnGroup* grp_in, void* stream) {
     const int64_t work = (int64_t)g.total_tiles * stages;
     if (wg_per_range > work) wg_per_range = work < 1 ? 1 : work;
     const int grid = (int)(8 * g.ranges_per_xcd * wg_per_range);
-    static bool attr_set = false;
-    if (!attr_set) {
-        QST_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TT_LDS));
-        attr_set = true;
-    }
+    static QstLdsAttr attr;
+    if (int rc = qst_ensure_lds(attr, (const void*)gemm_tn_group_kernel, TT_LDS)) return rc;
     gemm_tn_group_kernel<<<dim3(grid), dim3(512), TT_LDS, (hipStream_t)stream>>>(g);
     QST_LAUNCH_CHECK();
     return QST_OK;

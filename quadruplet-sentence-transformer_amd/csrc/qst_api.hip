@@ -484,11 +484,20 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
 // Stages of one backward pass, top to bottom: head (pool/normalise), layers N-1..0, embeddings. A caller may run
 // them in several calls (layer_hi > layer_lo) to launch the gradient all-reduce of finished layers in between;
 // the running d(loss)/d(x) lives in the workspace between calls.
-extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, const int64_t* mask,
-                                            const int64_t* type_ids, int nseq, int L, const float* params,
-                                            const void* shadow, const float* grad_emb, float* grads, void* saved,
-                                            size_t saved_bytes, void* workspace, size_t workspace_bytes,
-                                            int do_head, int layer_hi, int layer_lo, int do_embed, void* stream) {
+//
+// qst_encoder_backward_stage adds two flags for the LAST layer range of a data-parallel step: with
+// QST_BWD_SKIP_WGRAD the range's weight-gradient launch is left out (its operands stay in the workspace), so the
+// caller can finish the embedding stage first, start the all-reduce of the embedding gradients -- half of a MiniLM
+// arena, and otherwise the one bucket with nothing left to hide behind -- and then run the postponed launch with
+// QST_BWD_WGRAD_ONLY underneath it.
+extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, const int64_t* mask,
+                                          const int64_t* type_ids, int nseq, int L, const float* params,
+                                          const void* shadow, const float* grad_emb, float* grads, void* saved,
+                                          size_t saved_bytes, void* workspace, size_t workspace_bytes,
+                                          int flags, int layer_hi, int layer_lo, void* stream) {
+    const int do_head = (flags & QST_BWD_HEAD) != 0, do_embed = (flags & QST_BWD_EMBED) != 0;
+    const bool skip_wgrad = (flags & QST_BWD_SKIP_WGRAD) != 0, wgrad_only = (flags & QST_BWD_WGRAD_ONLY) != 0;
+    if (wgrad_only && (skip_wgrad || do_head || do_embed)) return QST_ERR_BAD_ARG;
     if (!e || !ids || !mask || !params || !shadow || !grads || !saved || !workspace) return QST_ERR_BAD_ARG;
     if (e->cfg.precision != QST_PREC_BF16) return QST_ERR_UNSUPPORTED;      // training runs the bf16 path
     if (do_head && !grad_emb) return QST_ERR_BAD_ARG;
@@ -541,10 +550,34 @@ extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, 
     }
     if (do_head)
         QST_TRY(qst_pool_norm_bwd(grad_emb, (const float*)(sv + p.pooled), mask, nseq, L, H, c.normalize, dxa, st));
-    for (int l = layer_hi - 1; l >= layer_lo; --l) {
+    // all four weight gradients (+ bias gradients) of a layer in one grouped launch
+    auto wgrad = [&](int l) -> int {
         const LayerAct& a = p.layers[l];
         const int b = lay.layer0[l];
         const void* xin_b = (l == 0) ? (const void*)(sv + p.x0b) : (const void*)(sv + p.layers[l - 1].xb);
+        QstTnGroup grp{};
+        grp.nprob = 4;
+        grp.splits = 0;
+        auto set = [&](int i, const void* dY, int N, const void* X, int K, int wseg, int bseg) {
+            QstGemmArgs& q = grp.prob[i];
+            q.A = dY; q.B = X; q.C = G(wseg); q.colsum = G(bseg); q.M = M; q.N = N; q.K = K;
+            q.lda = N; q.ldb = K; q.ldc = K;
+        };
+        set(0, dsb, H, sv + a.hact, I, b + W_2, b + B_2);          // dW2 [H, I]
+        set(1, du, I, sv + a.y1b, H, b + W_1, b + B_1);            // dW1 [I, H]
+        set(2, dsb1, H, sv + a.ctx, H, b + W_O, b + B_O);          // dWo [H, H]
+        set(3, dqkv, 3 * H, xin_b, H, b + W_QKV, b + B_QKV);       // dWqkv [3H, H]
+        return qst_gemm_tn_group(&grp, st);
+    };
+    if (wgrad_only) {
+        // the dY tensors of exactly one layer live in the workspace: the one whose stage ran with QST_BWD_SKIP_WGRAD
+        if (layer_hi - layer_lo != 1) return QST_ERR_BAD_ARG;
+        return wgrad(layer_lo);
+    }
+    if (skip_wgrad && layer_hi - layer_lo != 1) return QST_ERR_BAD_ARG;
+    for (int l = layer_hi - 1; l >= layer_lo; --l) {
+        const LayerAct& a = p.layers[l];
+        const int b = lay.layer0[l];
         // LN2 -> ds2 (fp32 for the residual path, bf16 for the GEMMs). Fused mode: only the top layer runs it as a
         // row kernel; below, (ds, dsb) were written by the QKV dgrad of layer l+1.
         if (!fuse_ln || l == c.num_layers - 1)
@@ -567,22 +600,7 @@ extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, 
         QST_TRY(nt(dsb1, H, WT(b + W_O), H, dctx, H, nullptr, nullptr, nullptr, nullptr, 0, M, H, H, QST_EPI_BF16, st));
         QST_TRY(qst_attention_bwd(sv + a.qkv, sv + a.ctx, dctx, (const float*)(sv + a.lse), mask, rel, nseq, L, A, d,
                                   dqkv, drel, (float*)(ws + w.delta), st));
-        // all four weight gradients (+ bias gradients) of the layer in one grouped launch
-        {
-            QstTnGroup grp{};
-            grp.nprob = 4;
-            grp.splits = 0;
-            auto set = [&](int i, const void* dY, int N, const void* X, int K, int wseg, int bseg) {
-                QstGemmArgs& q = grp.prob[i];
-                q.A = dY; q.B = X; q.C = G(wseg); q.colsum = G(bseg); q.M = M; q.N = N; q.K = K;
-                q.lda = N; q.ldb = K; q.ldc = K;
-            };
-            set(0, dsb, H, sv + a.hact, I, b + W_2, b + B_2);          // dW2 [H, I]
-            set(1, du, I, sv + a.y1b, H, b + W_1, b + B_1);            // dW1 [I, H]
-            set(2, dsb1, H, sv + a.ctx, H, b + W_O, b + B_O);          // dWo [H, H]
-            set(3, dqkv, 3 * H, xin_b, H, b + W_QKV, b + B_QKV);       // dWqkv [3H, H]
-            QST_TRY(qst_gemm_tn_group(&grp, st));
-        }
+        if (!skip_wgrad) QST_TRY(wgrad(l));
         // QKV projection dgrad + residual: dx_in = dqkv . Wqkv + ds1. Fused mode: followed in the same kernel by the
         // backward of the LayerNorm that produced this layer's input (LN2 of layer l-1, or the embedding LayerNorm)
         if (fuse_ln && l > 0) {
@@ -614,6 +632,16 @@ extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, 
         QST_TRY(qst_rel_pos_bwd(drel, e->rel_lut, c.rel_buckets, A, L, G(lay.rel), st));
     }
     return QST_OK;
+}
+
+extern "C" int qst_encoder_backward_partial(qst_encoder* e, const int64_t* ids, const int64_t* mask,
+                                            const int64_t* type_ids, int nseq, int L, const float* params,
+                                            const void* shadow, const float* grad_emb, float* grads, void* saved,
+                                            size_t saved_bytes, void* workspace, size_t workspace_bytes,
+                                            int do_head, int layer_hi, int layer_lo, int do_embed, void* stream) {
+    return qst_encoder_backward_stage(e, ids, mask, type_ids, nseq, L, params, shadow, grad_emb, grads, saved, saved_bytes,
+                                      workspace, workspace_bytes, (do_head ? QST_BWD_HEAD : 0) | (do_embed ? QST_BWD_EMBED : 0),
+                                      layer_hi, layer_lo, stream);
 }
 
 extern "C" int qst_encoder_backward(qst_encoder* e, const int64_t* ids, const int64_t* mask, const int64_t* type_ids,

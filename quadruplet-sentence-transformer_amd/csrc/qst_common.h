@@ -28,6 +28,23 @@ extern "C" int qst_set_hip_error(int code);
 
 #define QST_LAUNCH_CHECK() QST_HIP_CHECK(hipGetLastError())
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): one of these per kernel remembers the
+// devices it has been raised on (bit = device ordinal), so a second encoder on another GPU of the same process is
+// covered and concurrent callers at worst both set the same value.
+#ifdef __cplusplus
+#include <atomic>
+struct QstLdsAttr { std::atomic<uint64_t> done{0}; };
+static inline int qst_ensure_lds(QstLdsAttr& st, const void* fn, int bytes) {
+    int dev = 0;
+    QST_HIP_CHECK(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (st.done.load(std::memory_order_acquire) & bit) return QST_OK;
+    QST_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    st.done.fetch_or(bit, std::memory_order_release);
+    return QST_OK;
+}
+#endif
+
 // Wave64 all-reduce on the VALU cross-lane path (DPP + readlane) instead of __shfl_xor, which lowers to
 // ds_bpermute: six dependent LDS round trips per reduction made the row kernels latency-bound.
 // Butterfly inside each row of 16 lanes (quad_perm xor1, xor2, row_half_mirror, row_mirror: sums are symmetric,

@@ -125,6 +125,66 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* scores, int
     }
 }
 
+// Euclidean score 1 / (1 + ||q - c||_2): the reference's own third score function (models/evaluators.py:392-405,
+// `1 / (1 + torch.cdist(a, b, p=2))`, passed as score_functions['euclid_score'] by training/main.py:57 and
+// ir_evauation_script.py:71). Distances are summed from the differences themselves (an fp32 FMA chain per pair): the
+// |q|^2 + |c|^2 - 2 q.c form loses the distance of near-duplicates to cancellation, and those are the pairs that decide
+// a ranking. 64 x 64 pairs per workgroup, 4 x 4 per thread, 32-dimension slabs staged transposed ([dim][row]) so that a
+// thread's four rows are one 16-byte LDS read. VALU-bound: 2 instructions per pair and dimension.
+__global__ __launch_bounds__(256) void euclid_scores_kernel(const float* q, const float* c, int nq, int nc, int dim,
+                                                            float* out, int ldo) {
+    __shared__ __attribute__((aligned(16))) float qs[32][68];
+    __shared__ __attribute__((aligned(16))) float cs[32][68];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int q0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int lrow = tid >> 2, lk = (tid & 3) * 8;          // staging: row lrow, dims lk .. lk+7 of the slab
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k0 = 0; k0 < dim; k0 += 32) {
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
+        if (q0 + lrow < nq) {
+            a0 = *(const f32x4*)(q + (size_t)(q0 + lrow) * dim + k0 + lk);
+            a1 = *(const f32x4*)(q + (size_t)(q0 + lrow) * dim + k0 + lk + 4);
+        }
+        if (c0 + lrow < nc) {
+            b0 = *(const f32x4*)(c + (size_t)(c0 + lrow) * dim + k0 + lk);
+            b1 = *(const f32x4*)(c + (size_t)(c0 + lrow) * dim + k0 + lk + 4);
+        }
+        __syncthreads();                                    // the previous slab's readers are done
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            qs[lk + e][lrow] = a0[e]; qs[lk + 4 + e][lrow] = a1[e];
+            cs[lk + e][lrow] = b0[e]; cs[lk + 4 + e][lrow] = b1[e];
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int d = 0; d < 32; ++d) {
+            const f32x4 a = *(const f32x4*)(&qs[d][ty * 4]);
+            const f32x4 b = *(const f32x4*)(&cs[d][tx * 4]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float df = a[i] - b[j];
+                    acc[i][j] = fmaf(df, df, acc[i][j]);
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int qi = q0 + ty * 4 + i;
+        if (qi >= nq) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cj = c0 + tx * 4 + j;
+            if (cj < ldo) out[(size_t)qi * ldo + cj] = cj < nc ? 1.f / (1.f + sqrtf(acc[i][j])) : 0.f;
+        }
+    }
+}
+
 constexpr int kQueryBlock = 2048;        // score matrix rows per GEMM launch (keeps byte offsets inside 32 bits)
 
 inline size_t pad4(size_t n) { return (n + 3) / 4 * 4; }
@@ -146,28 +206,53 @@ extern "C" size_t qst_topk_workspace_bytes(int nq, int nc, int dim) {
     return (pad4((size_t)nq) + pad4((size_t)nc)) * dim * sizeof(float) + qrows * pad4((size_t)nc) * sizeof(float) + 1024;
 }
 
-static int topk_scores_impl(const float* queries, const float* corpus, int nq, int nc, int dim, int k, int cosine, float cap,
+static int topk_scores_impl(const float* queries, const float* corpus, int nq, int nc, int dim, int k, int mode, float cap,
                             float* out_scores, int64_t* out_index, void* workspace, size_t workspace_bytes, void* stream);
 
-extern "C" int qst_topk_scores(const float* queries, const float* corpus, int nq, int nc, int dim, int k, int cosine,
+extern "C" int qst_topk_scores(const float* queries, const float* corpus, int nq, int nc, int dim, int k, int mode,
                                float* out_scores, int64_t* out_index, void* workspace, size_t workspace_bytes,
                                void* stream) {
-    return topk_scores_impl(queries, corpus, nq, nc, dim, k, cosine, INFINITY, out_scores, out_index, workspace,
+    return topk_scores_impl(queries, corpus, nq, nc, dim, k, mode, INFINITY, out_scores, out_index, workspace,
                             workspace_bytes, stream);
 }
 
-extern "C" int qst_topk_scores_capped(const float* queries, const float* corpus, int nq, int nc, int dim, int k, int cosine,
+extern "C" int qst_topk_scores_capped(const float* queries, const float* corpus, int nq, int nc, int dim, int k, int mode,
                                       float max_score, float* out_scores, int64_t* out_index, void* workspace,
                                       size_t workspace_bytes, void* stream) {
     if (max_score != max_score) return QST_ERR_BAD_ARG;
-    return topk_scores_impl(queries, corpus, nq, nc, dim, k, cosine, max_score, out_scores, out_index, workspace,
+    return topk_scores_impl(queries, corpus, nq, nc, dim, k, mode, max_score, out_scores, out_index, workspace,
                             workspace_bytes, stream);
 }
 
-static int topk_scores_impl(const float* queries, const float* corpus, int nq, int nc, int dim, int k, int cosine, float cap,
+// scores of query rows [q0, q0 + rows) against the whole corpus into sc [rows, ncp]; qn / cn = prepared operands
+static int score_block(const float* qn, const float* cn, int rows, int nc, int ncp, int dim, int mode, float* sc,
+                       hipStream_t st) {
+    if (mode == QST_SCORE_EUCLID) {
+        euclid_scores_kernel<<<dim3((ncp + 63) / 64, (rows + 63) / 64), 256, 0, st>>>(qn, cn, rows, nc, dim, sc, ncp);
+        QST_LAUNCH_CHECK();
+        return QST_OK;
+    }
+    QstGemmArgs g{};
+    g.A = qn; g.B = cn; g.C = sc;
+    g.M = rows; g.N = ncp; g.K = dim; g.lda = dim; g.ldb = dim; g.ldc = ncp;
+    return qst_gemm_nt_x3(&g, 0, st);
+}
+
+static int prep_operands(const float* queries, const float* corpus, int nq, int nc, int dim, int mode, float* qn, float* cn,
+                         hipStream_t st) {
+    const int nqp = (int)pad4(nq), ncp = (int)pad4(nc);
+    prep_rows_kernel<<<(nqp + 3) / 4, 256, 0, st>>>(queries, nq, nqp, dim, mode == QST_SCORE_COS, qn);
+    QST_LAUNCH_CHECK();
+    prep_rows_kernel<<<(ncp + 3) / 4, 256, 0, st>>>(corpus, nc, ncp, dim, mode == QST_SCORE_COS, cn);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+static int topk_scores_impl(const float* queries, const float* corpus, int nq, int nc, int dim, int k, int mode, float cap,
                             float* out_scores, int64_t* out_index, void* workspace, size_t workspace_bytes, void* stream) {
     if (!queries || !corpus || !out_scores || !out_index || !workspace || nq <= 0 || nc <= 0 || dim <= 0 || k <= 0)
         return QST_ERR_BAD_ARG;
+    if (mode != QST_SCORE_DOT && mode != QST_SCORE_COS && mode != QST_SCORE_EUCLID) return QST_ERR_BAD_ARG;
     if (k > nc || k > TOPK_MAX || dim % 32 != 0) return QST_ERR_UNSUPPORTED;
     if (workspace_bytes < qst_topk_workspace_bytes(nq, nc, dim)) return QST_ERR_WORKSPACE;
     if ((int64_t)pad4(nc) * dim * 4 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
@@ -176,20 +261,42 @@ static int topk_scores_impl(const float* queries, const float* corpus, int nq, i
     float* qn = (float*)workspace;
     float* cn = qn + (size_t)nqp * dim;
     float* sc = cn + (size_t)ncp * dim;
-    prep_rows_kernel<<<(nqp + 3) / 4, 256, 0, st>>>(queries, nq, nqp, dim, cosine, qn);
-    QST_LAUNCH_CHECK();
-    prep_rows_kernel<<<(ncp + 3) / 4, 256, 0, st>>>(corpus, nc, ncp, dim, cosine, cn);
-    QST_LAUNCH_CHECK();
+    int rc = prep_operands(queries, corpus, nq, nc, dim, mode, qn, cn, st);
+    if (rc != QST_OK) return rc;
     for (int q0 = 0; q0 < nq; q0 += kQueryBlock) {
         const int rows = nq - q0 < kQueryBlock ? nq - q0 : kQueryBlock;
-        QstGemmArgs g{};
-        g.A = qn + (size_t)q0 * dim; g.B = cn; g.C = sc;
-        g.M = rows; g.N = ncp; g.K = dim; g.lda = dim; g.ldb = dim; g.ldc = ncp;
-        int rc = qst_gemm_nt_x3(&g, 0, st);
+        rc = score_block(qn + (size_t)q0 * dim, cn, rows, nc, ncp, dim, mode, sc, st);
         if (rc != QST_OK) return rc;
         topk_rows_kernel<<<rows, 256, 0, st>>>(sc, ncp, nullptr, nc, k, cap, out_scores + (size_t)q0 * k,
                                                out_index + (size_t)q0 * k);
         QST_LAUNCH_CHECK();
+    }
+    return QST_OK;
+}
+
+// The whole score matrix (sentence_transformers.util.cos_sim / dot_score and the reference's euclidean_score as
+// functions): out f32 [nq, ld_out], ld_out = nc rounded up to a multiple of 4 (the pad columns are written too).
+extern "C" size_t qst_score_workspace_bytes(int nq, int nc, int dim) {
+    if (nq <= 0 || nc <= 0 || dim <= 0) return 0;
+    return (pad4((size_t)nq) + pad4((size_t)nc)) * dim * sizeof(float) + 1024;
+}
+extern "C" int qst_score_matrix(const float* queries, const float* corpus, int nq, int nc, int dim, int mode, float* out,
+                                int64_t ld_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!queries || !corpus || !out || !workspace || nq <= 0 || nc <= 0 || dim <= 0) return QST_ERR_BAD_ARG;
+    if (mode != QST_SCORE_DOT && mode != QST_SCORE_COS && mode != QST_SCORE_EUCLID) return QST_ERR_BAD_ARG;
+    if (dim % 32 != 0 || ld_out != (int64_t)pad4(nc)) return QST_ERR_UNSUPPORTED;
+    if (workspace_bytes < qst_score_workspace_bytes(nq, nc, dim)) return QST_ERR_WORKSPACE;
+    if ((int64_t)pad4(nc) * dim * 4 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int nqp = (int)pad4(nq), ncp = (int)pad4(nc);
+    float* qn = (float*)workspace;
+    float* cn = qn + (size_t)nqp * dim;
+    int rc = prep_operands(queries, corpus, nq, nc, dim, mode, qn, cn, st);
+    if (rc != QST_OK) return rc;
+    for (int q0 = 0; q0 < nq; q0 += kQueryBlock) {
+        const int rows = nq - q0 < kQueryBlock ? nq - q0 : kQueryBlock;
+        rc = score_block(qn + (size_t)q0 * dim, cn, rows, nc, ncp, dim, mode, out + (size_t)q0 * ncp, st);
+        if (rc != QST_OK) return rc;
     }
     return QST_OK;
 }

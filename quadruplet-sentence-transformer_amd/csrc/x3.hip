@@ -313,11 +313,8 @@ extern "C" int qst_attention_fwd_x3(const float* qkv, const int64_t* mask, const
     if (d == 32) {
         attn_fwd_x3_kernel<32><<<grid, 256, lds, st>>>(a);
     } else {
-        static bool attr_set = false;
-        if (!attr_set) {
-            QST_HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_x3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 70000));
-            attr_set = true;
-        }
+        static QstLdsAttr attr;
+        if (int rc = qst_ensure_lds(attr, (const void*)attn_fwd_x3_kernel<64>, 70000)) return rc;
         attn_fwd_x3_kernel<64><<<grid, 256, lds, st>>>(a);
     }
     QST_LAUNCH_CHECK();

@@ -249,9 +249,18 @@ def quadruplet_loss_raw(xa, xp, xq, xn, gamma, m_pn, m_pq, m_qn, p, swap, reduct
     dev = xa.device
     out = torch.empty(B if reduction == 0 else 1, dtype=torch.float32, device=dev)
     scratch = torch.empty(B, dtype=torch.float32, device=dev)
-    grads = [torch.empty_like(xa) for _ in range(4)] if want_grads else [None] * 4
+    # the four gradients are the slabs of ONE [4, B, D] buffer: viewed as [4B, D] it is the encoder backward's
+    # grad_emb for the fused four-column pass, with no concatenation in between
+    grads = torch.empty(4, B, D, dtype=torch.float32, device=dev).unbind(0) if want_grads else [None] * 4
     _lib.check(lib.qst_quadruplet_loss(
         xa.data_ptr(), xp.data_ptr(), xq.data_ptr(), xn.data_ptr(), B, D, gamma, m_pn, m_pq, m_qn, p, int(swap),
         reduction, out.data_ptr(), _lib.ptr(grad_out), *[_lib.ptr(g) for g in grads], scratch.data_ptr(),
         _lib.current_stream_ptr()), "qst_quadruplet_loss")
-    return out, grads
+    return out, list(grads)
+
+
+def stacked(grads) -> torch.Tensor:
+    """The [4B, D] view behind the four gradient slabs quadruplet_loss_raw returned (no copy)."""
+    base = grads[0]._base
+    assert base is not None and base.dim() == 3 and all(g._base is base for g in grads)
+    return base.view(-1, base.shape[-1])

@@ -120,13 +120,57 @@ def ir_metrics(queries_result_list: List[List[dict]], queries_ids: List[str], re
             "mrr@k": {k: mrr[k] / n for k in mrr}, "map@k": {k: float(np.mean(v)) for k, v in ap.items()}}
 
 
+_KNOWN_SCORE_NAMES = {"cos_sim": 1, "dot_score": 0, "euclid_score": 2, "euclidean_score": 2}
+
+
+def resolve_score_function(name: str, fn: Optional[Callable], device=None):
+    """How one `score_functions` entry is evaluated: ("native", mode) = the fused libqst score + top-k kernel,
+    ("callable", fn) = call fn(query_emb, corpus_emb) -> [nq, nc] and select with qst_topk_rows.
+
+    Native is chosen by BEHAVIOUR, never by the dictionary key alone: this package's own util.cos_sim / dot_score /
+    euclidean_score carry a mode tag; any other callable (e.g. the reference's `euclidean_score`,
+    /root/reference/models/evaluators.py:392-405, which arrives as a foreign function object) is run once on a small
+    fixed probe and taken over by the native mode whose score matrix it reproduces; a callable that matches none of
+    them -- including a custom function registered under the name 'cos_sim' -- is called as given. `None` is accepted
+    for the three known names."""
+    import torch
+    if fn is None:
+        if name not in _KNOWN_SCORE_NAMES:
+            raise ValueError(f"score function {name!r} is None: give a callable, or one of {sorted(_KNOWN_SCORE_NAMES)}")
+        return ("native", _KNOWN_SCORE_NAMES[name])
+    if not callable(fn):
+        raise ValueError(f"score function {name!r} must be callable (got {type(fn).__name__})")
+    mode = getattr(fn, "_qst_mode", None)
+    if mode is not None:
+        return ("native", int(mode))
+    from . import util
+    try:
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        g = torch.Generator().manual_seed(20240229)
+        q = (torch.randn(6, 32, generator=g) * 1.7 + 0.3).to(dev)
+        c = (torch.randn(9, 32, generator=g) * 0.6 - 0.2).to(dev)
+        got = torch.as_tensor(fn(q, c)).to(dev, torch.float32)
+        if tuple(got.shape) == (6, 9):
+            for m in (1, 0, 2):
+                if torch.allclose(got, util.score_matrix(q, c, m), rtol=1e-4, atol=1e-5):
+                    return ("native", m)
+    except Exception:          # a callable that cannot take the probe is simply called on the real embeddings later
+        pass
+    return ("callable", fn)
+
+
 class InformationRetrievalEvaluator(SentenceEvaluator):
-    """Queries against a corpus: encode both, score (cos_sim / dot_score), keep the top max(k) hits per query across
-    corpus chunks, report Accuracy/Precision/Recall/MRR/NDCG/MAP @k. Constructor, CSV layout and return value follow
-    sentence-transformers 2.2.2 as the reference drives it (models/evaluators.py:572-588,
-    ir_evauation_script.py:107-131): the main score is max over score functions of MAP@max(map_at_k) unless
-    main_score_function names one. Scoring and top-k selection run in libqst (one fused call per corpus chunk, the
-    per-chunk results merged by a second top-k over the candidates); only the metric arithmetic is host Python."""
+    """Queries against a corpus: encode both, score, keep the top max(k) hits per query across corpus chunks, report
+    Accuracy/Precision/Recall/MRR/NDCG/MAP @k. Constructor, CSV layout and return value follow sentence-transformers
+    2.2.2 as the reference drives it (models/evaluators.py:572-588, ir_evauation_script.py:107-131): the main score is
+    max over score functions of MAP@max(map_at_k) unless main_score_function names one.
+
+    score_functions is any {name: callable} dictionary, as in ST -- the reference always passes
+    {'cos_sim': cos_sim, 'dot_score': dot_score, 'euclid_score': euclidean_score} (training/main.py:57,
+    ir_evauation_script.py:71). Entries that are, or behave like, cosine / dot / 1/(1+L2) scoring run as ONE fused
+    libqst call per corpus chunk (qst_topk_scores); any other callable is called and its matrix goes through
+    qst_topk_rows (see resolve_score_function). Per-chunk results are merged by a second top-k over the candidates;
+    only the metric arithmetic is host Python."""
 
     def __init__(self, queries: Dict[str, str], corpus: Dict[str, str], relevant_docs: Dict[str, Set[str]],
                  corpus_chunk_size: int = 50000, mrr_at_k: List[int] = [10], ndcg_at_k: List[int] = [10],
@@ -143,15 +187,16 @@ class InformationRetrievalEvaluator(SentenceEvaluator):
         self.mrr_at_k, self.ndcg_at_k, self.accuracy_at_k = mrr_at_k, ndcg_at_k, accuracy_at_k
         self.precision_recall_at_k, self.map_at_k = precision_recall_at_k, map_at_k
         self.show_progress_bar, self.batch_size, self.name, self.write_csv = show_progress_bar, batch_size, name, write_csv
-        # score functions by name; callables are accepted for signature compatibility, but the names decide the
-        # arithmetic: anything called 'cos_sim' / 'dot_score' (the reference passes exactly these two) runs natively
-        if score_functions is None:
+        if score_functions is None:              # ST's default: {'cos_sim': cos_sim, 'dot_score': dot_score}
             score_functions = {"cos_sim": None, "dot_score": None}
-        self.score_functions = score_functions
-        self.score_function_names = sorted(score_functions.keys())
-        for nm in self.score_function_names:
-            if nm not in ("cos_sim", "dot_score"):
-                raise ValueError(f"score function {nm!r}: this evaluator scores with 'cos_sim' and/or 'dot_score'")
+        self.score_functions = dict(score_functions)
+        self.score_function_names = sorted(self.score_functions.keys())
+        for nm, fn in self.score_functions.items():
+            if fn is None and nm not in _KNOWN_SCORE_NAMES:
+                raise ValueError(f"score function {nm!r} is None: give a callable, or one of {sorted(_KNOWN_SCORE_NAMES)}")
+            if fn is not None and not callable(fn):
+                raise ValueError(f"score function {nm!r} must be callable (got {type(fn).__name__})")
+        self._resolved = None                    # name -> ("native", mode) | ("callable", fn); needs the device
         self.main_score_function = main_score_function
         self.csv_file = "Information-Retrieval_evaluation" + ("_" + name if name else "") + "_results.csv"
         self.csv_headers = ["epoch", "steps"]
@@ -207,6 +252,9 @@ class InformationRetrievalEvaluator(SentenceEvaluator):
         max_k = max(max(self.mrr_at_k), max(self.ndcg_at_k), max(self.accuracy_at_k), max(self.precision_recall_at_k),
                     max(self.map_at_k))
         q_emb = self._embed(model, self.queries)
+        if self._resolved is None:
+            self._resolved = {nm: resolve_score_function(nm, self.score_functions[nm], q_emb.device)
+                              for nm in self.score_function_names}
         best = {nm: None for nm in self.score_function_names}        # name -> (scores [nq, <=max_k], corpus rows)
         for start in range(0, len(self.corpus), self.corpus_chunk_size):
             end = min(start + self.corpus_chunk_size, len(self.corpus))
@@ -215,7 +263,15 @@ class InformationRetrievalEvaluator(SentenceEvaluator):
             c_emb = torch.as_tensor(c_emb).to(q_emb.device)
             k = min(max_k, end - start)
             for nm in self.score_function_names:
-                sc, idx = util.topk_scores(q_emb, c_emb, k, cosine=(nm == "cos_sim"))
+                kind, how = self._resolved[nm]
+                if kind == "native":
+                    sc, idx = util.topk_scores(q_emb, c_emb, k, mode=how)
+                else:                                                # foreign callable: its matrix, our selection
+                    full = torch.as_tensor(how(q_emb, c_emb)).to(q_emb.device, torch.float32)
+                    if tuple(full.shape) != (q_emb.shape[0], c_emb.shape[0]):
+                        raise ValueError(f"score function {nm!r} returned shape {tuple(full.shape)}, expected "
+                                         f"{(q_emb.shape[0], c_emb.shape[0])}")
+                    sc, idx = util.topk_rows(full, k)
                 idx = idx + start
                 if best[nm] is not None:                             # merge with the hits of earlier chunks
                     sc = torch.cat([best[nm][0], sc], dim=1)

@@ -30,7 +30,7 @@ from . import _lib
 from .config import ARCH_BERT, ARCH_MPNET, PRESETS, EncoderConfig, hf_param_views
 from .encoder import HipEncoder
 from .synthetic import synthetic_params
-from .trainer import warmup_linear_lr
+from .trainer import gradient_buckets, staged_backward, warmup_linear_lr
 
 logger = logging.getLogger(__name__)
 
@@ -109,13 +109,26 @@ class _EncodeFn(torch.autograd.Function):
             saved = torch.empty(nbytes, dtype=torch.uint8, device=enc.device)   # one arena per live graph
         emb, _, saved = enc.forward(ids, mask, types, training=training, saved=saved)
         ctx.model, ctx.saved, ctx.inputs = model, saved, (ids, mask, types)
+        if training:
+            model._live_graphs += 1
         return emb
 
     @staticmethod
     def backward(ctx, grad_emb):
         model = ctx.model
         ids, mask, types = ctx.inputs
-        model._enc.backward(ids, mask, types, grad_emb.to(torch.float32), ctx.saved)
+        grad_emb = grad_emb.to(torch.float32)
+        model._live_graphs = max(0, model._live_graphs - 1)
+        dp = model._dp
+        if dp is not None and model._live_graphs == 0:
+            # data-parallel fit(): the LAST outstanding encoder pass of the step (the only one on the fused [4B, L]
+            # path) runs in stages with each finished layer's gradients handed to the all-reduce; gradients of earlier
+            # passes of the same step are already in the arena and travel with them
+            model._dp_works += staged_backward(model._enc, ids, mask, types, grad_emb, ctx.saved, None, dp["buckets"],
+                                               dp["group"], dp["overlap"])
+            model._dp_reduced = True
+        else:
+            model._enc.backward(ids, mask, types, grad_emb, ctx.saved)
         ctx.saved = None
         return None, None, None, None, None, None
 
@@ -127,7 +140,14 @@ class _Holder(nn.Module):
 # ------------------------------------------------------------------------------------------------ the model
 class SentenceTransformer(nn.Module):
     def __init__(self, model_name_or_path: Optional[str] = None, modules=None, device=None,
-                 cache_folder: Optional[str] = None, config: Optional[EncoderConfig] = None, seed: int = 14):
+                 cache_folder: Optional[str] = None, config: Optional[EncoderConfig] = None, seed: int = 14,
+                 allow_random_init: Optional[bool] = None):
+        """model_name_or_path: a local ST/HF model directory, or a model NAME, which is resolved offline the way
+        sentence-transformers 2.2.2 resolves it -- `cache_folder` (or $SENTENCE_TRANSFORMERS_HOME), then the Hugging Face
+        hub cache. A name with no checkpoint on disk RAISES: fine-tuning or evaluating random weights under a
+        pretrained model's name is never what a caller of the reference scripts wants. Random-init weights of a named
+        architecture are available on request only: `allow_random_init=True` (or QST_ALLOW_RANDOM_INIT=1), or an
+        explicit `config=`; the `tiny-*` presets are synthetic test architectures and always random-init."""
         super().__init__()
         if modules is not None:
             raise NotImplementedError("custom module lists are outside the hot path this build covers")
@@ -139,13 +159,25 @@ class SentenceTransformer(nn.Module):
         elif model_name_or_path is not None and os.path.isdir(str(model_name_or_path)):
             cfg, arena, tok_dir = _load_model_dir(str(model_name_or_path))
         else:
-            name = str(model_name_or_path or "all-MiniLM-L6-v2").split("/")[-1]
-            if name not in PRESETS:
-                raise ValueError(f"unknown model '{model_name_or_path}': pass a local model directory or one of "
-                                 f"{sorted(PRESETS)} (no network access to fetch checkpoints)")
-            cfg = PRESETS[name]
-            logger.warning("No checkpoint for '%s' is available offline: using seeded random-init weights of that "
-                           "architecture (seed %d).", name, seed)
+            full = str(model_name_or_path or "all-MiniLM-L6-v2")
+            name = full.split("/")[-1]
+            found = _find_cached_model(full, cache_folder)
+            if found is not None:
+                cfg, arena, tok_dir = _load_model_dir(found)
+            else:
+                if name not in PRESETS:
+                    raise ValueError(f"unknown model '{model_name_or_path}': pass a local model directory or one of "
+                                     f"{sorted(PRESETS)} (no network access to fetch checkpoints)")
+                if allow_random_init is None:
+                    allow_random_init = name.startswith("tiny-") or os.environ.get("QST_ALLOW_RANDOM_INIT", "") == "1"
+                if not allow_random_init:
+                    raise FileNotFoundError(
+                        f"no checkpoint for '{full}' on this machine (looked in cache_folder={cache_folder!r}, "
+                        "$SENTENCE_TRANSFORMERS_HOME and the Hugging Face hub cache; there is no network access). Pass a "
+                        "local model directory, or allow_random_init=True / QST_ALLOW_RANDOM_INIT=1 for seeded "
+                        "random-init weights of that architecture.")
+                cfg = PRESETS[name]
+                logger.warning("'%s': seeded random-init weights of that architecture (seed %d), as requested.", name, seed)
         self.cfg = cfg
         if device is None:
             device = "cuda"
@@ -173,6 +205,9 @@ class SentenceTransformer(nn.Module):
             self._synthetic_tokenizer = SyntheticTokenizer(cfg)
         # "bf16" (throughput) or "bf16x3" (fp32-class parity path) for no-grad forwards: encode() and evaluators
         self.inference_precision = "bf16"
+        self._live_graphs = 0          # training forwards whose backward has not run yet
+        self._dp = None                # data-parallel state of a running fit(): {"group", "buckets", "overlap"}
+        self._dp_works, self._dp_reduced = [], False
         self._anchor = nn.Parameter(torch.zeros((), device=dev))      # makes the Function's output require grad
         self._build_named_parameters()
         self.best_score = -9999999
@@ -301,11 +336,30 @@ class SentenceTransformer(nn.Module):
             save_best_model: bool = True, max_grad_norm: float = 1, use_amp: bool = False,
             callback: Callable[[float, int, int], None] = None, show_progress_bar: bool = True,
             checkpoint_path: str = None, checkpoint_save_steps: int = 500, checkpoint_save_total_limit: int = 0,
-            resume_from_checkpoint: str = None):
+            resume_from_checkpoint: str = None, data_parallel: Optional[str] = None, process_group=None,
+            overlap_grad_reduce: bool = True):
         """Same keyword set as sentence-transformers 2.2.2 `fit` (the reference passes all of them,
         training/main.py:128-148) plus `resume_from_checkpoint`: a checkpoint directory written by this method
         (weights + Adam moments + step counters; the reference's checkpoints hold weights only)
-        from which training continues with the schedule where it stopped."""
+        from which training continues with the schedule where it stopped.
+
+        Data parallelism (one process per GPU, e.g. the unchanged training script under
+        `python -m torch.distributed.run`): when torch.distributed is initialised with more than one rank, every step's
+        gradients are summed over the ranks (RCCL all-reduce of the arena, per layer, overlapped with the rest of the
+        backward: trainer.staged_backward), clipped on the GLOBAL norm and applied with 1/world, so replicas stay
+        bit-identical. `data_parallel`:
+          "split_batch" (default under torch.distributed) -- every rank's dataloader yields the SAME batch (same seed,
+              as the reference's script sets it) and rank r trains on rows r::world of it: the run is the single-GPU run,
+              step for step, with the batch spread over the GPUs;
+          "per_rank_batches" -- every rank feeds its own batches (a DistributedSampler-style loader): the global batch
+              is world x larger;
+          "off" -- no exchange (every rank trains alone).
+        Files (evaluator CSVs, best model, checkpoints) are written by rank 0 only; the evaluator itself runs on every
+        rank so that score-driven control flow (early stopping) stays in step.
+
+        Dropout: this path trains with dropout = 0. The reference's fit() runs HF modules in train() mode
+        (hidden_dropout_prob = attention_probs_dropout_prob = 0.1), so a run here is regularised differently and a
+        step does slightly less work; bench.py states "dropout off" in its workload string."""
         optimizer_params = dict(optimizer_params or {"lr": 2e-5})
         if optimizer_class not in (torch.optim.AdamW,):
             raise NotImplementedError(f"fit() drives the fused HIP AdamW; optimizer_class={optimizer_class} is not supported")
@@ -338,6 +392,18 @@ class SentenceTransformer(nn.Module):
         enc = self._enc
         enc.ensure_train_state()
         enc.grads.zero_()
+        # ---- data parallelism
+        import torch.distributed as dist
+        world, rank = 1, 0
+        if data_parallel != "off" and dist.is_available() and dist.is_initialized():
+            world, rank = dist.get_world_size(process_group), dist.get_rank(process_group)
+        if data_parallel not in (None, "off", "split_batch", "per_rank_batches"):
+            raise ValueError(f"data_parallel={data_parallel!r}: expected 'split_batch', 'per_rank_batches' or 'off'")
+        dp_mode = (data_parallel or "split_batch") if world > 1 else "off"
+        self._dp = None if world == 1 else {"group": process_group, "buckets": gradient_buckets(self.cfg),
+                                            "overlap": bool(overlap_grad_reduce)}
+        self._dp_works, self._dp_reduced, self._live_graphs = [], False, 0
+        is_main = rank == 0
         global_step = 0
         if resume_from_checkpoint is not None:
             global_step = self._load_training_state(resume_from_checkpoint)
@@ -362,25 +428,41 @@ class SentenceTransformer(nn.Module):
                         iters[idx] = iter(dataloaders[idx])
                         data = next(iters[idx])
                     features, labels = data
-                    labels = labels.to(self._target_device)
-                    features = [batch_to_device(f, self._target_device) for f in features]
-                    loss_value = lm(features, labels)
-                    loss_value.backward()
+                    weight = 1.0
+                    if dp_mode == "split_batch":
+                        features, labels, n_total, n_mine = _shard_batch(features, labels, rank, world)
+                        weight = float(n_mine) * world / float(max(1, n_total))   # mean over the GLOBAL batch after the 1/world
+                    if _loss_reduction(lm) == "sum":
+                        weight = float(world)
+                    if labels.numel() > 0:
+                        labels = labels.to(self._target_device)
+                        features = [batch_to_device(f, self._target_device) for f in features]
+                        loss_value = lm(features, labels)
+                        (loss_value if weight == 1.0 else loss_value * weight).backward()
+                    if world > 1:
+                        if not self._dp_reduced:          # empty shard, or a loss model that bypassed _EncodeFn
+                            dist.all_reduce(enc.grads, op=dist.ReduceOp.SUM, group=process_group)
+                        for w in self._dp_works:
+                            w.wait()
+                        self._dp_works, self._dp_reduced, self._live_graphs = [], False, 0
                     # clip_grad_norm_ + AdamW.step + zero_grad, one pass over the arena, norm stays on the device
-                    enc.adamw_step(lr_at(global_step), betas, eps, weight_decay, float(max_grad_norm))
+                    enc.adamw_step(lr_at(global_step), betas, eps, weight_decay, float(max_grad_norm), 1.0 / world)
                 training_steps += 1
                 global_step += 1
                 if evaluation_steps > 0 and training_steps % evaluation_steps == 0:
-                    self._eval_during_training(evaluator, output_path, save_best_model, epoch, training_steps, callback)
+                    self._eval_during_training(evaluator, output_path if is_main else None, save_best_model and is_main,
+                                               epoch, training_steps, callback)
                     for lm in loss_models:
                         lm.train()
                 if checkpoint_path is not None and checkpoint_save_steps is not None and checkpoint_save_steps > 0 \
-                        and global_step % checkpoint_save_steps == 0:
+                        and global_step % checkpoint_save_steps == 0 and is_main:
                     self._save_checkpoint(checkpoint_path, checkpoint_save_total_limit, global_step)
-            self._eval_during_training(evaluator, output_path, save_best_model, epoch, -1, callback)
-        if evaluator is None and output_path is not None:
+            self._eval_during_training(evaluator, output_path if is_main else None, save_best_model and is_main, epoch, -1,
+                                       callback)
+        self._dp = None
+        if evaluator is None and output_path is not None and is_main:
             self.save(output_path)
-        if checkpoint_path is not None:
+        if checkpoint_path is not None and is_main:
             self._save_checkpoint(checkpoint_path, checkpoint_save_total_limit, global_step)
 
     def _rebind_grads(self):
@@ -475,6 +557,63 @@ class SentenceTransformer(nn.Module):
             self.tokenizer.save_pretrained(path)
 
 
+def _shard_batch(features, labels, rank: int, world: int):
+    """Rows rank::world of a collated batch ([dict of [B, L_k] tensors] x columns, labels [B]); a dict-of-columns batch
+    (the reference's glue also accepts {'reference': ..., ...}, quadruplet_sentence_transformer.py:24-33) likewise."""
+    n_total = int(labels.shape[0])
+    sel = torch.arange(n_total)[rank::world]
+
+    def cut(f):
+        return {k: (v[sel] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == n_total else v)
+                for k, v in f.items()}
+    if isinstance(features, dict):
+        feats = {k: (cut(v) if isinstance(v, dict) else v) for k, v in features.items()}
+    else:
+        feats = [cut(f) for f in features]
+    return feats, labels[sel], n_total, int(sel.numel())
+
+
+def _loss_reduction(loss_model) -> str:
+    for obj in (loss_model, getattr(loss_model, "_quadruplet_loss", None)):
+        red = getattr(obj, "reduction", None)
+        if isinstance(red, str):
+            return red
+    return "mean"
+
+
+def _find_cached_model(name: str, cache_folder: Optional[str] = None) -> Optional[str]:
+    """Directory of a named model among the places sentence-transformers 2.2.2 / huggingface_hub leave one:
+    <cache>/<org>_<name> (ST's snapshot layout, org 'sentence-transformers' when the name has none), <cache>/<name>,
+    and <hub cache>/models--<org>--<name>/snapshots/<rev>. None if there is no config.json + weights anywhere."""
+    org, _, short = name.rpartition("/")
+    orgs = [org] if org else ["sentence-transformers", ""]
+    roots = [cache_folder, os.environ.get("SENTENCE_TRANSFORMERS_HOME"),
+             os.path.join(os.environ.get("TORCH_HOME", os.path.join(os.path.expanduser("~"), ".cache", "torch")),
+                          "sentence_transformers")]
+    cands = []
+    for root in roots:
+        if not root:
+            continue
+        for o in orgs:
+            cands.append(os.path.join(root, f"{o}_{short}" if o else short))
+            if o:
+                cands.append(os.path.join(root, o, short))
+    hub = os.environ.get("HF_HUB_CACHE") or os.path.join(
+        os.environ.get("HF_HOME", os.path.join(os.path.expanduser("~"), ".cache", "huggingface")), "hub")
+    for root in [hub, cache_folder]:
+        if not root:
+            continue
+        for o in orgs:
+            snaps = os.path.join(root, f"models--{o}--{short}" if o else f"models--{short}", "snapshots")
+            if os.path.isdir(snaps):
+                cands += sorted((os.path.join(snaps, d) for d in os.listdir(snaps)), key=os.path.getmtime, reverse=True)
+    for c in cands:
+        if os.path.isfile(os.path.join(c, "config.json")) and any(
+                os.path.isfile(os.path.join(c, f)) for f in ("model.safetensors", "pytorch_model.bin")):
+            return c
+    return None
+
+
 def _load_model_dir(path: str):
     """Read an ST/HF model directory (as written by save() above or by sentence-transformers)."""
     cfg_path = os.path.join(path, "config.json")
@@ -487,7 +626,21 @@ def _load_model_dir(path: str):
     normalize, max_seq = False, min(512, int(hf.get("max_position_embeddings", 512)))
     mj = os.path.join(path, "modules.json")
     if os.path.exists(mj):
-        normalize = any(m.get("type", "").endswith("Normalize") for m in json.load(open(mj)))
+        mods = json.load(open(mj))
+        normalize = any(m.get("type", "").endswith("Normalize") for m in mods)
+        for m in mods:
+            kind = m.get("type", "").rsplit(".", 1)[-1]
+            if kind not in ("Transformer", "Pooling", "Normalize"):
+                raise NotImplementedError(f"{path}: module '{m.get('type')}' is not on the accelerated path "
+                                          "(Transformer -> Pooling(mean) -> [Normalize])")
+            if kind == "Pooling":
+                pc = os.path.join(path, m.get("path", "1_Pooling"), "config.json")
+                if os.path.exists(pc):
+                    pool = json.load(open(pc))
+                    on = sorted(k for k, v in pool.items() if k.startswith("pooling_mode_") and v)
+                    if on != ["pooling_mode_mean_tokens"]:
+                        raise NotImplementedError(f"{path}: pooling {on} -- only mean-token pooling is implemented "
+                                                  "(pool_norm_fwd/bwd); this checkpoint would be pooled wrongly")
     sb = os.path.join(path, "sentence_bert_config.json")
     if os.path.exists(sb):
         max_seq = int(json.load(open(sb)).get("max_seq_length", max_seq))

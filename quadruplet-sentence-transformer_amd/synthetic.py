@@ -93,3 +93,19 @@ def synthetic_quadruplets(cfg: EncoderConfig, batch: int, seq_len: int, seed: in
         ids = np.where(mask == 1, ids, cfg.pad_token_id)
     types = np.zeros_like(ids)
     return ids, mask, types
+
+
+def mask_edge_cases(ids: np.ndarray, mask: np.ndarray, pad_id: int):
+    """Attention-mask shapes a tokenizer never produces but callers can: given a [4, B>=3, L>=64] batch, make
+    sequence (0, 1) all padding (HF: every key carries finfo.min -> uniform attention; ST: mask sum clamped at 1e-9 ->
+    zero embedding), (1, 0) LEFT-padded by 40 positions (whole leading 32-key tile masked) and (2, 2) left-padded by
+    exactly one 32-key tile. Returns modified copies."""
+    ids, mask = ids.copy(), mask.copy()
+    L = mask.shape[2]
+    mask[0, 1, :] = 0
+    mask[1, 0, :40] = 0
+    mask[1, 0, 40:] = 1
+    mask[2, 2, :32] = 0
+    mask[2, 2, 32:L - 3] = 1
+    ids = np.where(mask == 1, np.where(ids == pad_id, pad_id + 7, ids), pad_id)
+    return ids, mask

@@ -20,7 +20,7 @@ import torch
 
 from . import _lib
 from .config import EncoderConfig, build_layout
-from .encoder import HipEncoder, quadruplet_loss_raw
+from .encoder import HipEncoder, quadruplet_loss_raw, stacked
 
 _REDUCTION = {"none": 0, "sum": 1, "mean": 2}
 
@@ -47,6 +47,53 @@ def allreduce_ranges(flat: torch.Tensor, ranges: Sequence[Tuple[int, int]], grou
         w = dist.all_reduce(flat[b:e], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         if async_op:
             works.append(w)
+    return works
+
+
+BWD_HEAD, BWD_EMBED, BWD_SKIP_WGRAD, BWD_WGRAD_ONLY = 1, 2, 4, 8      # include/qst.h: QST_BWD_*
+
+
+def staged_backward(enc: HipEncoder, ids, mask, types, grad_emb, saved, ws=None, buckets=None, group=None,
+                    overlap: bool = True):
+    """One backward pass of the encoder with the data-parallel gradient exchange inside it.
+
+    Stages run top-down on the compute stream; after each finished layer its contiguous slice of the gradient arena
+    goes into an asynchronous sum all-reduce (torch.distributed: RCCL over xGMI on its own stream), so the exchange of
+    layer l overlaps the backward of layers l-1 ... 0. The tail is ordered for the largest bucket: layer 0 runs WITHOUT
+    its weight-gradient launch, the embedding stage follows, the embedding bucket (word table = half of a MiniLM arena)
+    starts its all-reduce, and only then does layer 0's grouped weight-gradient kernel run -- underneath that exchange --
+    followed by layer 0's own (small) bucket. Returns the list of pending works; the caller waits on them before the
+    optimiser step (the global-norm clip needs every reduced gradient, so replicas stay bit-identical).
+
+    buckets=None (single process): one call, no exchange."""
+    lib, st = enc.lib, _lib.current_stream_ptr()
+    n, L = ids.shape
+    if ws is None:
+        ws = enc._arena("_ws", lib.qst_encoder_bwd_workspace_bytes(enc.handle, n, L))
+    grad_emb = grad_emb.contiguous()
+    N = enc.cfg.num_layers
+
+    def stage(flags, hi, lo):
+        _lib.check(lib.qst_encoder_backward_stage(
+            enc.handle, ids.data_ptr(), mask.data_ptr(), _lib.ptr(types), n, L, enc.params.data_ptr(),
+            enc.shadow.data_ptr(), grad_emb.data_ptr(), enc.grads.data_ptr(), saved.data_ptr(), saved.numel(),
+            ws.data_ptr(), ws.numel(), int(flags), hi, lo, st), "qst_encoder_backward_stage")
+
+    if buckets is None:
+        stage(BWD_HEAD | BWD_EMBED, N, 0)
+        return []
+    if not overlap:
+        stage(BWD_HEAD | BWD_EMBED, N, 0)
+        allreduce_ranges(enc.grads, [(0, enc.total)], group)
+        return []
+    works = []
+    for k, l in enumerate(range(N - 1, 0, -1)):                        # layers N-1 ... 1
+        stage(BWD_HEAD if k == 0 else 0, l + 1, l)
+        works += allreduce_ranges(enc.grads, [buckets[k]], group, async_op=True)
+    stage((BWD_HEAD if N == 1 else 0) | BWD_SKIP_WGRAD | BWD_EMBED, 1, 0)      # layer 0 dgrads + embeddings
+    works += allreduce_ranges(enc.grads, [buckets[N]], group, async_op=True)  # embedding bucket: the big one
+    stage(BWD_WGRAD_ONLY, 1, 0)                                               # layer 0 weight gradients, under it
+    works += allreduce_ranges(enc.grads, [buckets[N - 1]], group, async_op=True)
     return works
 
 
@@ -148,32 +195,9 @@ class QuadrupletTrainer:
         enc = self.enc
         loss, _, g, saved, (ids, mask, types) = self.forward_loss(ids4, mask4, types4, training=True, want_grads=True,
                                                                  saved=saved)
-        grad_emb = torch.cat(g, 0)
-        n, L = ids.shape
-        lib, st = enc.lib, _lib.current_stream_ptr()
-        if ws is None:
-            ws = enc._arena("_ws", lib.qst_encoder_bwd_workspace_bytes(enc.handle, n, L))
-        N = self.cfg.num_layers
-
-        def stage(head, hi, lo, emb_):
-            _lib.check(lib.qst_encoder_backward_partial(
-                enc.handle, ids.data_ptr(), mask.data_ptr(), _lib.ptr(types), n, L, enc.params.data_ptr(),
-                enc.shadow.data_ptr(), grad_emb.data_ptr(), enc.grads.data_ptr(), saved.data_ptr(), saved.numel(),
-                ws.data_ptr(), ws.numel(), int(head), hi, lo, int(emb_), st), "qst_encoder_backward_partial")
-
-        if self.world > 1 and self.overlap:
-            works = []
-            for k, l in enumerate(range(N - 1, -1, -1)):
-                stage(k == 0, l + 1, l, False)
-                works += allreduce_ranges(enc.grads, [self.buckets[k]], self.group, async_op=True)
-            stage(False, 0, 0, True)
-            works += allreduce_ranges(enc.grads, [self.buckets[N]], self.group, async_op=True)
-            for w in works:
-                w.wait()
-        else:
-            stage(True, N, 0, True)
-            if self.world > 1:
-                allreduce_ranges(enc.grads, [(0, enc.total)], self.group)
+        for w in staged_backward(enc, ids, mask, types, stacked(g), saved, ws, self.buckets if self.world > 1 else None,
+                                 self.group, self.overlap):
+            w.wait()
         if sched_on_device:
             opt0 = enc.opt_step
             enc.adamw_step_sched(self.lr, self.warmup_steps, self.total_steps, self.betas, self.eps, self.wd,

@@ -1,5 +1,7 @@
-"""CPU, world_size 2, gloo: the data-parallel exchange step (bucketed sum all-reduce of the gradient arena +
-1/world scaling) gives every rank the average gradient, bucket by bucket, in backward-completion order."""
+"""CPU, world_size 2 and 4, gloo: the data-parallel exchange step (bucketed sum all-reduce of the gradient arena +
+1/world scaling) gives every rank the average gradient, bucket by bucket, in the order the staged backward hands
+buckets over (layers N-1 .. 1, the embedding bucket, layer 0 -- trainer.staged_backward); plus the host logic of
+fit()'s batch sharding."""
 import os
 import socket
 
@@ -32,8 +34,12 @@ def _worker(rank, world, port, ret):
     grads = torch.randn(total, generator=g)
     local = grads.clone()
     works = []
-    for b in gradient_buckets(cfg):                      # same order as the overlapped step
-        works += allreduce_ranges(grads, [b], None, async_op=True)
+    bk = gradient_buckets(cfg)
+    N = cfg.num_layers
+    order = list(range(N - 1)) + [N, N - 1]              # staged_backward: layers N-1..1, embeddings, layer 0
+    assert sorted(order) == list(range(N + 1))
+    for k in order:
+        works += allreduce_ranges(grads, [bk[k]], None, async_op=True)
     for w in works:
         w.wait()
     grads *= 1.0 / world                                  # qst_clip_adamw_step's grad_scale
@@ -49,8 +55,43 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_bucketed_allreduce_world2():
-    world = 2
+def test_gradient_buckets_tile_the_arena():
+    from quadruplet_sentence_transformer_amd.config import PRESETS, build_layout
+    from quadruplet_sentence_transformer_amd.trainer import gradient_buckets
+    for name in ("tiny-bert", "tiny-mpnet", "all-MiniLM-L6-v2", "all-mpnet-base-v2", "bert-base-uncased"):
+        cfg = PRESETS[name]
+        segs, total = build_layout(cfg)
+        bk = gradient_buckets(cfg)
+        assert len(bk) == cfg.num_layers + 1
+        spans = sorted(bk)
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))          # contiguous, disjoint, complete
+        for k, (b, e) in enumerate(bk[:-1]):                                 # bucket k = layer N-1-k, whole segments
+            names = {s.name.split(".")[1] for s in segs if b <= s.offset < e}
+            assert names == {str(cfg.num_layers - 1 - k)}
+        assert all(not s.name.startswith("layer.") for s in segs if s.offset < bk[-1][1])
+
+
+def test_fit_batch_sharding_rows():
+    from quadruplet_sentence_transformer_amd.sentence_transformer import _shard_batch
+    B = 10
+    feats = [{"input_ids": torch.arange(B * 3).view(B, 3) + 100 * c, "attention_mask": torch.ones(B, 3, dtype=torch.int64)}
+             for c in range(4)]
+    labels = torch.arange(B)
+    seen = []
+    for r in range(4):
+        f, l, n_total, n_mine = _shard_batch(feats, labels, r, 4)
+        assert n_total == B and n_mine == l.numel() == len(range(r, B, 4))
+        for c in range(4):
+            assert torch.equal(f[c]["input_ids"], feats[c]["input_ids"][r::4])
+        seen += l.tolist()
+    assert sorted(seen) == list(range(B))                                   # every row on exactly one rank
+    f, l, _, n = _shard_batch(feats, labels[:2], 3, 4)                      # more ranks than rows: an empty shard
+    assert n == 0 and l.numel() == 0
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bucketed_allreduce(world):
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()

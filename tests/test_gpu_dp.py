@@ -23,17 +23,27 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, overlap, out_dir):
+def _dp_case(name):
+    """(config, quadruplets per rank, seq_len). "minilm-c4": the code path BASELINE configs[3] runs on every rank --
+    MiniLM layer dimensions with M = 4*32*128 = 16384 token rows per rank, i.e. the fused GEMM+LayerNorm kernels (forward
+    and backward, whose gamma/beta partials of layer l-1 are produced during layer l's stage), the single-workgroup
+    attention backward and the 8-range grouped wgrad -- on 2 layers and a small vocabulary to keep the test short."""
+    from dataclasses import replace
+    from quadruplet_sentence_transformer_amd.config import PRESETS
+    if name == "minilm-c4":
+        return replace(PRESETS["all-MiniLM-L6-v2"], num_layers=2, vocab_size=4096), 32, 128
+    return PRESETS[name], 4, 32
+
+
+def _worker(rank, world, port, overlap, out_dir, case="tiny-bert"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from quadruplet_sentence_transformer_amd.config import PRESETS
     from quadruplet_sentence_transformer_amd.synthetic import synthetic_params, synthetic_quadruplets
     from quadruplet_sentence_transformer_amd.trainer import QuadrupletTrainer
     torch.cuda.set_device(0)
-    cfg = PRESETS["tiny-bert"]
+    cfg, B, L = _dp_case(case)
     arena = synthetic_params(cfg, seed=14, std=0.05, bias_std=0.02, ln_jitter=0.05)
-    B, L = 4, 32
     tr = QuadrupletTrainer(cfg, arena=arena, device="cuda:0", lr=1e-3, world_size=world, overlap=overlap)
     for step in range(2):
         ids, mask, types = synthetic_quadruplets(cfg, world * B, L, seed=14, ragged=True, step=step)
@@ -45,21 +55,20 @@ def _worker(rank, world, port, overlap, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_two_rank_step_equals_single_rank_on_global_batch(tmp_path, overlap):
-    from quadruplet_sentence_transformer_amd.config import PRESETS
+@pytest.mark.parametrize("overlap,case", [(True, "tiny-bert"), (False, "tiny-bert"), (True, "minilm-c4")])
+def test_two_rank_step_equals_single_rank_on_global_batch(tmp_path, overlap, case):
     from quadruplet_sentence_transformer_amd.synthetic import synthetic_params, synthetic_quadruplets
     from quadruplet_sentence_transformer_amd.trainer import QuadrupletTrainer
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), overlap, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), overlap, str(tmp_path), case), nprocs=world, join=True)
     p0 = np.load(tmp_path / "params_0.npy")
     p1 = np.load(tmp_path / "params_1.npy")
     np.testing.assert_array_equal(p0, p1)                   # replicas stay bit-identical
-    cfg = PRESETS["tiny-bert"]
+    cfg, B, L = _dp_case(case)
     arena = synthetic_params(cfg, seed=14, std=0.05, bias_std=0.02, ln_jitter=0.05)
     tr = QuadrupletTrainer(cfg, arena=arena, device="cuda:0", lr=1e-3, world_size=1)
     for step in range(2):
-        ids, mask, types = synthetic_quadruplets(cfg, world * 4, 32, seed=14, ragged=True, step=step)
+        ids, mask, types = synthetic_quadruplets(cfg, world * B, L, seed=14, ragged=True, step=step)
         tr.step(*[torch.from_numpy(x).cuda() for x in (ids, mask, types)])
     ref = tr.enc.params.cpu().numpy()
     moved = np.abs(ref - arena).max()
@@ -70,3 +79,110 @@ def test_two_rank_step_equals_single_rank_on_global_batch(tmp_path, overlap):
     bad = np.abs(p0 - ref) > 0.05 * moved
     assert bad.mean() < 1e-3, f"{bad.sum()} of {bad.size} parameters differ"
     assert np.abs(p0 - ref).max() <= 2.1e-3 and np.abs(p0 - ref).mean() < 2e-3 * moved
+
+
+def _grads_after(cfg, arena, batch, mode):
+    """Gradient arena of one forward + loss + backward on `batch`: mode "oneshot" = qst_encoder_backward in one call,
+    "staged" = trainer.staged_backward's call sequence (per-layer stages, layer 0 without its weight gradients, the
+    embedding stage, then the postponed weight-gradient launch) with a one-member process group standing in for the
+    exchange."""
+    from quadruplet_sentence_transformer_amd.encoder import stacked
+    from quadruplet_sentence_transformer_amd.trainer import QuadrupletTrainer, gradient_buckets, staged_backward
+    tr = QuadrupletTrainer(cfg, arena=arena, device="cuda:0")
+    enc = tr.enc
+    enc.grads.zero_()
+    loss, _, g, saved, (ids, mask, types) = tr.forward_loss(*batch, training=True, want_grads=True)
+    if mode == "oneshot":
+        enc.backward(ids, mask, types, stacked(g), saved)
+    else:
+        for w in staged_backward(enc, ids, mask, types, stacked(g), saved, None, gradient_buckets(cfg), None, True):
+            w.wait()
+    torch.cuda.synchronize()
+    return enc.grads.clone(), float(loss.item())
+
+
+def _one_rank_group_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from quadruplet_sentence_transformer_amd.synthetic import synthetic_params, synthetic_quadruplets
+    torch.cuda.set_device(0)
+    cfg, B, L = _dp_case("minilm-c4")
+    arena = synthetic_params(cfg, seed=14, std=0.05, bias_std=0.02, ln_jitter=0.05)
+    batch = [torch.from_numpy(x).cuda() for x in synthetic_quadruplets(cfg, B, L, seed=14, ragged=True)]
+    g1, l1 = _grads_after(cfg, arena, batch, "oneshot")
+    g2, l2 = _grads_after(cfg, arena, batch, "staged")
+    np.save(os.path.join(out_dir, "g_oneshot.npy"), g1.cpu().numpy())
+    np.save(os.path.join(out_dir, "g_staged.npy"), g2.cpu().numpy())
+    np.save(os.path.join(out_dir, "loss.npy"), np.array([l1, l2]))
+    dist.destroy_process_group()
+
+
+def test_staged_backward_matches_one_call_on_the_fused_path(tmp_path):
+    """The staged call order configs[3] relies on -- layer l's stage writes layer l-1's LayerNorm-2 gamma/beta partials and
+    reduces them in that call; layer 0 runs without its weight gradients, the embedding stage follows, the postponed
+    grouped wgrad comes last -- must produce the gradients of the single call. fp32 atomics make the weight gradients
+    order-dependent in the last bits, so equality is per-tensor relative L2 < 1e-5 (two one-call runs differ as much)."""
+    from quadruplet_sentence_transformer_amd.config import build_layout
+    mp.spawn(_one_rank_group_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    g1, g2 = np.load(tmp_path / "g_oneshot.npy"), np.load(tmp_path / "g_staged.npy")
+    l = np.load(tmp_path / "loss.npy")
+    assert l[0] == l[1] and np.isfinite(g1).all() and np.isfinite(g2).all()
+    cfg, _, _ = _dp_case("minilm-c4")
+    segs, _ = build_layout(cfg)
+    for s in segs:
+        a, b = g1[s.offset:s.offset + s.numel], g2[s.offset:s.offset + s.numel]
+        na = float(np.linalg.norm(a))
+        assert na > 0 or "b_qkv" in s.name, s.name
+        assert float(np.linalg.norm(a - b)) <= 1e-5 * max(na, 1e-12) + 1e-9, s.name
+
+
+def _fit_worker(rank, world, port, out_dir):
+    """The reference's training call (training/main.py:128-148) on the drop-in, one process per rank."""
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from torch.utils.data import DataLoader
+    from quadruplet_sentence_transformer_amd.losses import GammaQuadrupletLoss
+    from quadruplet_sentence_transformer_amd.quadruplet_model import QuadrupletSentenceTransformerLossModel
+    from quadruplet_sentence_transformer_amd.sentence_transformer import InputExample, SentenceTransformer
+    torch.cuda.set_device(0)
+    words = "a man rides red horse two dogs play in park woman eats green apple near old bridge small cat sleeps".split()
+    rng = np.random.RandomState(3)
+    examples = [InputExample(texts=[" ".join(rng.choice(words, size=rng.randint(3, 9))) for _ in range(4)])
+                for _ in range(24)]
+    model = SentenceTransformer("tiny-bert", device="cuda:0")
+    loss = GammaQuadrupletLoss(gamma=0.6, margin_pos_neg=1.0, margin_pos_part=0.5, margin_part_neg=0.5)
+    lm = QuadrupletSentenceTransformerLossModel(st_model=model, quadruplet_loss=loss)
+    dl = DataLoader(examples, batch_size=6, shuffle=False)             # 6 rows over 2 ranks: 3 + 3; over 4: 2+2+1+1
+    model.fit(train_objectives=[(dl, lm)], evaluator=None, epochs=1, steps_per_epoch=None, scheduler="WarmupLinear",
+              warmup_steps=2, optimizer_class=torch.optim.AdamW, optimizer_params={"lr": 1e-3}, weight_decay=0.01,
+              evaluation_steps=0, output_path=os.path.join(out_dir, f"model_w{world}"), save_best_model=True,
+              max_grad_norm=1.0, use_amp=False, callback=None, show_progress_bar=False,
+              checkpoint_path=os.path.join(out_dir, f"ckpt_w{world}"), checkpoint_save_steps=2,
+              checkpoint_save_total_limit=1)
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f"fit_w{world}_r{rank}.npy"), model._enc.params.cpu().numpy())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_fit_is_data_parallel_under_torch_distributed(tmp_path):
+    """SentenceTransformer.fit -- the only training entry point the reference uses -- all-reduces when torch.distributed
+    is initialised: two ranks splitting every batch end where one process on the whole batch ends, replicas identical,
+    files written by rank 0 only."""
+    mp.spawn(_fit_worker, args=(1, 0, str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_fit_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    single = np.load(tmp_path / "fit_w1_r0.npy")
+    r0, r1 = np.load(tmp_path / "fit_w2_r0.npy"), np.load(tmp_path / "fit_w2_r1.npy")
+    np.testing.assert_array_equal(r0, r1)
+    from quadruplet_sentence_transformer_amd.config import PRESETS
+    from quadruplet_sentence_transformer_amd.synthetic import synthetic_params
+    moved = np.abs(single - synthetic_params(PRESETS["tiny-bert"], seed=14)).max()
+    assert moved > 1e-4
+    bad = np.abs(r0 - single) > 0.05 * moved
+    assert bad.mean() < 2e-3, f"{bad.sum()} of {bad.size} parameters differ"
+    assert os.path.isfile(tmp_path / "model_w2" / "model.safetensors")          # evaluator=None: rank 0 saved at the end
+    assert sorted(os.listdir(tmp_path / "ckpt_w2")) == ["4"]                     # 4 steps, limit 1

@@ -23,10 +23,14 @@ from oracle import torch_ref as R  # noqa: E402
 LOSS_KW = dict(gamma=0.6, margin_pos_neg=1.0, margin_pos_part=0.5, margin_part_neg=0.5, p=2.0, swap=False)
 
 
-def run_case(name, B, L, ragged, weights_kw, check_grads=True, emb_atol_vs_bf16_oracle=1e-4, scale_by_emb=False):
+def run_case(name, B, L, ragged, weights_kw, check_grads=True, emb_atol_vs_bf16_oracle=1e-4, scale_by_emb=False,
+             mask_edges=False):
     cfg = PRESETS[name]
     arena = synthetic_params(cfg, seed=14, **weights_kw)
     ids, mask, types = synthetic_quadruplets(cfg, B, L, seed=14, ragged=ragged)
+    if mask_edges:
+        from quadruplet_sentence_transformer_amd.synthetic import mask_edge_cases
+        ids, mask = mask_edge_cases(ids, mask, cfg.pad_token_id)
     ids_t, mask_t, types_t = torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(types)
 
     # oracle
@@ -105,6 +109,21 @@ def test_minilm_dims_at_the_fused_layernorm_size():
         run_case("minilm-2l", 32, 128, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), emb_atol_vs_bf16_oracle=1.5e-3)
     finally:
         del PRESETS["minilm-2l"]
+
+
+@pytest.mark.parametrize("base,L", [("all-MiniLM-L6-v2", 128), ("all-MiniLM-L6-v2", 256), ("all-mpnet-base-v2", 256)])
+def test_all_padding_and_left_padded_sequences(base, L):
+    """An all-zero attention_mask row and left-padded rows (a whole leading 32-key tile masked), forward AND backward,
+    on every attention code path: d = 32 single-workgroup backward (L = 128), d = 32 two-kernel backward (L = 256), d = 64
+    with the relative-position bias. HF's finfo.min mask makes such a row attend uniformly and ST's clamp(min=1e-9) gives
+    a zero embedding; a -inf mask gave NaN here, and one NaN row reaches every weight through the wgrad GEMMs."""
+    from dataclasses import replace
+    PRESETS["edge-2l"] = replace(PRESETS[base], num_layers=2, vocab_size=4096)
+    try:
+        run_case("edge-2l", 3, L, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), emb_atol_vs_bf16_oracle=1.5e-3,
+                 mask_edges=True)
+    finally:
+        del PRESETS["edge-2l"]
 
 
 def test_minilm_full_dims_ragged():

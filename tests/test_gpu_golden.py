@@ -13,7 +13,7 @@ from quadruplet_sentence_transformer_amd.config import PRESETS, build_layout  # 
 from quadruplet_sentence_transformer_amd.encoder import HipEncoder, quadruplet_loss_raw  # noqa: E402
 from quadruplet_sentence_transformer_amd.losses import GammaQuadrupletLoss, gamma_quadruplet_loss  # noqa: E402
 from quadruplet_sentence_transformer_amd.synthetic import approx_normal, synthetic_params, synthetic_quadruplets  # noqa: E402
-from tests.test_oracle_golden import CLI, CLS, ENC_CASES, LOSS_CASES, loss_inputs  # noqa: E402
+from tests.test_oracle_golden import CLI, CLS, ENC_CASES, LOSS_CASES, golden_inputs, loss_inputs  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -64,7 +64,7 @@ def test_hip_encoder_matches_hf_vectors(enc_g, key, preset, B, L, wkw, store):
     measured bf16 rounding floor (atol 2e-3; DESIGN.md 'Precision'); gradients relative L2 < 3e-2 per tensor."""
     cfg = PRESETS[preset]
     arena = synthetic_params(cfg, seed=14, **wkw)
-    ids, mask, types = synthetic_quadruplets(cfg, B, L, seed=14, ragged=True)
+    ids, mask, types = golden_inputs(key, cfg, B, L)
     enc = HipEncoder(cfg)
     enc.load_arena(arena)
     n = 4 * B
@@ -76,10 +76,13 @@ def test_hip_encoder_matches_hf_vectors(enc_g, key, preset, B, L, wkw, store):
     loss, g = quadruplet_loss_raw(e4[0], e4[1], e4[2], e4[3], 0.6, 1.0, 0.5, 0.5, 2.0, False, 2, want_grads=True)
     assert abs(loss.item() - float(enc_g[key + "_loss"])) < 1e-3
     np.testing.assert_allclose(e4.cpu().numpy(), enc_g[key + "_emb"], rtol=0, atol=2e-3)
+    if key.endswith("maskedge"):
+        assert (e4[0, 1] == 0).all()                     # the all-padding sequence: exactly HF + ST's zero embedding
     enc.ensure_train_state()
     enc.grads.zero_()
     enc.backward(idd, mdd, tdd, torch.cat(g, 0), saved)
     ga = enc.grads.cpu().numpy()
+    assert np.isfinite(ga).all()
     segs, _ = build_layout(cfg)
     if store == "full":
         ref = enc_g[key + "_grads"]
@@ -98,7 +101,7 @@ def test_hip_parity_precision_matches_hf_vectors(enc_g, key, preset, B, L, wkw, 
     north-star tolerance: embeddings rtol 1e-3 / atol 1e-4, loss within 1e-4."""
     cfg = PRESETS[preset]
     arena = synthetic_params(cfg, seed=14, **wkw)
-    ids, mask, types = synthetic_quadruplets(cfg, B, L, seed=14, ragged=True)
+    ids, mask, types = golden_inputs(key, cfg, B, L)
     enc = HipEncoder(cfg)
     enc.load_arena(arena)
     n = 4 * B

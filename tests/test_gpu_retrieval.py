@@ -78,6 +78,46 @@ def test_topk_scores_matches_fp64_ranking(nq, nc, dim, k, cosine):
     assert gap_ok <= max(2, nq * k // 200)
 
 
+@pytest.mark.parametrize("nq,nc,dim,k", [(5, 37, 64, 10), (33, 1001, 384, 100), (130, 300, 96, 7), (1, 64, 768, 64)])
+def test_topk_scores_euclid_matches_fp64_ranking(nq, nc, dim, k):
+    """mode 'euclid' = the reference's euclidean_score (models/evaluators.py:392-405). Near-duplicates of the queries are
+    planted in the corpus: their distances (1e-3 .. 1e-1 at norm ~ sqrt(dim)) are what a |q|^2+|c|^2-2qc formulation
+    would lose; the direct-difference kernel must rank them as float64 does."""
+    g = torch.Generator().manual_seed(nq * 7 + nc + dim)
+    q = torch.randn(nq, dim, generator=g)
+    c = torch.randn(nc, dim, generator=g) * (0.5 + torch.rand(nc, 1, generator=g))
+    ndup = min(nq, nc // 3, 8)
+    for t in range(ndup):
+        c[3 * t] = q[t] + 10.0 ** (-3 + 2 * t / max(1, ndup - 1)) * torch.randn(dim, generator=g) / dim ** 0.5
+    vals, idx = util.topk_scores(q.cuda(), c.cuda(), k, mode="euclid")
+    want_s, want_i = ir_oracle.rank(q.numpy(), c.numpy(), k, "euclid")
+    np.testing.assert_allclose(vals.cpu().numpy(), want_s, rtol=2e-6, atol=1e-7)      # fp32 FMA chain + sqrt + rcp
+    got_i = idx.cpu().numpy()
+    full = ir_oracle.scores(q.numpy(), c.numpy(), "euclid")
+    for r in range(nq):
+        for a, b in zip(got_i[r], want_i[r]):
+            assert a == b or abs(full[r, a] - full[r, b]) < 1e-6, (r, a, b)
+    for t in range(ndup):
+        assert got_i[t, 0] == 3 * t                                                    # the planted near-duplicate wins
+
+
+@pytest.mark.parametrize("nq,nc,dim", [(3, 5, 32), (17, 130, 384), (2, 9, 100)])
+def test_score_functions_match_fp64(nq, nc, dim):
+    """util.cos_sim / dot_score / euclidean_score as functions (qst_score_matrix); dim 100 exercises the zero padding."""
+    g = torch.Generator().manual_seed(nq + nc + dim)
+    q = torch.randn(nq, dim, generator=g) * 1.3
+    c = torch.randn(nc, dim, generator=g) * 0.7 + 0.1
+    for fn, mode, tol in ((util.cos_sim, "cos", 2e-5), (util.dot_score, "dot", None), (util.euclidean_score, "euclid", 1e-6)):
+        want = ir_oracle.scores(q.numpy(), c.numpy(), mode)
+        got = fn(q.cuda(), c.cuda())
+        assert got.is_cuda and tuple(got.shape) == (nq, nc)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=tol if tol else 2e-5 * float(np.abs(want).max()))
+        host = fn(q, c)                                     # host tensors in -> host tensor out, same arithmetic
+        assert not host.is_cuda and torch.equal(host, got.cpu())
+    one = util.cos_sim(q[0], c[1])                          # 1-D inputs are rows, as in sentence_transformers.util
+    assert tuple(one.shape) == (1, 1)
+
+
 class _HashTexts:
     """Deterministic pseudo-sentences over a small vocabulary (the synthetic tokenizer hashes words to ids)."""
     words = ("a man rides red horse two dogs play in park woman eats green apple near old bridge small cat sleeps "
@@ -118,6 +158,66 @@ def test_ir_evaluator_end_to_end(tmp_path, preset, chunk):
     assert score == pytest.approx(max(got[n]["map@k"][30] for n in ("cos_sim", "dot_score")), abs=1e-12)
     rows = open(os.path.join(str(tmp_path), ev.csv_file)).read().strip().splitlines()
     assert len(rows) == 2 and rows[0].split(",") == ev.csv_headers and rows[1].startswith("1,2,")
+
+
+def _reference_euclidean_score(a, b):
+    """models/evaluators.py:392-405 restated (the reference module cannot be imported offline): a foreign callable."""
+    a = a if isinstance(a, torch.Tensor) else torch.tensor(a)
+    b = b if isinstance(b, torch.Tensor) else torch.tensor(b)
+    a = a.unsqueeze(0) if a.dim() == 1 else a
+    b = b.unsqueeze(0) if b.dim() == 1 else b
+    return 1 / (1 + torch.cdist(a, b, p=2))
+
+
+def test_score_function_resolution_is_by_behaviour():
+    from quadruplet_sentence_transformer_amd.evaluation import resolve_score_function
+    assert resolve_score_function("euclid_score", _reference_euclidean_score, "cuda") == ("native", 2)
+    assert resolve_score_function("whatever", lambda a, b: a @ b.T, "cuda") == ("native", 0)
+    custom = lambda a, b: -torch.cdist(a, b, p=1)                                  # Manhattan: none of the native modes
+    assert resolve_score_function("cos_sim", custom, "cuda") == ("callable", custom)    # the NAME does not decide
+    cpu_only = lambda a, b: torch.tensor(np.asarray(a.cpu()) @ np.asarray(b.cpu()).T)   # returns a host tensor
+    assert resolve_score_function("np_dot", cpu_only, "cuda") == ("native", 0)
+    broken = lambda a, b: (_ for _ in ()).throw(RuntimeError("no probe"))
+    assert resolve_score_function("x", broken, "cuda") == ("callable", broken)
+
+
+@pytest.mark.parametrize("chunk", [50000, 17])
+def test_ir_evaluator_with_the_reference_score_functions(tmp_path, chunk):
+    """Exactly the dictionary training/main.py:57 / ir_evauation_script.py:71 build, through the constructor call of
+    models/evaluators.py:572-588, on one and on several corpus chunks; plus a custom callable under a stock name."""
+    model = SentenceTransformer("tiny-bert", device="cuda")
+    corpus = {f"d{i}": _HashTexts.make(i, 5 + i % 9) for i in range(90)}
+    queries, relevant = {}, {}
+    rng = np.random.RandomState(5)
+    for qn in range(19):
+        base = rng.randint(0, 90)
+        queries[f"q{qn}"] = corpus[f"d{base}"] + " " + _HashTexts.make(2000 + qn, 2)
+        relevant[f"q{qn}"] = {f"d{base}", f"d{(base + 3) % 90}"}
+    manhattan = lambda a, b: -torch.cdist(a, b, p=1)
+    score_functions = {"cos_sim": util.cos_sim, "dot_score": util.dot_score, "euclid_score": _reference_euclidean_score,
+                       "manhattan": manhattan}
+    ks = dict(mrr_at_k=[10], ndcg_at_k=[10], accuracy_at_k=[1, 3, 5, 10], precision_recall_at_k=[1, 3, 5, 10], map_at_k=[100])
+    ev = InformationRetrievalEvaluator(queries=queries, corpus=corpus, relevant_docs=relevant, corpus_chunk_size=chunk,
+                                       show_progress_bar=False, batch_size=32, name="exp", write_csv=True,
+                                       score_functions=score_functions, main_score_function=None, **ks)
+    got = ev.compute_metrices(model)
+    assert ev._resolved["euclid_score"] == ("native", 2) and ev._resolved["manhattan"][0] == "callable"
+    q_emb = model.encode(ev.queries, batch_size=32, convert_to_numpy=True)
+    c_emb = model.encode(ev.corpus, batch_size=32, convert_to_numpy=True)
+    man = -np.abs(q_emb.astype(np.float64)[:, None, :] - c_emb.astype(np.float64)[None, :, :]).sum(-1)
+    for name, mode in (("cos_sim", "cos"), ("dot_score", "dot"), ("euclid_score", "euclid"), ("manhattan", None)):
+        s = man if mode is None else ir_oracle.scores(q_emb, c_emb, mode)
+        order = np.lexsort((np.broadcast_to(np.arange(s.shape[1]), s.shape), -s), axis=1)[:, :90]
+        ranked = [[ev.corpus_ids[j] for j in row] for row in order]
+        want = ir_oracle.metrics(ranked, [relevant[q] for q in ev.queries_ids], ks["mrr_at_k"], ks["ndcg_at_k"],
+                                 ks["accuracy_at_k"], ks["precision_recall_at_k"], ks["map_at_k"])
+        for metric in want:
+            for k in want[metric]:
+                assert got[name][metric][k] == pytest.approx(want[metric][k], abs=1e-9), (name, metric, k)
+    score = ev(model, output_path=str(tmp_path), epoch=0, steps=5)
+    assert score == pytest.approx(max(got[n]["map@k"][100] for n in score_functions), abs=1e-12)
+    rows = open(os.path.join(str(tmp_path), ev.csv_file)).read().strip().splitlines()
+    assert rows[0].split(",") == ev.csv_headers and "euclid_score-MAP@100" in rows[0]
 
 
 def test_hard_negative_mining_matches_brute_force():

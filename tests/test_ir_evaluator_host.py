@@ -63,7 +63,55 @@ def test_evaluator_constructor_follows_st_conventions():
                               "dot_score-Precision@1", "dot_score-Recall@1", "dot_score-MRR@10", "dot_score-NDCG@10",
                               "dot_score-MAP@100"]
     with pytest.raises(ValueError):
-        InformationRetrievalEvaluator(queries, corpus, rel, score_functions={"manhattan": None})
+        InformationRetrievalEvaluator(queries, corpus, rel, score_functions={"manhattan": None})     # no callable, unknown name
+    with pytest.raises(ValueError):
+        InformationRetrievalEvaluator(queries, corpus, rel, score_functions={"cos_sim": 3})          # not callable
+
+
+def _reference_euclidean_score(a, b):
+    """What the reference defines at models/evaluators.py:392-405 (restated: the reference module cannot be imported
+    offline) -- a FOREIGN callable as far as this package is concerned."""
+    import torch
+    a = a if isinstance(a, torch.Tensor) else torch.tensor(a)
+    b = b if isinstance(b, torch.Tensor) else torch.tensor(b)
+    a = a.unsqueeze(0) if a.dim() == 1 else a
+    b = b.unsqueeze(0) if b.dim() == 1 else b
+    return 1 / (1 + torch.cdist(a, b, p=2))
+
+
+def test_evaluator_takes_the_score_functions_the_reference_passes():
+    """training/main.py:57 and ir_evauation_script.py:71 always build this dictionary; main.py:74-93 /
+    evaluators.py:572-588 forward it with exactly these keyword arguments."""
+    from quadruplet_sentence_transformer_amd import util
+    from quadruplet_sentence_transformer_amd.evaluation import resolve_score_function
+    score_functions = {"cos_sim": util.cos_sim, "dot_score": util.dot_score, "euclid_score": _reference_euclidean_score}
+    ev = InformationRetrievalEvaluator(
+        queries={"q1": "a"}, corpus={"d1": "x", "d2": "y"}, relevant_docs={"q1": {"d1"}}, corpus_chunk_size=50000,
+        mrr_at_k=[10], ndcg_at_k=[10], accuracy_at_k=[1, 3, 5, 10], precision_recall_at_k=[1, 3, 5, 10], map_at_k=[100],
+        show_progress_bar=False, batch_size=32, name="exp", write_csv=True, score_functions=score_functions,
+        main_score_function=None)
+    assert ev.score_function_names == ["cos_sim", "dot_score", "euclid_score"]
+    assert "euclid_score-MAP@100" in ev.csv_headers and len(ev.csv_headers) == 2 + 3 * 15
+    # this package's own functions are native by their tag, whatever name they are registered under; None needs a known name
+    assert resolve_score_function("anything", util.euclidean_score) == ("native", 2)
+    assert resolve_score_function("cos_sim", None) == ("native", 1)
+    assert resolve_score_function("euclid_score", None) == ("native", 2)
+    with pytest.raises(ValueError):
+        resolve_score_function("manhattan", None)
+
+
+def test_fit_accepts_the_reference_keyword_set():
+    """training/main.py:128-148 verbatim: every keyword binds to the drop-in's fit()."""
+    import inspect
+    import torch
+    from quadruplet_sentence_transformer_amd.sentence_transformer import SentenceTransformer
+    kwargs = dict(train_objectives=[(None, None)], evaluator=None, epochs=1, steps_per_epoch=None, scheduler="WarmupLinear",
+                  warmup_steps=100, optimizer_class=torch.optim.AdamW, optimizer_params={"lr": 2e-5}, weight_decay=0.01,
+                  evaluation_steps=0, output_path="out", save_best_model=True, max_grad_norm=1.0, use_amp=False,
+                  callback=None, show_progress_bar=False, checkpoint_path="ckpt", checkpoint_save_steps=500,
+                  checkpoint_save_total_limit=0)
+    bound = inspect.signature(SentenceTransformer.fit).bind(None, **kwargs)
+    assert set(kwargs) <= set(bound.arguments)
 
 
 def test_dropin_namespace_exports_what_the_reference_imports():
@@ -93,3 +141,8 @@ def test_topk_refuses_cpu_tensors():
         pytest.skip("libqst.so not built")
     with pytest.raises(_lib.QstError):
         util.topk_scores(torch.zeros(2, 32), torch.zeros(4, 32), 1)
+    with pytest.raises(_lib.QstError):
+        util.topk_rows(torch.zeros(2, 32), 1)
+    if not torch.cuda.is_available():                  # score functions have no CPU arithmetic either
+        with pytest.raises(_lib.QstError):
+            util.cos_sim(torch.zeros(2, 32), torch.zeros(4, 32))

@@ -90,14 +90,26 @@ def test_loss_invariants_from_reference_notebook():
 ENC_CASES = [("tinybert_hfinit", "tiny-bert", 2, 32, dict(std=0.02), "full"),
              ("tinybert_trained", "tiny-bert", 3, 64, dict(std=0.08, bias_std=0.05, ln_jitter=0.1), "full"),
              ("tinympnet_trained", "tiny-mpnet", 2, 64, dict(std=0.08, bias_std=0.05, ln_jitter=0.1), "full"),
-             ("minilm_c1", "all-MiniLM-L6-v2", 8, 32, dict(std=0.04, bias_std=0.02, ln_jitter=0.05), "norms")]
+             ("minilm_c1", "all-MiniLM-L6-v2", 8, 32, dict(std=0.04, bias_std=0.02, ln_jitter=0.05), "norms"),
+             # an all-padding sequence and left-padded ones (synthetic.mask_edge_cases)
+             ("tinybert_maskedge", "tiny-bert", 3, 64, dict(std=0.08, bias_std=0.05, ln_jitter=0.1), "full"),
+             ("tinympnet_maskedge", "tiny-mpnet", 3, 64, dict(std=0.08, bias_std=0.05, ln_jitter=0.1), "full")]
+
+
+def golden_inputs(key, cfg, B, L):
+    """The inputs oracle/make_golden.py used for encoder case `key`."""
+    from quadruplet_sentence_transformer_amd.synthetic import mask_edge_cases
+    ids, mask, types = synthetic_quadruplets(cfg, B, L, seed=14, ragged=True)
+    if key.endswith("maskedge"):
+        ids, mask = mask_edge_cases(ids, mask, cfg.pad_token_id)
+    return ids, mask, types
 
 
 @pytest.mark.parametrize("key,preset,B,L,wkw,store", ENC_CASES)
 def test_encoder_oracles_match_hf(enc_g, key, preset, B, L, wkw, store):
     cfg = PRESETS[preset]
     arena = synthetic_params(cfg, seed=14, **wkw)
-    ids, mask, types = synthetic_quadruplets(cfg, B, L, seed=14, ragged=True)
+    ids, mask, types = golden_inputs(key, cfg, B, L)
     P = R.arena_to_dict(arena, cfg, requires_grad=True)
     loss, emb = R.quadruplet_step(P, cfg, torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(types), CLI)
     np.testing.assert_allclose(emb.detach().numpy(), enc_g[key + "_emb"], rtol=1e-4, atol=2e-6)
