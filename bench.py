@@ -132,7 +132,7 @@ def config1_on_gpu(cfg, arena, cpu_losses=None):
     1e-3' on BASELINE configs[0], measured in the run."""
     import torch
     from quadruplet_sentence_transformer_amd.trainer import QuadrupletTrainer
-    tr = QuadrupletTrainer(cfg, arena=arena, device="cuda", lr=2e-5, weight_decay=0.01, max_grad_norm=1.0)
+    tr = QuadrupletTrainer(cfg, arena=arena, device=f"cuda:{torch.cuda.current_device()}", lr=2e-5, weight_decay=0.01, max_grad_norm=1.0)
     batches = [[torch.from_numpy(x).cuda() for x in b] for b in _c1_batches(cfg)]
     out = {}
     for prec in ("bf16", "bf16x3"):
@@ -216,23 +216,45 @@ def time_kernels(trainer, n, L, reps, batches):
         q.A, q.B, q.C, q.colsum = dY.data_ptr(), X.data_ptr(), C.data_ptr(), cs.data_ptr()
         q.M, q.N, q.K, q.lda, q.ldb, q.ldc = M, N, K, N, K, K
         keep += [dY, X, C, cs]
-    t_ffn1 = t_wgrad = 0.0
+    # the feed-forward block as one kernel (csrc/ffn.hip, inference variant: what encode() / the forward-only figure run)
+    chain = None
+    if lib.qst_ffn_chain_supported(H, I) and M >= 16384:
+        W2 = (torch.randn(H, I, device=dev) * 0.02).to(bf)
+        b2, gamma, beta = torch.zeros(H, device=dev), torch.ones(H, device=dev), torch.zeros(H, device=dev)
+        resid = torch.randn(M, H, device=dev)
+        y, yb, xh = torch.empty(M, H, device=dev), torch.empty(M, H, dtype=bf, device=dev), torch.empty(M, H, dtype=bf, device=dev)
+        rs = torch.empty(M, device=dev)
+        fa, le = _lib.QstFfnArgs(), _lib.QstLnEpi()
+        fa.A, fa.B1, fa.B2, fa.bias1, fa.bias2, fa.resid = (A.data_ptr(), W.data_ptr(), W2.data_ptr(), bias.data_ptr(),
+                                                           b2.data_ptr(), resid.data_ptr())
+        fa.C, fa.C2, fa.M, fa.H, fa.I = y.data_ptr(), yb.data_ptr(), M, H, I
+        le.gamma, le.beta, le.eps, le.xhat, le.rstd = gamma.data_ptr(), beta.data_ptr(), 1e-12, xh.data_ptr(), rs.data_ptr()
+        chain = (fa, le)
+        keep += [W2, b2, gamma, beta, resid, y, yb, xh, rs]
+    t_ffn1 = t_wgrad = t_chain = 0.0
     for i in range(reps):
         trainer.step(*batches[i % len(batches)])
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
         _lib.check(lib.qst_gemm_tn_group(grp, st))
         ev[1].record()
         _lib.check(lib.qst_gemm_nt(g, 2, st))
         ev[2].record()
+        if chain is not None:
+            _lib.check(lib.qst_ffn_chain(chain[0], chain[1], 0, st))
+        ev[3].record()
         torch.cuda.synchronize()
         t_wgrad += ev[0].elapsed_time(ev[1])
         t_ffn1 += ev[1].elapsed_time(ev[2])
+        t_chain += ev[2].elapsed_time(ev[3])
     wflops = 2.0 * M * (H * I + I * H + H * H + 3 * H * H)
+    third = None if chain is None else {
+        "kernel": "ffn_chain_kernel<0, false> (FFN-1 + GELU + FFN-2 + LayerNorm in one launch; inference forward)",
+        "ms": t_chain / reps, "flops_per_launch": 4.0 * M * I * H, "shape": [M, I, H]}
     return ({"kernel": "gemm_tn_group_kernel (all 4 wgrads of one layer: dW2, dW1, dWo, dWqkv + bias grads)",
              "ms": t_wgrad / reps, "flops_per_launch": wflops, "shape": [M, H, I]},
             {"kernel": "gemm_nt_kernel<2, 2, 2> (FFN1 fwd, bias+GELU epilogue)", "ms": t_ffn1 / reps,
-             "flops_per_launch": 2.0 * M * I * H, "shape": [M, I, H]})
+             "flops_per_launch": 2.0 * M * I * H, "shape": [M, I, H]}, third)
 
 
 def time_fwd_only(trainer, batches, steps, precision="bf16"):
@@ -345,7 +367,7 @@ def main():
 
     out = None
     # every rank runs the kernel timing: its interleaved training steps are collective (gradient all-reduce)
-    dk, dk2 = time_kernels(trainer, 4 * B, L, args.kernel_reps, batches)
+    dk, dk2, dk3 = time_kernels(trainer, 4 * B, L, args.kernel_reps, batches)
     if rank == 0:
         fwd_flops_q = 4.0 * forward_flops_per_sequence(cfg, L)
         train_flops_q = 3.0 * fwd_flops_q
@@ -391,6 +413,11 @@ def main():
                                   "unit": "TFLOP/s", "frac": round(achieved2 / PEAK_BF16_TFLOPS, 4), "traffic": traffic2,
                                   "kernel": dk2["kernel"], "avg_launch_ms": round(dk2["ms"], 5), "shape_MNK": dk2["shape"]},
         }
+        if dk3 is not None:
+            a3 = dk3["flops_per_launch"] / (dk3["ms"] * 1e-3) / 1e12
+            out["roofline_ffn_inference"] = {"bound": "mfma", "achieved": round(a3, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                             "frac": round(a3 / PEAK_BF16_TFLOPS, 4), "traffic": None, "kernel": dk3["kernel"],
+                                             "avg_launch_ms": round(dk3["ms"], 5), "shape_MNK": dk3["shape"]}
         if world == 1 and not args.no_extras:
             t_f = time_fwd_only(trainer, batches, max(5, args.steps // 2))
             out["fwd_only"] = {"value": round(B / t_f, 1), "unit": "quadruplets/s", "ms_per_step": round(t_f * 1e3, 4),

@@ -41,6 +41,11 @@ class QstLnEpi(C.Structure):
     _fields_ = [("gamma", vp), ("beta", vp), ("eps", C.c_float), ("xhat", vp), ("rstd", vp), ("partials", vp)]
 
 
+class QstFfnArgs(C.Structure):
+    _fields_ = [("A", vp), ("B1", vp), ("B2", vp), ("bias1", vp), ("bias2", vp), ("resid", vp), ("aux", vp),
+                ("save_gp", vp), ("save_h", vp), ("C", vp), ("C2", vp), ("M", C.c_int32), ("H", C.c_int32), ("I", C.c_int32)]
+
+
 class QstTnGroup(C.Structure):
     _fields_ = [("nprob", C.c_int32), ("splits", C.c_int32), ("total_tiles", C.c_int32), ("ranges_per_xcd", C.c_int32),
                 ("tiles", C.c_int32 * 8),
@@ -87,6 +92,8 @@ SIGNATURES = {
     "qst_quant_rows_fp8": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
     "qst_gemm_nt_ln_supported": (C.c_int, [C.c_int]),
     "qst_gemm_nt_ln": (C.c_int, [C.POINTER(QstGemmArgs), C.POINTER(QstLnEpi), C.c_int, vp]),
+    "qst_ffn_chain_supported": (C.c_int, [C.c_int, C.c_int]),
+    "qst_ffn_chain": (C.c_int, [C.POINTER(QstFfnArgs), C.POINTER(QstLnEpi), C.c_int, vp]),
     "qst_gemm_tn": (C.c_int, [C.POINTER(QstGemmArgs), vp]),
     "qst_gemm_tn_group": (C.c_int, [C.POINTER(QstTnGroup), vp]),
     "qst_embed_ln_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp]),

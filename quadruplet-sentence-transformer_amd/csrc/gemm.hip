@@ -726,7 +726,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, bytes);
             // an operand stage is 768 chunks = 12 wave-instructions of 1 KB. LDS position p = q*64 + lane -> row p/24,
             // chunk position p%24 -> logical chunk = pos ^ swz(row). Columns beyond the matrix width must not alias
-            // the next row: those lanes get an out-of-range offset (-> zero fill).
+            // the next row: those lanes get an out-of-range offset (-> zero fill). (Cutting the stage into three
+            // [32][64] sub-images so that every instruction moves 8 whole 128-byte lines changed nothing: 169.2 vs
+            // 168.3 us, same-process A/B.)
             uint32_t vo[6];
 #pragma unroll
             for (int t = 0; t < 6; ++t) {

@@ -13,6 +13,13 @@ extern "C" int qst_adamw_launch(float*, float*, float*, float*, const uint8_t*, 
                                 float, float, float, int64_t, float*, float*, hipStream_t);
 
 static thread_local int g_last_hip_error = 0;
+// Where the one-kernel feed-forward block (csrc/ffn.hip) is used: bit 0 = inference forward (default: the [M, I] tensor
+// never leaves the chip, 121 vs 144 us per layer at M = 32768), bit 1 = training forward, bit 2 = backward. The training
+// variants are correct and tested but measured SLOWER than the two-kernel path (178 vs 144 us and 157 vs 125 us): their
+// side outputs (gelu'(u), h / du: 100-200 MB per call) are stored by the same waves that wait on the LDS-DMA stream, and
+// stores and DMAs retire through one in-order counter. qst_debug_fuse_ffn sets the mask (tests, experiments).
+static int g_fuse_ffn = 1;
+extern "C" void qst_debug_fuse_ffn(int mask) { g_fuse_ffn = mask; }
 extern "C" int qst_set_hip_error(int code) { g_last_hip_error = code; return code; }
 extern "C" int qst_last_hip_error(void) { return g_last_hip_error; }
 extern "C" int qst_version(void) { return 100; }
@@ -329,6 +336,18 @@ int tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, float*
     return qst_gemm_tn(&g, st);
 }
 
+// the feed-forward block as one kernel (csrc/ffn.hip): mode 0 forward, mode 1 backward
+int ffn_chain(const void* A, const void* B1, const void* B2, const float* bias1, const float* bias2, const float* resid,
+              const void* aux, void* save_gp, void* save_h, float* C, void* C2, int M, int H, int I, int mode,
+              const float* gamma, const float* beta, float eps, void* xhat, float* rstd, float* partials, hipStream_t st) {
+    QstFfnArgs g{};
+    g.A = A; g.B1 = B1; g.B2 = B2; g.bias1 = bias1; g.bias2 = bias2; g.resid = resid; g.aux = aux;
+    g.save_gp = save_gp; g.save_h = save_h; g.C = C; g.C2 = C2; g.M = M; g.H = H; g.I = I;
+    QstLnEpi e{};
+    e.gamma = gamma; e.beta = beta; e.eps = eps; e.xhat = xhat; e.rstd = rstd; e.partials = partials;
+    return qst_ffn_chain(&g, &e, mode, st);
+}
+
 constexpr int kFuseLnMinRows = 16384;      // token rows from which the fused GEMM+LayerNorm kernels win (see forward)
 
 #define QST_TRY(expr) do { int _rc = (expr); if (_rc != QST_OK) return _rc; } while (0)
@@ -450,6 +469,9 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     // token rows on: one 128-row tile per workgroup gives a small batch too few workgroups (measured: the unfused pair
     // is 5-25% faster up to M = 8192, equal at 16384, 25% slower at 32768)
     const bool fuse_ln = !w8 && qst_gemm_nt_ln_supported(H) != 0 && M >= kFuseLnMinRows;
+    // ... and the whole feed-forward block (FFN-1, GELU, FFN-2, LayerNorm) is ONE kernel: h never returns from HBM, and
+    // an inference forward does not write it at all
+    const bool fuse_ffn = fuse_ln && (g_fuse_ffn & (training ? 2 : 1)) && qst_ffn_chain_supported(H, I) != 0;
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerAct& a = p.layers[l];
         const int b = lay.layer0[l];
@@ -462,6 +484,15 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
             QST_TRY(linear(sv + a.ctx, H, b + W_O, s, H, nullptr, b + B_O, x, QST_EPI_F32_RESID));
             QST_TRY(qst_ln_fwd(s, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, (float*)(sv + a.y1), sv + a.y1b,
                                sv + a.xh1, (float*)(sv + a.rs1), st));
+        }
+        if (fuse_ffn) {
+            QST_TRY(ffn_chain(sv + a.y1b, W(b + W_1), W(b + W_2), P(b + B_1), P(b + B_2), (const float*)(sv + a.y1), nullptr,
+                              training ? sv + a.u : nullptr, training ? sv + a.hact : nullptr, (float*)(sv + a.x), sv + a.xb,
+                              M, H, I, 0, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, sv + a.xh2, (float*)(sv + a.rs2),
+                              nullptr, st));
+            x = (const float*)(sv + a.x);
+            xb = sv + a.xb;
+            continue;
         }
         QST_TRY(linear(sv + a.y1b, H, b + W_1, sv + a.u, I, sv + a.hact, b + B_1, nullptr, QST_EPI_GELU));
         if (fuse_ln) {
@@ -533,6 +564,7 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
     // H = 384: every LayerNorm backward except the top one (whose input comes from the pooling head, not from a GEMM)
     // runs inside the epilogue of the dgrad GEMM that produces its input; those write one partial row per 128-row tile
     const bool fuse_ln = qst_gemm_nt_ln_supported(H) != 0 && M >= kFuseLnMinRows;
+    const bool fuse_ffn = fuse_ln && (g_fuse_ffn & 4) && qst_ffn_chain_supported(H, I) != 0;
     const int fused_rows = (M + 127) / 128;
     auto ln_slot = [&](int slot, float* dg, float* db, int nrows = 0) {
         float* sp = (float*)(ws + w.lnred + (size_t)slot * w.lnred_stride);
@@ -584,10 +616,18 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
             QST_TRY(qst_ln_bwd(dxa, sv + a.xh2, (const float*)(sv + a.rs2), P(b + LN2_G), M, H, ds, dsb, nullptr, nullptr,
                                ln_slot(2 * l + 1, G(b + LN2_G), G(b + LN2_B)), st));
         // FFN2 dgrad through GELU: du = (ds2 . W2) * gelu'(u)   (a.u holds gelu'(u), written by the forward epilogue)
-        QST_TRY(nt(dsb, H, WT(b + W_2), H, du, I, nullptr, sv + a.u, nullptr, nullptr, 0, M, I, H, QST_EPI_GELU_BWD, st));
+        if (!fuse_ffn)
+            QST_TRY(nt(dsb, H, WT(b + W_2), H, du, I, nullptr, sv + a.u, nullptr, nullptr, 0, M, I, H, QST_EPI_GELU_BWD, st));
         // FFN1 dgrad + residual: dy1 = du . W1 + ds2 ; LN1 backward -> ds1 (fp32 in `ds1`, bf16 in dsb1)
         const float* ds1 = ds;
-        if (fuse_ln) {
+        if (fuse_ffn) {
+            // both dgrads of the feed-forward block and the LayerNorm-1 backward in one kernel; du is written once
+            // (the weight gradients need it) and never read back by this chain
+            QST_TRY(ffn_chain(dsb, WT(b + W_2), WT(b + W_1), nullptr, nullptr, ds, sv + a.u, nullptr, du, dxb, dsb1, M, H, I, 1,
+                              P(b + LN1_G), nullptr, 0.f, sv + a.xh1, (float*)(sv + a.rs1),
+                              ln_slot(2 * l, G(b + LN1_G), G(b + LN1_B), fused_rows), st));
+            ds1 = dxb;
+        } else if (fuse_ln) {
             QST_TRY(nt_ln(du, I, WT(b + W_1), I, dxb, dsb1, nullptr, ds, M, H, I, 1, P(b + LN1_G), nullptr, 0.f, sv + a.xh1,
                           (float*)(sv + a.rs1), ln_slot(2 * l, G(b + LN1_G), G(b + LN1_B), fused_rows), st));
             ds1 = dxb;

@@ -57,6 +57,30 @@ typedef struct {
 } QstLnEpi;
 int qst_gemm_nt_ln_supported(int N);
 int qst_gemm_nt_ln(const QstGemmArgs* a, const QstLnEpi* ln, int mode, void* stream);
+/* The feed-forward block of a layer as one kernel (H = 384 token rows complete per tile; csrc/ffn.hip):
+ *  mode 0 (forward):  u = A.B1^T + bias1 ; h = gelu(u) ; v = h.B2^T + bias2 + resid ; y = LayerNorm(v) -> C (f32),
+ *                     C2 (bf16, nullable), ln->xhat / ln->rstd (nullable). save_gp / save_h (both or neither) receive
+ *                     gelu'(u) and h as bf16 [M, I] for the backward pass; NULL = inference, the [M, I] tensor never
+ *                     leaves the chip.
+ *  mode 1 (backward): du = (A.B1^T) * aux -> save_h (bf16 [M, I], required: the weight gradients read it) ;
+ *                     dy = du.B2^T + resid ; C / C2 / ln->partials as qst_gemm_nt_ln mode 1.
+ * A bf16 [M, H]; B1 bf16 [I, H]; B2 bf16 [H, I]; aux bf16 [M, I]; resid f32 [M, H]. All contiguous. */
+typedef struct {
+    const void* A;
+    const void* B1;
+    const void* B2;
+    const float* bias1;
+    const float* bias2;
+    const float* resid;
+    const void* aux;
+    void* save_gp;
+    void* save_h;
+    float* C;
+    void* C2;
+    int32_t M, H, I;
+} QstFfnArgs;
+int qst_ffn_chain_supported(int H, int I);
+int qst_ffn_chain(const QstFfnArgs* a, const QstLnEpi* ln, int mode, void* stream);
 /* C[N,K] (f32, atomically accumulated) += A[M,N]^T . B[M,K]; colsum[N] += sum_m A[m,:]. */
 int qst_gemm_tn(const QstGemmArgs* a, void* stream);
 /* Several such products over the same M in ONE launch (all weight gradients of a layer). */

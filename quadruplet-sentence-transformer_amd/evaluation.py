@@ -152,7 +152,10 @@ def resolve_score_function(name: str, fn: Optional[Callable], device=None):
         got = torch.as_tensor(fn(q, c)).to(dev, torch.float32)
         if tuple(got.shape) == (6, 9):
             for m in (1, 0, 2):
-                if torch.allclose(got, util.score_matrix(q, c, m), rtol=1e-4, atol=1e-5):
+                ref = util.score_matrix(q, c, m)
+                # split-bf16 x3 products are accurate to ~2^-17 of sum |a_k b_k|, i.e. relative to the matrix's scale,
+                # not to each (possibly cancelling) entry; the three native modes differ by O(1) on this probe
+                if float((got - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max())):
                     return ("native", m)
     except Exception:          # a callable that cannot take the probe is simply called on the real embeddings later
         pass

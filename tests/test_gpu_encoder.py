@@ -18,6 +18,7 @@ import quadruplet_sentence_transformer_amd as qst  # noqa: E402
 from quadruplet_sentence_transformer_amd.config import PRESETS, build_layout  # noqa: E402
 from quadruplet_sentence_transformer_amd.encoder import HipEncoder, quadruplet_loss_raw  # noqa: E402
 from quadruplet_sentence_transformer_amd.synthetic import synthetic_params, synthetic_quadruplets  # noqa: E402
+from quadruplet_sentence_transformer_amd import _lib  # noqa: E402
 from oracle import torch_ref as R  # noqa: E402
 
 LOSS_KW = dict(gamma=0.6, margin_pos_neg=1.0, margin_pos_part=0.5, margin_part_neg=0.5, p=2.0, swap=False)
@@ -124,6 +125,36 @@ def test_all_padding_and_left_padded_sequences(base, L):
                  mask_edges=True)
     finally:
         del PRESETS["edge-2l"]
+
+
+def test_feed_forward_block_as_one_kernel():
+    """csrc/ffn.hip inside the encoder (M = 16384 rows, MiniLM layer dims): (a) the inference forward takes it by default
+    and must give the embeddings of the training forward (two-kernel feed-forward path) -- same rounding points;
+    (b) with the training variants switched on (qst_debug_fuse_ffn(7): forward saving gelu'(u) and h, backward producing
+    du + LayerNorm-1 backward) the whole oracle comparison of run_case, gradients included, must still hold."""
+    import ctypes as C
+    from dataclasses import replace
+    lib = _lib.load()
+    lib.qst_debug_fuse_ffn.argtypes = [C.c_int]
+    PRESETS["minilm-2l"] = replace(PRESETS["all-MiniLM-L6-v2"], num_layers=2, vocab_size=4096)
+    try:
+        cfg = PRESETS["minilm-2l"]
+        arena = synthetic_params(cfg, seed=14, std=0.03, bias_std=0.02, ln_jitter=0.05)
+        ids, mask, types = [torch.from_numpy(x).view(128, 128).cuda() for x in synthetic_quadruplets(cfg, 32, 128, seed=14, ragged=True)]
+        enc = HipEncoder(cfg)
+        enc.load_arena(arena)
+        e_train = enc.forward(ids, mask, types, training=True)[0].clone()
+        e_inf = enc.forward(ids, mask, types, training=False)[0].clone()
+        lib.qst_debug_fuse_ffn(0)
+        e_inf0 = enc.forward(ids, mask, types, training=False)[0].clone()
+        lib.qst_debug_fuse_ffn(1)
+        torch.testing.assert_close(e_inf, e_train, rtol=0, atol=2e-5)       # bf16 h re-rounds identically; fp32 sums reorder
+        torch.testing.assert_close(e_inf, e_inf0, rtol=0, atol=2e-5)
+        lib.qst_debug_fuse_ffn(7)
+        run_case("minilm-2l", 32, 128, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), emb_atol_vs_bf16_oracle=1.5e-3)
+    finally:
+        lib.qst_debug_fuse_ffn(1)
+        del PRESETS["minilm-2l"]
 
 
 def test_minilm_full_dims_ragged():

@@ -294,6 +294,101 @@ def test_gemm_nt_fused_layernorm(lib, M, K):
                               ln_epi(gamma=gamma, xhat=xh0, rstd=rs0), 1, stream()) == -2
 
 
+@pytest.mark.parametrize("M,I", [(128, 192), (416, 768), (1000, 1536), (4096, 1536)])
+def test_ffn_chain_matches_the_two_kernel_path(lib, M, I):
+    """qst_ffn_chain (csrc/ffn.hip: the feed-forward block as one kernel) against the launches it replaces --
+    forward: qst_gemm_nt(GELU) + qst_gemm_nt_ln(mode 0); backward: qst_gemm_nt(GELU_BWD) + qst_gemm_nt_ln(mode 1).
+    The rounding points are the same (h / du are rounded to bf16 before the second product in both forms), so fp32
+    outputs agree to accumulation-order noise; plus a plain fp32 torch reference of the forward."""
+    H = 384
+    assert lib.qst_ffn_chain_supported(H, I) == 1 and lib.qst_ffn_chain_supported(768, 3072) == 0
+    g = torch.Generator().manual_seed(M + I)
+    bf = torch.bfloat16
+    A = dev(bfr(torch.randn(M, H, generator=g)).to(bf))
+    W1 = dev(bfr(torch.randn(I, H, generator=g) * 0.05).to(bf))
+    W2 = dev(bfr(torch.randn(H, I, generator=g) * 0.05).to(bf))
+    W1t, W2t = W1.t().contiguous(), W2.t().contiguous()                 # the "W^T shadows" the dgrads read
+    b1, b2 = dev(0.3 * torch.randn(I, generator=g)), dev(0.3 * torch.randn(H, generator=g))
+    resid = dev(torch.randn(M, H, generator=g))
+    gamma, beta = dev(1 + 0.1 * torch.randn(H, generator=g)), dev(0.1 * torch.randn(H, generator=g))
+    eps = 1e-12
+
+    def ln_epi(**kw):
+        e = _lib.QstLnEpi()
+        e._keep = [v for v in kw.values() if torch.is_tensor(v)]
+        for k, v in kw.items():
+            setattr(e, k, v.data_ptr() if torch.is_tensor(v) else v)
+        return e
+
+    def ffn_args(**kw):
+        a = _lib.QstFfnArgs()
+        a._keep = [v for v in kw.values() if torch.is_tensor(v)]
+        for k, v in kw.items():
+            setattr(a, k, v.data_ptr() if torch.is_tensor(v) else v)
+        return a
+
+    def f32(*shape):
+        return torch.empty(*shape, dtype=torch.float32, device="cuda")
+
+    def b16(*shape):
+        return torch.empty(*shape, dtype=bf, device="cuda")
+
+    # ---- forward, two kernels
+    gp0, h0 = b16(M, I), b16(M, I)
+    _lib.check(lib.qst_gemm_nt(gemm_args(A=A, B=W1, C=gp0, C2=h0, bias=b1, M=M, N=I, K=H, lda=H, ldb=H, ldc=I), 2, stream()))
+    y0, yb0, xh0, rs0 = f32(M, H), b16(M, H), b16(M, H), f32(M)
+    _lib.check(lib.qst_gemm_nt_ln(gemm_args(A=h0, B=W2, C=y0, C2=yb0, bias=b2, resid=resid, M=M, N=H, K=I, lda=I, ldb=I,
+                                            ldc=H, ldr=H), ln_epi(gamma=gamma, beta=beta, eps=eps, xhat=xh0, rstd=rs0), 0,
+                                  stream()))
+    # ---- forward, one kernel (training: side outputs; inference: none)
+    gp1, h1 = torch.full((M, I), 7.0, dtype=bf, device="cuda"), torch.full((M, I), 7.0, dtype=bf, device="cuda")
+    y1, yb1, xh1, rs1 = f32(M, H), b16(M, H), b16(M, H), f32(M)
+    _lib.check(lib.qst_ffn_chain(ffn_args(A=A, B1=W1, B2=W2, bias1=b1, bias2=b2, resid=resid, save_gp=gp1, save_h=h1, C=y1,
+                                          C2=yb1, M=M, H=H, I=I),
+                                 ln_epi(gamma=gamma, beta=beta, eps=eps, xhat=xh1, rstd=rs1), 0, stream()))
+    torch.cuda.synchronize()
+    assert (gp1.float() - gp0.float()).abs().max().item() <= 2 ** -7 and (h1.float() - h0.float()).abs().max().item() <= \
+        2 ** -7 * max(1.0, h0.float().abs().max().item())
+    assert (h1 != h0).float().mean().item() < 1e-3                      # the same values up to rare last-bit roundings
+    torch.testing.assert_close(y1, y0, rtol=1e-4, atol=2e-4)
+    torch.testing.assert_close(rs1, rs0, rtol=1e-4, atol=0)
+    torch.testing.assert_close(yb1.float(), yb0.float(), rtol=8e-3, atol=1e-2)
+    torch.testing.assert_close(xh1.float(), xh0.float(), rtol=8e-3, atol=1e-2)
+    u = A.float() @ W1.float().t() + b1
+    href = bfr(torch.nn.functional.gelu(u))
+    ref = torch.nn.functional.layer_norm(href @ W2.float().t() + b2 + resid, (H,), gamma, beta, eps)
+    torch.testing.assert_close(y1, ref, rtol=1e-3, atol=2e-3)
+    y2 = f32(M, H)
+    _lib.check(lib.qst_ffn_chain(ffn_args(A=A, B1=W1, B2=W2, bias1=b1, bias2=b2, resid=resid, C=y2, M=M, H=H, I=I),
+                                 ln_epi(gamma=gamma, beta=beta, eps=eps), 0, stream()))
+    torch.testing.assert_close(y2, y1, rtol=0, atol=0)                  # inference variant: same arithmetic
+
+    # ---- backward: du = (ds2 . W2) * gelu'(u) ; ds1 = LN1'(du . W1 + ds2)
+    ds2 = dev(torch.randn(M, H, generator=g))
+    ds2b = ds2.to(bf)
+    du0 = b16(M, I)
+    _lib.check(lib.qst_gemm_nt(gemm_args(A=ds2b, B=W2t, C=du0, aux=gp0, M=M, N=I, K=H, lda=H, ldb=H, ldc=I), 3, stream()))
+    ntile = (M + 127) // 128
+    o0, ob0, part0 = f32(M, H), b16(M, H), f32(ntile, 2, H)
+    _lib.check(lib.qst_gemm_nt_ln(gemm_args(A=du0, B=W1t, C=o0, C2=ob0, resid=ds2, M=M, N=H, K=I, lda=I, ldb=I, ldc=H, ldr=H),
+                                  ln_epi(gamma=gamma, xhat=xh0, rstd=rs0, partials=part0), 1, stream()))
+    du1 = torch.full((M, I), 7.0, dtype=bf, device="cuda")
+    o1, ob1, part1 = f32(M, H), b16(M, H), torch.full((ntile, 2, H), float("nan"), device="cuda")
+    _lib.check(lib.qst_ffn_chain(ffn_args(A=ds2b, B1=W2t, B2=W1t, resid=ds2, aux=gp0, save_h=du1, C=o1, C2=ob1, M=M, H=H, I=I),
+                                 ln_epi(gamma=gamma, xhat=xh0, rstd=rs0, partials=part1), 1, stream()))
+    torch.cuda.synchronize()
+    sc = du0.float().abs().max().item()
+    assert (du1.float() - du0.float()).abs().max().item() <= 2 ** -7 * sc and (du1 != du0).float().mean().item() < 1e-3
+    scale = o0.abs().max().item()
+    torch.testing.assert_close(o1, o0, rtol=1e-4, atol=2e-4 * scale)
+    torch.testing.assert_close(ob1.float(), ob0.float(), rtol=8e-3, atol=1e-2 * scale)
+    torch.testing.assert_close(part1.sum(0), part0.sum(0), rtol=1e-3, atol=1e-3 * math.sqrt(M) * scale)
+    # refused, not mis-computed
+    assert lib.qst_ffn_chain(ffn_args(A=A, B1=W1, B2=W2, C=y2, M=M, H=768, I=I), ln_epi(gamma=gamma, beta=beta), 0, stream()) == -2
+    assert lib.qst_ffn_chain(ffn_args(A=A, B1=W1, B2=W2, C=y2, save_h=h1, M=M, H=H, I=I), ln_epi(gamma=gamma, beta=beta), 0,
+                             stream()) == -1                            # save_h without save_gp
+
+
 # ------------------------------------------------------------------ attention
 def attn_ref(qkv, mask, rel, n, L, A, d):
     H = A * d

@@ -97,6 +97,30 @@ def main():
             t_pair = timeit(pair)
             t_fused = timeit(lambda: _lib.check(lib.qst_gemm_nt_ln(g, e, mode, st)))
             print(f"ln {name:31s} fused {t_fused:7.1f} us   unfused pair {t_pair:7.1f} us")
+    # the feed-forward block as one kernel (csrc/ffn.hip) against the two launches it replaces
+    if lib.qst_ffn_chain_supported(H, I):
+        A = torch.randn(M, H, device=dev).to(bf)
+        W1 = (torch.randn(I, H, device=dev) * 0.02).to(bf); W2 = (torch.randn(H, I, device=dev) * 0.02).to(bf)
+        b1 = torch.zeros(I, device=dev); b2 = torch.zeros(H, device=dev); gamma = torch.ones(H, device=dev); beta = torch.zeros(H, device=dev)
+        resid = torch.randn(M, H, device=dev)
+        gp = torch.empty(M, I, device=dev, dtype=bf); hh = torch.empty(M, I, device=dev, dtype=bf); du = torch.empty(M, I, device=dev, dtype=bf)
+        y = torch.empty(M, H, device=dev); yb = torch.empty(M, H, device=dev, dtype=bf); xh = torch.empty(M, H, device=dev, dtype=bf)
+        rs = torch.rand(M, device=dev) + 0.5
+        part = torch.empty((M + 127) // 128, 2, H, device=dev)
+        e = _lib.QstLnEpi()
+        e.gamma, e.beta, e.eps, e.xhat, e.rstd, e.partials = gamma.data_ptr(), beta.data_ptr(), 1e-12, xh.data_ptr(), rs.data_ptr(), part.data_ptr()
+        f = _lib.QstFfnArgs()
+        f.A, f.B1, f.B2, f.bias1, f.bias2, f.resid = A.data_ptr(), W1.data_ptr(), W2.data_ptr(), b1.data_ptr(), b2.data_ptr(), resid.data_ptr()
+        f.C, f.C2, f.M, f.H, f.I = y.data_ptr(), yb.data_ptr(), M, H, I
+        f.save_gp, f.save_h = gp.data_ptr(), hh.data_ptr()
+        t_tr = timeit(lambda: _lib.check(lib.qst_ffn_chain(f, e, 0, st)))
+        f.save_gp, f.save_h = None, None
+        t_inf = timeit(lambda: _lib.check(lib.qst_ffn_chain(f, e, 0, st)))
+        f.aux, f.save_h, f.bias1, f.bias2 = gp.data_ptr(), du.data_ptr(), None, None
+        t_bw = timeit(lambda: _lib.check(lib.qst_ffn_chain(f, e, 1, st)))
+        fl = 4.0 * M * H * I
+        print(f"ffn chain fwd (training, saves gelu' + h)  {t_tr:8.1f} us {fl / t_tr / 1e6:8.1f} TF   inference {t_inf:8.1f} us {fl / t_inf / 1e6:8.1f} TF   "
+              f"bwd (du + LN1') {t_bw:8.1f} us {fl / t_bw / 1e6:8.1f} TF")
     for name, N, K in [("dW2 [H,I]", H, I), ("dW1 [I,H]", I, H), ("dWo [H,H]", H, H), ("dWqkv [3H,H]", 3 * H, H)]:
         A = torch.randn(M, N, device=dev).to(bf)
         B = torch.randn(M, K, device=dev).to(bf)
