@@ -91,6 +91,41 @@ class SyntheticTokenizer:
         return out
 
 
+def load_tokenizer(tok_dir: Optional[str], cfg: EncoderConfig):
+    """The model directory's own tokenizer (transformers.AutoTokenizer over vocab.txt / tokenizer.json / ..., strictly
+    offline) or None when the directory holds no vocabulary. A vocabulary whose ids do not fit the embedding table is an
+    error, not a fallback: silently hashing words instead would train a different model."""
+    if tok_dir is None or not any(os.path.exists(os.path.join(tok_dir, f))
+                                  for f in ("tokenizer.json", "vocab.txt", "vocab.json", "sentencepiece.bpe.model")):
+        return None
+    from transformers import AutoTokenizer
+    tok = AutoTokenizer.from_pretrained(tok_dir, local_files_only=True)
+    if len(tok) > cfg.vocab_size:
+        raise ValueError(f"{tok_dir}: tokenizer has {len(tok)} entries but the embedding table only {cfg.vocab_size} rows")
+    return tok
+
+
+def tokenize_texts(tokenizer, cfg: EncoderConfig, texts, max_len: int) -> Dict[str, torch.Tensor]:
+    """sentence_transformers.models.Transformer.tokenize as ST 2.2.2 runs it for a list of strings:
+    strip, then padding=True, truncation='longest_first', max_length, return_tensors='pt'."""
+    texts = [str(t).strip() for t in texts]
+    if isinstance(tokenizer, SyntheticTokenizer):
+        return tokenizer(texts, max_len)
+    out = tokenizer(texts, padding=True, truncation="longest_first", return_tensors="pt", max_length=max_len)
+    out = {k: v for k, v in out.items()}
+    if cfg.type_vocab_size > 0 and "token_type_ids" not in out:
+        out["token_type_ids"] = torch.zeros_like(out["input_ids"])
+    if cfg.type_vocab_size == 0:
+        out.pop("token_type_ids", None)
+    return out
+
+
+def count_tokens(tokenizer, text: str, max_len: int) -> int:
+    if isinstance(tokenizer, SyntheticTokenizer):
+        return min(max_len, len(tokenizer._ids(str(text).strip())) + 2)
+    return len(tokenizer(str(text).strip(), truncation="longest_first", max_length=max_len)["input_ids"])
+
+
 # ------------------------------------------------------------------------------------------------ autograd bridge
 class _EncodeFn(torch.autograd.Function):
     """forward: qst_encoder_forward; backward: qst_encoder_backward accumulating straight into the gradient
@@ -192,15 +227,7 @@ class SentenceTransformer(nn.Module):
         self._enc = HipEncoder(cfg, device=dev)
         self._enc.load_arena(arena if arena is not None else synthetic_params(cfg, seed=seed))
         self.max_seq_length = cfg.max_seq_length
-        self.tokenizer = None
-        has_vocab = tok_dir is not None and any(os.path.exists(os.path.join(tok_dir, f))
-                                                 for f in ("tokenizer.json", "vocab.txt", "vocab.json", "sentencepiece.bpe.model"))
-        if has_vocab:
-            try:
-                from transformers import AutoTokenizer
-                self.tokenizer = AutoTokenizer.from_pretrained(tok_dir, local_files_only=True)
-            except Exception as e:   # no vocab in the directory
-                logger.warning("no usable tokenizer in %s (%s): falling back to SyntheticTokenizer", tok_dir, e)
+        self.tokenizer = load_tokenizer(tok_dir, cfg)
         if self.tokenizer is None:
             self._synthetic_tokenizer = SyntheticTokenizer(cfg)
         # "bf16" (throughput) or "bf16x3" (fp32-class parity path) for no-grad forwards: encode() and evaluators
@@ -252,15 +279,19 @@ class SentenceTransformer(nn.Module):
 
     # ---- tokenisation (SURVEY.md 8a row a7)
     def tokenize(self, texts: Union[List[str], List[Dict], List[Tuple[str, str]]]):
-        texts = [str(t).strip() for t in texts]
+        return tokenize_texts(self.tokenizer if self.tokenizer is not None else self._synthetic_tokenizer, self.cfg,
+                              texts, min(self.max_seq_length, 512))
+
+    def token_lengths(self, examples: Iterable) -> List[int]:
+        """Tokens the fused [4B, L] pass will spend on each example: the longest of its texts after truncation, special
+        tokens included (input of data.LengthBucketBatchSampler). `examples`: InputExample objects or lists of texts."""
         max_len = min(self.max_seq_length, 512)
-        if self.tokenizer is not None:
-            out = self.tokenizer(texts, padding=True, truncation="longest_first", return_tensors="pt", max_length=max_len)
-            out = {k: v for k, v in out.items()}
-            if self.cfg.type_vocab_size > 0 and "token_type_ids" not in out:
-                out["token_type_ids"] = torch.zeros_like(out["input_ids"])
-            return out
-        return self._synthetic_tokenizer(texts, max_len)
+        tok = self.tokenizer if self.tokenizer is not None else self._synthetic_tokenizer
+        out = []
+        for ex in examples:
+            texts = ex.texts if hasattr(ex, "texts") else ([ex] if isinstance(ex, str) else list(ex))
+            out.append(max(count_tokens(tok, t, max_len) for t in texts))
+        return out
 
     def smart_batching_collate(self, batch):
         """[InputExample] -> (list of per-column tokenised dicts, labels tensor) as ST 2.2.2 does."""
