@@ -426,6 +426,13 @@ def main():
             t_8 = time_fwd_only(trainer, batches, max(5, args.steps // 2), precision="fp8w")
             out["fwd_only_fp8w"] = {"value": round(B / t_8, 1), "unit": "quadruplets/s", "ms_per_step": round(t_8 * 1e3, 4),
                                     "what": "same, Linear weights as fp8 e4m3 + per-row scales (QST_PREC_FP8W, inference)"}
+            if cfg.hidden_size % 128 == 0 and cfg.intermediate_size % 128 == 0:
+                t_m = time_fwd_only(trainer, batches, max(5, args.steps // 2), precision="fp8")
+                out["fwd_only_fp8"] = {"value": round(B / t_m, 1), "unit": "quadruplets/s", "ms_per_step": round(t_m * 1e3, 4),
+                                       "speedup_vs_bf16": round(t_f / t_m, 3),
+                                       "what": "same on the fp8 matrix cores: MXFP8 weights AND activations, block-scaled MFMA "
+                                               "(QST_PREC_FP8, inference; BASELINE configs[4])",
+                                       "mfma_frac_of_fp8_peak": round(B / t_m * fwd_flops_q / 1e12 / (2 * PEAK_BF16_TFLOPS), 4)}
             t_3 = time_fwd_only(trainer, batches, max(5, args.steps // 2), precision="bf16x3")
             out["fwd_only_bf16x3"] = {"value": round(B / t_3, 1), "unit": "quadruplets/s", "ms_per_step": round(t_3 * 1e3, 4),
                                       "what": "same, parity precision (split-bf16 x3 MFMA, fp32 activations): the "

@@ -18,6 +18,9 @@
  * QST_PREC_FP8W (inference only; BASELINE configs[4] "fp8 weights") keeps every
  * Linear weight as fp8 e4m3 (OCP) with one fp32 scale per output row
  * (qst_refresh_shadow8), bf16 activations, fp32 accumulation.
+ * QST_PREC_FP8 (inference only; BASELINE configs[4] "CDNA4 fp8 MFMA GEMMs") runs every Linear on the fp8 matrix
+ * cores: weights AND activations as OCP MXFP8 (e4m3 elements, one E8M0 scale per 32 input features;
+ * v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulation), attention in bf16, residual stream / LayerNorm in fp32.
  */
 #ifndef QST_H
 #define QST_H
@@ -39,7 +42,7 @@ typedef enum {
 } qst_status;
 
 enum { QST_ARCH_BERT = 0, QST_ARCH_MPNET = 1 };
-enum { QST_PREC_BF16 = 0, QST_PREC_BF16X3 = 1, QST_PREC_FP8W = 2 };
+enum { QST_PREC_BF16 = 0, QST_PREC_BF16X3 = 1, QST_PREC_FP8W = 2, QST_PREC_FP8 = 3 };
 enum { QST_REDUCE_NONE = 0, QST_REDUCE_SUM = 1, QST_REDUCE_MEAN = 2 };
 
 /* Encoder architecture. Mirrors HF BertConfig / MPNetConfig fields that the
@@ -96,6 +99,10 @@ int qst_refresh_shadow(const qst_encoder* enc, const float* params, void* shadow
 /* QST_PREC_FP8W: quantise every GEMM weight of the fp32 arena into the fp8 shadow (per output row: scale = max|w| / 448,
  * round to nearest even). qst_encoder_forward on a QST_PREC_FP8W handle takes this buffer as its `shadow` argument. */
 int qst_refresh_shadow8(const qst_encoder* enc, const float* params, void* shadow_fp8, void* stream);
+/* QST_PREC_FP8: the same buffer size (qst_shadow8_bytes) holds every GEMM weight as MXFP8: e4m3 bytes, then one E8M0
+ * scale per 32 input features of each output row (qst_quant_mx). qst_encoder_forward on a QST_PREC_FP8 handle takes it
+ * as its `shadow` argument. */
+int qst_refresh_shadow_mx(const qst_encoder* enc, const float* params, void* shadow_mx, void* stream);
 
 /*
  * Replaces SentenceTransformer.forward = Sequential(Transformer, Pooling(mean)[, Normalize])

@@ -179,6 +179,77 @@ def quadruplet_step(P, cfg, ids4, mask4, types4=None, loss_kw=None, bf16_operand
     return loss, emb
 
 
+def mx_quant(x: torch.Tensor):
+    """MXFP8 (OCP e4m3 elements, one E8M0 power-of-two scale per 32 consecutive elements of the last dimension) as
+    libqst quantises it (csrc/gemm.hip mx_exponent / quant_mx_kernel): per block, e = the smallest exponent with
+    amax * 2^-e <= 448 -- from amax's own exponent E and mantissa: e = E - 8, +1 when the mantissa exceeds 1.75 --
+    clamped to [-127, 126], -127 for an all-zero block; elements = round-to-nearest-even(x * 2^-e) to e4m3.
+    Returns (q uint8 [..., K], scale uint8 [..., K/32] = e + 127, dequantised fp32 [..., K])."""
+    K = x.shape[-1]
+    assert K % 32 == 0
+    xb = x.detach().to(torch.float32).reshape(-1, K // 32, 32)
+    amax = xb.abs().amax(-1)
+    bits = amax.contiguous().view(torch.int32)
+    E = ((bits >> 23) & 0xFF) - 127
+    e = E - 8 + ((bits & 0x7FFFFF) > 0x600000).to(torch.int32)
+    e = torch.where(((bits >> 23) & 0xFF) == 0, torch.full_like(e, -127), e.clamp(-127, 126))
+    scaled = torch.ldexp(xb, (-e)[..., None])
+    q8 = scaled.to(torch.float8_e4m3fn)
+    deq = torch.ldexp(q8.to(torch.float32), e[..., None]).reshape(x.shape)
+    return q8.view(torch.uint8).reshape(x.shape), (e + 127).to(torch.uint8).reshape(*x.shape[:-1], K // 32), deq
+
+
+def _mx(x: torch.Tensor, via_bf16: bool) -> torch.Tensor:
+    """Operand of an MXFP8 GEMM: optionally rounded to bf16 first (activations that reach the quantiser as bf16 tensors)."""
+    if via_bf16:
+        x = x.to(torch.bfloat16).to(torch.float32)
+    return mx_quant(x)[2]
+
+
+def encoder_forward_mx(P: Dict[str, torch.Tensor], cfg, ids: torch.Tensor, mask: torch.Tensor,
+                       type_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """QST_PREC_FP8 oracle (inference): encoder_forward with every Linear computed on MXFP8 operands -- weights
+    quantised from fp32; the layer input, the attention output and the LayerNorm-1 output quantised from their bf16
+    copies; gelu(u) quantised from fp32 (it never exists in another format) -- and attention on bf16 operands, as the
+    HIP pipeline does (csrc/qst_api.hip forward_mx)."""
+    n, L = ids.shape
+    H, A = cfg.hidden_size, cfg.num_heads
+    d = H // A
+    if cfg.arch == 0:
+        x = P["word_emb"][ids]
+        if cfg.type_vocab_size > 0:
+            tt = type_ids if type_ids is not None else torch.zeros_like(ids)
+            x = x + P["type_emb"][tt]
+        x = x + P["pos_emb"][torch.arange(L)][None]
+        rel = None
+    else:
+        x = P["word_emb"][ids] + P["pos_emb"][mpnet_position_ids(ids, cfg.pad_token_id)]
+        bucket = mpnet_bucket_table(L, cfg.rel_buckets, cfg.rel_max_distance)
+        rel = P["rel_bias"][bucket].permute(2, 0, 1)[None]
+    x = F.layer_norm(x, (H,), P["emb_ln_g"], P["emb_ln_b"], cfg.layer_norm_eps)
+    neg = torch.finfo(torch.float32).min
+    add_mask = (1.0 - mask[:, None, None, :].to(torch.float32)) * neg
+
+    def lin(a, w, b, via_bf16):
+        return F.linear(_mx(a, via_bf16), _mx(w, False), b)
+    for l in range(cfg.num_layers):
+        p = f"layer.{l}."
+        qkv = _r(lin(x, P[p + "w_qkv"], P[p + "b_qkv"], True), True)            # the QKV GEMM writes bf16
+        q, k, v = [t.view(n, L, A, d).transpose(1, 2) for t in qkv.split(H, dim=-1)]
+        s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d)
+        if rel is not None:
+            s = s + rel
+        s = s + add_mask
+        pr = torch.softmax(s, dim=-1)
+        ctx = torch.matmul(_r(pr, True), v).transpose(1, 2).reshape(n, L, H)
+        a = lin(ctx, P[p + "w_o"], P[p + "b_o"], True)
+        x = F.layer_norm(a + x, (H,), P[p + "ln1_g"], P[p + "ln1_b"], cfg.layer_norm_eps)
+        h = F.gelu(lin(x, P[p + "w_1"], P[p + "b_1"], True))
+        o = lin(h, P[p + "w_2"], P[p + "b_2"], False)
+        x = F.layer_norm(o + x, (H,), P[p + "ln2_g"], P[p + "ln2_b"], cfg.layer_norm_eps)
+    return x
+
+
 def fp8_weight_arena(arena, cfg):
     """QST_PREC_FP8W oracle: every Linear weight replaced by its fp8 e4m3 (OCP) round trip with one scale per output
     row -- scale = max|row| / 448 (1 for an all-zero row), q = round-to-nearest-even(w / scale), w' = q * scale -- which

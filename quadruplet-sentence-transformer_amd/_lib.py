@@ -66,6 +66,7 @@ SIGNATURES = {
     "qst_encoder_saved_bytes": (C.c_size_t, [vp, C.c_int, C.c_int, C.c_int]),
     "qst_encoder_bwd_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int]),
     "qst_refresh_shadow": (C.c_int, [vp, vp, vp, vp]),
+    "qst_refresh_shadow_mx": (C.c_int, [vp, vp, vp, vp]),
     "qst_encoder_forward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_size_t, C.c_int, vp]),
     "qst_encoder_backward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp]),
     "qst_encoder_backward_partial": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t,
@@ -89,6 +90,8 @@ SIGNATURES = {
     # kernel level (include/qst_kernels.h)
     "qst_gemm_nt": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int, vp]),
     "qst_gemm_nt_w8": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int, vp]),
+    "qst_gemm_nt_f8": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int, vp]),
+    "qst_quant_mx": (C.c_int, [vp, C.c_int, C.c_int64, C.c_int, vp, vp, vp]),
     "qst_quant_rows_fp8": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
     "qst_gemm_nt_ln_supported": (C.c_int, [C.c_int]),
     "qst_gemm_nt_ln": (C.c_int, [C.POINTER(QstGemmArgs), C.POINTER(QstLnEpi), C.c_int, vp]),

@@ -474,6 +474,237 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_w8_kernel(QstGemmArgs g) {
     nt_epilogue<EPI, 2>(g, acc, stg, bias_s, m0 + wm * 64, n0 + wn * 96, lane, scale_s);
 }
 
+// ---------------------------------------------------------------- NT on the fp8 matrix cores (MXFP8, inference)
+// C = A . B^T with BOTH operands in OCP MXFP8: e4m3 elements + one E8M0 scale (a power of two) per 32 consecutive K
+// elements of a row, multiplied by v_mfma_scale_f32_32x32x64_f8f6f4 -- 64 K per instruction at twice the FLOP rate of the
+// bf16 MFMA, the de-quantisation done by the instruction. BASELINE configs[4] ("CDNA4 fp8 MFMA GEMMs"); SURVEY.md 7 step 9.
+//
+// Operand layout of the instruction (not the obvious one; established with exact integer data by
+// tools/probe/mfma_f8_probe.hip and mfma_f8_scalemap.hip): the 64-deep step is two 32-deep MX blocks; lane l = 32h + r
+// holds, in registers 0-3, bytes k = 16h .. 16h+15 of block 0 of row r and, in registers 4-7, bytes k = 32+16h .. of
+// block 1; the scale of block b of row r is the low byte of the scale register of lane 32b + r. So lane (h, r) reads two
+// 16-byte chunks of its row (positions 16h and 32 + 16h of the 64-byte step) and supplies the scale of block h.
+//
+// Same tiling as gemm_nt_kernel<EPI, 2, 2>: 128 x 192 tile, 4 waves of 64 x 96, two workgroups per CU, 2-slot ring of
+// 40 KB stages -- a stage is now 128 K deep (128-byte fp8 rows: the whole-line DMA shape), i.e. half as many stages,
+// barriers and DMA bytes per FLOP as the bf16 loop. The scales do not go through LDS (two workgroups per CU leave no
+// room): each lane loads the five dwords it needs for the NEXT stage (4 scale bytes per row and stage) straight into
+// registers right after that stage's DMAs are issued.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+__device__ __forceinline__ i32x8 f8_frag(const char* img, int row, int ks, int h) {
+    const u32x4 lo = *(const u32x4*)(img + nt_off(row, 4 * ks + h));
+    const u32x4 hi = *(const u32x4*)(img + nt_off(row, 4 * ks + 2 + h));
+    i32x8 f;
+    f[0] = (int)lo[0]; f[1] = (int)lo[1]; f[2] = (int)lo[2]; f[3] = (int)lo[3];
+    f[4] = (int)hi[0]; f[5] = (int)hi[1]; f[6] = (int)hi[2]; f[7] = (int)hi[3];
+    return f;
+}
+
+// MX scale exponent of a block with largest magnitude amax: the smallest e with amax * 2^-e <= 448 (e4m3's largest
+// value), from the float's own exponent and mantissa -- integer arithmetic, so the oracle reproduces it bit for bit.
+// (The OCP recipe floor(log2 amax) - 8 lets elements in (448, 512) saturate; this one never saturates.) amax = 0 -> -127.
+__device__ __forceinline__ int mx_exponent(float amax) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, amax);
+    if ((u & 0x7F800000u) == 0u) return -127;                       // zero (or a float denormal: quantises to zero)
+    int e = (int)((u >> 23) & 0xFF) - 127 - 8 + ((u & 0x7FFFFFu) > 0x600000u ? 1 : 0);
+    return e < -127 ? -127 : (e > 126 ? 126 : e);
+}
+__device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (uint32_t)(e + 127) << 23); }   // -126 <= e <= 127
+
+constexpr int QST_EPI_GELU_MX_ = 5;          // = QST_EPI_GELU_MX: C = e4m3 of gelu(acc + bias) [M, ldc bytes], C2 = E8M0 [M, ldc / 32]
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_f8_kernel(QstGemmArgs g) {
+    constexpr int NBM = 128, NBN = 192, BKB = 128;                  // stage depth in K elements = bytes
+    constexpr int A_BYTES = NBM * BKB, B_BYTES = NBN * BKB, STAGE = A_BYTES + B_BYTES;      // 16 + 24 KB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (g.N + NBN - 1) / NBN, ntm = (g.M + NBM - 1) / NBM;
+    const int wg = xcd_remap(blockIdx.x, ntm * ntn);
+    const int m0 = (wg / ntn) * NBM, n0 = (wg % ntn) * NBN;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int rows_a = min(NBM, g.M - m0), rows_b = min(NBN, g.N - n0);
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc((const uint8_t*)g.A + (size_t)m0 * g.lda, (uint32_t)rows_a * g.lda);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc((const uint8_t*)g.B + (size_t)n0 * g.ldb, (uint32_t)rows_b * g.ldb);
+    // scales are stored stage-major, [K/128][rows][4]: the dwords of 32 consecutive rows for one stage are one 128-byte
+    // line (row-major [rows][K/32] made every scale load touch 32 lines: four times the line requests of the stage's DMAs)
+    const uint32_t* sA = (const uint32_t*)g.aux;
+    const uint32_t* sB = (const uint32_t*)g.bscale;
+    uint32_t va[4], vb[6];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {                                   // 8 rows of 128 B per DMA instruction
+        const int row = (wave * 4 + t) * 8 + (lane >> 3);
+        va[t] = (uint32_t)row * g.lda + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+    }
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const int row = (wave * 6 + t) * 8 + (lane >> 3);
+        vb[t] = (uint32_t)row * g.ldb + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+    }
+    auto issue = [&](int kt) {
+        char* st = smem + (kt & 1) * STAGE;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dma16(ra, st + (wave * 4 + t) * 1024, va[t], (uint32_t)kt * BKB);
+#pragma unroll
+        for (int t = 0; t < 6; ++t) dma16(rb, st + A_BYTES + (wave * 6 + t) * 1024, vb[t], (uint32_t)kt * BKB);
+    };
+    // the four scale bytes of this lane's rows for stage kt (rows past the matrix read as 0 = 2^-127 next to zero data)
+    uint32_t sa[2], sb[3], sa_n[2], sb_n[3];
+    auto load_scales = [&](int kt, uint32_t (&xa)[2], uint32_t (&xb)[3]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + wm * 64 + i * 32 + fr;
+            xa[i] = m < g.M ? sA[(size_t)kt * g.M + m] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int n = n0 + wn * 96 + j * 32 + fr;
+            xb[j] = n < g.N ? sB[(size_t)kt * g.N + n] : 0u;
+        }
+    };
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nk = g.K / BKB;
+    issue(0);
+    load_scales(0, sa_n, sb_n);
+    for (int kt = 0; kt < nk; ++kt) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) sa[i] = sa_n[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) sb[j] = sb_n[j];
+        if (kt + 1 < nk) { issue(kt + 1); load_scales(kt + 1, sa_n, sb_n); }
+        const char* pa = smem + (kt & 1) * STAGE;
+        const char* pb = pa + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            i32x8 fa[2], fb[3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = f8_frag(pa, wm * 64 + i * 32 + fr, ks, fh);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) fb[j] = f8_frag(pb, wn * 96 + j * 32 + fr, ks, fh);
+            const int sh = 16 * ks + 8 * fh;                        // this lane's MX block of the step: 2 ks + h
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j], fa[i], acc[i][j], 0, 0, 0,
+                                                                                 (int)(sb[j] >> sh), 0, (int)(sa[i] >> sh));
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+
+    float* stg = (float*)smem + wave * (32 * NT_STG_LD);
+    float* bias_s = (float*)smem + 4 * (32 * NT_STG_LD) + wave * 96;
+    for (int c = lane; c < 96; c += 64) {
+        const int n = n0 + wn * 96 + c;
+        bias_s[c] = (g.bias && n < g.N) ? g.bias[n] : 0.f;
+    }
+    if constexpr (EPI != QST_EPI_GELU_MX_) {
+        nt_epilogue<EPI, 2>(g, acc, stg, bias_s, m0 + wm * 64, n0 + wn * 96, lane);
+    } else {
+        // h = gelu(acc + bias) leaves as MXFP8 for the second feed-forward product: 8 columns per lane, 4 lanes = one
+        // 32-column MX block (aligned quads: 12 lanes per row), block amax by two DPP steps inside the quad
+        uint8_t* Cq = (uint8_t*)g.C;
+        uint8_t* Cs = (uint8_t*)g.C2;
+        const int m_base = m0 + wm * 64, n_base = n0 + wn * 96;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g4 + e];
+                    *(f32x4*)(stg + fr * NT_STG_LD + j * 32 + 8 * g4 + 4 * fh) = v;
+                }
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const int idx = t * 64 + lane;
+                const int row = idx / 12, c8 = idx % 12;
+                const int m = m_base + i * 32 + row, n = n_base + c8 * 8;
+                const f32x4 lo = *(const f32x4*)(stg + row * NT_STG_LD + c8 * 8), hi = *(const f32x4*)(stg + row * NT_STG_LD + c8 * 8 + 4);
+                const f32x4 blo = *(const f32x4*)(bias_s + c8 * 8), bhi = *(const f32x4*)(bias_s + c8 * 8 + 4);
+                float hv[8];
+                float amax = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hv[e] = gelu_erf(lo[e] + blo[e]);
+                    hv[4 + e] = gelu_erf(hi[e] + bhi[e]);
+                    amax = fmaxf(amax, fmaxf(fabsf(hv[e]), fabsf(hv[4 + e])));
+                }
+                amax = fmaxf(amax, dpp_mov<0xB1>(amax));             // quad_perm [1,0,3,2]
+                amax = fmaxf(amax, dpp_mov<0x4E>(amax));             // quad_perm [2,3,0,1]
+                const int ex = mx_exponent(amax);
+                const float inv = pow2f(-ex);
+                uint32_t p0 = 0, p1 = 0;
+                p0 = __builtin_amdgcn_cvt_pk_fp8_f32(hv[0] * inv, hv[1] * inv, p0, false);
+                p0 = __builtin_amdgcn_cvt_pk_fp8_f32(hv[2] * inv, hv[3] * inv, p0, true);
+                p1 = __builtin_amdgcn_cvt_pk_fp8_f32(hv[4] * inv, hv[5] * inv, p1, false);
+                p1 = __builtin_amdgcn_cvt_pk_fp8_f32(hv[6] * inv, hv[7] * inv, p1, true);
+                if (m < g.M && n < g.N) {
+                    u32x2 pk; pk[0] = p0; pk[1] = p1;
+                    *(u32x2*)(Cq + (size_t)m * g.ldc + n) = pk;
+                    if ((c8 & 3) == 0) Cs[((size_t)(n >> 7) * g.M + m) * 4 + ((n >> 5) & 3)] = (uint8_t)(ex + 127);   // stage-major
+                }
+            }
+        }
+    }
+}
+
+// MXFP8 quantisation of a [rows, K] matrix (fp32: weights at shadow refresh; bf16: activations between kernels):
+// 8 elements per thread, 4 threads = one 32-element block.
+template <typename SRC>
+__global__ __launch_bounds__(256) void quant_mx_kernel(const SRC* src, int64_t n8, int64_t rows, int K, uint8_t* q, uint8_t* sc) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;     // 8-element group index; n8 % 4 == 0 (K % 32 == 0)
+    float v[8];
+    if (i < n8) {
+        if constexpr (sizeof(SRC) == 4) {
+            const f32x4 a = *(const f32x4*)((const float*)src + i * 8), b = *(const f32x4*)((const float*)src + i * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+        } else {
+            const u32x4 a = *(const u32x4*)((const bf16*)src + i * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] = bf16lo(a[e]); v[2 * e + 1] = bf16hi(a[e]); }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+    amax = fmaxf(amax, dpp_mov<0xB1>(amax));
+    amax = fmaxf(amax, dpp_mov<0x4E>(amax));
+    const int ex = mx_exponent(amax);
+    const float inv = pow2f(-ex);
+    uint32_t p0 = 0, p1 = 0;
+    p0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, p0, false);
+    p0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, p0, true);
+    p1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, p1, false);
+    p1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, p1, true);
+    if (i < n8) {
+        u32x2 pk; pk[0] = p0; pk[1] = p1;
+        *(u32x2*)(q + i * 8) = pk;
+        if ((i & 3) == 0) {                                   // scale of block kb of row r -> stage-major [K/128][rows][4]
+            const int64_t blk = i >> 2, r = blk / (K >> 5);
+            const int kb = (int)(blk - r * (K >> 5));
+            sc[((int64_t)(kb >> 2) * rows + r) * 4 + (kb & 3)] = (uint8_t)(ex + 127);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- NT with a LayerNorm fused into the epilogue
 // For N = 384 (MiniLM's hidden size) one 128 x 384 tile spans whole rows, so the LayerNorm that always follows the
 // attention-output / FFN-2 projection (forward) and the LayerNorm backward that always follows the FFN-1 / QKV dgrad
@@ -905,6 +1136,44 @@ extern "C" int qst_gemm_nt_w8(const QstGemmArgs* a, int epi, void* stream) {
         case QST_EPI_GELU: return launch_nt_w8<QST_EPI_GELU>(a, st);
         default: return QST_ERR_BAD_ARG;
     }
+}
+
+template <int EPI>
+static int launch_nt_f8(const QstGemmArgs* a, hipStream_t st) {
+    constexpr int lds = 2 * (128 + 192) * 128;                  // 80 KB ring; the epilogue staging (52.7 KB) fits inside
+    static QstLdsAttr attr;
+    if (int rc = qst_ensure_lds(attr, (const void*)gemm_nt_f8_kernel<EPI>, lds)) return rc;
+    const int ntm = (a->M + 127) / 128, ntn = (a->N + 191) / 192;
+    gemm_nt_f8_kernel<EPI><<<dim3(ntm * ntn), dim3(256), lds, st>>>(*a);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+extern "C" int qst_gemm_nt_f8(const QstGemmArgs* a, int epi, void* stream) {
+    if (!a || !a->A || !a->B || !a->C || !a->aux || !a->bscale || a->M <= 0 || a->N <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
+    if (a->K % 128 != 0 || a->lda % 16 != 0 || a->ldb % 16 != 0 || a->N % 8 != 0) return QST_ERR_UNSUPPORTED;
+    if (epi == QST_EPI_GELU_MX && a->ldc != a->N) return QST_ERR_UNSUPPORTED;          // stage-major scales: one matrix, no sub-views
+    if ((int64_t)128 * a->lda >= 0x7FFFFF00LL || (int64_t)192 * a->ldb >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    switch (epi) {
+        case QST_EPI_BF16: return a->ldc % 4 ? QST_ERR_UNSUPPORTED : launch_nt_f8<QST_EPI_BF16>(a, st);
+        case QST_EPI_F32_RESID: return a->ldc % 4 ? QST_ERR_UNSUPPORTED : launch_nt_f8<QST_EPI_F32_RESID>(a, st);
+        case QST_EPI_GELU_MX:
+            if (!a->C2 || a->ldc % 32 != 0 || a->N % 32 != 0) return QST_ERR_UNSUPPORTED;
+            return launch_nt_f8<QST_EPI_GELU_MX_>(a, st);
+        default: return QST_ERR_BAD_ARG;
+    }
+}
+
+extern "C" int qst_quant_mx(const void* src, int src_is_bf16, int64_t rows, int K, void* q, void* scales, void* stream) {
+    if (!src || !q || !scales || rows <= 0 || K <= 0) return QST_ERR_BAD_ARG;
+    if (K % 32 != 0) return QST_ERR_UNSUPPORTED;
+    const int64_t n8 = rows * K / 8;
+    const unsigned grid = (unsigned)((n8 + 255) / 256);
+    if (src_is_bf16) quant_mx_kernel<bf16><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16*)src, n8, rows, K, (uint8_t*)q, (uint8_t*)scales);
+    else quant_mx_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)src, n8, rows, K, (uint8_t*)q, (uint8_t*)scales);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
 }
 
 extern "C" int qst_gemm_nt_ln_supported(int N) { return N == LN_N ? 1 : 0; }

@@ -162,8 +162,11 @@ extern "C" int qst_encoder_create(const qst_config* cfg, qst_encoder** out) {
     if (cfg->hidden_size % cfg->num_heads != 0 || (d != 32 && d != 64)) return QST_ERR_UNSUPPORTED;
     if (cfg->hidden_size % 64 != 0 || cfg->intermediate_size % 64 != 0 || cfg->hidden_size > 1024) return QST_ERR_UNSUPPORTED;
     if (cfg->type_vocab_size > 2) return QST_ERR_UNSUPPORTED;
-    if (cfg->precision != QST_PREC_BF16 && cfg->precision != QST_PREC_BF16X3 && cfg->precision != QST_PREC_FP8W)
+    if (cfg->precision != QST_PREC_BF16 && cfg->precision != QST_PREC_BF16X3 && cfg->precision != QST_PREC_FP8W &&
+        cfg->precision != QST_PREC_FP8)
         return QST_ERR_UNSUPPORTED;
+    if (cfg->precision == QST_PREC_FP8 && (cfg->hidden_size % 128 != 0 || cfg->intermediate_size % 128 != 0))
+        return QST_ERR_UNSUPPORTED;                      // the fp8 K loop takes 128-deep stages
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return QST_ERR_NO_DEVICE;
     qst_encoder* e = new qst_encoder();
@@ -270,6 +273,25 @@ X3Plan plan_x3(const qst_config& c, int nseq, int L) {
     return p;
 }
 
+// QST_PREC_FP8 forward (inference): MXFP8 operands for every Linear, bf16 attention, fp32 residual stream / LayerNorm
+struct MxPlan { size_t pos_ids, x[2], xb, xq, xs, qkv, ctx, cq, cs, s, y1, y1b, yq, ys, hq, hs, pooled, rel, total; };
+MxPlan plan_mx(const qst_config& c, int nseq, int L) {
+    MxPlan p;
+    const size_t M = (size_t)nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    p.pos_ids = take(M * 4);
+    p.x[0] = take(M * H * 4); p.x[1] = take(M * H * 4);
+    p.xb = take(M * H * 2); p.xq = take(M * H); p.xs = take(M * H / 32);
+    p.qkv = take(M * 3 * H * 2); p.ctx = take(M * H * 2); p.cq = take(M * H); p.cs = take(M * H / 32);
+    p.s = take(M * H * 4); p.y1 = take(M * H * 4); p.y1b = take(M * H * 2); p.yq = take(M * H); p.ys = take(M * H / 32);
+    p.hq = take(M * I); p.hs = take(M * I / 32);
+    p.pooled = take((size_t)nseq * H * 4);
+    p.rel = (c.arch == QST_ARCH_MPNET) ? take(A * (size_t)2 * L * 4) : 0;
+    p.total = off;
+    return p;
+}
+
 struct BwdPlan { size_t dxa, dxb, ds, dsb, dsb1, du, dctx, dqkv, drel, lnred, lnred_stride, delta, total; };
 BwdPlan plan_bwd(const qst_config& c, int nseq, int L) {
     BwdPlan p;
@@ -357,6 +379,7 @@ constexpr int kFuseLnMinRows = 16384;      // token rows from which the fused GE
 extern "C" size_t qst_encoder_saved_bytes(const qst_encoder* e, int nseq, int L, int training) {
     if (shape_ok(e, nseq, L) != QST_OK) return 0;
     if (e->cfg.precision == QST_PREC_BF16X3) return training ? 0 : plan_x3(e->cfg, nseq, L).total;
+    if (e->cfg.precision == QST_PREC_FP8) return training ? 0 : plan_mx(e->cfg, nseq, L).total;
     return plan_acts(e->cfg, nseq, L, training != 0).total;
 }
 extern "C" size_t qst_encoder_bwd_workspace_bytes(const qst_encoder* e, int nseq, int L) {
@@ -378,6 +401,75 @@ extern "C" int qst_refresh_shadow8(const qst_encoder* e, const float* params, vo
         int rc = qst_quant_rows_fp8(params + s.off, s.rows, s.cols, w8, sc, stream);
         if (rc != QST_OK) return rc;
     }
+    return QST_OK;
+}
+
+// QST_PREC_FP8: every GEMM weight as MXFP8 -- e4m3 bytes at the segment's shadow offset, E8M0 block scales (one per 32
+// input features of an output row) behind them at shadow_off + align(numel); the buffer is qst_shadow8_bytes() long.
+extern "C" int qst_refresh_shadow_mx(const qst_encoder* e, const float* params, void* shadow_mx, void* stream) {
+    if (!e || !params || !shadow_mx) return QST_ERR_BAD_ARG;
+    for (const Seg& s : e->lay.segs) {
+        if (!s.gemm) continue;
+        if (s.cols % 32 != 0) return QST_ERR_UNSUPPORTED;
+        uint8_t* q = (uint8_t*)shadow_mx + s.shadow_off;
+        uint8_t* sc = q + qst_align_up(s.numel, kAlign);
+        int rc = qst_quant_mx(params + s.off, 0, s.rows, s.cols, q, sc, stream);
+        if (rc != QST_OK) return rc;
+    }
+    return QST_OK;
+}
+
+// fp8 matrix-core forward (QST_PREC_FP8; BASELINE configs[4]): the operator sequence of the bf16 forward with every
+// Linear on MXFP8 operands (qst_gemm_nt_f8). Activations are quantised where they are produced when the producer is a
+// GEMM (gelu(u) never exists in another format) and by qst_quant_mx from the bf16 copies the LayerNorm / attention
+// kernels already write otherwise.
+static int forward_mx(qst_encoder* e, const int64_t* ids, const int64_t* mask, const int64_t* type_ids, int nseq, int L,
+                      const float* params, const void* shadow, float* out_emb, float* out_tok, void* saved, size_t saved_bytes,
+                      hipStream_t st) {
+    const qst_config& c = e->cfg;
+    const MxPlan p = plan_mx(c, nseq, L);
+    if (saved_bytes < p.total) return QST_ERR_WORKSPACE;
+    char* sv = (char*)saved;
+    const int M = nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads, d = H / A;
+    const Layout& lay = e->lay;
+    auto P = [&](int seg) { return params + lay.segs[seg].off; };
+    auto WQ = [&](int seg) { return (const uint8_t*)shadow + lay.segs[seg].shadow_off; };
+    auto WS = [&](int seg) { return (const uint8_t*)shadow + lay.segs[seg].shadow_off + qst_align_up(lay.segs[seg].numel, kAlign); };
+    auto gemm = [&](const void* Aq, const void* As, int K, int wseg, void* Cout, void* C2, int N, int bseg, const float* resid, int epi) {
+        QstGemmArgs g{};
+        g.A = Aq; g.aux = As; g.B = WQ(wseg); g.bscale = (const float*)WS(wseg); g.C = Cout; g.C2 = C2; g.bias = P(bseg); g.resid = resid;
+        g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.ldr = N;
+        return qst_gemm_nt_f8(&g, epi, st);
+    };
+    int32_t* pos_ids = (int32_t*)(sv + p.pos_ids);
+    QST_TRY(qst_position_ids(ids, nseq, L, c.arch, c.pad_token_id, pos_ids, st));
+    float* x = (float*)(sv + p.x[0]);
+    QST_TRY(qst_embed_ln_fwd(ids, type_ids, pos_ids, P(lay.word), P(lay.pos), lay.type >= 0 ? P(lay.type) : nullptr,
+                             P(lay.eg), P(lay.eb), c.layer_norm_eps, M, H, x, sv + p.xb, nullptr, nullptr, st));
+    const float* rel = nullptr;
+    if (c.arch == QST_ARCH_MPNET) {
+        QST_TRY(qst_rel_pos_fwd(P(lay.rel), e->rel_lut, A, L, (float*)(sv + p.rel), st));
+        rel = (const float*)(sv + p.rel);
+    }
+    float* s = (float*)(sv + p.s);
+    float* y1 = (float*)(sv + p.y1);
+    for (int l = 0; l < c.num_layers; ++l) {
+        const int b = lay.layer0[l];
+        float* xn = (float*)(sv + p.x[(l + 1) & 1]);
+        QST_TRY(qst_quant_mx(sv + p.xb, 1, M, H, sv + p.xq, sv + p.xs, st));
+        QST_TRY(gemm(sv + p.xq, sv + p.xs, H, b + W_QKV, sv + p.qkv, nullptr, 3 * H, b + B_QKV, nullptr, QST_EPI_BF16));
+        QST_TRY(qst_attention_fwd(sv + p.qkv, mask, rel, nseq, L, A, d, sv + p.ctx, nullptr, st));
+        QST_TRY(qst_quant_mx(sv + p.ctx, 1, M, H, sv + p.cq, sv + p.cs, st));
+        QST_TRY(gemm(sv + p.cq, sv + p.cs, H, b + W_O, s, nullptr, H, b + B_O, x, QST_EPI_F32_RESID));
+        QST_TRY(qst_ln_fwd(s, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, y1, sv + p.y1b, nullptr, nullptr, st));
+        QST_TRY(qst_quant_mx(sv + p.y1b, 1, M, H, sv + p.yq, sv + p.ys, st));
+        QST_TRY(gemm(sv + p.yq, sv + p.ys, H, b + W_1, sv + p.hq, sv + p.hs, I, b + B_1, nullptr, QST_EPI_GELU_MX));
+        QST_TRY(gemm(sv + p.hq, sv + p.hs, I, b + W_2, s, nullptr, H, b + B_2, y1, QST_EPI_F32_RESID));
+        QST_TRY(qst_ln_fwd(s, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, M, H, xn, sv + p.xb, nullptr, nullptr, st));
+        x = xn;
+    }
+    QST_TRY(qst_pool_norm_fwd(x, mask, nseq, L, H, c.normalize, out_emb, (float*)(sv + p.pooled), st));
+    if (out_tok) QST_HIP_CHECK(hipMemcpyAsync(out_tok, x, (size_t)M * H * 4, hipMemcpyDeviceToDevice, st));
     return QST_OK;
 }
 
@@ -431,6 +523,9 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
         return training ? QST_ERR_UNSUPPORTED
                         : forward_x3(e, ids, mask, type_ids, nseq, L, params, out_emb, out_tok, saved, saved_bytes, (hipStream_t)stream);
     if (!shadow) return QST_ERR_BAD_ARG;
+    if (c.precision == QST_PREC_FP8)
+        return training ? QST_ERR_UNSUPPORTED
+                        : forward_mx(e, ids, mask, type_ids, nseq, L, params, shadow, out_emb, out_tok, saved, saved_bytes, (hipStream_t)stream);
     const bool w8 = c.precision == QST_PREC_FP8W;       // fp8 weights (shadow = qst_refresh_shadow8's buffer): inference only
     if (w8 && training) return QST_ERR_UNSUPPORTED;
     const ActPlan p = plan_acts(c, nseq, L, training != 0);

@@ -14,7 +14,8 @@ enum {
     QST_EPI_F32_RESID = 1,       // C(f32)  = acc + bias + resid
     QST_EPI_GELU = 2,            // u = acc + bias ; C(bf16) = gelu'(u) (saved for backward) ; C2(bf16) = gelu(u)
     QST_EPI_GELU_BWD = 3,        // C(bf16) = acc * aux   (aux = the gelu'(u) saved by QST_EPI_GELU)
-    QST_EPI_F32_RESID_BF16 = 4   // C(f32) = acc + bias + resid ; C2(bf16) = same
+    QST_EPI_F32_RESID_BF16 = 4,  // C(f32) = acc + bias + resid ; C2(bf16) = same
+    QST_EPI_GELU_MX = 5          // qst_gemm_nt_f8 only: gelu(acc + bias) as MXFP8: C = e4m3 [M, ldc], C2 = E8M0 [M, ldc/32]
 };
 
 typedef struct {
@@ -37,6 +38,17 @@ int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream);
 /* NT GEMM with fp8 (e4m3, OCP) weights: C = (A . Q^T) * bscale[n] (+ epilogue). B = Q: fp8 [N, K] (ldb in bytes,
  * % 16 == 0), bscale f32 [N]. epi: QST_EPI_BF16, QST_EPI_F32_RESID, QST_EPI_GELU. Inference path (QST_PREC_FP8W). */
 int qst_gemm_nt_w8(const QstGemmArgs* a, int epi, void* stream);
+/* NT GEMM on the fp8 matrix cores, both operands MXFP8 (OCP e4m3 elements + one E8M0 power-of-two scale per 32
+ * consecutive K elements of a row; v_mfma_scale_f32_32x32x64_f8f6f4): A = e4m3 [M, K] (lda bytes), aux = its scales;
+ * B = e4m3 [N, K] (ldb bytes), bscale = its scales (uint8 arrays in the layout qst_quant_mx writes). K % 128 == 0.
+ * epi: QST_EPI_BF16, QST_EPI_F32_RESID, QST_EPI_GELU_MX. Inference path (QST_PREC_FP8, BASELINE configs[4]). */
+int qst_gemm_nt_f8(const QstGemmArgs* a, int epi, void* stream);
+/* MXFP8 quantisation of a contiguous [rows, K] matrix (src f32, or bf16 when src_is_bf16): per 32-element block the
+ * scale exponent e = the smallest with amax * 2^-e <= 448 (-127 for an all-zero block), elements = RNE(x * 2^-e) to
+ * e4m3; q = uint8 [rows, K]; scales = uint8 holding e + 127, STAGE-MAJOR: block kb of row r at
+ * ((kb / 4) * rows + r) * 4 + kb % 4, ceil(K / 128) * rows * 4 bytes in all -- the four scales a GEMM stage (128 K) needs
+ * from a row are one aligned dword, and 32 consecutive rows one 128-byte line. K % 32 == 0. */
+int qst_quant_mx(const void* src, int src_is_bf16, int64_t rows, int K, void* q, void* scales, void* stream);
 /* Per-row symmetric quantisation of a [rows, cols] f32 matrix to fp8 e4m3: scale[r] = max|row| / 448 (1 for an
  * all-zero row), dst = round-to-nearest-even(src / scale). cols % 4 == 0. */
 int qst_quant_rows_fp8(const float* src, int rows, int cols, void* dst_fp8, float* scales, void* stream);

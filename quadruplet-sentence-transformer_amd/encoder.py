@@ -38,7 +38,10 @@ class HipEncoder:
         self.handle = h
         self.handle_x3 = None         # QST_PREC_BF16X3 handle over the SAME arenas, created on first use
         self.handle_fp8 = None        # QST_PREC_FP8W handle (fp8 e4m3 weights + row scales, inference), on first use
+        self.handle_mx = None         # QST_PREC_FP8 handle (MXFP8 weights and activations on the fp8 matrix cores, inference)
         self.shadow8: Optional[torch.Tensor] = None
+        self.shadow_mx: Optional[torch.Tensor] = None
+        self.shadow_mx_stale = True
         self.params = torch.zeros(self.total, dtype=torch.float32, device=self.device)
         self.grads: Optional[torch.Tensor] = None
         self.exp_avg: Optional[torch.Tensor] = None
@@ -55,7 +58,7 @@ class HipEncoder:
 
     def __del__(self):
         try:
-            for attr in ("handle", "handle_x3", "handle_fp8"):
+            for attr in ("handle", "handle_x3", "handle_fp8", "handle_mx"):
                 if getattr(self, attr, None):
                     self.lib.qst_encoder_destroy(getattr(self, attr))
                     setattr(self, attr, None)
@@ -70,6 +73,7 @@ class HipEncoder:
         self.params.copy_(t.to(self.device))
         self.shadow_stale = True
         self.shadow8_stale = True
+        self.shadow_mx_stale = True
 
     def named_views(self) -> Dict[str, torch.Tensor]:
         """HF-named views into the parameter arena (no copies)."""
@@ -103,6 +107,12 @@ class HipEncoder:
         _lib.check(self.lib.qst_refresh_shadow8(self.handle_fp8, self.params.data_ptr(), self.shadow8.data_ptr(),
                                                 _lib.current_stream_ptr()), "qst_refresh_shadow8")
         self.shadow8_stale = False
+
+    def refresh_shadow_mx(self) -> None:
+        """Quantise every Linear weight to MXFP8 (e4m3 + one E8M0 scale per 32 input features; QST_PREC_FP8)."""
+        _lib.check(self.lib.qst_refresh_shadow_mx(self.handle_mx, self.params.data_ptr(), self.shadow_mx.data_ptr(),
+                                                  _lib.current_stream_ptr()), "qst_refresh_shadow_mx")
+        self.shadow_mx_stale = False
 
     def refresh_shadow(self) -> None:
         _lib.check(self.lib.qst_refresh_shadow(self.handle, self.params.data_ptr(), self.shadow.data_ptr(),
@@ -142,8 +152,16 @@ class HipEncoder:
                 self.shadow8 = torch.zeros(self.lib.qst_shadow8_bytes(self.ccfg), dtype=torch.uint8, device=self.device)
                 self.shadow8_stale = True
             return self.handle_fp8
+        if precision in ("fp8", 3):
+            if self.handle_mx is None:
+                h = _lib.vp()
+                _lib.check(self.lib.qst_encoder_create(_lib.make_config(self.cfg, 3), h), "qst_encoder_create(fp8)")
+                self.handle_mx = h
+                self.shadow_mx = torch.zeros(self.lib.qst_shadow8_bytes(self.ccfg), dtype=torch.uint8, device=self.device)
+                self.shadow_mx_stale = True
+            return self.handle_mx
         if precision not in ("bf16x3", 1):
-            raise ValueError(f"unknown precision {precision!r} (bf16 | bf16x3 | fp8w)")
+            raise ValueError(f"unknown precision {precision!r} (bf16 | bf16x3 | fp8w | fp8)")
         if self.handle_x3 is None:
             h = _lib.vp()
             _lib.check(self.lib.qst_encoder_create(_lib.make_config(self.cfg, 1), h), "qst_encoder_create(x3)")
@@ -154,7 +172,8 @@ class HipEncoder:
                 training: bool = False, want_tokens: bool = False, saved: Optional[torch.Tensor] = None,
                 precision: str = "bf16"):
         """ids/mask int64 [n, L] on this device, L % 32 == 0. Returns (emb [n,H], tok [n,L,H] or None, saved).
-        precision="bf16x3" runs the fp32-class parity path, "fp8w" the fp8-weight path (both forward only)."""
+        precision="bf16x3" runs the fp32-class parity path, "fp8w" the fp8-weight path, "fp8" the fp8 matrix-core path
+        (MXFP8 weights and activations) -- all three forward only."""
         assert ids.dtype == torch.int64 and mask.dtype == torch.int64 and ids.is_cuda and ids.is_contiguous()
         n, L = ids.shape
         handle = self._handle_for(precision)
@@ -167,6 +186,10 @@ class HipEncoder:
             if self.shadow8_stale:
                 self.refresh_shadow8()
             shadow = self.shadow8
+        if handle is self.handle_mx and handle is not None:
+            if self.shadow_mx_stale:
+                self.refresh_shadow_mx()
+            shadow = self.shadow_mx
         nbytes = self.lib.qst_encoder_saved_bytes(handle, n, L, int(training))
         if nbytes == 0:
             raise _lib.QstError(f"unsupported shape nseq={n} L={L} for this encoder (L % 32 == 0, L <= 512)")
@@ -203,6 +226,7 @@ class HipEncoder:
             "qst_clip_adamw_step")
         self.shadow_stale = True
         self.shadow8_stale = True
+        self.shadow_mx_stale = True
 
 
     # ------------------------------------------------------------------ optimiser state (true resume)
@@ -239,6 +263,7 @@ class HipEncoder:
             self._scratch.data_ptr(), _lib.current_stream_ptr()), "qst_clip_adamw_step_sched")
         self.shadow_stale = True
         self.shadow8_stale = True
+        self.shadow_mx_stale = True
 
 
 def quadruplet_loss_raw(xa, xp, xq, xn, gamma, m_pn, m_pq, m_qn, p, swap, reduction: int,

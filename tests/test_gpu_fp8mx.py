@@ -1,0 +1,172 @@
+"""GPU: the fp8 matrix-core path (QST_PREC_FP8, BASELINE configs[4]): MXFP8 quantisation (bit-exact against the
+oracle), the block-scaled MFMA GEMM and its epilogues against fp32 torch on the SAME de-quantised operands, and the
+encoder forward against the MX oracle at bert-base dimensions, seq_len 384."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import quadruplet_sentence_transformer_amd  # noqa: E402,F401
+from quadruplet_sentence_transformer_amd import _lib  # noqa: E402
+from oracle import torch_ref as R  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return _lib.load()
+
+
+def st():
+    return _lib.current_stream_ptr()
+
+
+def stage_major(s_rowmajor):
+    """[rows, K/32] scale bytes -> the library's layout [ceil(K/128)][rows][4] (zero-padded), flattened."""
+    rows, nb = s_rowmajor.shape
+    pad = (-nb) % 4
+    t = torch.nn.functional.pad(s_rowmajor, (0, pad))
+    return t.view(rows, (nb + pad) // 4, 4).permute(1, 0, 2).contiguous().view(-1)
+
+
+def row_major(s_stage, rows, K):
+    nb = K // 32
+    return s_stage.view((nb + 3) // 4, rows, 4).permute(1, 0, 2).reshape(rows, -1)[:, :nb]
+
+
+def quant_dev(lib, x, bf16=False):
+    rows, K = x.shape
+    src = x.cuda().to(torch.bfloat16 if bf16 else torch.float32).contiguous()
+    q = torch.empty(rows, K, dtype=torch.uint8, device="cuda")
+    s = torch.zeros((K + 127) // 128 * rows * 4, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.qst_quant_mx(src.data_ptr(), int(bf16), rows, K, q.data_ptr(), s.data_ptr(), st()))
+    return q, s
+
+
+@pytest.mark.parametrize("rows,K", [(1, 32), (7, 96), (130, 768), (64, 3072)])
+def test_mx_quantisation_is_bit_exact(lib, rows, K):
+    g = torch.Generator().manual_seed(rows + K)
+    x = torch.randn(rows, K, generator=g) * torch.exp(3 * torch.randn(rows, 1, generator=g))       # rows of very different scale
+    x[0, :32] = 0.0                                                    # an all-zero block
+    if rows > 2:
+        x[1, 5] = 448.0
+        x[2, 7] = 449.0                                                # mantissa just past 1.75: the exponent steps up
+        x[2, 40] = 1e-30
+    for bf16 in (False, True):
+        src = x.to(torch.bfloat16).to(torch.float32) if bf16 else x
+        q, s = quant_dev(lib, src, bf16)
+        qr, sr, _ = R.mx_quant(src)
+        assert torch.equal(s.cpu(), stage_major(sr)) and torch.equal(q.cpu(), qr)
+    assert lib.qst_quant_mx(x.cuda().data_ptr(), 0, rows, 48, q.data_ptr(), s.data_ptr(), st()) == -2     # K % 32
+
+
+def gemm_args(**kw):
+    a = _lib.QstGemmArgs()
+    a._keep = [v for v in kw.values() if torch.is_tensor(v)]
+    for k, v in kw.items():
+        setattr(a, k, v.data_ptr() if torch.is_tensor(v) else v)
+    return a
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 192, 128), (300, 384, 768), (1000, 2304, 768), (520, 768, 3072)])
+def test_gemm_f8_matches_fp32_on_dequantised_operands(lib, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g) * 4)
+    B = torch.randn(N, K, generator=g) * 0.05
+    bias = torch.randn(N, generator=g) * 0.3
+    resid = torch.randn(M, N, generator=g)
+    (Aq, As), (Bq, Bs) = quant_dev(lib, A), quant_dev(lib, B)
+    Ad, Bd = R.mx_quant(A)[2], R.mx_quant(B)[2]
+    ref = Ad.double() @ Bd.double().t()
+    scale = float(ref.abs().max())
+    # the block-scaled MFMA does not sum its 64 products as an fp32 fma chain: measured error up to ~1e-5 of sum |a||b|
+    acc_scale = float((Ad.abs().double() @ Bd.abs().double().t()).max())
+    # fp32 out + bias + residual
+    C = torch.empty(M, N, device="cuda")
+    _lib.check(lib.qst_gemm_nt_f8(gemm_args(A=Aq, B=Bq, aux=As, bscale=Bs, C=C, bias=bias.cuda(), resid=resid.cuda(), M=M, N=N, K=K,
+                                            lda=K, ldb=K, ldc=N, ldr=N), 1, st()))
+    np.testing.assert_allclose(C.cpu().double().numpy(), (ref + bias.double() + resid.double()).numpy(), rtol=0, atol=2e-5 * acc_scale + 1e-5)
+    # bf16 out + bias
+    Cb = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.qst_gemm_nt_f8(gemm_args(A=Aq, B=Bq, aux=As, bscale=Bs, C=Cb, bias=bias.cuda(), M=M, N=N, K=K, lda=K, ldb=K, ldc=N),
+                                  0, st()))
+    np.testing.assert_allclose(Cb.float().cpu().double().numpy(), (ref + bias.double()).numpy(), rtol=8e-3, atol=8e-3 * scale)
+    # gelu(acc + bias) as MXFP8
+    if N % 128 == 0:
+        Hq = torch.zeros(M, N, dtype=torch.uint8, device="cuda")
+        Hs = torch.zeros(N // 128 * M * 4, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.qst_gemm_nt_f8(gemm_args(A=Aq, B=Bq, aux=As, bscale=Bs, C=Hq, C2=Hs, bias=bias.cuda(), M=M, N=N, K=K, lda=K, ldb=K,
+                                                ldc=N), 5, st()))
+        h = torch.nn.functional.gelu((ref + bias.double()).float())
+        qr, sr, dr = R.mx_quant(h)
+        Hs = row_major(Hs.cpu(), M, N)
+        got = torch.ldexp(Hq.cpu().view(torch.float8_e4m3fn).float().reshape(M, N // 32, 32),
+                          (Hs.to(torch.int32) - 127)[..., None]).reshape(M, N)
+        # fp32 sums in another order move a value across an e4m3 rounding boundary now and then (one step = 2^-3 relative),
+        # and a block maximum across a power of two very rarely; everything else is bit-identical
+        assert (Hs != sr).float().mean().item() < 2e-3
+        step = torch.ldexp(torch.ones(()), (sr.to(torch.int32) - 127 + 8 - 3))[..., None].expand(M, N // 32, 32).reshape(M, N)
+        assert ((got - dr).abs() <= 1.01 * step).all()
+        assert (Hq.cpu() != qr).float().mean().item() < 2e-2
+    # refused shapes
+    assert lib.qst_gemm_nt_f8(gemm_args(A=Aq, B=Bq, aux=As, bscale=Bs, C=C, M=M, N=N, K=K - 32, lda=K, ldb=K, ldc=N), 1, st()) == -2
+    assert lib.qst_gemm_nt_f8(gemm_args(A=Aq, B=Bq, aux=As, C=C, M=M, N=N, K=K, lda=K, ldb=K, ldc=N), 1, st()) == -1
+
+
+def run_encoder_mx(name, B, L, weights_kw, layers=None, emb_atol=3e-3):
+    from dataclasses import replace
+    from quadruplet_sentence_transformer_amd.config import PRESETS
+    from quadruplet_sentence_transformer_amd.encoder import HipEncoder
+    from quadruplet_sentence_transformer_amd.synthetic import synthetic_params, synthetic_quadruplets
+    cfg = PRESETS[name]
+    if layers is not None:
+        cfg = replace(cfg, num_layers=layers, vocab_size=4096)
+    arena = synthetic_params(cfg, seed=14, **weights_kw)
+    ids, mask, types = synthetic_quadruplets(cfg, B, L, seed=14, ragged=True)
+    n = 4 * B
+    ids_t, mask_t, types_t = [torch.from_numpy(x).view(n, L) for x in (ids, mask, types)]
+    P = R.arena_to_dict(arena, cfg)
+    with torch.no_grad():
+        tok_mx = R.encoder_forward_mx(P, cfg, ids_t, mask_t, types_t if cfg.type_vocab_size else None)
+        emb_mx = R.st_head(tok_mx, mask_t, cfg.normalize)
+        tok32 = R.encoder_forward(P, cfg, ids_t, mask_t, types_t if cfg.type_vocab_size else None)
+        emb32 = R.st_head(tok32, mask_t, cfg.normalize)
+    enc = HipEncoder(cfg)
+    enc.load_arena(arena)
+    dev = [t.cuda() for t in (ids_t, mask_t, types_t)]
+    emb, tok, _ = enc.forward(dev[0], dev[1], dev[2] if cfg.type_vocab_size else None, want_tokens=True, precision="fp8")
+    torch.cuda.synchronize()
+    assert torch.isfinite(emb).all()
+    sc = float(emb32.norm(dim=-1).mean())                  # bare bert-base has no Normalize module: scale the tolerance
+    # against the oracle on the SAME quantised operands: what is left is accumulation order, bf16 roundings of q/k/v/P
+    # landing differently, and elements that cross an e4m3 rounding boundary
+    d_oracle = float((emb.cpu() - emb_mx).abs().max()) / sc
+    d_fp32 = float((emb.cpu() - emb32).abs().max()) / sc
+    cos = torch.nn.functional.cosine_similarity(emb.cpu(), emb32, dim=1).min().item()
+    assert d_oracle < emb_atol, (d_oracle, d_fp32)
+    assert cos > 0.995 and d_fp32 < 6e-2, (cos, d_fp32)     # fp8 vs the fp32 model: 3 mantissa bits per operand element
+    # token level: an e4m3 step is 2^-3 relative, so a bf16-level difference upstream flips roundings downstream and the two
+    # implementations of the SAME quantised network drift apart by a fraction of the quantisation noise itself -- the bar is
+    # that the kernel path stays closer to its oracle than the oracle is to the fp32 network
+    m = mask_t.bool()
+    rel = float((tok.cpu()[m] - tok_mx[m]).norm() / tok_mx[m].norm())
+    rel_q = float((tok_mx[m] - tok32[m]).norm() / tok32[m].norm())
+    assert rel < 0.8 * rel_q and rel < 0.1, (rel, rel_q)
+    with pytest.raises(_lib.QstError):
+        enc.forward(dev[0], dev[1], dev[2] if cfg.type_vocab_size else None, training=True, precision="fp8")
+    print(f"fp8 {name} B={B} L={L}: max|emb - mx oracle| {d_oracle:.2e}, vs fp32 {d_fp32:.2e}, min cos {cos:.5f}, token rel {rel:.3f} (oracle vs fp32 {rel_q:.3f})")
+    return d_oracle, d_fp32, cos
+
+
+def test_encoder_fp8_bert_base_dims_l384():
+    """BASELINE configs[4] architecture and sequence length (bert-base-uncased dims, 12 layers, L = 384: three key chunks
+    per attention row), MXFP8 weights and activations on the fp8 matrix cores, against the oracle that quantises the same
+    tensors at the same points (oracle/torch_ref.py encoder_forward_mx)."""
+    run_encoder_mx("bert-base-uncased", 1, 384, dict(std=0.02), emb_atol=4e-3)
+
+
+def test_encoder_fp8_trained_like_weights_and_mpnet():
+    run_encoder_mx("bert-base-uncased", 2, 128, dict(std=0.05, bias_std=0.02, ln_jitter=0.05), layers=2, emb_atol=4e-3)
+    run_encoder_mx("all-mpnet-base-v2", 1, 256, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), layers=2, emb_atol=4e-3)
