@@ -421,8 +421,8 @@ extern "C" int qst_refresh_shadow_mx(const qst_encoder* e, const float* params, 
 
 // fp8 matrix-core forward (QST_PREC_FP8; BASELINE configs[4]): the operator sequence of the bf16 forward with every
 // Linear on MXFP8 operands (qst_gemm_nt_f8). Activations are quantised where they are produced when the producer is a
-// GEMM (gelu(u) never exists in another format) and by qst_quant_mx from the bf16 copies the LayerNorm / attention
-// kernels already write otherwise.
+// GEMM (gelu(u) never exists in another format) or a LayerNorm (qst_ln_fwd_mx), and by qst_quant_mx from the bf16 tensor
+// the attention kernel writes.
 static int forward_mx(qst_encoder* e, const int64_t* ids, const int64_t* mask, const int64_t* type_ids, int nseq, int L,
                       const float* params, const void* shadow, float* out_emb, float* out_tok, void* saved, size_t saved_bytes,
                       hipStream_t st) {
@@ -444,8 +444,8 @@ static int forward_mx(qst_encoder* e, const int64_t* ids, const int64_t* mask, c
     int32_t* pos_ids = (int32_t*)(sv + p.pos_ids);
     QST_TRY(qst_position_ids(ids, nseq, L, c.arch, c.pad_token_id, pos_ids, st));
     float* x = (float*)(sv + p.x[0]);
-    QST_TRY(qst_embed_ln_fwd(ids, type_ids, pos_ids, P(lay.word), P(lay.pos), lay.type >= 0 ? P(lay.type) : nullptr,
-                             P(lay.eg), P(lay.eb), c.layer_norm_eps, M, H, x, sv + p.xb, nullptr, nullptr, st));
+    QST_TRY(qst_embed_ln_fwd_mx(ids, type_ids, pos_ids, P(lay.word), P(lay.pos), lay.type >= 0 ? P(lay.type) : nullptr,
+                                P(lay.eg), P(lay.eb), c.layer_norm_eps, M, H, x, nullptr, sv + p.xq, sv + p.xs, st));
     const float* rel = nullptr;
     if (c.arch == QST_ARCH_MPNET) {
         QST_TRY(qst_rel_pos_fwd(P(lay.rel), e->rel_lut, A, L, (float*)(sv + p.rel), st));
@@ -456,16 +456,14 @@ static int forward_mx(qst_encoder* e, const int64_t* ids, const int64_t* mask, c
     for (int l = 0; l < c.num_layers; ++l) {
         const int b = lay.layer0[l];
         float* xn = (float*)(sv + p.x[(l + 1) & 1]);
-        QST_TRY(qst_quant_mx(sv + p.xb, 1, M, H, sv + p.xq, sv + p.xs, st));
         QST_TRY(gemm(sv + p.xq, sv + p.xs, H, b + W_QKV, sv + p.qkv, nullptr, 3 * H, b + B_QKV, nullptr, QST_EPI_BF16));
         QST_TRY(qst_attention_fwd(sv + p.qkv, mask, rel, nseq, L, A, d, sv + p.ctx, nullptr, st));
         QST_TRY(qst_quant_mx(sv + p.ctx, 1, M, H, sv + p.cq, sv + p.cs, st));
         QST_TRY(gemm(sv + p.cq, sv + p.cs, H, b + W_O, s, nullptr, H, b + B_O, x, QST_EPI_F32_RESID));
-        QST_TRY(qst_ln_fwd(s, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, y1, sv + p.y1b, nullptr, nullptr, st));
-        QST_TRY(qst_quant_mx(sv + p.y1b, 1, M, H, sv + p.yq, sv + p.ys, st));
+        QST_TRY(qst_ln_fwd_mx(s, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, y1, nullptr, sv + p.yq, sv + p.ys, st));
         QST_TRY(gemm(sv + p.yq, sv + p.ys, H, b + W_1, sv + p.hq, sv + p.hs, I, b + B_1, nullptr, QST_EPI_GELU_MX));
         QST_TRY(gemm(sv + p.hq, sv + p.hs, I, b + W_2, s, nullptr, H, b + B_2, y1, QST_EPI_F32_RESID));
-        QST_TRY(qst_ln_fwd(s, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, M, H, xn, sv + p.xb, nullptr, nullptr, st));
+        QST_TRY(qst_ln_fwd_mx(s, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, M, H, xn, nullptr, sv + p.xq, sv + p.xs, st));
         x = xn;
     }
     QST_TRY(qst_pool_norm_fwd(x, mask, nseq, L, H, c.normalize, out_emb, (float*)(sv + p.pooled), st));

@@ -116,6 +116,15 @@ int qst_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int32_t*
 /* LayerNorm over rows of s f32 [M,H]. */
 int qst_ln_fwd(const float* s, const float* gamma, const float* beta, float eps, int M, int H,
                float* y, void* y_bf16, void* xhat_bf16, float* rstd, void* stream);
+/* The same two kernels with the output ALSO as MXFP8 (yq e4m3 [M, H], ys scales in qst_quant_mx's layout), quantised
+ * from the bf16-rounded values -- what qst_quant_mx over y_bf16 would give, without the extra pass. y_bf16 may be NULL.
+ * H % 64 == 0. QST_PREC_FP8 forward. */
+int qst_ln_fwd_mx(const float* s, const float* gamma, const float* beta, float eps, int M, int H,
+                  float* y, void* y_bf16, void* yq, void* ys, void* stream);
+int qst_embed_ln_fwd_mx(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
+                        const float* word_emb, const float* pos_emb, const float* type_emb,
+                        const float* gamma, const float* beta, float eps, int M, int H,
+                        float* y, void* y_bf16, void* yq, void* ys, void* stream);
 /* LayerNorm backward: ds = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)); dgamma += sum dy*xhat; dbeta += sum dy. */
 /* scratch: qst_ln_bwd_scratch_bytes(M, H) of per-block partial sums reduced in a fixed order (deterministic);
  * NULL falls back to float atomics on dgamma/dbeta. */

@@ -13,10 +13,19 @@ namespace {
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
+// MX scale exponent and power of two as csrc/gemm.hip defines them (mx_exponent / pow2f)
+__device__ __forceinline__ int mx_exponent_r(float amax) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, amax);
+    if ((u & 0x7F800000u) == 0u) return -127;
+    int e = (int)((u >> 23) & 0xFF) - 127 - 8 + ((u & 0x7FFFFFu) > 0x600000u ? 1 : 0);
+    return e < -127 ? -127 : (e > 126 ? 126 : e);
+}
+
 template <int VPL>
 __device__ __forceinline__ void ln_row_finish(const f32x2 (&v)[VPL], int lane, int H, int row,
                                               const float* gamma, const float* beta, float eps,
-                                              float* y, bf16* yb, bf16* xh, float* rstd_out) {
+                                              float* y, bf16* yb, bf16* xh, float* rstd_out,
+                                              uint8_t* yq = nullptr, uint8_t* ys = nullptr, int M = 0) {
     const int nv = H >> 1;
     float s = 0.f;
 #pragma unroll
@@ -48,6 +57,33 @@ __device__ __forceinline__ void ln_row_finish(const f32x2 (&v)[VPL], int lane, i
             if (xh) *(uint32_t*)(xh + base + 2 * c) = pack_bf16x2(h0, h1);
         }
     }
+    if (yq) {
+        // the same output as MXFP8 for an fp8 GEMM (QST_PREC_FP8): quantised from the bf16-rounded values, as a separate
+        // qst_quant_mx pass over yb would; 16 consecutive lanes (2 columns each) form one 32-column block. H % 64 == 0 here,
+        // so a block never straddles the valid / invalid column boundary and all 64 lanes take part in the DPP reduction.
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lane + 64 * i;
+            float o0 = 0.f, o1 = 0.f;
+            if (c < nv) {
+                const float h0 = (v[i][0] - mean) * rstd, h1 = (v[i][1] - mean) * rstd;
+                const f32x2 g = *(const f32x2*)(gamma + 2 * c), b = *(const f32x2*)(beta + 2 * c);
+                const uint32_t pk = pack_bf16x2(h0 * g[0] + b[0], h1 * g[1] + b[1]);
+                o0 = bf16lo(pk); o1 = bf16hi(pk);
+            }
+            const float amax = row16_max(fmaxf(fabsf(o0), fabsf(o1)));
+            const int ex = mx_exponent_r(amax);
+            const float inv = __builtin_bit_cast(float, (uint32_t)(127 - ex) << 23);
+            const uint32_t p = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(o0 * inv, o1 * inv, 0, false);
+            if (c < nv) {
+                *(uint16_t*)(yq + base + 2 * c) = (uint16_t)(p & 0xFFFFu);
+                if ((lane & 15) == 0) {
+                    const int kb = (2 * c) >> 5;
+                    ys[((size_t)(kb >> 2) * M + row) * 4 + (kb & 3)] = (uint8_t)(ex + 127);
+                }
+            }
+        }
+    }
 }
 
 template <int VPL>
@@ -55,7 +91,8 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, c
                                                            const int32_t* pos_ids, const float* word,
                                                            const float* pos, const float* type,
                                                            const float* gamma, const float* beta, float eps,
-                                                           int M, int H, float* y, bf16* yb, bf16* xh, float* rstd) {
+                                                           int M, int H, float* y, bf16* yb, bf16* xh, float* rstd,
+                                                           uint8_t* yq, uint8_t* ys) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -77,12 +114,13 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, c
             v[i][1] = w[1] + p[1];
         } else { v[i][0] = 0.f; v[i][1] = 0.f; }
     }
-    ln_row_finish<VPL>(v, lane, H, row, gamma, beta, eps, y, yb, xh, rstd);
+    ln_row_finish<VPL>(v, lane, H, row, gamma, beta, eps, y, yb, xh, rstd, yq, ys, M);
 }
 
 template <int VPL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* s, const float* gamma, const float* beta, float eps,
-                                                     int M, int H, float* y, bf16* yb, bf16* xh, float* rstd) {
+                                                     int M, int H, float* y, bf16* yb, bf16* xh, float* rstd,
+                                                     uint8_t* yq, uint8_t* ys) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -94,7 +132,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* s, const float
         if (c < nv) v[i] = *(const f32x2*)(s + (size_t)row * H + 2 * c);
         else { v[i][0] = 0.f; v[i][1] = 0.f; }
     }
-    ln_row_finish<VPL>(v, lane, H, row, gamma, beta, eps, y, yb, xh, rstd);
+    ln_row_finish<VPL>(v, lane, H, row, gamma, beta, eps, y, yb, xh, rstd, yq, ys, M);
 }
 
 // LayerNorm backward. Each wave walks ROWS_PER_WAVE rows, keeps dgamma/dbeta partials for its columns in
@@ -511,6 +549,10 @@ __global__ __launch_bounds__(256) void shadow_all_kernel(const float* params, bf
 
 }  // namespace
 
+extern "C" int qst_embed_ln_fwd_mx(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
+                                   const float* word_emb, const float* pos_emb, const float* type_emb,
+                                   const float* gamma, const float* beta, float eps, int M, int H,
+                                   float* y, void* y_bf16, void* yq, void* ys, void* stream);
 extern "C" int qst_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
                                 const float* word_emb, const float* pos_emb, const float* type_emb,
                                 const float* gamma, const float* beta, float eps, int M, int H,
@@ -520,7 +562,32 @@ extern "C" int qst_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, con
     hipStream_t st = (hipStream_t)stream;
     QST_VPL_DISPATCH(H, (embed_ln_fwd_kernel<VPL><<<(M + 3) / 4, 256, 0, st>>>(
                             ids, type_ids, pos_ids, word_emb, pos_emb, type_emb, gamma, beta, eps, M, H, y,
-                            (bf16*)y_bf16, (bf16*)xhat_bf16, rstd)));
+                            (bf16*)y_bf16, (bf16*)xhat_bf16, rstd, nullptr, nullptr)));
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+extern "C" int qst_embed_ln_fwd_mx(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
+                                   const float* word_emb, const float* pos_emb, const float* type_emb,
+                                   const float* gamma, const float* beta, float eps, int M, int H,
+                                   float* y, void* y_bf16, void* yq, void* ys, void* stream) {
+    if (!ids || !pos_ids || !word_emb || !pos_emb || !gamma || !beta || !y || !yq || !ys || M <= 0 || H <= 0) return QST_ERR_BAD_ARG;
+    if (H % 64 != 0) return QST_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    QST_VPL_DISPATCH(H, (embed_ln_fwd_kernel<VPL><<<(M + 3) / 4, 256, 0, st>>>(
+                            ids, type_ids, pos_ids, word_emb, pos_emb, type_emb, gamma, beta, eps, M, H, y,
+                            (bf16*)y_bf16, nullptr, nullptr, (uint8_t*)yq, (uint8_t*)ys)));
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+extern "C" int qst_ln_fwd_mx(const float* s, const float* gamma, const float* beta, float eps, int M, int H,
+                             float* y, void* y_bf16, void* yq, void* ys, void* stream) {
+    if (!s || !gamma || !beta || !y || !yq || !ys || M <= 0 || H <= 0) return QST_ERR_BAD_ARG;
+    if (H % 64 != 0) return QST_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    QST_VPL_DISPATCH(H, (ln_fwd_kernel<VPL><<<(M + 3) / 4, 256, 0, st>>>(s, gamma, beta, eps, M, H, y, (bf16*)y_bf16, nullptr,
+                                                                         nullptr, (uint8_t*)yq, (uint8_t*)ys)));
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
@@ -530,7 +597,7 @@ extern "C" int qst_ln_fwd(const float* s, const float* gamma, const float* beta,
     if (!s || !gamma || !beta || !y || M <= 0 || H <= 0 || (H & 1)) return QST_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     QST_VPL_DISPATCH(H, (ln_fwd_kernel<VPL><<<(M + 3) / 4, 256, 0, st>>>(s, gamma, beta, eps, M, H, y, (bf16*)y_bf16,
-                                                                         (bf16*)xhat_bf16, rstd)));
+                                                                         (bf16*)xhat_bf16, rstd, nullptr, nullptr)));
     QST_LAUNCH_CHECK();
     return QST_OK;
 }

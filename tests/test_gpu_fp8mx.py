@@ -170,3 +170,33 @@ def test_encoder_fp8_bert_base_dims_l384():
 def test_encoder_fp8_trained_like_weights_and_mpnet():
     run_encoder_mx("bert-base-uncased", 2, 128, dict(std=0.05, bias_std=0.02, ln_jitter=0.05), layers=2, emb_atol=4e-3)
     run_encoder_mx("all-mpnet-base-v2", 1, 256, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), layers=2, emb_atol=4e-3)
+
+
+@pytest.mark.parametrize("M,H", [(37, 768), (128, 384), (5, 1024)])
+def test_layernorm_mx_output_equals_quantising_its_bf16_output(lib, M, H):
+    """qst_ln_fwd_mx / qst_embed_ln_fwd_mx: the MXFP8 copy must be bit for bit what qst_quant_mx (= the oracle's mx_quant)
+    makes of the kernel's own bf16 output."""
+    g = torch.Generator().manual_seed(M + H)
+    s = (torch.randn(M, H, generator=g) * 3 + 0.5).cuda()
+    gamma, beta = (1 + 0.2 * torch.randn(H, generator=g)).cuda(), (0.3 * torch.randn(H, generator=g)).cuda()
+    y = torch.empty(M, H, device="cuda")
+    yb = torch.empty(M, H, dtype=torch.bfloat16, device="cuda")
+    yq = torch.empty(M, H, dtype=torch.uint8, device="cuda")
+    ys = torch.zeros(H // 128 * M * 4, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.qst_ln_fwd_mx(s.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-12, M, H, y.data_ptr(), yb.data_ptr(),
+                                 yq.data_ptr(), ys.data_ptr(), st()))
+    ref = torch.nn.functional.layer_norm(s, (H,), gamma, beta, 1e-12)
+    torch.testing.assert_close(y, ref, rtol=1e-5, atol=1e-5)
+    qr, sr, _ = R.mx_quant(yb.float().cpu())
+    assert torch.equal(yq.cpu(), qr) and torch.equal(ys.cpu(), stage_major(sr))
+    # embedding gather + LayerNorm
+    V = 50
+    ids = torch.randint(0, V, (M,), generator=g).cuda()
+    pos = torch.arange(M, dtype=torch.int32).cuda() % 16
+    word, pe = torch.randn(V, H, generator=g).cuda(), torch.randn(16, H, generator=g).cuda()
+    _lib.check(lib.qst_embed_ln_fwd_mx(ids.data_ptr(), None, pos.data_ptr(), word.data_ptr(), pe.data_ptr(), None, gamma.data_ptr(),
+                                       beta.data_ptr(), 1e-12, M, H, y.data_ptr(), yb.data_ptr(), yq.data_ptr(), ys.data_ptr(), st()))
+    ref = torch.nn.functional.layer_norm(word[ids] + pe[pos.long()], (H,), gamma, beta, 1e-12)
+    torch.testing.assert_close(y, ref, rtol=1e-5, atol=1e-5)
+    qr, sr, _ = R.mx_quant(yb.float().cpu())
+    assert torch.equal(yq.cpu(), qr) and torch.equal(ys.cpu(), stage_major(sr))
