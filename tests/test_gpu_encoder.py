@@ -69,6 +69,7 @@ def run_case(name, B, L, ragged, weights_kw, check_grads=True, emb_atol_vs_bf16_
         segs, _ = build_layout(cfg)
         ga = enc.grads.cpu()
         worst = 0.0
+        errs = []
         for s in segs:
             ref = Pb[s.name].grad
             got = ga[s.offset:s.offset + s.numel].view(*s.shape)
@@ -78,10 +79,21 @@ def run_case(name, B, L, ragged, weights_kw, check_grads=True, emb_atol_vs_bf16_
                 continue
             err = ((got - ref).norm() / denom).item()
             worst = max(worst, err)
-            # attention key biases have a mathematically zero gradient (softmax shift invariance): their
-            # b_qkv segment is mostly rounding noise, so biases get a looser bound
-            lim = 6e-2 if s.name.split(".")[-1].startswith("b_") else 2e-2
+            # Bounds per tensor class, against the oracle that rounds the same GEMM operands to bf16 (measured maxima over
+            # every case of this file in brackets):
+            #   weight matrices, embedding tables, rel_bias: 1e-2 [7.7e-3] -- accumulation order and bf16 roundings of
+            #     gradient activations (dY is a bf16 GEMM operand here, fp32 in autograd);
+            #   bias / LayerNorm vectors: 3e-2 [1.9e-2] -- they are column sums of the bf16-ROUNDED dY fragments the wgrad
+            #     kernel already holds (autograd sums the unrounded fp32 dY), i.e. sqrt(M)-averaged 2^-9 noise, largest on
+            #     the smallest batch (M = 256 rows);
+            #   b_qkv: 4e-2 [3.0e-2] -- its key third has a mathematically zero gradient (softmax shift invariance), so a
+            #     third of the vector is pure rounding noise in both implementations.
+            leaf = s.name.split(".")[-1]
+            lim = 4e-2 if leaf == "b_qkv" else (3e-2 if (leaf.startswith("b_") or leaf.startswith("ln") or leaf.startswith("emb_ln")) else 1e-2)
             assert err < lim, f"{name} grad {s.name}: relative L2 error {err:.3e} (ref norm {denom:.3e})"
+            errs.append((err, s.name))
+        errs.sort(reverse=True)
+        print(f"[grad-err] {name} B={B} L={L}: " + ", ".join(f"{n} {e:.2e}" for e, n in errs[:4]))
         return loss.item(), worst
     return loss.item(), None
 
