@@ -73,8 +73,12 @@ __device__ __forceinline__ uint32_t nt_off(int row, int chunk) {
 
 // Prologue + K loop shared by every NT kernel: leaves the wave's 64 x 96 sub-tile in acc (D rows = n, D column = m)
 // and returns after a workgroup barrier, so the caller may reuse the ring for its epilogue.
-template <int WAVES_M, int WAVES_N>
-__device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, int m0, int n0, f32x16 (&acc)[2][3]) {
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// after_first_issue: run once, right after the first stage's DMAs are on their way (work whose own memory latency should
+// overlap that first round trip instead of preceding it)
+template <int WAVES_M, int WAVES_N, typename HOOK = NoHook>
+__device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, int m0, int n0, f32x16 (&acc)[2][3],
+                                            HOOK after_first_issue = HOOK()) {
     constexpr int NBM = 64 * WAVES_M, NBN = 96 * WAVES_N, NW = WAVES_M * WAVES_N;
     constexpr int NT_A_BYTES = NBM * NBK * 2, NT_B_BYTES = NBN * NBK * 2;
     constexpr int NT_STAGE = NT_A_BYTES + NT_B_BYTES;
@@ -122,6 +126,7 @@ __device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, in
     const int nk = g.K / NBK;
     const int fr = lane & 31, fh = lane >> 5;
     issue(0);
+    after_first_issue();
     for (int kt = 0; kt < nk; ++kt) {
         wait_vmcnt<0>();                              // stage kt has landed for this wave's DMAs
         __builtin_amdgcn_s_barrier();                 // ... for everyone's; and everyone is done reading slot (kt-1)&1
@@ -715,7 +720,8 @@ __global__ __launch_bounds__(256) void quant_mx_kernel(const SRC* src, int64_t n
 // four waves of a row panel stage their sub-tiles into one [32][384] fp32 slab, then each takes 8 complete rows
 // (6 columns per lane, as the row kernels in rowops.hip do).
 constexpr int LN_N = 384, LN_LD = 388;               // slab row stride 1552 B: ds_write_b128 conflict-free
-constexpr int LN_LDS = 2 * (128 + LN_N) * NBK * 2;   // the K-loop ring (128 KB); slabs + vectors need 104 KB of it
+constexpr int LN_RING = 2 * (128 + LN_N) * NBK * 2;  // the K-loop ring (128 KB); the epilogue slabs reuse 99 KB of it
+constexpr int LN_LDS = LN_RING + 3 * LN_N * 4;       // + bias / gamma / beta, loaded before the K loop
 
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLnEpi e) {
@@ -726,19 +732,57 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
     const int ntm = (g.M + 127) / 128;
     const int m0 = xcd_remap(blockIdx.x, ntm) * 128;
     const int fr = lane & 31, fh = lane >> 5;
-    f32x16 acc[2][3];
-    nt_mainloop<2, 4>(g, smem, m0, 0, acc);
-
+    // diagnostic (QstGemmArgs.splits bit 3, mode 0 only): s_memtime at the phase boundaries of wave 0 -> e.partials as
+    // uint64 [workgroup][8]; costs one scalar branch per stamp when off
+    const bool stamp_on = MODE == 0 && (g.splits & 8) && e.partials != nullptr;
+#define LN_STAMP(k_) do { if (stamp_on && tid == 0) ((unsigned long long*)e.partials)[blockIdx.x * 8 + (k_)] = __builtin_readcyclecounter(); } while (0)
+    LN_STAMP(0);
+    // Everything the epilogue reads from global memory is requested BEFORE the K loop (the three vectors into LDS beyond
+    // the ring, pass 0's residual / xhat rows into registers) or, for pass 1, while pass 0 is being normalised: issued
+    // where they were first used, each of these loads exposed its full miss latency (~2 us apiece, three of them in a row)
+    // with every wave of the CU waiting -- a quarter of the K = 384 launches.
     float* slab = (float*)smem + wm * (32 * LN_LD);
-    float* vec_s = (float*)smem + 2 * (32 * LN_LD);          // [3][384]: bias, gamma, beta
-    for (int c = tid; c < 3 * LN_N; c += 512) {
-        const int which = c / LN_N, n = c - which * LN_N;
-        float v = 0.f;
-        if (which == 0) v = g.bias ? g.bias[n] : 0.f;
-        else if (which == 1) v = e.gamma[n];
-        else if (MODE == 0) v = e.beta[n];
-        vec_s[c] = v;
-    }
+    float* vec_s = (float*)(smem + LN_RING);                 // [3][384]: bias, gamma, beta (beyond the ring)
+    f32x2 rv[2][8][3];
+    uint32_t xv[2][8][3];
+    float rs[2][8];
+#define LN_PREFETCH(i_) do {                                                                                             \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                                  \
+            const int m = m0 + wm * 64 + (i_) * 32 + wn * 8 + k;                                                         \
+            const bool ok = m < g.M;                                                                                     \
+            _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                              \
+                const int c = 2 * (lane + 64 * t);                                                                       \
+                rv[i_][k][t][0] = rv[i_][k][t][1] = 0.f;                                                                 \
+                xv[i_][k][t] = 0u;                                                                                       \
+                if (ok && g.resid) rv[i_][k][t] = *(const f32x2*)(g.resid + (size_t)m * g.ldr + c);                      \
+                if (MODE == 1 && ok) xv[i_][k][t] = *(const uint32_t*)((const bf16*)e.xhat + (size_t)m * LN_N + c);      \
+            }                                                                                                            \
+            rs[i_][k] = (MODE == 1 && ok) ? e.rstd[m] : 0.f;                                                             \
+        }                                                                                                                \
+    } while (0)
+    f32x16 acc[2][3];
+    auto early_loads = [&]() __attribute__((always_inline)) {
+        // (stamps showed 7,300 cycles between kernel entry and the first DMA when these loads came first)
+        float v3[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int c = tid + 512 * q;                     // 3 * 384 = 1152 <= 3 * 512
+            const int which = c / LN_N, n = c - which * LN_N;
+            v3[q] = 0.f;
+            if (c < 3 * LN_N) {
+                if (which == 0) v3[q] = g.bias ? g.bias[n] : 0.f;
+                else if (which == 1) v3[q] = e.gamma[n];
+                else if (MODE == 0) v3[q] = e.beta[n];
+            }
+        }
+        LN_PREFETCH(0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (tid + 512 * q < 3 * LN_N) vec_s[tid + 512 * q] = v3[q];
+    };
+    nt_mainloop<2, 4>(g, smem, m0, 0, acc, early_loads);
+    LN_STAMP(2);
+
     f32x2 ag[3], ab[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) { ag[t][0] = ag[t][1] = ab[t][0] = ab[t][1] = 0.f; }
@@ -746,24 +790,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
 
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        // every global input of this wave's 8 rows is requested before the pass touches LDS or stores anything
-        f32x2 rv[8][3];
-        uint32_t xv[8][3];
-        float rs[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int m = m0 + wm * 64 + i * 32 + wn * 8 + k;
-            const bool ok = m < g.M;
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const int c = 2 * (lane + 64 * t);
-                rv[k][t][0] = rv[k][t][1] = 0.f;
-                xv[k][t] = 0u;
-                if (ok && g.resid) rv[k][t] = *(const f32x2*)(g.resid + (size_t)m * g.ldr + c);
-                if (MODE == 1 && ok) xv[k][t] = *(const uint32_t*)((const bf16*)e.xhat + (size_t)m * LN_N + c);
-            }
-            rs[k] = (MODE == 1 && ok) ? e.rstd[m] : 0.f;
-        }
         if (i > 0) __builtin_amdgcn_s_barrier();             // everyone has finished reading pass 0's slab
 #pragma unroll
         for (int j = 0; j < 3; ++j)
@@ -774,7 +800,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
                 for (int q = 0; q < 4; ++q) v[q] = acc[i][j][4 * g4 + q];
                 *(f32x4*)(slab + fr * LN_LD + wn * 96 + j * 32 + 8 * g4 + 4 * fh) = v;
             }
-        __syncthreads();                                     // slab (and, in pass 0, the vectors) complete
+        __syncthreads();                                     // slab complete
+        LN_STAMP(3 + 2 * i);
+        if (i == 0) LN_PREFETCH(1);                          // pass 1's rows travel while pass 0 is normalised and stored
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int row = wn * 8 + k;
@@ -787,8 +815,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     const f32x2 b = *(const f32x2*)(vec_s + 2 * (lane + 64 * t));
-                    v[t][0] = (v[t][0] + b[0]) + rv[k][t][0];        // same association as the unfused epilogue
-                    v[t][1] = (v[t][1] + b[1]) + rv[k][t][1];
+                    v[t][0] = (v[t][0] + b[0]) + rv[i][k][t][0];        // same association as the unfused epilogue
+                    v[t][1] = (v[t][1] + b[1]) + rv[i][k][t][1];
                     s += v[t][0] + v[t][1];
                 }
                 const float mean = wave_sum(s) * inv_n;
@@ -809,9 +837,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
                         f32x2 o;
                         o[0] = h0 * ga[0] + be[0];
                         o[1] = h1 * ga[1] + be[1];
-                        *(f32x2*)((float*)g.C + (size_t)m * g.ldc + c) = o;
-                        if (g.C2) *(uint32_t*)((bf16*)g.C2 + (size_t)m * g.ldc + c) = pack_bf16x2(o[0], o[1]);
-                        if (e.xhat) *(uint32_t*)((bf16*)e.xhat + (size_t)m * LN_N + c) = pack_bf16x2(h0, h1);
+                        if (!(g.splits & 4)) *(f32x2*)((float*)g.C + (size_t)m * g.ldc + c) = o;
+                        if (g.C2 && !(g.splits & 1)) *(uint32_t*)((bf16*)g.C2 + (size_t)m * g.ldc + c) = pack_bf16x2(o[0], o[1]);
+                        if (e.xhat && !(g.splits & 2)) *(uint32_t*)((bf16*)e.xhat + (size_t)m * LN_N + c) = pack_bf16x2(h0, h1);
                     }
                 }
             } else {
@@ -820,9 +848,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     const f32x2 ga = *(const f32x2*)(vec_s + LN_N + 2 * (lane + 64 * t));
-                    x[t][0] = bf16lo(xv[k][t]); x[t][1] = bf16hi(xv[k][t]);
-                    v[t][0] += rv[k][t][0];                        // dy = dgrad + residual-path gradient
-                    v[t][1] += rv[k][t][1];
+                    x[t][0] = bf16lo(xv[i][k][t]); x[t][1] = bf16hi(xv[i][k][t]);
+                    v[t][0] += rv[i][k][t][0];                        // dy = dgrad + residual-path gradient
+                    v[t][1] += rv[i][k][t][1];
                     ag[t][0] += v[t][0] * x[t][0]; ag[t][1] += v[t][1] * x[t][1];
                     ab[t][0] += v[t][0];           ab[t][1] += v[t][1];
                     v[t][0] *= ga[0]; v[t][1] *= ga[1];            // dxhat
@@ -835,15 +863,17 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
                     for (int t = 0; t < 3; ++t) {
                         const int c = 2 * (lane + 64 * t);
                         f32x2 o;
-                        o[0] = rs[k] * (v[t][0] - m1 - x[t][0] * m2);
-                        o[1] = rs[k] * (v[t][1] - m1 - x[t][1] * m2);
+                        o[0] = rs[i][k] * (v[t][0] - m1 - x[t][0] * m2);
+                        o[1] = rs[i][k] * (v[t][1] - m1 - x[t][1] * m2);
                         *(f32x2*)((float*)g.C + (size_t)m * g.ldc + c) = o;
                         if (g.C2) *(uint32_t*)((bf16*)g.C2 + (size_t)m * g.ldc + c) = pack_bf16x2(o[0], o[1]);
                     }
                 }
             }
         }
+        LN_STAMP(4 + 2 * i);
     }
+    LN_STAMP(7);
     if (MODE == 1 && e.partials) {
         // dgamma / dbeta of this tile's 128 rows: 8 waves x 6 columns per lane -> LDS -> one [2][384] row per tile,
         // reduced over tiles by ln_bwd_reduce_batch_kernel in a fixed order
