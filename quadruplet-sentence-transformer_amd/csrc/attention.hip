@@ -114,7 +114,16 @@ struct AttnArgs {
     const bf16* qkv; const bf16* ctx; const bf16* dctx; const float* lse_in; const int64_t* mask;
     const float* rel; bf16* out; bf16* dqkv; float* lse_out; float* drel; float* delta;
     int nseq, L, A, H; float scale;
+    // q / k / v (and their gradients) of one (sequence, head) are [L] rows of `ld` elements starting at qkv_base(); the k
+    // and v parts follow at + woff and + 2 woff. Token-major [M, 3H] (q | k | v, heads concatenated): ld = 3H, woff = H,
+    // a head's rows are 2d-byte slices of 6H-byte rows (d = 32: half a cache line each). Head-major [nseq][3][A][L][d]
+    // (written by the QKV epilogue, QstGemmArgs.c_head_L): ld = d, woff = A L d, a head's q, k and v are contiguous
+    // L x d blocks -- every load and store of these kernels moves whole lines.
+    int ld; int64_t woff; int head_major;
 };
+__device__ __forceinline__ size_t qkv_base(const AttnArgs& a, int seq, int head, int D) {
+    return a.head_major ? ((size_t)seq * 3 * a.A + head) * a.L * D : (size_t)seq * a.L * a.ld + (size_t)head * D;
+}
 
 // ------------------------------------------------------------------ forward
 template <int D>
@@ -135,8 +144,8 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs
     if (D == 32 && nqb == 1 && (a.A & 1) == 0 && (gridDim.x & 15) == 0)
         bid = 2 * ((bid >> 4) * 8 + (bid & 7)) + ((bid >> 3) & 1);
     const int qb = bid % nqb, head = (bid / nqb) % a.A, seq = bid / (nqb * a.A);
-    const int ld = 3 * a.H;
-    const bf16* base = a.qkv + (size_t)seq * a.L * ld + head * D;
+    const int ld = a.ld;
+    const bf16* base = a.qkv + qkv_base(a, seq, head, D);
     const int i0 = qb * 128 + wave * 32;
     const bool active = i0 < a.L;
     const int qi = i0 + fr;
@@ -166,8 +175,8 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs
         __syncthreads();
         {
             Stager<D> sg;
-            sg.load(0, base + (size_t)c * 128 * ld + a.H, ld, rows, tid);
-            sg.load(1, base + (size_t)c * 128 * ld + 2 * a.H, ld, rows, tid);
+            sg.load(0, base + (size_t)c * 128 * ld + a.woff, ld, rows, tid);
+            sg.load(1, base + (size_t)c * 128 * ld + 2 * a.woff, ld, rows, tid);
             sg.template store<false>(0, kimg, tid);
             sg.template store<true>(1, vimg, tid);
         }
@@ -254,8 +263,8 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dq_kernel(AttnA
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, fr = lane & 31;
     const int nqb = (a.L + 127) / 128;
     const int qb = blockIdx.x % nqb, head = (blockIdx.x / nqb) % a.A, seq = blockIdx.x / (nqb * a.A);
-    const int ld = 3 * a.H;
-    const bf16* base = a.qkv + (size_t)seq * a.L * ld + head * D;
+    const int ld = a.ld;
+    const bf16* base = a.qkv + qkv_base(a, seq, head, D);
     const int i0 = qb * 128 + wave * 32;
     const bool active = i0 < a.L;
     const int qi = i0 + fr;
@@ -293,8 +302,8 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dq_kernel(AttnA
         __syncthreads();
         {
             Stager<D> sg;
-            sg.load(0, base + (size_t)c * 128 * ld + a.H, ld, rows, tid);
-            sg.load(1, base + (size_t)c * 128 * ld + 2 * a.H, ld, rows, tid);
+            sg.load(0, base + (size_t)c * 128 * ld + a.woff, ld, rows, tid);
+            sg.load(1, base + (size_t)c * 128 * ld + 2 * a.woff, ld, rows, tid);
             sg.template store<false>(0, kimg, tid);
             sg.template store<true>(0, ktr, tid);
             sg.template store<false>(1, vimg, tid);
@@ -334,7 +343,7 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dq_kernel(AttnA
         }
     }
     if (!active) return;
-    bf16* orow = a.dqkv + ((size_t)seq * a.L + qi) * ld + head * D;
+    bf16* orow = a.dqkv + qkv_base(a, seq, head, D) + (size_t)qi * ld;
 #pragma unroll
     for (int b = 0; b < DB; ++b)
 #pragma unroll
@@ -362,8 +371,8 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dkv_kernel(Attn
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, fr = lane & 31;
     const int nkb = (a.L + 127) / 128;
     const int kb = blockIdx.x % nkb, head = (blockIdx.x / nkb) % a.A, seq = blockIdx.x / (nkb * a.A);
-    const int ld = 3 * a.H;
-    const bf16* base = a.qkv + (size_t)seq * a.L * ld + head * D;
+    const int ld = a.ld;
+    const bf16* base = a.qkv + qkv_base(a, seq, head, D);
     const bf16* dbase = a.dctx + (size_t)seq * a.L * a.H + head * D;
     const int j0 = kb * 128 + wave * 32;
     const bool active = j0 < a.L;
@@ -379,8 +388,8 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dkv_kernel(Attn
     if (active) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            kf[s] = *(const bf16x8*)(base + (size_t)kj * ld + a.H + 16 * s + 8 * h);
-            vf[s] = *(const bf16x8*)(base + (size_t)kj * ld + 2 * a.H + 16 * s + 8 * h);
+            kf[s] = *(const bf16x8*)(base + (size_t)kj * ld + a.woff + 16 * s + 8 * h);
+            vf[s] = *(const bf16x8*)(base + (size_t)kj * ld + 2 * a.woff + 16 * s + 8 * h);
         }
         madd = a.mask[(size_t)seq * a.L + kj] ? 0.f : kMaskMin;
     }
@@ -463,8 +472,8 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dkv_kernel(Attn
         }
     }
     if (active) {
-        bf16* krow = a.dqkv + ((size_t)seq * a.L + kj) * ld + a.H + head * D;
-        bf16* vrow = krow + a.H;
+        bf16* krow = a.dqkv + qkv_base(a, seq, head, D) + (size_t)kj * ld + a.woff;
+        bf16* vrow = krow + a.woff;
 #pragma unroll
         for (int b = 0; b < DB; ++b)
 #pragma unroll
@@ -514,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
     float* relv = del_s + 128;                           // this head's relative-position bias [2L], log2 units
     float* drel_s = relv + 2 * a.L;                      // its gradient: one private [2L] array per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, fr = lane & 31;
-    const int ld = 3 * a.H, rows = a.L;
+    const int ld = a.ld, rows = a.L;
     const int j0 = wave * 32;
     const bool active = j0 < rows;
     const int kj = j0 + fr;
@@ -530,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
     // the ten loads took 3700 cycles to get through it while nothing else ran); part < 0 issues everything.
     auto prefetch = [&](int item, int part) {
         const int head = item % a.A, seq = item / a.A;
-        const bf16* base = a.qkv + (size_t)seq * a.L * ld + head * D;
+        const bf16* base = a.qkv + qkv_base(a, seq, head, D);
         const bf16* dbase = a.dctx + (size_t)seq * a.L * a.H + head * D;
         const bf16* obase = a.ctx + (size_t)seq * a.L * a.H + head * D;
         const u32x4 z = {0, 0, 0, 0};
@@ -546,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
                 const int idx = tid + 256 * k, row = idx / CPR, c = idx % CPR;
-                pk[k] = row < rows ? *(const u32x4*)(base + (size_t)row * ld + a.H + c * 8) : z;
+                pk[k] = row < rows ? *(const u32x4*)(base + (size_t)row * ld + a.woff + c * 8) : z;
             }
             if (tid < rows) nlse = a.lse_in[((size_t)seq * a.A + head) * a.L + tid];
         }
@@ -554,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
                 const int idx = tid + 256 * k, row = idx / CPR, c = idx % CPR;
-                pv[k] = row < rows ? *(const u32x4*)(base + (size_t)row * ld + 2 * a.H + c * 8) : z;
+                pv[k] = row < rows ? *(const u32x4*)(base + (size_t)row * ld + 2 * a.woff + c * 8) : z;
             }
         }
         if (part < 0 || part == 3) {
@@ -758,14 +767,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
                     *(u32x2*)(stg + 2 * 32 * D * 2 + off) = o2;
                 }
             // wave-private staging: no workgroup barrier, the LDS queue is in order within a wave
-            bf16* obase2 = a.dqkv + ((size_t)seq * a.L + j0) * ld + head * D;
+            bf16* obase2 = a.dqkv + qkv_base(a, seq, head, D) + (size_t)j0 * ld;
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
                 for (int k = 0; k < 32 * CPR / 64; ++k) {
                     const int idx = lane + 64 * k, row = idx / CPR, c = idx % CPR;
                     const u32x4 v = *(const u32x4*)(stg + t * 32 * D * 2 + rr_off<D>(row, c));
-                    *(u32x4*)(obase2 + (size_t)row * ld + t * a.H + c * 8) = v;
+                    *(u32x4*)(obase2 + (size_t)row * ld + t * a.woff + c * 8) = v;
                 }
             QST_STAMP(6);
         }
@@ -795,6 +804,7 @@ extern "C" int qst_attention_fwd(const void* qkv, const int64_t* mask, const flo
     AttnArgs a{};
     a.qkv = (const bf16*)qkv; a.mask = mask; a.rel = rel_bias; a.out = (bf16*)ctx; a.lse_out = lse;
     a.nseq = nseq; a.L = L; a.A = A; a.H = A * d; a.scale = 1.0f / sqrtf((float)d);
+    a.ld = 3 * a.H; a.woff = a.H; a.head_major = 0;
     const int grid = nseq * A * ((L + 127) / 128);
     const size_t lds = (size_t)2 * 128 * d * 2 + (((size_t)L * 4 + 15) & ~(size_t)15) + (size_t)4 * 32 * d * 2 +
                        (rel_bias ? (size_t)2 * L * 4 : 0);
@@ -816,6 +826,7 @@ extern "C" int qst_attention_bwd(const void* qkv, const void* ctx, const void* d
     a.qkv = (const bf16*)qkv; a.ctx = (const bf16*)ctx; a.dctx = (const bf16*)dctx; a.lse_in = lse; a.mask = mask;
     a.rel = rel_bias; a.dqkv = (bf16*)dqkv; a.drel = drel; a.delta = delta_scratch;
     a.nseq = nseq; a.L = L; a.A = A; a.H = A * d; a.scale = 1.0f / sqrtf((float)d);
+    a.ld = 3 * a.H; a.woff = a.H; a.head_major = 0;
     const int grid = nseq * A * ((L + 127) / 128);
     const size_t lds_q = (size_t)3 * 128 * d * 2 + (((size_t)L + 3) & ~(size_t)3) * 4 + (rel_bias ? (size_t)2 * L * 4 : 0);
     const size_t lds_kv = (size_t)4 * 128 * d * 2 + 256 * 4 + (rel_bias ? (size_t)10 * L * 4 : 0);

@@ -1,199 +1,3 @@
-// qst_kernels.h -- kernel-level C entry points of libqst.so (internal building blocks of
-// qst_encoder_forward/backward; exported so tests can check each kernel against the oracle).
-// Public mirror: include/qst_kernels.h includes this file.
+// The kernel-level C-ABI lives in include/qst_kernels.h (one copy, the public one).
 #pragma once
-#include <stddef.h>
-#include <stdint.h>
-
-#ifdef __cplusplus
-extern "C" {
-#endif
-
-enum {
-    QST_EPI_BF16 = 0,            // C(bf16) = acc + bias
-    QST_EPI_F32_RESID = 1,       // C(f32)  = acc + bias + resid
-    QST_EPI_GELU = 2,            // u = acc + bias ; C(bf16) = gelu'(u) (saved for backward) ; C2(bf16) = gelu(u)
-    QST_EPI_GELU_BWD = 3,        // C(bf16) = acc * aux   (aux = the gelu'(u) saved by QST_EPI_GELU)
-    QST_EPI_F32_RESID_BF16 = 4,  // C(f32) = acc + bias + resid ; C2(bf16) = same
-    QST_EPI_GELU_MX = 5          // qst_gemm_nt_f8 only: gelu(acc + bias) as MXFP8: C = e4m3 [M, ldc], C2 = E8M0 [M, ldc/32]
-};
-
-typedef struct {
-    const void* A;        // bf16
-    const void* B;        // bf16
-    void* C;
-    void* C2;
-    const void* aux;      // bf16, same shape/ld as C (GELU_BWD)
-    const float* bias;    // [N] or NULL
-    const float* resid;   // f32 [M, ldr] or NULL
-    float* colsum;        // tn only: f32 [N] += column sums of A (bias gradient), or NULL
-    int32_t M, N, K;
-    int32_t lda, ldb, ldc, ldr;
-    int32_t splits;       // tn only: reduction splits over M (0 = auto); nt: tile-variant selector (tests / tuning)
-    const float* bscale;  // qst_gemm_nt_w8 only: f32 [N] quantisation scale of each fp8 weight row
-} QstGemmArgs;
-
-/* C[M,N] = A[M,K] . B[N,K]^T with epilogue `epi`. K % 64 == 0, lda/ldb % 8 == 0. */
-int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream);
-/* NT GEMM with fp8 (e4m3, OCP) weights: C = (A . Q^T) * bscale[n] (+ epilogue). B = Q: fp8 [N, K] (ldb in bytes,
- * % 16 == 0), bscale f32 [N]. epi: QST_EPI_BF16, QST_EPI_F32_RESID, QST_EPI_GELU. Inference path (QST_PREC_FP8W). */
-int qst_gemm_nt_w8(const QstGemmArgs* a, int epi, void* stream);
-/* NT GEMM on the fp8 matrix cores, both operands MXFP8 (OCP e4m3 elements + one E8M0 power-of-two scale per 32
- * consecutive K elements of a row; v_mfma_scale_f32_32x32x64_f8f6f4): A = e4m3 [M, K] (lda bytes), aux = its scales;
- * B = e4m3 [N, K] (ldb bytes), bscale = its scales (uint8 arrays in the layout qst_quant_mx writes). K % 128 == 0.
- * epi: QST_EPI_BF16, QST_EPI_F32_RESID, QST_EPI_GELU_MX. Inference path (QST_PREC_FP8, BASELINE configs[4]). */
-int qst_gemm_nt_f8(const QstGemmArgs* a, int epi, void* stream);
-/* MXFP8 quantisation of a contiguous [rows, K] matrix (src f32, or bf16 when src_is_bf16): per 32-element block the
- * scale exponent e = the smallest with amax * 2^-e <= 448 (-127 for an all-zero block), elements = RNE(x * 2^-e) to
- * e4m3; q = uint8 [rows, K]; scales = uint8 holding e + 127, STAGE-MAJOR: block kb of row r at
- * ((kb / 4) * rows + r) * 4 + kb % 4, ceil(K / 128) * rows * 4 bytes in all -- the four scales a GEMM stage (128 K) needs
- * from a row are one aligned dword, and 32 consecutive rows one 128-byte line. K % 32 == 0. */
-int qst_quant_mx(const void* src, int src_is_bf16, int64_t rows, int K, void* q, void* scales, void* stream);
-/* Per-row symmetric quantisation of a [rows, cols] f32 matrix to fp8 e4m3: scale[r] = max|row| / 448 (1 for an
- * all-zero row), dst = round-to-nearest-even(src / scale). cols % 4 == 0. */
-int qst_quant_rows_fp8(const float* src, int rows, int cols, void* dst_fp8, float* scales, void* stream);
-/* NT GEMM with a LayerNorm fused into the epilogue (one 128 x 384 tile spans whole rows: N must be 384;
- * qst_gemm_nt_ln_supported(N) tells). xhat is bf16 [M, 384] contiguous, rstd f32 [M].
- *  mode 0 (forward):  v = A.B^T + bias + resid ; y = LayerNorm(v) -> C (f32), C2 (bf16, nullable);
- *                     xhat, rstd (nullable) are written for the backward pass.
- *  mode 1 (backward): dy = A.B^T + resid ; ds = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)) -> C (f32),
- *                     C2 (bf16, nullable); partials (nullable) f32 [ceil(M/128)][2][384] receives each tile's
- *                     sum(dy*xhat) and sum(dy) rows (reduce with qst_ln_bwd_reduce_batch). */
-typedef struct {
-    const float* gamma;
-    const float* beta;
-    float eps;
-    void* xhat;
-    float* rstd;
-    float* partials;
-} QstLnEpi;
-int qst_gemm_nt_ln_supported(int N);
-int qst_gemm_nt_ln(const QstGemmArgs* a, const QstLnEpi* ln, int mode, void* stream);
-/* The feed-forward block of a layer as one kernel (H = 384 token rows complete per tile; csrc/ffn.hip):
- *  mode 0 (forward):  u = A.B1^T + bias1 ; h = gelu(u) ; v = h.B2^T + bias2 + resid ; y = LayerNorm(v) -> C (f32),
- *                     C2 (bf16, nullable), ln->xhat / ln->rstd (nullable). save_gp / save_h (both or neither) receive
- *                     gelu'(u) and h as bf16 [M, I] for the backward pass; NULL = inference, the [M, I] tensor never
- *                     leaves the chip.
- *  mode 1 (backward): du = (A.B1^T) * aux -> save_h (bf16 [M, I], required: the weight gradients read it) ;
- *                     dy = du.B2^T + resid ; C / C2 / ln->partials as qst_gemm_nt_ln mode 1.
- * A bf16 [M, H]; B1 bf16 [I, H]; B2 bf16 [H, I]; aux bf16 [M, I]; resid f32 [M, H]. All contiguous. */
-typedef struct {
-    const void* A;
-    const void* B1;
-    const void* B2;
-    const float* bias1;
-    const float* bias2;
-    const float* resid;
-    const void* aux;
-    void* save_gp;
-    void* save_h;
-    float* C;
-    void* C2;
-    int32_t M, H, I;
-} QstFfnArgs;
-int qst_ffn_chain_supported(int H, int I);
-int qst_ffn_chain(const QstFfnArgs* a, const QstLnEpi* ln, int mode, void* stream);
-/* C[N,K] (f32, atomically accumulated) += A[M,N]^T . B[M,K]; colsum[N] += sum_m A[m,:]. */
-int qst_gemm_tn(const QstGemmArgs* a, void* stream);
-/* Several such products over the same M in ONE launch (all weight gradients of a layer). */
-#define QST_TN_MAX_PROB 8
-typedef struct {
-    int32_t nprob;
-    int32_t splits;               /* reduction ranges over M, rounded up to a multiple of 8; 0 = auto */
-    int32_t total_tiles;          /* filled by the library */
-    int32_t ranges_per_xcd;       /* filled by the library */
-    int32_t tiles[QST_TN_MAX_PROB];
-    QstGemmArgs prob[QST_TN_MAX_PROB];
-} QstTnGroup;
-int qst_gemm_tn_group(const QstTnGroup* grp, void* stream);
-
-/* Embedding gather + LayerNorm (BertEmbeddings / MPNetEmbeddings forward).
- * pos_ids: int32 [M] position row per token. type_emb may be NULL. Outputs: y f32, y bf16, xhat bf16, rstd f32. */
-int qst_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
-                     const float* word_emb, const float* pos_emb, const float* type_emb,
-                     const float* gamma, const float* beta, float eps, int M, int H,
-                     float* y, void* y_bf16, void* xhat_bf16, float* rstd, void* stream);
-/* LayerNorm over rows of s f32 [M,H]. */
-int qst_ln_fwd(const float* s, const float* gamma, const float* beta, float eps, int M, int H,
-               float* y, void* y_bf16, void* xhat_bf16, float* rstd, void* stream);
-/* The same two kernels with the output ALSO as MXFP8 (yq e4m3 [M, H], ys scales in qst_quant_mx's layout), quantised
- * from the bf16-rounded values -- what qst_quant_mx over y_bf16 would give, without the extra pass. y_bf16 may be NULL.
- * H % 64 == 0. QST_PREC_FP8 forward. */
-int qst_ln_fwd_mx(const float* s, const float* gamma, const float* beta, float eps, int M, int H,
-                  float* y, void* y_bf16, void* yq, void* ys, void* stream);
-int qst_embed_ln_fwd_mx(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
-                        const float* word_emb, const float* pos_emb, const float* type_emb,
-                        const float* gamma, const float* beta, float eps, int M, int H,
-                        float* y, void* y_bf16, void* yq, void* ys, void* stream);
-/* LayerNorm backward: ds = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)); dgamma += sum dy*xhat; dbeta += sum dy. */
-/* scratch: qst_ln_bwd_scratch_bytes(M, H) of per-block partial sums reduced in a fixed order (deterministic);
- * NULL falls back to float atomics on dgamma/dbeta. */
-size_t qst_ln_bwd_scratch_bytes(int M, int H);
-int qst_ln_bwd(const float* dy, const void* xhat_bf16, const float* rstd, const float* gamma, int M, int H,
-               float* ds, void* ds_bf16, float* dgamma, float* dbeta, float* scratch, void* stream);
-/* Deferred second stage: qst_ln_bwd called with dgamma = dbeta = NULL only writes its partials into `scratch`;
- * this reduces up to QST_LN_BATCH_MAX such buffers (same M, H) into their dgamma/dbeta in one launch. */
-#define QST_LN_BATCH_MAX 32
-typedef struct {
-    int32_t count, H, nblocks;      /* nblocks = qst_ln_bwd_scratch_bytes(M, H) / (2 * H * 4) */
-    const float* partials[QST_LN_BATCH_MAX];
-    float* dgamma[QST_LN_BATCH_MAX];
-    float* dbeta[QST_LN_BATCH_MAX];
-    int32_t nblocks_each[QST_LN_BATCH_MAX];   /* per-entry row count of partials; 0 = nblocks */
-} QstLnReduceBatch;
-int qst_ln_bwd_reduce_batch(const QstLnReduceBatch* b, void* stream);
-/* Embedding backward: scatter ds rows into word/pos/type gradient tables. */
-int qst_embed_bwd(const float* ds, const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
-                  int nseq, int L, int H, int num_types, float* dword, float* dpos, float* dtype_, void* stream);
-/* MPNet position ids (cumsum of non-pad) or BERT arange -> int32 [nseq*L]. */
-int qst_position_ids(const int64_t* ids, int nseq, int L, int arch, int pad_id, int32_t* pos_ids, void* stream);
-
-/* ST Pooling(mean) + optional Normalize. tok f32 [nseq,L,H]; pooled f32 [nseq,H] (pre-normalize, saved). */
-int qst_pool_norm_fwd(const float* tok, const int64_t* mask, int nseq, int L, int H, int normalize,
-                      float* emb, float* pooled, void* stream);
-int qst_pool_norm_bwd(const float* demb, const float* pooled, const int64_t* mask, int nseq, int L, int H,
-                      int normalize, float* dtok, void* stream);
-
-/* Self-attention forward: qkv bf16 [nseq*L, 3H] token-major (q | k | v, heads concatenated),
- * mask int64 [nseq, L], rel_pos f32 [A, 2L] (qst_rel_pos_fwd: bias of relative position j - i at entry j - i + L)
- * or NULL -> ctx bf16 [nseq*L, H], lse f32 [nseq, A, L]. */
-int qst_attention_fwd(const void* qkv, const int64_t* mask, const float* rel_pos, int nseq, int L, int A, int d,
-                      void* ctx, float* lse, void* stream);
-/* Backward: dctx bf16 [nseq*L, H] -> dqkv bf16 [nseq*L, 3H]; drel_pos f32 [A, 2L] += (or NULL; needs rel_pos).
- * delta_scratch: f32 [nseq, A, L] (dO.O per query, written by the dQ kernel, read by the dK/dV kernel). */
-int qst_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, const int64_t* mask,
-                      const float* rel_bias, int nseq, int L, int A, int d, void* dqkv, float* drel,
-                      float* delta_scratch, void* stream);
-
-/* MPNet relative position bias: rel_bias[a, i, j] = table[lut[(j - i) + 511]][a]; lut = int32 [1023] device
- * table of qst_rel_bucket_host(j - i). Backward accumulates drel [A, L, L] into dtable [buckets, A]. */
-int qst_rel_bucket_host(int rel, int num_buckets, int max_distance);
-int qst_rel_bias_fwd(const float* table, const int32_t* lut, int A, int L, float* rel_bias, void* stream);
-int qst_rel_bias_bwd(const float* drel, const int32_t* lut, int buckets, int A, int L, float* dtable, void* stream);
-/* The same bias as relative-position vectors [A][2L] (entry j - i + L; entry 0 unused): the form the bf16 attention
- * kernels take (each workgroup keeps its head's 2L values in LDS instead of gathering from an [A, L, L] table), and
- * the reduction of their gradient back onto the bucket table. */
-int qst_rel_pos_fwd(const float* table, const int32_t* lut, int A, int L, float* rel_pos, void* stream);
-int qst_rel_pos_bwd(const float* drel_pos, const int32_t* lut, int buckets, int A, int L, float* dtable, void* stream);
-
-/* Parity-precision (QST_PREC_BF16X3) forward kernels: fp32 operands split into hi+lo bf16 on the fly, three MFMAs
- * per product, fp32 out. epi: 0 = +bias, 1 = +bias +resid, 2 = gelu(+bias). K % 32 == 0. */
-int qst_gemm_nt_x3(const QstGemmArgs* a, int epi, void* stream);
-int qst_attention_fwd_x3(const float* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A, int d,
-                         float* ctx, void* stream);
-
-/* k best entries of every row of scores f32 [nrows, ld] (first n columns), sorted by descending score (ties: ascending
- * index). index_map (nullable, int64, same ld) translates column numbers into caller ids -- used to merge the
- * per-chunk results of qst_topk_scores. k <= min(n, 1024). */
-int qst_topk_rows(const float* scores, int64_t ld, const int64_t* index_map, int nrows, int n, int k,
-                  float* out_scores, int64_t* out_index, void* stream);
-
-/* All GEMM weights of the arena in one launch; table_dev = int64 [nseg][6] {src off, rows, cols, dst off, dstT off,
- * first block} (built by qst_encoder_create). */
-int qst_shadow_all(const float* params, void* shadow, const int64_t* table_dev, int nseg, int nblocks, void* stream);
-/* bf16 shadow: dst[i] = bf16(src[i]) and dstT = transpose for a [rows, cols] matrix. */
-int qst_shadow_matrix(const float* src, int rows, int cols, void* dst_bf16, void* dstT_bf16, void* stream);
-
-#ifdef __cplusplus
-}
-#endif
+#include "../../include/qst_kernels.h"

@@ -23,7 +23,7 @@ def make_group(M=32768, H=384, I=1536, dev="cuda"):
 
 if __name__ == "__main__":
     lib = _lib.load(); st = _lib.current_stream_ptr()
-    grp, keep, flops = make_group()
+    grp, keep, flops = make_group(M=int(os.environ.get("QST_M", "16384")))
     for _ in range(5):
         _lib.check(lib.qst_gemm_tn_group(grp, st))
     torch.cuda.synchronize()
