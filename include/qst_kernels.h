@@ -31,6 +31,12 @@ typedef struct {
     int32_t lda, ldb, ldc, ldr;
     int32_t splits;       // tn only: reduction splits over M (0 = auto); nt: tile-variant selector (tests / tuning)
     const float* bscale;  // qst_gemm_nt_w8 only: f32 [N] quantisation scale of each fp8 weight row
+    // Head-major q/k/v tensors (0 = the operand is a plain row-major matrix). A [M, 3H] q|k|v matrix whose rows are tokens
+    // of sequences of L tokens can instead be stored as [M / L][3H / d][L][d] (d = head width, 32 or 64): every
+    // (sequence, q/k/v, head) is a contiguous L x d block, what the attention kernels read and write whole lines of.
+    //   c_head_L, c_head_d: layout of C for QST_EPI_BF16 (the QKV projection writes it); N % d == 0, M % L == 0
+    //   a_head_L, a_head_d: layout of A (the QKV dgrad and wgrad read dqkv); nt: K % 64 == 0 as ever, tn: L % 32 == 0
+    int32_t a_head_L, a_head_d, c_head_L, c_head_d;
 } QstGemmArgs;
 
 /* C[M,N] = A[M,K] . B[N,K]^T with epilogue `epi`. K % 64 == 0, lda/ldb % 8 == 0. */
@@ -164,6 +170,13 @@ int qst_attention_fwd(const void* qkv, const int64_t* mask, const float* rel_pos
 int qst_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, const int64_t* mask,
                       const float* rel_bias, int nseq, int L, int A, int d, void* dqkv, float* drel,
                       float* delta_scratch, void* stream);
+/* The same two kernels on head-major q/k/v: qkv and dqkv are bf16 [nseq][3][A][L][d] (every (sequence, q/k/v, head) a
+ * contiguous L x d block; what QST_EPI_BF16 writes with QstGemmArgs.c_head_L set). ctx / dctx stay [nseq*L, H]. */
+int qst_attention_fwd_hm(const void* qkv, const int64_t* mask, const float* rel_pos, int nseq, int L, int A, int d,
+                         void* ctx, float* lse, void* stream);
+int qst_attention_bwd_hm(const void* qkv, const void* ctx, const void* dctx, const float* lse, const int64_t* mask,
+                         const float* rel_bias, int nseq, int L, int A, int d, void* dqkv, float* drel,
+                         float* delta_scratch, void* stream);
 
 /* MPNet relative position bias: rel_bias[a, i, j] = table[lut[(j - i) + 511]][a]; lut = int32 [1023] device
  * table of qst_rel_bucket_host(j - i). Backward accumulates drel [A, L, L] into dtable [buckets, A]. */

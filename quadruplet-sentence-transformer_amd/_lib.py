@@ -34,7 +34,8 @@ class QstConfig(C.Structure):
 class QstGemmArgs(C.Structure):
     _fields_ = [("A", vp), ("B", vp), ("C", vp), ("C2", vp), ("aux", vp), ("bias", vp), ("resid", vp),
                 ("colsum", vp), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32),
-                ("ldb", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32), ("splits", C.c_int32), ("bscale", vp)]
+                ("ldb", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32), ("splits", C.c_int32), ("bscale", vp),
+                ("a_head_L", C.c_int32), ("a_head_d", C.c_int32), ("c_head_L", C.c_int32), ("c_head_d", C.c_int32)]
 
 
 class QstLnEpi(C.Structure):
@@ -112,6 +113,8 @@ SIGNATURES = {
     "qst_pool_norm_bwd": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "qst_attention_fwd": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "qst_attention_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "qst_attention_fwd_hm": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "qst_attention_bwd_hm": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "qst_rel_bucket_host": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "qst_rel_bias_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
     "qst_rel_bias_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),

@@ -796,15 +796,16 @@ static int check_attn(int nseq, int L, int A, int d) {
     return QST_OK;
 }
 
-extern "C" int qst_attention_fwd(const void* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A,
-                                 int d, void* ctx, float* lse, void* stream) {
+static int attention_fwd(const void* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A,
+                         int d, void* ctx, float* lse, void* stream, int head_major) {
     if (!qkv || !mask || !ctx) return QST_ERR_BAD_ARG;
     int rc = check_attn(nseq, L, A, d);
     if (rc) return rc;
     AttnArgs a{};
     a.qkv = (const bf16*)qkv; a.mask = mask; a.rel = rel_bias; a.out = (bf16*)ctx; a.lse_out = lse;
     a.nseq = nseq; a.L = L; a.A = A; a.H = A * d; a.scale = 1.0f / sqrtf((float)d);
-    a.ld = 3 * a.H; a.woff = a.H; a.head_major = 0;
+    if (head_major) { a.ld = d; a.woff = (int64_t)A * L * d; a.head_major = 1; }
+    else { a.ld = 3 * a.H; a.woff = a.H; a.head_major = 0; }
     const int grid = nseq * A * ((L + 127) / 128);
     const size_t lds = (size_t)2 * 128 * d * 2 + (((size_t)L * 4 + 15) & ~(size_t)15) + (size_t)4 * 32 * d * 2 +
                        (rel_bias ? (size_t)2 * L * 4 : 0);
@@ -815,9 +816,9 @@ extern "C" int qst_attention_fwd(const void* qkv, const int64_t* mask, const flo
     return QST_OK;
 }
 
-extern "C" int qst_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse,
-                                 const int64_t* mask, const float* rel_bias, int nseq, int L, int A, int d,
-                                 void* dqkv, float* drel, float* delta_scratch, void* stream) {
+static int attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse,
+                         const int64_t* mask, const float* rel_bias, int nseq, int L, int A, int d,
+                         void* dqkv, float* drel, float* delta_scratch, void* stream, int head_major) {
     if (!qkv || !ctx || !dctx || !lse || !mask || !dqkv || !delta_scratch) return QST_ERR_BAD_ARG;
     if (drel && !rel_bias) return QST_ERR_BAD_ARG;
     int rc = check_attn(nseq, L, A, d);
@@ -826,7 +827,8 @@ extern "C" int qst_attention_bwd(const void* qkv, const void* ctx, const void* d
     a.qkv = (const bf16*)qkv; a.ctx = (const bf16*)ctx; a.dctx = (const bf16*)dctx; a.lse_in = lse; a.mask = mask;
     a.rel = rel_bias; a.dqkv = (bf16*)dqkv; a.drel = drel; a.delta = delta_scratch;
     a.nseq = nseq; a.L = L; a.A = A; a.H = A * d; a.scale = 1.0f / sqrtf((float)d);
-    a.ld = 3 * a.H; a.woff = a.H; a.head_major = 0;
+    if (head_major) { a.ld = d; a.woff = (int64_t)A * L * d; a.head_major = 1; }
+    else { a.ld = 3 * a.H; a.woff = a.H; a.head_major = 0; }
     const int grid = nseq * A * ((L + 127) / 128);
     const size_t lds_q = (size_t)3 * 128 * d * 2 + (((size_t)L + 3) & ~(size_t)3) * 4 + (rel_bias ? (size_t)2 * L * 4 : 0);
     const size_t lds_kv = (size_t)4 * 128 * d * 2 + 256 * 4 + (rel_bias ? (size_t)10 * L * 4 : 0);
@@ -880,4 +882,23 @@ extern "C" int qst_debug_attn_occupancy(int which, int lds_bytes) {
     if (which == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dq_kernel<32>, 256, lds_bytes);
     if (which == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dkv_kernel<32, false>, 256, lds_bytes);
     return n;
+}
+
+extern "C" int qst_attention_fwd(const void* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A,
+                                 int d, void* ctx, float* lse, void* stream) {
+    return attention_fwd(qkv, mask, rel_bias, nseq, L, A, d, ctx, lse, stream, 0);
+}
+extern "C" int qst_attention_fwd_hm(const void* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A,
+                                    int d, void* ctx, float* lse, void* stream) {
+    return attention_fwd(qkv, mask, rel_bias, nseq, L, A, d, ctx, lse, stream, 1);
+}
+extern "C" int qst_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse,
+                                 const int64_t* mask, const float* rel_bias, int nseq, int L, int A, int d,
+                                 void* dqkv, float* drel, float* delta_scratch, void* stream) {
+    return attention_bwd(qkv, ctx, dctx, lse, mask, rel_bias, nseq, L, A, d, dqkv, drel, delta_scratch, stream, 0);
+}
+extern "C" int qst_attention_bwd_hm(const void* qkv, const void* ctx, const void* dctx, const float* lse,
+                                    const int64_t* mask, const float* rel_bias, int nseq, int L, int A, int d,
+                                    void* dqkv, float* drel, float* delta_scratch, void* stream) {
+    return attention_bwd(qkv, ctx, dctx, lse, mask, rel_bias, nseq, L, A, d, dqkv, drel, delta_scratch, stream, 1);
 }

@@ -89,9 +89,10 @@ __device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, in
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
     const int rows_a = min(NBM, g.M - m0), rows_b = min(NBN, g.N - n0);
-    const bf16* Ab = (const bf16*)g.A + (size_t)m0 * g.lda;
+    const bool a_heads = g.a_head_L != 0;            // A is a head-major q|k|v tensor (QstGemmArgs): absolute offsets
+    const bf16* Ab = (const bf16*)g.A + (a_heads ? (size_t)0 : (size_t)m0 * g.lda);
     const bf16* Bb = (const bf16*)g.B + (size_t)n0 * g.ldb;
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc(Ab, (uint32_t)rows_a * g.lda * 2u);
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(Ab, a_heads ? (uint32_t)g.M * g.lda * 2u : (uint32_t)rows_a * g.lda * 2u);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(Bb, (uint32_t)rows_b * g.ldb * 2u);
 
     // DMA map: one wave-instruction = 1 KB = 8 rows x 128 B. LDS position p (16-B units) = q*64 + lane -> row p/8,
@@ -102,6 +103,23 @@ __device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, in
         const int row = (wave * A_PER_WAVE + t) * 8 + (lane >> 3);
         va[t] = (uint32_t)row * g.lda * 2u + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
     }
+    // Head-major A: element (m, k) of the [M, K] matrix sits at ((m / L) * (K / d) + k / d) * L * d + (m % L) * d + k % d.
+    // A stage is 64 consecutive k = 64 / d whole heads, so stages are 64 * L elements apart and a row's 128 stage bytes
+    // become 64 / d pieces of 2d bytes; the 8 rows of one DMA instruction never straddle a sequence (L % 32 == 0).
+    uint32_t ka_stride = NBK * 2;
+    if (a_heads) {
+        const int L = g.a_head_L, d = g.a_head_d, dsh = 31 - __builtin_clz(d);
+        ka_stride = (uint32_t)NBK * L * 2u;
+#pragma unroll
+        for (int t = 0; t < A_PER_WAVE; ++t) {
+            const int row8 = (wave * A_PER_WAVE + t) * 8;
+            const int mb = m0 + row8, seq = mb / L, l = mb - seq * L + (lane >> 3);
+            const int row = row8 + (lane >> 3);
+            const int kc = ((lane & 7) ^ ((row >> 1) & 7)) * 8;                  // first k of this lane's chunk
+            const uint32_t e = ((uint32_t)seq * (g.K >> dsh) + (kc >> dsh)) * L * d + (uint32_t)l * d + (kc & (d - 1));
+            va[t] = (row < rows_a) ? e * 2u : kOOB;
+        }
+    }
 #pragma unroll
     for (int t = 0; t < B_PER_WAVE; ++t) {
         const int row = (wave * B_PER_WAVE + t) * 8 + (lane >> 3);
@@ -109,9 +127,9 @@ __device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, in
     }
     auto issue = [&](int kt) {
         char* st = smem + (kt & 1) * NT_STAGE;
-        const uint32_t ko = (uint32_t)kt * (NBK * 2);
+        const uint32_t ko = (uint32_t)kt * (NBK * 2), koa = (uint32_t)kt * ka_stride;
 #pragma unroll
-        for (int t = 0; t < A_PER_WAVE; ++t) dma16(ra, st + (wave * A_PER_WAVE + t) * 1024, va[t], ko);
+        for (int t = 0; t < A_PER_WAVE; ++t) dma16(ra, st + (wave * A_PER_WAVE + t) * 1024, va[t], koa);
 #pragma unroll
         for (int t = 0; t < B_PER_WAVE; ++t) dma16(rb, st + NT_A_BYTES + (wave * B_PER_WAVE + t) * 1024, vb[t], ko);
     };
@@ -326,7 +344,14 @@ __device__ __forceinline__ void nt_epilogue(const QstGemmArgs& g, f32x16 (&acc)[
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[e] += lo[e]; v[4 + e] += hi[e]; }
                 }
-                const size_t o = (size_t)m * g.ldc + n;
+                size_t o = (size_t)m * g.ldc + n;
+                if (EPI == QST_EPI_BF16 && g.c_head_L) {
+                    // head-major q|k|v output (QstGemmArgs): the 32 rows of this pass lie in one sequence (L % 32 == 0),
+                    // 8 consecutive columns in one head
+                    const int L = g.c_head_L, d = g.c_head_d, dsh = 31 - __builtin_clz(d);
+                    const int mb = m_base + i * 32, seq = mb / L, l = mb - seq * L + row;
+                    o = ((size_t)seq * (g.N >> dsh) + (n >> dsh)) * L * d + (size_t)l * d + (n & (d - 1));
+                }
                 // N % 8 != 0 tails fall back to two 8-byte halves (N % 4 == 0 is required)
                 const bool full = n + 8 <= g.N;
                 u32x4 pk;
@@ -982,9 +1007,13 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
             const bool isA = wave < 6;
             const int half = wave & 1;
             const int ld = isA ? g.lda : g.ldb, c0 = isA ? n0 : k0, width = isA ? g.N : g.K;
-            const bf16* base = (const bf16*)(isA ? g.A : g.B) + (size_t)row0 * ld + c0;
+            // head-major dY (QstGemmArgs.a_head_L: the q|k|v gradient as the attention backward writes it): absolute
+            // offsets; a 32-row stage lies in one sequence (ranges start at multiples of 32 rows, L % 32 == 0)
+            const int hL = isA ? g.a_head_L : 0, hd = isA ? g.a_head_d : 1, hsh = 31 - __builtin_clz(hd);
+            const bf16* base = (const bf16*)(isA ? g.A : g.B) + (hL ? (size_t)0 : (size_t)row0 * ld + c0);
             // range = rows [row0, mend); the last row's tail past the allocation reads as zero
-            const uint32_t bytes = (uint32_t)min((size_t)(mend - row0) * ld * 2u - (size_t)c0 * 2u, (size_t)0x7FFFFF00u);
+            const uint32_t bytes = hL ? (uint32_t)((size_t)M * ld * 2u)        // (offsets span whole sequence blocks)
+                                      : (uint32_t)min((size_t)(mend - row0) * ld * 2u - (size_t)c0 * 2u, (size_t)0x7FFFFF00u);
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, bytes);
             // an operand stage is 768 chunks = 12 wave-instructions of 1 KB. LDS position p = q*64 + lane -> row p/24,
             // chunk position p%24 -> logical chunk = pos ^ swz(row). Columns beyond the matrix width must not alias
@@ -997,10 +1026,18 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
                 const int pp = (half * 6 + t) * 64 + lane;
                 const int row = pp / 24, chunk = (pp % 24) ^ tn_swz(row);
                 vo[t] = (c0 + chunk * 8 < width) ? (uint32_t)row * ld * 2u + chunk * 16u : kOOB;
+                if (hL) {
+                    const int n = c0 + chunk * 8;
+                    vo[t] = (n < width) ? (((uint32_t)(n >> hsh) * hL + row) * hd + (n & (hd - 1))) * 2u : kOOB;
+                }
             }
             auto issue = [&](int mt) {
                 char* st = smem + (mt % TSTAGES) * TT_STAGE + (isA ? 0 : TT_TILE);
-                const uint32_t so = (uint32_t)mt * TBK * ld * 2u;
+                uint32_t so = (uint32_t)mt * TBK * ld * 2u;
+                if (hL) {
+                    const int m = row0 + mt * TBK, seq = m / hL, l0 = m - seq * hL;
+                    so = __builtin_amdgcn_readfirstlane(((uint32_t)seq * ld * hL + (uint32_t)l0 * hd) * 2u);
+                }
 #pragma unroll
                 for (int t = 0; t < 6; ++t) dma16(rs, st + (half * 6 + t) * 1024, vo[t], so);  // kOOB + so < 2^32: no wrap
             };
@@ -1098,6 +1135,22 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
 
 }  // namespace
 
+// head-major operand descriptions of QstGemmArgs: which kernels take which, and the shapes they assume
+static int check_heads(const QstGemmArgs* a, bool a_ok, bool c_ok, int epi) {
+    if (a->a_head_L) {
+        const int L = a->a_head_L, d = a->a_head_d;
+        if (!a_ok) return QST_ERR_UNSUPPORTED;
+        if (L <= 0 || L % 32 != 0 || (d != 32 && d != 64) || a->M % L != 0) return QST_ERR_BAD_ARG;
+        if ((int64_t)a->M * a->lda * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
+    }
+    if (a->c_head_L) {
+        const int L = a->c_head_L, d = a->c_head_d;
+        if (!c_ok || epi != QST_EPI_BF16) return QST_ERR_UNSUPPORTED;
+        if (L <= 0 || L % 32 != 0 || (d != 32 && d != 64) || a->M % L != 0 || a->N % d != 0) return QST_ERR_BAD_ARG;
+    }
+    return QST_OK;
+}
+
 template <int EPI, int WAVES_M, int WAVES_N = 2, int TI = 2>
 static int launch_nt(const QstGemmArgs* a, hipStream_t st) {
     constexpr int NBM = 32 * TI * WAVES_M, NBN = 96 * WAVES_N;
@@ -1115,6 +1168,7 @@ extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
     if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
     if (a->K % NBK != 0 || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->N % 4 != 0 || a->ldc % 4 != 0) return QST_ERR_UNSUPPORTED;
     if ((int64_t)256 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)384 * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
+    if (int rc = check_heads(a, a->lda == a->K, true, epi)) return rc;
     hipStream_t st = (hipStream_t)stream;
     // Two 128-row workgroups per CU beat one 256-row workgroup on every shape of the step (their MFMA and
     // store phases interleave); a->splits (unused by nt otherwise) can force the tile height: 1 = 128, 2 = 256 rows.
@@ -1126,7 +1180,7 @@ extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
     const bool tall_ok = epi == QST_EPI_BF16 || epi == QST_EPI_GELU || epi == QST_EPI_GELU_BWD;
     const int64_t tall_tiles = (int64_t)((a->M + 255) / 256) * ((a->N + 191) / 192);
     const bool tall_auto = (a->splits & 7) == 0 && a->K >= 768 && a->N >= 1536 && tall_tiles >= 1024;
-    if (tall_ok && ((a->splits & 7) == 4 || tall_auto)) {
+    if (tall_ok && !a->a_head_L && ((a->splits & 7) == 4 || tall_auto)) {       // (the tall K loop reads plain A only)
         switch (epi) {
             case QST_EPI_BF16: return launch_nt<QST_EPI_BF16, 2, 2, 4>(a, st);
             case QST_EPI_GELU: return launch_nt<QST_EPI_GELU, 2, 2, 4>(a, st);
@@ -1160,6 +1214,7 @@ extern "C" int qst_gemm_nt_w8(const QstGemmArgs* a, int epi, void* stream) {
     if (!a || !a->A || !a->B || !a->C || !a->bscale || a->M <= 0 || a->N <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
     if (a->K % NBK != 0 || a->lda % 8 != 0 || a->ldb % 16 != 0 || a->N % 4 != 0 || a->ldc % 4 != 0) return QST_ERR_UNSUPPORTED;
     if ((int64_t)128 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)192 * a->ldb >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
+    if (int rc = check_heads(a, false, true, epi)) return rc;
     hipStream_t st = (hipStream_t)stream;
     switch (epi) {
         case QST_EPI_BF16: return launch_nt_w8<QST_EPI_BF16>(a, st);
@@ -1185,6 +1240,7 @@ extern "C" int qst_gemm_nt_f8(const QstGemmArgs* a, int epi, void* stream) {
     if (a->K % 128 != 0 || a->lda % 16 != 0 || a->ldb % 16 != 0 || a->N % 8 != 0) return QST_ERR_UNSUPPORTED;
     if (epi == QST_EPI_GELU_MX && a->ldc != a->N) return QST_ERR_UNSUPPORTED;          // stage-major scales: one matrix, no sub-views
     if ((int64_t)128 * a->lda >= 0x7FFFFF00LL || (int64_t)192 * a->ldb >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
+    if (int rc = check_heads(a, false, true, epi)) return rc;
     hipStream_t st = (hipStream_t)stream;
     switch (epi) {
         case QST_EPI_BF16: return a->ldc % 4 ? QST_ERR_UNSUPPORTED : launch_nt_f8<QST_EPI_BF16>(a, st);
@@ -1217,6 +1273,7 @@ extern "C" int qst_gemm_nt_ln(const QstGemmArgs* a, const QstLnEpi* ln, int mode
     if (a->N != LN_N || a->K % NBK != 0 || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->ldc % 2 != 0 || (a->resid && a->ldr % 2 != 0))
         return QST_ERR_UNSUPPORTED;
     if ((int64_t)128 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)LN_N * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
+    if (int rc = check_heads(a, a->lda == a->K, false, -1)) return rc;
     static QstLdsAttr attr0, attr1;
     if (int rc = qst_ensure_lds(attr0, (const void*)gemm_nt_ln_kernel<0>, LN_LDS)) return rc;
     if (int rc = qst_ensure_lds(attr1, (const void*)gemm_nt_ln_kernel<1>, LN_LDS)) return rc;
@@ -1235,6 +1292,7 @@ extern "C" int qst_gemm_tn_group(const QstTnGroup* grp_in, void* stream) {
         const QstGemmArgs& a = g.prob[i];
         if (!a.A || !a.B || !a.C || a.M <= 0 || a.N <= 0 || a.K <= 0 || a.M != g.prob[0].M) return QST_ERR_BAD_ARG;
         if (a.lda % 8 != 0 || a.ldb % 8 != 0 || a.N % 8 != 0 || a.K % 8 != 0) return QST_ERR_UNSUPPORTED;
+        if (int rc = check_heads(&a, a.lda == a.N && a.N % (a.a_head_d ? a.a_head_d : 1) == 0, false, -1)) return rc;
         if ((int64_t)a.M * a.lda * 2 >= 0x7FFFFF00LL || (int64_t)a.M * a.ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
         g.tiles[i] = ((a.N + TT - 1) / TT) * ((a.K + TT - 1) / TT);
         g.total_tiles += g.tiles[i];

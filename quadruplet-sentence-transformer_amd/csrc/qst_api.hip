@@ -325,11 +325,30 @@ int nt3(const float* A, int lda, const float* B, int ldb, float* C, int ldc, con
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
     return qst_gemm_nt_x3(&g, epi, st);
 }
+// Optional head-major q/k/v ([nseq][3A][L][d], QstGemmArgs / AttnArgs): the QKV projection writes that layout, attention
+// reads and writes whole L x d blocks, the QKV dgrad and wgrad read it back. Built to give d = 32 heads whole 128-byte
+// lines, measured (MiniLM c2 step, same-process A/B and rocprofv3 per kernel): attention forward 29.2 -> 28.2 us, fused
+// backward 61.9 -> 60.0 us, but the scattered QKV epilogue +3.6 us: step 4.765 vs 4.763 ms, forward-only 1.645 vs
+// 1.632 ms -- the attention kernels are latency-bound, not line-bound. So the default stays token-major [M, 3H];
+// qst_debug_head_major(1) selects the other layout (tests run both). The GEMM helpers below take the layout of their next
+// call from this one-shot description (set by heads_c / heads_a right before the call).
+struct HeadLayout { int aL, ad, cL, cd; };
+static thread_local HeadLayout t_heads = {0, 0, 0, 0};
+static int g_head_major = 0;
+static void take_heads(QstGemmArgs& g) {
+    g.a_head_L = t_heads.aL; g.a_head_d = t_heads.ad; g.c_head_L = t_heads.cL; g.c_head_d = t_heads.cd;
+    t_heads = HeadLayout{0, 0, 0, 0};
+}
+static void heads_c(bool on, int L, int d) { if (on) { t_heads.cL = L; t_heads.cd = d; } }
+static void heads_a(bool on, int L, int d) { if (on) { t_heads.aL = L; t_heads.ad = d; } }
+extern "C" void qst_debug_head_major(int on) { g_head_major = on; }
+
 int nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* C2, const void* aux, const float* bias,
        const float* resid, int ldr, int M, int N, int K, int epi, hipStream_t st) {
     QstGemmArgs g{};
     g.A = A; g.B = B; g.C = C; g.C2 = C2; g.aux = aux; g.bias = bias; g.resid = resid;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
+    take_heads(g);
     return qst_gemm_nt(&g, epi, st);
 }
 int nt_w8(const void* A, int lda, const void* B8, const float* bscale, int ldb, void* C, int ldc, void* C2, const float* bias,
@@ -337,6 +356,7 @@ int nt_w8(const void* A, int lda, const void* B8, const float* bscale, int ldb, 
     QstGemmArgs g{};
     g.A = A; g.B = B8; g.C = C; g.C2 = C2; g.bias = bias; g.resid = resid; g.bscale = bscale;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
+    take_heads(g);
     return qst_gemm_nt_w8(&g, epi, st);
 }
 // GEMM with the following LayerNorm (mode 0) / LayerNorm backward (mode 1) fused into its epilogue (N = H = 384)
@@ -346,6 +366,7 @@ int nt_ln(const void* A, int lda, const void* B, int ldb, float* C, void* C2, co
     QstGemmArgs g{};
     g.A = A; g.B = B; g.C = C; g.C2 = C2; g.bias = bias; g.resid = resid;
     g.M = M; g.N = H; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = H; g.ldr = H;
+    take_heads(g);
     QstLnEpi e{};
     e.gamma = gamma; e.beta = beta; e.eps = eps; e.xhat = xhat; e.rstd = rstd; e.partials = partials;
     return qst_gemm_nt_ln(&g, &e, mode, st);
@@ -439,6 +460,7 @@ static int forward_mx(qst_encoder* e, const int64_t* ids, const int64_t* mask, c
         QstGemmArgs g{};
         g.A = Aq; g.aux = As; g.B = WQ(wseg); g.bscale = (const float*)WS(wseg); g.C = Cout; g.C2 = C2; g.bias = P(bseg); g.resid = resid;
         g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.ldr = N;
+        take_heads(g);
         return qst_gemm_nt_f8(&g, epi, st);
     };
     int32_t* pos_ids = (int32_t*)(sv + p.pos_ids);
@@ -453,11 +475,13 @@ static int forward_mx(qst_encoder* e, const int64_t* ids, const int64_t* mask, c
     }
     float* s = (float*)(sv + p.s);
     float* y1 = (float*)(sv + p.y1);
+    const bool hm = g_head_major != 0;
     for (int l = 0; l < c.num_layers; ++l) {
         const int b = lay.layer0[l];
         float* xn = (float*)(sv + p.x[(l + 1) & 1]);
+        heads_c(hm, L, d);
         QST_TRY(gemm(sv + p.xq, sv + p.xs, H, b + W_QKV, sv + p.qkv, nullptr, 3 * H, b + B_QKV, nullptr, QST_EPI_BF16));
-        QST_TRY(qst_attention_fwd(sv + p.qkv, mask, rel, nseq, L, A, d, sv + p.ctx, nullptr, st));
+        QST_TRY((hm ? qst_attention_fwd_hm : qst_attention_fwd)(sv + p.qkv, mask, rel, nseq, L, A, d, sv + p.ctx, nullptr, st));
         QST_TRY(qst_quant_mx(sv + p.ctx, 1, M, H, sv + p.cq, sv + p.cs, st));
         QST_TRY(gemm(sv + p.cq, sv + p.cs, H, b + W_O, s, nullptr, H, b + B_O, x, QST_EPI_F32_RESID));
         QST_TRY(qst_ln_fwd_mx(s, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, y1, nullptr, sv + p.yq, sv + p.ys, st));
@@ -562,14 +586,18 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     // token rows on: one 128-row tile per workgroup gives a small batch too few workgroups (measured: the unfused pair
     // is 5-25% faster up to M = 8192, equal at 16384, 25% slower at 32768)
     const bool fuse_ln = !w8 && qst_gemm_nt_ln_supported(H) != 0 && M >= kFuseLnMinRows;
+    t_heads = HeadLayout{0, 0, 0, 0};
     // ... and the whole feed-forward block (FFN-1, GELU, FFN-2, LayerNorm) is ONE kernel: h never returns from HBM, and
     // an inference forward does not write it at all
     const bool fuse_ffn = fuse_ln && (g_fuse_ffn & (training ? 2 : 1)) && qst_ffn_chain_supported(H, I) != 0;
+    const bool hm = g_head_major != 0;
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerAct& a = p.layers[l];
         const int b = lay.layer0[l];
+        heads_c(hm, L, d);
         QST_TRY(linear(xb, H, b + W_QKV, sv + a.qkv, 3 * H, nullptr, b + B_QKV, nullptr, QST_EPI_BF16));
-        QST_TRY(qst_attention_fwd(sv + a.qkv, mask, rel, nseq, L, A, d, sv + a.ctx, (float*)(sv + a.lse), st));
+        QST_TRY((hm ? qst_attention_fwd_hm : qst_attention_fwd)(sv + a.qkv, mask, rel, nseq, L, A, d, sv + a.ctx,
+                                                               (float*)(sv + a.lse), st));
         if (fuse_ln) {
             QST_TRY(nt_ln(sv + a.ctx, H, W(b + W_O), H, (float*)(sv + a.y1), sv + a.y1b, P(b + B_O), x, M, H, H, 0,
                           P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, sv + a.xh1, (float*)(sv + a.rs1), nullptr, st));
@@ -657,6 +685,8 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
     // H = 384: every LayerNorm backward except the top one (whose input comes from the pooling head, not from a GEMM)
     // runs inside the epilogue of the dgrad GEMM that produces its input; those write one partial row per 128-row tile
     const bool fuse_ln = qst_gemm_nt_ln_supported(H) != 0 && M >= kFuseLnMinRows;
+    const bool hm = g_head_major != 0;
+    t_heads = HeadLayout{0, 0, 0, 0};
     const bool fuse_ffn = fuse_ln && (g_fuse_ffn & 4) && qst_ffn_chain_supported(H, I) != 0;
     const int fused_rows = (M + 127) / 128;
     auto ln_slot = [&](int slot, float* dg, float* db, int nrows = 0) {
@@ -692,6 +722,7 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
         set(1, du, I, sv + a.y1b, H, b + W_1, b + B_1);            // dW1 [I, H]
         set(2, dsb1, H, sv + a.ctx, H, b + W_O, b + B_O);          // dWo [H, H]
         set(3, dqkv, 3 * H, xin_b, H, b + W_QKV, b + B_QKV);       // dWqkv [3H, H]
+        if (hm) { grp.prob[3].a_head_L = L; grp.prob[3].a_head_d = d; }
         return qst_gemm_tn_group(&grp, st);
     };
     if (wgrad_only) {
@@ -731,11 +762,12 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
         }
         // attention output projection dgrad, attention core
         QST_TRY(nt(dsb1, H, WT(b + W_O), H, dctx, H, nullptr, nullptr, nullptr, nullptr, 0, M, H, H, QST_EPI_BF16, st));
-        QST_TRY(qst_attention_bwd(sv + a.qkv, sv + a.ctx, dctx, (const float*)(sv + a.lse), mask, rel, nseq, L, A, d,
+        QST_TRY((hm ? qst_attention_bwd_hm : qst_attention_bwd)(sv + a.qkv, sv + a.ctx, dctx, (const float*)(sv + a.lse), mask, rel, nseq, L, A, d,
                                   dqkv, drel, (float*)(ws + w.delta), st));
         if (!skip_wgrad) QST_TRY(wgrad(l));
         // QKV projection dgrad + residual: dx_in = dqkv . Wqkv + ds1. Fused mode: followed in the same kernel by the
         // backward of the LayerNorm that produced this layer's input (LN2 of layer l-1, or the embedding LayerNorm)
+        heads_a(hm, L, d);
         if (fuse_ln && l > 0) {
             const LayerAct& lo = p.layers[l - 1];
             const int bl = lay.layer0[l - 1];

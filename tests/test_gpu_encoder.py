@@ -172,6 +172,40 @@ def test_feed_forward_block_as_one_kernel():
         del PRESETS["minilm-2l"]
 
 
+def test_head_major_qkv_layout_is_bit_identical():
+    """qst_debug_head_major(1): q/k/v and their gradients as [nseq][3A][L][d] between the QKV projection, attention and
+    the QKV dgrad / wgrad. Same arithmetic on another layout: embeddings and every gradient must not change by a bit
+    (weight gradients: up to the order of their float atomics). Fused-LayerNorm size (M = 16384) and a small mpnet one."""
+    import ctypes as C
+    from dataclasses import replace
+    lib = _lib.load()
+    lib.qst_debug_head_major.argtypes = [C.c_int]
+    PRESETS["minilm-2l"] = replace(PRESETS["all-MiniLM-L6-v2"], num_layers=2, vocab_size=4096)
+    try:
+        for name, B, L in (("minilm-2l", 32, 128), ("tiny-mpnet", 4, 64)):
+            cfg = PRESETS[name]
+            arena = synthetic_params(cfg, seed=14, std=0.03, bias_std=0.02, ln_jitter=0.05)
+            ids, mask, types = [torch.from_numpy(x).view(4 * B, L).cuda() for x in synthetic_quadruplets(cfg, B, L, seed=14, ragged=True)]
+            types = types if cfg.type_vocab_size else None
+            res = []
+            for hm in (0, 1):
+                lib.qst_debug_head_major(hm)
+                enc = HipEncoder(cfg)
+                enc.load_arena(arena)
+                enc.ensure_train_state()
+                emb, _, saved = enc.forward(ids, mask, types, training=True)
+                enc.grads.zero_()
+                g = torch.randn(emb.shape, generator=torch.Generator().manual_seed(3)).cuda()
+                enc.backward(ids, mask, types, g, saved)
+                torch.cuda.synchronize()
+                res.append((emb.clone(), enc.grads.clone()))
+            assert torch.equal(res[0][0], res[1][0]), name
+            torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-5, atol=1e-6 * res[0][1].abs().max().item())
+    finally:
+        lib.qst_debug_head_major(0)
+        del PRESETS["minilm-2l"]
+
+
 def test_minilm_full_dims_ragged():
     run_case("all-MiniLM-L6-v2", 2, 128, True, dict(std=0.02))
 
