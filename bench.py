@@ -33,6 +33,9 @@ def parse():
     ap.add_argument("--model", default="all-MiniLM-L6-v2")
     ap.add_argument("--batch", type=int, default=64, help="quadruplets per GPU")
     ap.add_argument("--seq-len", type=int, default=128)
+    ap.add_argument("--dropout", type=float, default=0.1,
+                    help="hidden + attention-probability dropout of the timed training step (the reference's fit() trains "
+                         "HF modules in train() mode: 0.1 / 0.1); 0 = off. The step without it is reported beside it.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=10)
@@ -335,7 +338,8 @@ def main():
     trainer = QuadrupletTrainer(cfg, arena=arena, device=f"cuda:{dev_index}", lr=2e-5, weight_decay=0.01,
                                 max_grad_norm=1.0, warmup_steps=10000, total_steps=1000000,
                                 process_group=None, world_size=world, overlap=not args.no_overlap,
-                                use_graph=args.graph and world == 1)
+                                use_graph=args.graph and world == 1,
+                                dropout=(args.dropout if args.dropout > 0 else None), dropout_seed=14 + rank)
     # a few distinct synthetic batches, resident in HBM before the timed region (rank-offset streams)
     nb = 4
     batches = []
@@ -364,6 +368,25 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = B * world * args.steps / dt
     final_loss = float(loss.item())
+    # side figure: the same step with dropout off (what rounds 1 measured; eager path only -- a captured graph holds its masks' launches)
+    no_drop = None
+    if args.dropout > 0 and not args.graph:
+        trainer.enc.set_dropout(0.0, 0.0)
+        for i in range(3):
+            trainer.step(*batches[i % nb])
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            trainer.step(*batches[i % nb])
+        barrier()
+        dt1 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt1], device="cuda", dtype=torch.float32)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt1 = float(t.item())
+        no_drop = {"value": round(B * world * args.steps / dt1, 1), "unit": "quadruplets/s",
+                   "ms_per_step": round(dt1 / args.steps * 1e3, 4), "what": "the same training step with dropout off"}
+        trainer.enc.set_dropout(args.dropout, args.dropout, 14 + rank)
 
     out = None
     # every rank runs the kernel timing: its interleaved training steps are collective (gradient all-reduce)
@@ -398,12 +421,15 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.model} dims (random-init), {B} quadruplets/GPU x {world} GPU, seq_len={L}, "
-                                   "fwd + gamma-quadruplet loss + bwd + clip + AdamW, dropout off (BASELINE.json configs[1]"
+                                   "fwd + gamma-quadruplet loss + bwd + clip + AdamW, "
+                                   + (f"dropout {args.dropout:g} on hidden states and attention probabilities as the reference's "
+                                      "train() mode" if args.dropout > 0 else "dropout off") + " (BASELINE.json configs[1]"
                                    + ("/[3]" if world > 1 else "") + ")",
                        "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}",
                        "precision": "bf16 MFMA operands, fp32 accumulate/residual/LN/softmax/loss/optimizer",
                        "launch": "hip graph replay" if (args.graph and world == 1) else "eager"},
             "loss": round(final_loss, 6),
+            "step_without_dropout": no_drop,
             "step_tflops": round(step_tflops, 2),
             "step_mfma_frac": round(step_tflops / (PEAK_BF16_TFLOPS * world), 4),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

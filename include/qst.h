@@ -119,6 +119,17 @@ int qst_encoder_forward(qst_encoder* enc, const int64_t* ids, const int64_t* mas
                         float* out_emb, float* out_tok, void* saved, size_t saved_bytes, int training,
                         void* stream);
 
+/* Dropout for training forwards/backwards of this handle (HF hidden_dropout_prob on the embeddings and on both
+ * projection outputs of every layer, attention_probs_dropout_prob on the softmax probabilities; the reference trains
+ * in train() mode with HF's defaults 0.1 / 0.1: /root/reference/training/main.py:128). p_* in [0, 1); 0 / 0 turns it off
+ * (the state of a new handle). state_dev: device uint32[4] owned by the caller, initialised with qst_dropout_init; every
+ * qst_encoder_forward(training != 0) of a handle with dropout on first advances its step counter (on the stream, so the
+ * step can sit inside a captured graph), and the backward of that forward recomputes the same masks from it -- no mask
+ * is ever stored (include/qst_kernels.h: QstDrop). Inference forwards never drop. */
+int qst_encoder_set_dropout(qst_encoder* enc, float p_hidden, float p_attn, uint32_t* state_dev);
+int qst_dropout_init(uint32_t* state_dev, uint64_t seed, void* stream);
+int qst_dropout_advance(uint32_t* state_dev, void* stream);
+
 /*
  * Backward of the call above (replaces autograd through the same modules;
  * reference call site: `loss.backward()` inside SentenceTransformer.fit).

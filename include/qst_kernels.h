@@ -18,6 +18,26 @@ enum {
     QST_EPI_GELU_MX = 5          // qst_gemm_nt_f8 only: gelu(acc + bias) as MXFP8: C = e4m3 [M, ldc], C2 = E8M0 [M, ldc/32]
 };
 
+/* Dropout masks are a pure function of (state, site, element index): nothing is stored between forward and backward,
+ * both recompute the same mask. state = device uint32[4] {seed lo, seed hi, step, 0} (qst_dropout_init / _advance in
+ * qst.h); site tells the tensors of one step apart (QST_DROP_SITE_*); an element of flat index i is DROPPED when its 16
+ * random bits -- the low (i even) or high (i odd) half of hash32((i >> 1) ^ key), key = hash32(seed lo ^
+ * hash32(step * 0x9E3779B9 + site) ^ rotl16(seed hi)), hash32 = x ^= x >> 16; x *= 0x7feb352d; x ^= x >> 15;
+ * x *= 0x846ca68b; x ^= x >> 16 -- are < thr16; kept elements are multiplied by 65536 / (65536 - thr16). So the
+ * effective rate is thr16 / 65536 (p = 0.1: thr16 = 6554). oracle/dropout_ref.py restates this in numpy.
+ * Flat indices: hidden states [M, H]: m * H + n; attention probabilities: ((seq * A + head) * L + query) * L + key. */
+typedef struct {
+    const uint32_t* state;   /* NULL = no dropout */
+    uint32_t site;
+    uint32_t thr16;          /* 0 = no dropout */
+} QstDrop;
+#define QST_DROP_SITE_EMBED 0xE0u
+#define QST_DROP_SITE_ATTN_OUT(layer) (4u * (uint32_t)(layer) + 0u)    /* output of the attention projection, [M, H]  */
+#define QST_DROP_SITE_FFN_OUT(layer) (4u * (uint32_t)(layer) + 1u)     /* output of the second feed-forward GEMM      */
+#define QST_DROP_SITE_PROBS(layer) (4u * (uint32_t)(layer) + 2u)       /* softmax probabilities, [nseq, A, L, L]      */
+/* test / debug: out[i] = multiplier (0 or 65536 / (65536 - thr16)) of element i, i < n */
+int qst_dropout_multipliers(const QstDrop* d, int64_t n, float* out, void* stream);
+
 typedef struct {
     const void* A;        // bf16
     const void* B;        // bf16
@@ -37,6 +57,15 @@ typedef struct {
     //   c_head_L, c_head_d: layout of C for QST_EPI_BF16 (the QKV projection writes it); N % d == 0, M % L == 0
     //   a_head_L, a_head_d: layout of A (the QKV dgrad and wgrad read dqkv); nt: K % 64 == 0 as ever, tn: L % 32 == 0
     int32_t a_head_L, a_head_d, c_head_L, c_head_d;
+    // Dropout (training; drop.thr16 == 0 / drop.state == NULL = none), element index m * N + n of the [M, N] result:
+    //   drop_where 1: the projection output, before the residual: C = (acc + bias) * mask + resid   (QST_EPI_F32_RESID*,
+    //                 qst_gemm_nt_ln mode 0) -- BertSelfOutput / BertOutput: LayerNorm(dropout(dense(x)) + input)
+    //   drop_where 2: qst_gemm_nt_ln mode 1: the bf16 copy C2 = ds * mask (the gradient that enters the dgrad / wgrad of the
+    //                 dropped projection; the fp32 C, which continues down the residual path, stays unmasked)
+    //   drop_where 3: qst_gemm_nt_ln mode 1: dy = (acc + resid) * mask before the LayerNorm backward (embedding dropout
+    //                 sits AFTER its LayerNorm)
+    QstDrop drop;
+    int32_t drop_where;
 } QstGemmArgs;
 
 /* C[M,N] = A[M,K] . B[N,K]^T with epilogue `epi`. K % 64 == 0, lda/ldb % 8 == 0. */
@@ -119,6 +148,11 @@ int qst_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int32_t*
                      const float* word_emb, const float* pos_emb, const float* type_emb,
                      const float* gamma, const float* beta, float eps, int M, int H,
                      float* y, void* y_bf16, void* xhat_bf16, float* rstd, void* stream);
+/* ... followed by dropout of y / y_bf16 (BertEmbeddings: dropout(LayerNorm(e))); xhat / rstd describe the undropped row. */
+int qst_embed_ln_fwd_drop(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
+                          const float* word_emb, const float* pos_emb, const float* type_emb,
+                          const float* gamma, const float* beta, float eps, int M, int H,
+                          float* y, void* y_bf16, void* xhat_bf16, float* rstd, const QstDrop* drop, void* stream);
 /* LayerNorm over rows of s f32 [M,H]. */
 int qst_ln_fwd(const float* s, const float* gamma, const float* beta, float eps, int M, int H,
                float* y, void* y_bf16, void* xhat_bf16, float* rstd, void* stream);
@@ -137,6 +171,12 @@ int qst_embed_ln_fwd_mx(const int64_t* ids, const int64_t* type_ids, const int32
 size_t qst_ln_bwd_scratch_bytes(int M, int H);
 int qst_ln_bwd(const float* dy, const void* xhat_bf16, const float* rstd, const float* gamma, int M, int H,
                float* ds, void* ds_bf16, float* dgamma, float* dbeta, float* scratch, void* stream);
+/* The same with dropout masks recomputed: drop_in (nullable) multiplies dy first (a dropout that followed this
+ * LayerNorm: the embeddings); drop_out (nullable) multiplies ds_bf16 only (the dropout that preceded the residual add in
+ * front of this LayerNorm: ds_bf16 is the gradient of the dropped projection output, ds of the residual). */
+int qst_ln_bwd_drop(const float* dy, const void* xhat_bf16, const float* rstd, const float* gamma, int M, int H,
+                    float* ds, void* ds_bf16, float* dgamma, float* dbeta, float* scratch,
+                    const QstDrop* drop_in, const QstDrop* drop_out, void* stream);
 /* Deferred second stage: qst_ln_bwd called with dgamma = dbeta = NULL only writes its partials into `scratch`;
  * this reduces up to QST_LN_BATCH_MAX such buffers (same M, H) into their dgamma/dbeta in one launch. */
 #define QST_LN_BATCH_MAX 32
@@ -170,13 +210,20 @@ int qst_attention_fwd(const void* qkv, const int64_t* mask, const float* rel_pos
 int qst_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, const int64_t* mask,
                       const float* rel_bias, int nseq, int L, int A, int d, void* dqkv, float* drel,
                       float* delta_scratch, void* stream);
-/* The same two kernels on head-major q/k/v: qkv and dqkv are bf16 [nseq][3][A][L][d] (every (sequence, q/k/v, head) a
- * contiguous L x d block; what QST_EPI_BF16 writes with QstGemmArgs.c_head_L set). ctx / dctx stay [nseq*L, H]. */
-int qst_attention_fwd_hm(const void* qkv, const int64_t* mask, const float* rel_pos, int nseq, int L, int A, int d,
-                         void* ctx, float* lse, void* stream);
-int qst_attention_bwd_hm(const void* qkv, const void* ctx, const void* dctx, const float* lse, const int64_t* mask,
-                         const float* rel_bias, int nseq, int L, int A, int d, void* dqkv, float* drel,
-                         float* delta_scratch, void* stream);
+/* The same two kernels with options: head_major != 0: qkv and dqkv are bf16 [nseq][3][A][L][d] (every (sequence, q/k/v,
+ * head) a contiguous L x d block; what QST_EPI_BF16 writes with QstGemmArgs.c_head_L set; ctx / dctx stay [nseq*L, H]);
+ * drop: dropout of the softmax probabilities (BertSelfAttention: dropout(softmax(s)) . v), element index
+ * ((seq * A + head) * L + query) * L + key. lse stays the log-sum-exp of the undropped scores. */
+typedef struct {
+    const void* qkv; const int64_t* mask; const float* rel_pos;
+    int32_t nseq, L, A, d;
+    void* ctx; float* lse;                       /* forward: outputs; backward: inputs */
+    const void* dctx; void* dqkv; float* drel; float* delta_scratch;       /* backward only */
+    int32_t head_major;
+    QstDrop drop;
+} QstAttnDesc;
+int qst_attention_fwd_ex(const QstAttnDesc* a, void* stream);
+int qst_attention_bwd_ex(const QstAttnDesc* a, void* stream);
 
 /* MPNet relative position bias: rel_bias[a, i, j] = table[lut[(j - i) + 511]][a]; lut = int32 [1023] device
  * table of qst_rel_bucket_host(j - i). Backward accumulates drel [A, L, L] into dtable [buckets, A]. */
@@ -206,6 +253,10 @@ int qst_topk_rows(const float* scores, int64_t ld, const int64_t* index_map, int
 int qst_shadow_all(const float* params, void* shadow, const int64_t* table_dev, int nseg, int nblocks, void* stream);
 /* bf16 shadow: dst[i] = bf16(src[i]) and dstT = transpose for a [rows, cols] matrix. */
 int qst_shadow_matrix(const float* src, int rows, int cols, void* dst_bf16, void* dstT_bf16, void* stream);
+
+/* sizeof() of the argument structs above as this library was compiled, for bindings to check their mirror of the layout:
+ * which = 0 QstGemmArgs, 1 QstLnEpi, 2 QstFfnArgs, 3 QstTnGroup, 4 QstLnReduceBatch, 5 QstDrop, 6 QstAttnDesc. */
+int64_t qst_abi_sizeof(int which);
 
 #ifdef __cplusplus
 }

@@ -68,8 +68,11 @@ def mpnet_bucket_table(L: int, num_buckets: int = 32, max_distance: int = 128) -
 
 def encoder_forward(P: Dict[str, torch.Tensor], cfg, ids: torch.Tensor, mask: torch.Tensor,
                     type_ids: Optional[torch.Tensor] = None, bf16_operands: bool = False,
-                    collect: Optional[list] = None) -> torch.Tensor:
-    """Token embeddings [n, L, H]. P is keyed by the build's segment names (config.build_layout)."""
+                    collect: Optional[list] = None, dropout=None) -> torch.Tensor:
+    """Token embeddings [n, L, H]. P is keyed by the build's segment names (config.build_layout).
+    dropout: None (eval mode) or an oracle/dropout_ref.Masks -- train() mode with GIVEN masks at HF's four places:
+    BertEmbeddings (after its LayerNorm), BertSelfAttention (on the probabilities), BertSelfOutput and BertOutput (on the
+    dense output, before the residual add); MPNet has the same four (modeling_mpnet.py)."""
     n, L = ids.shape
     H, A = cfg.hidden_size, cfg.num_heads
     d = H // A
@@ -86,6 +89,8 @@ def encoder_forward(P: Dict[str, torch.Tensor], cfg, ids: torch.Tensor, mask: to
         bucket = mpnet_bucket_table(L, cfg.rel_buckets, cfg.rel_max_distance)
         rel = P["rel_bias"][bucket].permute(2, 0, 1)[None]          # [1, A, L, L]
     x = F.layer_norm(x, (H,), P["emb_ln_g"], P["emb_ln_b"], cfg.layer_norm_eps)
+    if dropout is not None:
+        x = x * dropout.embed(n, L, H)
     if collect is not None:
         collect.append(x)
     neg = torch.finfo(torch.float32).min
@@ -99,11 +104,17 @@ def encoder_forward(P: Dict[str, torch.Tensor], cfg, ids: torch.Tensor, mask: to
             s = s + rel
         s = s + add_mask
         pr = torch.softmax(s, dim=-1)
+        if dropout is not None:
+            pr = pr * dropout.probs(l, n, A, L)
         ctx = torch.matmul(_r(pr, bf), _r(v, bf)).transpose(1, 2).reshape(n, L, H)
         a = _linear(ctx, P[p + "w_o"], P[p + "b_o"], bf)
+        if dropout is not None:
+            a = a * dropout.attn_out(l, n, L, H)
         x = F.layer_norm(a + x, (H,), P[p + "ln1_g"], P[p + "ln1_b"], cfg.layer_norm_eps)
         h = F.gelu(_linear(x, P[p + "w_1"], P[p + "b_1"], bf))          # erf GELU
         o = _linear(h, P[p + "w_2"], P[p + "b_2"], bf)
+        if dropout is not None:
+            o = o * dropout.ffn_out(l, n, L, H)
         x = F.layer_norm(o + x, (H,), P[p + "ln2_g"], P[p + "ln2_b"], cfg.layer_norm_eps)
         if collect is not None:
             collect.append(x)
@@ -119,8 +130,8 @@ def st_head(tok: torch.Tensor, mask: torch.Tensor, normalize: bool) -> torch.Ten
     return e
 
 
-def sentence_embeddings(P, cfg, ids, mask, type_ids=None, bf16_operands=False):
-    return st_head(encoder_forward(P, cfg, ids, mask, type_ids, bf16_operands), mask, cfg.normalize)
+def sentence_embeddings(P, cfg, ids, mask, type_ids=None, bf16_operands=False, dropout=None):
+    return st_head(encoder_forward(P, cfg, ids, mask, type_ids, bf16_operands, dropout=dropout), mask, cfg.normalize)
 
 
 def _pdist(x1, x2, p, eps=1e-6):
@@ -163,7 +174,7 @@ def arena_to_dict(arena, cfg, requires_grad: bool = False) -> Dict[str, torch.Te
     return out
 
 
-def quadruplet_step(P, cfg, ids4, mask4, types4=None, loss_kw=None, bf16_operands=False):
+def quadruplet_step(P, cfg, ids4, mask4, types4=None, loss_kw=None, bf16_operands=False, dropout=None):
     """Forward of one quadruplet batch: ids4 [4,B,L] -> (loss, emb [4,B,H]).
 
     Column order = reference/positive/part_positive/negative
@@ -174,7 +185,7 @@ def quadruplet_step(P, cfg, ids4, mask4, types4=None, loss_kw=None, bf16_operand
     ids = ids4.reshape(4 * B, L)
     mask = mask4.reshape(4 * B, L)
     tt = types4.reshape(4 * B, L) if types4 is not None else None
-    emb = sentence_embeddings(P, cfg, ids, mask, tt, bf16_operands).view(4, B, -1)
+    emb = sentence_embeddings(P, cfg, ids, mask, tt, bf16_operands, dropout).view(4, B, -1)
     loss = gamma_quadruplet_loss_ref(emb[0], emb[1], emb[2], emb[3], **loss_kw)
     return loss, emb
 

@@ -31,11 +31,23 @@ class QstConfig(C.Structure):
                 ("pad_token_id", C.c_int32), ("precision", C.c_int32)]
 
 
+class QstDrop(C.Structure):
+    """include/qst_kernels.h: dropout mask = f(state {seed lo, seed hi, step, 0} on the device, site, element index)."""
+    _fields_ = [("state", vp), ("site", C.c_uint32), ("thr16", C.c_uint32)]
+
+
+class QstAttnDesc(C.Structure):
+    _fields_ = [("qkv", vp), ("mask", vp), ("rel_pos", vp), ("nseq", C.c_int32), ("L", C.c_int32), ("A", C.c_int32),
+                ("d", C.c_int32), ("ctx", vp), ("lse", vp), ("dctx", vp), ("dqkv", vp), ("drel", vp), ("delta_scratch", vp),
+                ("head_major", C.c_int32), ("drop", QstDrop)]
+
+
 class QstGemmArgs(C.Structure):
     _fields_ = [("A", vp), ("B", vp), ("C", vp), ("C2", vp), ("aux", vp), ("bias", vp), ("resid", vp),
                 ("colsum", vp), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32),
                 ("ldb", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32), ("splits", C.c_int32), ("bscale", vp),
-                ("a_head_L", C.c_int32), ("a_head_d", C.c_int32), ("c_head_L", C.c_int32), ("c_head_d", C.c_int32)]
+                ("a_head_L", C.c_int32), ("a_head_d", C.c_int32), ("c_head_L", C.c_int32), ("c_head_d", C.c_int32),
+                ("drop", QstDrop), ("drop_where", C.c_int32)]
 
 
 class QstLnEpi(C.Structure):
@@ -45,6 +57,11 @@ class QstLnEpi(C.Structure):
 class QstFfnArgs(C.Structure):
     _fields_ = [("A", vp), ("B1", vp), ("B2", vp), ("bias1", vp), ("bias2", vp), ("resid", vp), ("aux", vp),
                 ("save_gp", vp), ("save_h", vp), ("C", vp), ("C2", vp), ("M", C.c_int32), ("H", C.c_int32), ("I", C.c_int32)]
+
+
+class QstLnReduceBatch(C.Structure):
+    _fields_ = [("count", C.c_int32), ("H", C.c_int32), ("nblocks", C.c_int32), ("partials", vp * 32), ("dgamma", vp * 32),
+                ("dbeta", vp * 32), ("nblocks_each", C.c_int32 * 32)]
 
 
 class QstTnGroup(C.Structure):
@@ -101,20 +118,28 @@ SIGNATURES = {
     "qst_gemm_tn": (C.c_int, [C.POINTER(QstGemmArgs), vp]),
     "qst_gemm_tn_group": (C.c_int, [C.POINTER(QstTnGroup), vp]),
     "qst_embed_ln_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+    "qst_embed_ln_fwd_drop": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp,
+                                        C.POINTER(QstDrop), vp]),
     "qst_ln_fwd_mx": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "qst_embed_ln_fwd_mx": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "qst_ln_fwd": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "qst_ln_bwd_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "qst_ln_bwd_reduce_batch": (C.c_int, [vp, vp]),
     "qst_ln_bwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
+    "qst_ln_bwd_drop": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.POINTER(QstDrop), C.POINTER(QstDrop), vp]),
     "qst_embed_bwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "qst_position_ids": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "qst_pool_norm_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "qst_pool_norm_bwd": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "qst_attention_fwd": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "qst_attention_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
-    "qst_attention_fwd_hm": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
-    "qst_attention_bwd_hm": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "qst_attention_fwd_ex": (C.c_int, [C.POINTER(QstAttnDesc), vp]),
+    "qst_attention_bwd_ex": (C.c_int, [C.POINTER(QstAttnDesc), vp]),
+    "qst_dropout_multipliers": (C.c_int, [C.POINTER(QstDrop), C.c_int64, vp, vp]),
+    "qst_abi_sizeof": (C.c_int64, [C.c_int]),
+    "qst_dropout_init": (C.c_int, [vp, C.c_uint64, vp]),
+    "qst_dropout_advance": (C.c_int, [vp, vp]),
+    "qst_encoder_set_dropout": (C.c_int, [vp, C.c_float, C.c_float, vp]),
     "qst_rel_bucket_host": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "qst_rel_bias_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
     "qst_rel_bias_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),

@@ -120,13 +120,16 @@ struct AttnArgs {
     // (written by the QKV epilogue, QstGemmArgs.c_head_L): ld = d, woff = A L d, a head's q, k and v are contiguous
     // L x d blocks -- every load and store of these kernels moves whole lines.
     int ld; int64_t woff; int head_major;
+    // dropout of the probabilities (training): element ((seq * A + head) * L + query) * L + key of QstDrop's counter space;
+    // kernels instantiated with DROP recompute the mask wherever P or dP appears (nothing is stored)
+    QstDrop drop;
 };
 __device__ __forceinline__ size_t qkv_base(const AttnArgs& a, int seq, int head, int D) {
     return a.head_major ? ((size_t)seq * 3 * a.A + head) * a.L * D : (size_t)seq * a.L * a.ld + (size_t)head * D;
 }
 
 // ------------------------------------------------------------------ forward
-template <int D>
+template <int D, bool DROP = false>
 __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = D / 16, DB = D / 32, IMG = 128 * D * 2;
@@ -168,6 +171,8 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
     float m = -INFINITY, l = 0.f;
+    const DropCtx dc = DROP ? drop_ctx(a.drop) : DropCtx{0u, 0u, 1.f};
+    const uint32_t drow = ((uint32_t)(seq * a.A + head) * a.L + qi) * a.L;      // this lane's query row of the mask
 
     const int nchunk = (a.L + 127) / 128;
     for (int c = 0; c < nchunk; ++c) {
@@ -210,6 +215,16 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs
             ps += swap32(ps);
             l = l * alpha + ps;
             m = mn;
+            if (DROP && dc.thr) {
+                // dropped probabilities leave the P.V product only: l stays the full softmax denominator, the 1/(1-p)
+                // scale joins 1/l at the end. Registers r, r+1 (r even) are keys j, j+1 of one random word.
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const uint32_t b2 = drop_bits(dc, drow + j0 + acc_row(r, h));
+                    if (!drop_keep_lo(dc, b2)) s[r] = 0.f;
+                    if (!drop_keep_hi(dc, b2)) s[r + 1] = 0.f;
+                }
+            }
 #pragma unroll
             for (int b = 0; b < DB; ++b)
 #pragma unroll
@@ -226,7 +241,7 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs
         }
     }
     if (!active) return;
-    const float inv = 1.0f / l;
+    const float inv = dc.scale / l;
     // the wave's 32 x D output rows leave through a wave-private LDS staging area as 16-byte stores (four lanes cover
     // a row's 64-byte head slice); 8-byte-per-lane stores cost ~200 cycles each when every wave of the CU issues them
     char* stg = ostg + wave * (32 * D * 2);
@@ -251,7 +266,7 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs
 }
 
 // ------------------------------------------------------------------ backward: dQ
-template <int D>
+template <int D, bool DROP = false>
 __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dq_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = D / 16, DB = D / 32, IMG = 128 * D * 2;
@@ -295,6 +310,8 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dq_kernel(AttnA
     for (int b = 0; b < DB; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[b][r] = 0.f;
+    const DropCtx dc = DROP ? drop_ctx(a.drop) : DropCtx{0u, 0u, 1.f};
+    const uint32_t drow = ((uint32_t)(seq * a.A + head) * a.L + qi) * a.L;
 
     const int nchunk = (a.L + 127) / 128;
     for (int c = 0; c < nchunk; ++c) {
@@ -322,6 +339,15 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dq_kernel(AttnA
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);
             }
             const int j0 = c * 128 + jt * 32;
+            if (DROP && dc.thr) {
+                // dP = mask * dP~ (dp holds the gradient of the DROPPED probabilities); delta = dO.O is unchanged
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const uint32_t b2 = drop_bits(dc, drow + j0 + acc_row(r, h));
+                    dp[r] *= drop_keep_lo(dc, b2) ? dc.scale : 0.f;
+                    dp[r + 1] *= drop_keep_hi(dc, b2) ? dc.scale : 0.f;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = j0 + acc_row(r, h);
@@ -356,8 +382,8 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dq_kernel(AttnA
 }
 
 // ------------------------------------------------------------------ backward: dK, dV
-template <int D, bool REL>
-__global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+template <int D, bool REL, bool DROP = false>
+__global__ __launch_bounds__(256, (D == 32 && !DROP) ? 4 : 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = D / 16, DB = D / 32, IMG = 128 * D * 2;
     char* qimg = smem;                  // Q rows   (S = Q.K^T)
@@ -398,6 +424,8 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dkv_kernel(Attn
     for (int b = 0; b < DB; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[b][r] = 0.f; dv[b][r] = 0.f; }
+    const DropCtx dc = DROP ? drop_ctx(a.drop) : DropCtx{0u, 0u, 1.f};
+    const uint32_t dhead = (uint32_t)(seq * a.A + head) * a.L;            // mask row of query i: (dhead + i) * L
 
     const int nchunk = (a.L + 127) / 128;
     for (int c = 0; c < nchunk; ++c) {
@@ -443,8 +471,14 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dkv_kernel(Attn
                     if (REL) v += relv[kj - i + a.L];
                     v += madd;
                     const float pr = __expf(v - l4[e]);
-                    const float dsr = pr * (dp[r] - d4[e]);                    // dS (unscaled) = d(score)
-                    p[r] = pr;
+                    float mk = 1.f;
+                    if (DROP && dc.thr) {
+                        // this lane's key is one half of the random word of (query i, keys kj & ~1, kj | 1)
+                        const uint32_t b2 = drop_bits(dc, (dhead + (uint32_t)i) * a.L + (uint32_t)(kj & ~1));
+                        mk = ((kj & 1) ? drop_keep_hi(dc, b2) : drop_keep_lo(dc, b2)) ? dc.scale : 0.f;
+                    }
+                    const float dsr = pr * (dp[r] * mk - d4[e]);               // dS (unscaled) = d(score)
+                    p[r] = pr * mk;                                            // dV takes the dropped probabilities
                     s[r] = REL ? dsr : dsr * a.scale;                          // REL: unscaled until the bias gradient is taken
                 }
             }
@@ -508,7 +542,7 @@ constexpr int DS_IMG = 128 * 128 * 2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ uint32_t ds_off(int row, int byte) { return (uint32_t)(row * 256 + (byte ^ ((row & 3) << 6))); }
 
-template <int D, bool REL>
+template <int D, bool REL, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = D / 16, DB = D / 32, IMG = 128 * D * 2, CPR = D / 8, PER = 128 * CPR / 256;
@@ -593,10 +627,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
     const int nunits = paired ? nitems / 2 : nitems;
     auto item_of = [&](int unit) { return paired ? 2 * unit + bsub : unit; };
     int unit = bp, iter = 0;
+    const DropCtx dc = DROP ? drop_ctx(a.drop) : DropCtx{0u, 0u, 1.f};
     if (unit < nunits) prefetch(item_of(unit), -1);
     for (; unit < nunits; unit += stride, ++iter) {
         const int item = item_of(unit);
         const int head = item % a.A, seq = item / a.A;
+        const uint32_t dhead = (uint32_t)(seq * a.A + head) * a.L;       // mask row of query i: (dhead + i) * L
         __syncthreads();                                 // the previous item's readers of the images are done
         QST_STAMP(0);
         const float madd2 = nmadd * kLog2e;              // 0 or -inf
@@ -684,6 +720,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
                         f32x2 pr;
                         pr[0] = __builtin_amdgcn_exp2f(v[0]);
                         pr[1] = __builtin_amdgcn_exp2f(v[1]);
+                        if (DROP && dc.thr) {
+                            // dP = mask * dP~ and dV takes the dropped probabilities; this lane's key is one half of the
+                            // random word of (query, keys kj & ~1, kj | 1)
+                            const uint32_t e0 = (dhead + (uint32_t)(il + e)) * a.L + (uint32_t)(kj & ~1);
+                            const uint32_t b0 = drop_bits(dc, e0), b1 = drop_bits(dc, e0 + a.L);
+                            f32x2 mk;
+                            mk[0] = ((kj & 1) ? drop_keep_hi(dc, b0) : drop_keep_lo(dc, b0)) ? dc.scale : 0.f;
+                            mk[1] = ((kj & 1) ? drop_keep_hi(dc, b1) : drop_keep_lo(dc, b1)) ? dc.scale : 0.f;
+                            dpv *= mk;
+                            const f32x2 dsd = pr * (dpv - dv2);
+                            if (REL && a.drel) { diag_add(dsd[0], r, lane, dlo, dhi); diag_add(dsd[1], r + 1, lane, dlo, dhi); }
+                            pr *= mk;
+                            pw[g][e >> 1] = pack_bf16x2(pr[0], pr[1]);
+                            sw[g][e >> 1] = pack_bf16x2(dsd[0], dsd[1]);
+                            continue;
+                        }
                         const f32x2 dsr = pr * (dpv - dv2);                       // dS (unscaled) = d(score)
                         if (REL && a.drel) { diag_add(dsr[0], r, lane, dlo, dhi); diag_add(dsr[1], r + 1, lane, dlo, dhi); }
                         pw[g][e >> 1] = pack_bf16x2(pr[0], pr[1]);
@@ -796,81 +848,89 @@ static int check_attn(int nseq, int L, int A, int d) {
     return QST_OK;
 }
 
-static int attention_fwd(const void* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A,
-                         int d, void* ctx, float* lse, void* stream, int head_major) {
-    if (!qkv || !mask || !ctx) return QST_ERR_BAD_ARG;
-    int rc = check_attn(nseq, L, A, d);
-    if (rc) return rc;
-    AttnArgs a{};
-    a.qkv = (const bf16*)qkv; a.mask = mask; a.rel = rel_bias; a.out = (bf16*)ctx; a.lse_out = lse;
-    a.nseq = nseq; a.L = L; a.A = A; a.H = A * d; a.scale = 1.0f / sqrtf((float)d);
-    if (head_major) { a.ld = d; a.woff = (int64_t)A * L * d; a.head_major = 1; }
+static int fill_args(const QstAttnDesc* q, AttnArgs& a) {
+    if (!q || !q->qkv || !q->mask || !q->ctx) return QST_ERR_BAD_ARG;
+    if (int rc = check_attn(q->nseq, q->L, q->A, q->d)) return rc;
+    a.qkv = (const bf16*)q->qkv; a.mask = q->mask; a.rel = q->rel_pos;
+    a.nseq = q->nseq; a.L = q->L; a.A = q->A; a.H = q->A * q->d; a.scale = 1.0f / sqrtf((float)q->d);
+    if (q->head_major) { a.ld = q->d; a.woff = (int64_t)q->A * q->L * q->d; a.head_major = 1; }
     else { a.ld = 3 * a.H; a.woff = a.H; a.head_major = 0; }
+    a.drop = q->drop;
+    if (a.drop.thr16 > 65535u) return QST_ERR_BAD_ARG;
+    if (!a.drop.state) a.drop.thr16 = 0u;
+    if (a.drop.thr16 && (int64_t)q->nseq * q->A * q->L * q->L >= ((int64_t)1 << 32)) return QST_ERR_UNSUPPORTED;
+    return QST_OK;
+}
+
+extern "C" int qst_attention_fwd_ex(const QstAttnDesc* q, void* stream) {
+    AttnArgs a{};
+    if (int rc = fill_args(q, a)) return rc;
+    a.out = (bf16*)q->ctx; a.lse_out = q->lse;
+    const int nseq = a.nseq, L = a.L, A = a.A, d = q->d;
+    const bool rel = a.rel != nullptr, drop = a.drop.thr16 != 0u;
+    int rc;
     const int grid = nseq * A * ((L + 127) / 128);
     const size_t lds = (size_t)2 * 128 * d * 2 + (((size_t)L * 4 + 15) & ~(size_t)15) + (size_t)4 * 32 * d * 2 +
-                       (rel_bias ? (size_t)2 * L * 4 : 0);
+                       (rel ? (size_t)2 * L * 4 : 0);
     hipStream_t st = (hipStream_t)stream;
-    if (d == 32) { if ((rc = set_lds(attn_fwd_kernel<32>, lds))) return rc; attn_fwd_kernel<32><<<grid, 256, lds, st>>>(a); }
-    else         { if ((rc = set_lds(attn_fwd_kernel<64>, lds))) return rc; attn_fwd_kernel<64><<<grid, 256, lds, st>>>(a); }
+#define QST_FWD(D_, DR_) do { if ((rc = set_lds(attn_fwd_kernel<D_, DR_>, lds))) return rc; \
+                              attn_fwd_kernel<D_, DR_><<<grid, 256, lds, st>>>(a); } while (0)
+    if (d == 32) { if (drop) QST_FWD(32, true); else QST_FWD(32, false); }
+    else         { if (drop) QST_FWD(64, true); else QST_FWD(64, false); }
+#undef QST_FWD
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
 
-static int attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse,
-                         const int64_t* mask, const float* rel_bias, int nseq, int L, int A, int d,
-                         void* dqkv, float* drel, float* delta_scratch, void* stream, int head_major) {
-    if (!qkv || !ctx || !dctx || !lse || !mask || !dqkv || !delta_scratch) return QST_ERR_BAD_ARG;
-    if (drel && !rel_bias) return QST_ERR_BAD_ARG;
-    int rc = check_attn(nseq, L, A, d);
-    if (rc) return rc;
+extern "C" int qst_attention_bwd_ex(const QstAttnDesc* q, void* stream) {
     AttnArgs a{};
-    a.qkv = (const bf16*)qkv; a.ctx = (const bf16*)ctx; a.dctx = (const bf16*)dctx; a.lse_in = lse; a.mask = mask;
-    a.rel = rel_bias; a.dqkv = (bf16*)dqkv; a.drel = drel; a.delta = delta_scratch;
-    a.nseq = nseq; a.L = L; a.A = A; a.H = A * d; a.scale = 1.0f / sqrtf((float)d);
-    if (head_major) { a.ld = d; a.woff = (int64_t)A * L * d; a.head_major = 1; }
-    else { a.ld = 3 * a.H; a.woff = a.H; a.head_major = 0; }
+    if (int rc = fill_args(q, a)) return rc;
+    if (!q->dctx || !q->lse || !q->dqkv || !q->delta_scratch) return QST_ERR_BAD_ARG;
+    if (q->drel && !q->rel_pos) return QST_ERR_BAD_ARG;
+    a.ctx = (const bf16*)q->ctx; a.dctx = (const bf16*)q->dctx; a.lse_in = q->lse;
+    a.dqkv = (bf16*)q->dqkv; a.drel = q->drel; a.delta = q->delta_scratch;
+    const int nseq = a.nseq, L = a.L, A = a.A, d = q->d;
+    const bool rel = a.rel != nullptr, drop = a.drop.thr16 != 0u;
+    int rc;
     const int grid = nseq * A * ((L + 127) / 128);
-    const size_t lds_q = (size_t)3 * 128 * d * 2 + (((size_t)L + 3) & ~(size_t)3) * 4 + (rel_bias ? (size_t)2 * L * 4 : 0);
-    const size_t lds_kv = (size_t)4 * 128 * d * 2 + 256 * 4 + (rel_bias ? (size_t)10 * L * 4 : 0);
+    const size_t lds_q = (size_t)3 * 128 * d * 2 + (((size_t)L + 3) & ~(size_t)3) * 4 + (rel ? (size_t)2 * L * 4 : 0);
+    const size_t lds_kv = (size_t)4 * 128 * d * 2 + 256 * 4 + (rel ? (size_t)10 * L * 4 : 0);
     hipStream_t st = (hipStream_t)stream;
+#define QST_RUN(K_, G_, LDS_) do { if ((rc = set_lds(K_, LDS_))) return rc; K_<<<G_, 256, LDS_, st>>>(a); QST_LAUNCH_CHECK(); } while (0)
     if (L <= 128 && d == 32 && !g_attn_force_split) {
         // one workgroup per (sequence, head) computes dQ, dK and dV from a single evaluation of the score tile
-        const size_t lds_f = (size_t)5 * 128 * d * 2 + DS_IMG + 256 * 4 + (rel_bias ? (size_t)10 * L * 4 : 0);
-        if (rel_bias) {
-            if ((rc = set_lds(attn_bwd_fused_kernel<32, true>, lds_f))) return rc;
-            attn_bwd_fused_kernel<32, true><<<min(nseq * A, 512), 256, lds_f, st>>>(a);
-        } else {
-            if ((rc = set_lds(attn_bwd_fused_kernel<32, false>, lds_f))) return rc;
-            attn_bwd_fused_kernel<32, false><<<min(nseq * A, 512), 256, lds_f, st>>>(a);      // two per CU, persistent
-        }
-        QST_LAUNCH_CHECK();
+        const size_t lds_f = (size_t)5 * 128 * d * 2 + DS_IMG + 256 * 4 + (rel ? (size_t)10 * L * 4 : 0);
+        const int gf = min(nseq * A, 512);                                            // two per CU, persistent
+        if (rel) { if (drop) QST_RUN((attn_bwd_fused_kernel<32, true, true>), gf, lds_f); else QST_RUN((attn_bwd_fused_kernel<32, true, false>), gf, lds_f); }
+        else     { if (drop) QST_RUN((attn_bwd_fused_kernel<32, false, true>), gf, lds_f); else QST_RUN((attn_bwd_fused_kernel<32, false, false>), gf, lds_f); }
         return QST_OK;
     }
     if (d == 32) {
-        if ((rc = set_lds(attn_bwd_dq_kernel<32>, lds_q))) return rc;
-        attn_bwd_dq_kernel<32><<<grid, 256, lds_q, st>>>(a);
-        QST_LAUNCH_CHECK();
-        if (rel_bias) {
-            if ((rc = set_lds(attn_bwd_dkv_kernel<32, true>, lds_kv))) return rc;
-            attn_bwd_dkv_kernel<32, true><<<grid, 256, lds_kv, st>>>(a);
-        } else {
-            if ((rc = set_lds(attn_bwd_dkv_kernel<32, false>, lds_kv))) return rc;
-            attn_bwd_dkv_kernel<32, false><<<grid, 256, lds_kv, st>>>(a);
-        }
+        if (drop) QST_RUN((attn_bwd_dq_kernel<32, true>), grid, lds_q); else QST_RUN((attn_bwd_dq_kernel<32, false>), grid, lds_q);
+        if (rel) { if (drop) QST_RUN((attn_bwd_dkv_kernel<32, true, true>), grid, lds_kv); else QST_RUN((attn_bwd_dkv_kernel<32, true, false>), grid, lds_kv); }
+        else     { if (drop) QST_RUN((attn_bwd_dkv_kernel<32, false, true>), grid, lds_kv); else QST_RUN((attn_bwd_dkv_kernel<32, false, false>), grid, lds_kv); }
     } else {
-        if ((rc = set_lds(attn_bwd_dq_kernel<64>, lds_q))) return rc;
-        attn_bwd_dq_kernel<64><<<grid, 256, lds_q, st>>>(a);
-        QST_LAUNCH_CHECK();
-        if (rel_bias) {
-            if ((rc = set_lds(attn_bwd_dkv_kernel<64, true>, lds_kv))) return rc;
-            attn_bwd_dkv_kernel<64, true><<<grid, 256, lds_kv, st>>>(a);
-        } else {
-            if ((rc = set_lds(attn_bwd_dkv_kernel<64, false>, lds_kv))) return rc;
-            attn_bwd_dkv_kernel<64, false><<<grid, 256, lds_kv, st>>>(a);
-        }
+        if (drop) QST_RUN((attn_bwd_dq_kernel<64, true>), grid, lds_q); else QST_RUN((attn_bwd_dq_kernel<64, false>), grid, lds_q);
+        if (rel) { if (drop) QST_RUN((attn_bwd_dkv_kernel<64, true, true>), grid, lds_kv); else QST_RUN((attn_bwd_dkv_kernel<64, true, false>), grid, lds_kv); }
+        else     { if (drop) QST_RUN((attn_bwd_dkv_kernel<64, false, true>), grid, lds_kv); else QST_RUN((attn_bwd_dkv_kernel<64, false, false>), grid, lds_kv); }
     }
-    QST_LAUNCH_CHECK();
+#undef QST_RUN
     return QST_OK;
+}
+
+extern "C" int qst_attention_fwd(const void* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A,
+                                 int d, void* ctx, float* lse, void* stream) {
+    QstAttnDesc q{};
+    q.qkv = qkv; q.mask = mask; q.rel_pos = rel_bias; q.nseq = nseq; q.L = L; q.A = A; q.d = d; q.ctx = ctx; q.lse = lse;
+    return qst_attention_fwd_ex(&q, stream);
+}
+extern "C" int qst_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse,
+                                 const int64_t* mask, const float* rel_bias, int nseq, int L, int A, int d,
+                                 void* dqkv, float* drel, float* delta_scratch, void* stream) {
+    QstAttnDesc q{};
+    q.qkv = qkv; q.mask = mask; q.rel_pos = rel_bias; q.nseq = nseq; q.L = L; q.A = A; q.d = d; q.ctx = (void*)ctx;
+    q.lse = (float*)lse; q.dctx = dctx; q.dqkv = dqkv; q.drel = drel; q.delta_scratch = delta_scratch;
+    return qst_attention_bwd_ex(&q, stream);
 }
 
 extern "C" void qst_debug_attn_force_split(int on) { g_attn_force_split = on; }
@@ -882,23 +942,4 @@ extern "C" int qst_debug_attn_occupancy(int which, int lds_bytes) {
     if (which == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dq_kernel<32>, 256, lds_bytes);
     if (which == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dkv_kernel<32, false>, 256, lds_bytes);
     return n;
-}
-
-extern "C" int qst_attention_fwd(const void* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A,
-                                 int d, void* ctx, float* lse, void* stream) {
-    return attention_fwd(qkv, mask, rel_bias, nseq, L, A, d, ctx, lse, stream, 0);
-}
-extern "C" int qst_attention_fwd_hm(const void* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A,
-                                    int d, void* ctx, float* lse, void* stream) {
-    return attention_fwd(qkv, mask, rel_bias, nseq, L, A, d, ctx, lse, stream, 1);
-}
-extern "C" int qst_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse,
-                                 const int64_t* mask, const float* rel_bias, int nseq, int L, int A, int d,
-                                 void* dqkv, float* drel, float* delta_scratch, void* stream) {
-    return attention_bwd(qkv, ctx, dctx, lse, mask, rel_bias, nseq, L, A, d, dqkv, drel, delta_scratch, stream, 0);
-}
-extern "C" int qst_attention_bwd_hm(const void* qkv, const void* ctx, const void* dctx, const float* lse,
-                                    const int64_t* mask, const float* rel_bias, int nseq, int L, int A, int d,
-                                    void* dqkv, float* drel, float* delta_scratch, void* stream) {
-    return attention_bwd(qkv, ctx, dctx, lse, mask, rel_bias, nseq, L, A, d, dqkv, drel, delta_scratch, stream, 1);
 }

@@ -255,6 +255,8 @@ __device__ __forceinline__ void nt_epilogue(const QstGemmArgs& g, f32x16 (&acc)[
                                             int m_base, int n_base, int lane, const float* scale_s = nullptr) {
     const int fr = lane & 31, fh = lane >> 5;
     constexpr bool kF32Out = (EPI == QST_EPI_F32_RESID || EPI == QST_EPI_F32_RESID_BF16);
+    DropCtx dc = DropCtx{0u, 0u, 1.f};               // dropout of the projection output, before the residual (QstGemmArgs)
+    if (kF32Out && g.drop_where == 1) dc = drop_ctx(g.drop);
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
         if (kF32Out) {
@@ -289,6 +291,13 @@ __device__ __forceinline__ void nt_epilogue(const QstGemmArgs& g, f32x16 (&acc)[
                 f32x4 v = *(const f32x4*)(stg + row * NT_STG_LD + c4 * 4);
                 if (scale_s) v *= *(const f32x4*)(scale_s + c4 * 4);
                 if (g.bias) v += *(const f32x4*)(bias_s + c4 * 4);
+                if (dc.thr) {
+                    const uint32_t e = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+                    float k0, k1, k2, k3;
+                    drop_pair(dc, e, k0, k1);
+                    drop_pair(dc, e + 2, k2, k3);
+                    v[0] *= k0; v[1] *= k1; v[2] *= k2; v[3] *= k3;
+                }
                 v += rv[t];
                 const size_t o = (size_t)m * g.ldc + n;
                 *(f32x4*)((float*)g.C + o) = v;
@@ -748,7 +757,7 @@ constexpr int LN_N = 384, LN_LD = 388;               // slab row stride 1552 B: 
 constexpr int LN_RING = 2 * (128 + LN_N) * NBK * 2;  // the K-loop ring (128 KB); the epilogue slabs reuse 99 KB of it
 constexpr int LN_LDS = LN_RING + 3 * LN_N * 4;       // + bias / gamma / beta, loaded before the K loop
 
-template <int MODE>
+template <int MODE, bool DROP = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLnEpi e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -812,6 +821,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
 #pragma unroll
     for (int t = 0; t < 3; ++t) { ag[t][0] = ag[t][1] = ab[t][0] = ab[t][1] = 0.f; }
     const float inv_n = 1.f / (float)LN_N;
+    // dropout (QstGemmArgs.drop_where): mode 0: the projection output before the residual (1); mode 1: the bf16 copy of the
+    // result (2) or the incoming gradient (3). Masks are recomputed from (state, site, m * 384 + n), never stored.
+    // (a separate instantiation: the backward epilogue has no registers to spare -- 252 of 256 without it)
+    const DropCtx dc = DROP ? drop_ctx(g.drop) : DropCtx{0u, 0u, 1.f};
+    const int dwhere = (DROP && dc.thr) ? g.drop_where : 0;
 
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -827,7 +841,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
             }
         __syncthreads();                                     // slab complete
         LN_STAMP(3 + 2 * i);
-        if (i == 0) LN_PREFETCH(1);                          // pass 1's rows travel while pass 0 is normalised and stored
+        if (i == 0 && !(DROP && MODE == 1)) LN_PREFETCH(1);  // pass 1's rows travel while pass 0 is normalised and stored
+        if (i == 1 && DROP && MODE == 1) LN_PREFETCH(1);     // (the masked backward variant cannot hold both passes' rows)
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int row = wn * 8 + k;
@@ -840,8 +855,14 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     const f32x2 b = *(const f32x2*)(vec_s + 2 * (lane + 64 * t));
-                    v[t][0] = (v[t][0] + b[0]) + rv[i][k][t][0];        // same association as the unfused epilogue
-                    v[t][1] = (v[t][1] + b[1]) + rv[i][k][t][1];
+                    v[t][0] += b[0]; v[t][1] += b[1];
+                    if (DROP && dwhere == 1) {
+                        float k0, k1;
+                        drop_pair(dc, (uint32_t)m * LN_N + 2 * (lane + 64 * t), k0, k1);
+                        v[t][0] *= k0; v[t][1] *= k1;
+                    }
+                    v[t][0] += rv[i][k][t][0];                          // same association as the unfused epilogue
+                    v[t][1] += rv[i][k][t][1];
                     s += v[t][0] + v[t][1];
                 }
                 const float mean = wave_sum(s) * inv_n;
@@ -876,6 +897,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
                     x[t][0] = bf16lo(xv[i][k][t]); x[t][1] = bf16hi(xv[i][k][t]);
                     v[t][0] += rv[i][k][t][0];                        // dy = dgrad + residual-path gradient
                     v[t][1] += rv[i][k][t][1];
+                    if (DROP && dwhere == 3) {
+                        float k0, k1;
+                        drop_pair(dc, (uint32_t)m * LN_N + 2 * (lane + 64 * t), k0, k1);
+                        v[t][0] *= k0; v[t][1] *= k1;
+                    }
                     ag[t][0] += v[t][0] * x[t][0]; ag[t][1] += v[t][1] * x[t][1];
                     ab[t][0] += v[t][0];           ab[t][1] += v[t][1];
                     v[t][0] *= ga[0]; v[t][1] *= ga[1];            // dxhat
@@ -891,7 +917,14 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
                         o[0] = rs[i][k] * (v[t][0] - m1 - x[t][0] * m2);
                         o[1] = rs[i][k] * (v[t][1] - m1 - x[t][1] * m2);
                         *(f32x2*)((float*)g.C + (size_t)m * g.ldc + c) = o;
-                        if (g.C2) *(uint32_t*)((bf16*)g.C2 + (size_t)m * g.ldc + c) = pack_bf16x2(o[0], o[1]);
+                        if (g.C2) {
+                            if (DROP && dwhere == 2) {
+                                float k0, k1;
+                                drop_pair(dc, (uint32_t)m * LN_N + c, k0, k1);
+                                o[0] *= k0; o[1] *= k1;
+                            }
+                            *(uint32_t*)((bf16*)g.C2 + (size_t)m * g.ldc + c) = pack_bf16x2(o[0], o[1]);
+                        }
                     }
                 }
             }
@@ -1169,6 +1202,10 @@ extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
     if (a->K % NBK != 0 || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->N % 4 != 0 || a->ldc % 4 != 0) return QST_ERR_UNSUPPORTED;
     if ((int64_t)256 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)384 * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
     if (int rc = check_heads(a, a->lda == a->K, true, epi)) return rc;
+    if (a->drop.thr16 && a->drop.state) {
+        if (a->drop_where != 1 || (epi != QST_EPI_F32_RESID && epi != QST_EPI_F32_RESID_BF16)) return QST_ERR_BAD_ARG;
+        if (a->drop.thr16 > 65535u || (int64_t)a->M * a->N >= ((int64_t)1 << 32)) return QST_ERR_UNSUPPORTED;
+    }
     hipStream_t st = (hipStream_t)stream;
     // Two 128-row workgroups per CU beat one 256-row workgroup on every shape of the step (their MFMA and
     // store phases interleave); a->splits (unused by nt otherwise) can force the tile height: 1 = 128, 2 = 256 rows.
@@ -1274,10 +1311,22 @@ extern "C" int qst_gemm_nt_ln(const QstGemmArgs* a, const QstLnEpi* ln, int mode
         return QST_ERR_UNSUPPORTED;
     if ((int64_t)128 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)LN_N * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
     if (int rc = check_heads(a, a->lda == a->K, false, -1)) return rc;
-    static QstLdsAttr attr0, attr1;
+    if (a->drop.thr16 && a->drop.state) {
+        if (a->drop.thr16 > 65535u || (int64_t)a->M * a->N >= ((int64_t)1 << 32)) return QST_ERR_UNSUPPORTED;
+        if (mode == 0 ? a->drop_where != 1 : (a->drop_where != 2 && a->drop_where != 3)) return QST_ERR_BAD_ARG;
+    }
+    static QstLdsAttr attr0, attr1, attr0d, attr1d;
+    const int ntm = (a->M + 127) / 128;
+    if (a->drop.thr16 && a->drop.state) {
+        if (int rc = qst_ensure_lds(attr0d, (const void*)gemm_nt_ln_kernel<0, true>, LN_LDS)) return rc;
+        if (int rc = qst_ensure_lds(attr1d, (const void*)gemm_nt_ln_kernel<1, true>, LN_LDS)) return rc;
+        if (mode == 0) gemm_nt_ln_kernel<0, true><<<dim3(ntm), dim3(512), LN_LDS, (hipStream_t)stream>>>(*a, *ln);
+        else gemm_nt_ln_kernel<1, true><<<dim3(ntm), dim3(512), LN_LDS, (hipStream_t)stream>>>(*a, *ln);
+        QST_LAUNCH_CHECK();
+        return QST_OK;
+    }
     if (int rc = qst_ensure_lds(attr0, (const void*)gemm_nt_ln_kernel<0>, LN_LDS)) return rc;
     if (int rc = qst_ensure_lds(attr1, (const void*)gemm_nt_ln_kernel<1>, LN_LDS)) return rc;
-    const int ntm = (a->M + 127) / 128;
     if (mode == 0) gemm_nt_ln_kernel<0><<<dim3(ntm), dim3(512), LN_LDS, (hipStream_t)stream>>>(*a, *ln);
     else gemm_nt_ln_kernel<1><<<dim3(ntm), dim3(512), LN_LDS, (hipStream_t)stream>>>(*a, *ln);
     QST_LAUNCH_CHECK();

@@ -114,6 +114,10 @@ struct qst_encoder {
     int32_t* rel_lut = nullptr;       // device: MPNet bucket of (j - i), index (j - i) + 511
     int64_t* shadow_tab = nullptr;    // device: one row per GEMM weight for qst_shadow_all
     int shadow_nseg = 0, shadow_blocks = 0;
+    // dropout (qst_encoder_set_dropout): 16-bit thresholds of the hidden-state and attention-probability masks, and the
+    // caller's device counter {seed lo, seed hi, step, 0} that every training forward advances
+    uint32_t drop_hidden = 0, drop_attn = 0;
+    uint32_t* drop_state = nullptr;
 };
 
 extern "C" int64_t qst_arena_elems(const qst_config* cfg) { return cfg_ok(cfg) ? build_layout(cfg).total : QST_ERR_BAD_ARG; }
@@ -226,6 +230,7 @@ struct LayerAct {
 };
 struct ActPlan {
     size_t pos_ids, x0, x0b, xh0, rs0, s_scratch, pooled, rel;
+    size_t dropst;          // uint32[4]: the dropout counter as THIS forward used it (backward rebuilds the masks from it)
     std::vector<LayerAct> layers;
     size_t total;
 };
@@ -236,6 +241,7 @@ ActPlan plan_acts(const qst_config& c, int nseq, int L, bool training) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     p.pos_ids = take(M * 4);
+    p.dropst = take(16);
     p.x0 = take(M * H * 4); p.x0b = take(M * H * 2); p.xh0 = take(M * H * 2); p.rs0 = take(M * 4);
     p.s_scratch = take(M * H * 4);
     p.pooled = take((size_t)nseq * H * 4);
@@ -335,9 +341,35 @@ int nt3(const float* A, int lda, const float* B, int ldb, float* C, int ldc, con
 struct HeadLayout { int aL, ad, cL, cd; };
 static thread_local HeadLayout t_heads = {0, 0, 0, 0};
 static int g_head_major = 0;
+// ... and the dropout mask of their next call the same way (drop_next; QstGemmArgs.drop / drop_where)
+struct DropNext { QstDrop d; int where; };
+static thread_local DropNext t_drop = {{nullptr, 0u, 0u}, 0};
+// `state` = the counter copy inside the activation arena of the forward at hand: several training forwards may be live
+// before their backwards run (fit() encodes the four columns one after the other), each with its own step value
+static QstDrop drop_of(const qst_encoder* e, const void* state, bool attn, uint32_t site) {
+    QstDrop d = {nullptr, site, 0u};
+    const uint32_t thr = attn ? e->drop_attn : e->drop_hidden;
+    if (e->drop_state && thr) { d.state = (const uint32_t*)state; d.thr16 = thr; }
+    return d;
+}
+static void drop_next(const qst_encoder* e, const void* state, bool on, uint32_t site, int where) {
+    t_drop = DropNext{{nullptr, 0u, 0u}, 0};
+    if (on && e->drop_state && e->drop_hidden) t_drop = DropNext{drop_of(e, state, false, site), where};
+}
 static void take_heads(QstGemmArgs& g) {
     g.a_head_L = t_heads.aL; g.a_head_d = t_heads.ad; g.c_head_L = t_heads.cL; g.c_head_d = t_heads.cd;
     t_heads = HeadLayout{0, 0, 0, 0};
+    g.drop = t_drop.d; g.drop_where = t_drop.where;
+    t_drop = DropNext{{nullptr, 0u, 0u}, 0};
+}
+extern "C" int qst_encoder_set_dropout(qst_encoder* e, float p_hidden, float p_attn, uint32_t* state_dev) {
+    if (!e || !(p_hidden >= 0.f && p_hidden < 1.f) || !(p_attn >= 0.f && p_attn < 1.f)) return QST_ERR_BAD_ARG;
+    if ((p_hidden > 0.f || p_attn > 0.f) && !state_dev) return QST_ERR_BAD_ARG;
+    if ((p_hidden > 0.f || p_attn > 0.f) && e->cfg.precision != QST_PREC_BF16) return QST_ERR_UNSUPPORTED;   // training path only
+    auto thr = [](float p) { const long t = lroundf(p * 65536.f); return (uint32_t)(t > 65535 ? 65535 : t); };
+    e->drop_hidden = thr(p_hidden); e->drop_attn = thr(p_attn);
+    e->drop_state = (e->drop_hidden || e->drop_attn) ? state_dev : nullptr;
+    return QST_OK;
 }
 static void heads_c(bool on, int L, int d) { if (on) { t_heads.cL = L; t_heads.cd = d; } }
 static void heads_a(bool on, int L, int d) { if (on) { t_heads.aL = L; t_heads.ad = d; } }
@@ -481,7 +513,12 @@ static int forward_mx(qst_encoder* e, const int64_t* ids, const int64_t* mask, c
         float* xn = (float*)(sv + p.x[(l + 1) & 1]);
         heads_c(hm, L, d);
         QST_TRY(gemm(sv + p.xq, sv + p.xs, H, b + W_QKV, sv + p.qkv, nullptr, 3 * H, b + B_QKV, nullptr, QST_EPI_BF16));
-        QST_TRY((hm ? qst_attention_fwd_hm : qst_attention_fwd)(sv + p.qkv, mask, rel, nseq, L, A, d, sv + p.ctx, nullptr, st));
+        {
+            QstAttnDesc q{};
+            q.qkv = sv + p.qkv; q.mask = mask; q.rel_pos = rel; q.nseq = nseq; q.L = L; q.A = A; q.d = d;
+            q.ctx = sv + p.ctx; q.head_major = hm;
+            QST_TRY(qst_attention_fwd_ex(&q, st));
+        }
         QST_TRY(qst_quant_mx(sv + p.ctx, 1, M, H, sv + p.cq, sv + p.cs, st));
         QST_TRY(gemm(sv + p.cq, sv + p.cs, H, b + W_O, s, nullptr, H, b + B_O, x, QST_EPI_F32_RESID));
         QST_TRY(qst_ln_fwd_mx(s, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, y1, nullptr, sv + p.yq, sv + p.ys, st));
@@ -571,9 +608,19 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
 
     int32_t* pos_ids = (int32_t*)(sv + p.pos_ids);
     QST_TRY(qst_position_ids(ids, nseq, L, c.arch, c.pad_token_id, pos_ids, st));
-    QST_TRY(qst_embed_ln_fwd(ids, type_ids, pos_ids, P(lay.word), P(lay.pos), lay.type >= 0 ? P(lay.type) : nullptr,
-                             P(lay.eg), P(lay.eb), c.layer_norm_eps, M, H, (float*)(sv + p.x0), sv + p.x0b,
-                             sv + p.xh0, (float*)(sv + p.rs0), st));
+    // dropout: training forwards of a handle that has it on; the step counter moves first, backward reuses its value
+    const bool dropping = training && e->drop_state != nullptr;
+    const void* dst8 = sv + p.dropst;
+    if (dropping) {
+        QST_TRY(qst_dropout_advance(e->drop_state, st));
+        QST_HIP_CHECK(hipMemcpyAsync(sv + p.dropst, e->drop_state, 16, hipMemcpyDeviceToDevice, st));
+    }
+    {
+        const QstDrop de = drop_of(e, dst8, false, QST_DROP_SITE_EMBED);
+        QST_TRY(qst_embed_ln_fwd_drop(ids, type_ids, pos_ids, P(lay.word), P(lay.pos), lay.type >= 0 ? P(lay.type) : nullptr,
+                                      P(lay.eg), P(lay.eb), c.layer_norm_eps, M, H, (float*)(sv + p.x0), sv + p.x0b,
+                                      sv + p.xh0, (float*)(sv + p.rs0), dropping ? &de : nullptr, st));
+    }
     const float* rel = nullptr;
     if (c.arch == QST_ARCH_MPNET) {
         QST_TRY(qst_rel_pos_fwd(P(lay.rel), e->rel_lut, A, L, (float*)(sv + p.rel), st));
@@ -589,15 +636,21 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     t_heads = HeadLayout{0, 0, 0, 0};
     // ... and the whole feed-forward block (FFN-1, GELU, FFN-2, LayerNorm) is ONE kernel: h never returns from HBM, and
     // an inference forward does not write it at all
-    const bool fuse_ffn = fuse_ln && (g_fuse_ffn & (training ? 2 : 1)) && qst_ffn_chain_supported(H, I) != 0;
+    const bool fuse_ffn = fuse_ln && !dropping && (g_fuse_ffn & (training ? 2 : 1)) && qst_ffn_chain_supported(H, I) != 0;
     const bool hm = g_head_major != 0;
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerAct& a = p.layers[l];
         const int b = lay.layer0[l];
         heads_c(hm, L, d);
         QST_TRY(linear(xb, H, b + W_QKV, sv + a.qkv, 3 * H, nullptr, b + B_QKV, nullptr, QST_EPI_BF16));
-        QST_TRY((hm ? qst_attention_fwd_hm : qst_attention_fwd)(sv + a.qkv, mask, rel, nseq, L, A, d, sv + a.ctx,
-                                                               (float*)(sv + a.lse), st));
+        {
+            QstAttnDesc q{};
+            q.qkv = sv + a.qkv; q.mask = mask; q.rel_pos = rel; q.nseq = nseq; q.L = L; q.A = A; q.d = d;
+            q.ctx = sv + a.ctx; q.lse = (float*)(sv + a.lse); q.head_major = hm;
+            if (dropping) q.drop = drop_of(e, dst8, true, QST_DROP_SITE_PROBS(l));
+            QST_TRY(qst_attention_fwd_ex(&q, st));
+        }
+        drop_next(e, dst8, dropping, QST_DROP_SITE_ATTN_OUT(l), 1);
         if (fuse_ln) {
             QST_TRY(nt_ln(sv + a.ctx, H, W(b + W_O), H, (float*)(sv + a.y1), sv + a.y1b, P(b + B_O), x, M, H, H, 0,
                           P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, sv + a.xh1, (float*)(sv + a.rs1), nullptr, st));
@@ -616,6 +669,7 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
             continue;
         }
         QST_TRY(linear(sv + a.y1b, H, b + W_1, sv + a.u, I, sv + a.hact, b + B_1, nullptr, QST_EPI_GELU));
+        drop_next(e, dst8, dropping, QST_DROP_SITE_FFN_OUT(l), 1);
         if (fuse_ln) {
             QST_TRY(nt_ln(sv + a.hact, I, W(b + W_2), I, (float*)(sv + a.x), sv + a.xb, P(b + B_2),
                           (const float*)(sv + a.y1), M, H, I, 0, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, sv + a.xh2,
@@ -687,8 +741,16 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
     const bool fuse_ln = qst_gemm_nt_ln_supported(H) != 0 && M >= kFuseLnMinRows;
     const bool hm = g_head_major != 0;
     t_heads = HeadLayout{0, 0, 0, 0};
-    const bool fuse_ffn = fuse_ln && (g_fuse_ffn & 4) && qst_ffn_chain_supported(H, I) != 0;
+    // dropout on: the masks of the forward that filled `saved` are recomputed from the same (seed, step) -- see QstDrop
+    const bool dropping = e->drop_state != nullptr;
+    const void* dst8 = sv + p.dropst;
+    const bool fuse_ffn = fuse_ln && !dropping && (g_fuse_ffn & 4) && qst_ffn_chain_supported(H, I) != 0;
     const int fused_rows = (M + 127) / 128;
+    auto hdrop = [&](uint32_t site, QstDrop& d) -> const QstDrop* {          // hidden-state mask of `site`, or none
+        if (!dropping || !e->drop_hidden) return nullptr;
+        d = drop_of(e, dst8, false, site);
+        return &d;
+    };
     auto ln_slot = [&](int slot, float* dg, float* db, int nrows = 0) {
         float* sp = (float*)(ws + w.lnred + (size_t)slot * w.lnred_stride);
         lnb.partials[lnb.count] = sp; lnb.dgamma[lnb.count] = dg; lnb.dbeta[lnb.count] = db;
@@ -736,9 +798,11 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
         const int b = lay.layer0[l];
         // LN2 -> ds2 (fp32 for the residual path, bf16 for the GEMMs). Fused mode: only the top layer runs it as a
         // row kernel; below, (ds, dsb) were written by the QKV dgrad of layer l+1.
-        if (!fuse_ln || l == c.num_layers - 1)
-            QST_TRY(qst_ln_bwd(dxa, sv + a.xh2, (const float*)(sv + a.rs2), P(b + LN2_G), M, H, ds, dsb, nullptr, nullptr,
-                               ln_slot(2 * l + 1, G(b + LN2_G), G(b + LN2_B)), st));
+        if (!fuse_ln || l == c.num_layers - 1) {
+            QstDrop dd;
+            QST_TRY(qst_ln_bwd_drop(dxa, sv + a.xh2, (const float*)(sv + a.rs2), P(b + LN2_G), M, H, ds, dsb, nullptr, nullptr,
+                                    ln_slot(2 * l + 1, G(b + LN2_G), G(b + LN2_B)), nullptr, hdrop(QST_DROP_SITE_FFN_OUT(l), dd), st));
+        }
         // FFN2 dgrad through GELU: du = (ds2 . W2) * gelu'(u)   (a.u holds gelu'(u), written by the forward epilogue)
         if (!fuse_ffn)
             QST_TRY(nt(dsb, H, WT(b + W_2), H, du, I, nullptr, sv + a.u, nullptr, nullptr, 0, M, I, H, QST_EPI_GELU_BWD, st));
@@ -752,22 +816,32 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
                               ln_slot(2 * l, G(b + LN1_G), G(b + LN1_B), fused_rows), st));
             ds1 = dxb;
         } else if (fuse_ln) {
+            drop_next(e, dst8, dropping, QST_DROP_SITE_ATTN_OUT(l), 2);
             QST_TRY(nt_ln(du, I, WT(b + W_1), I, dxb, dsb1, nullptr, ds, M, H, I, 1, P(b + LN1_G), nullptr, 0.f, sv + a.xh1,
                           (float*)(sv + a.rs1), ln_slot(2 * l, G(b + LN1_G), G(b + LN1_B), fused_rows), st));
             ds1 = dxb;
         } else {
+            QstDrop dd;
             QST_TRY(nt(du, I, WT(b + W_1), I, dxb, H, nullptr, nullptr, nullptr, ds, H, M, H, I, QST_EPI_F32_RESID, st));
-            QST_TRY(qst_ln_bwd(dxb, sv + a.xh1, (const float*)(sv + a.rs1), P(b + LN1_G), M, H, ds, dsb1, nullptr, nullptr,
-                               ln_slot(2 * l, G(b + LN1_G), G(b + LN1_B)), st));
+            QST_TRY(qst_ln_bwd_drop(dxb, sv + a.xh1, (const float*)(sv + a.rs1), P(b + LN1_G), M, H, ds, dsb1, nullptr, nullptr,
+                                    ln_slot(2 * l, G(b + LN1_G), G(b + LN1_B)), nullptr, hdrop(QST_DROP_SITE_ATTN_OUT(l), dd), st));
         }
         // attention output projection dgrad, attention core
         QST_TRY(nt(dsb1, H, WT(b + W_O), H, dctx, H, nullptr, nullptr, nullptr, nullptr, 0, M, H, H, QST_EPI_BF16, st));
-        QST_TRY((hm ? qst_attention_bwd_hm : qst_attention_bwd)(sv + a.qkv, sv + a.ctx, dctx, (const float*)(sv + a.lse), mask, rel, nseq, L, A, d,
-                                  dqkv, drel, (float*)(ws + w.delta), st));
+        {
+            QstAttnDesc q{};
+            q.qkv = sv + a.qkv; q.mask = mask; q.rel_pos = rel; q.nseq = nseq; q.L = L; q.A = A; q.d = d;
+            q.ctx = sv + a.ctx; q.lse = (float*)(sv + a.lse); q.dctx = dctx; q.dqkv = dqkv; q.drel = drel;
+            q.delta_scratch = (float*)(ws + w.delta); q.head_major = hm;
+            if (dropping) q.drop = drop_of(e, dst8, true, QST_DROP_SITE_PROBS(l));
+            QST_TRY(qst_attention_bwd_ex(&q, st));
+        }
         if (!skip_wgrad) QST_TRY(wgrad(l));
         // QKV projection dgrad + residual: dx_in = dqkv . Wqkv + ds1. Fused mode: followed in the same kernel by the
         // backward of the LayerNorm that produced this layer's input (LN2 of layer l-1, or the embedding LayerNorm)
         heads_a(hm, L, d);
+        if (fuse_ln && l > 0) drop_next(e, dst8, dropping, QST_DROP_SITE_FFN_OUT(l - 1), 2);   // dsb = d(FFN-2 output of layer l-1)
+        else if (fuse_ln) drop_next(e, dst8, dropping, QST_DROP_SITE_EMBED, 3);                // embedding dropout follows its LN
         if (fuse_ln && l > 0) {
             const LayerAct& lo = p.layers[l - 1];
             const int bl = lay.layer0[l - 1];
@@ -782,9 +856,11 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
                        QST_EPI_F32_RESID, st));
         }
     }
-    if (do_embed && !fuse_ln)
-        QST_TRY(qst_ln_bwd(dxa, sv + p.xh0, (const float*)(sv + p.rs0), P(lay.eg), M, H, ds, nullptr, nullptr, nullptr,
-                           ln_slot(2 * c.num_layers, G(lay.eg), G(lay.eb)), st));
+    if (do_embed && !fuse_ln) {
+        QstDrop dd;
+        QST_TRY(qst_ln_bwd_drop(dxa, sv + p.xh0, (const float*)(sv + p.rs0), P(lay.eg), M, H, ds, nullptr, nullptr, nullptr,
+                                ln_slot(2 * c.num_layers, G(lay.eg), G(lay.eb)), hdrop(QST_DROP_SITE_EMBED, dd), nullptr, st));
+    }
     if (lnb.count > 0) {
         if (lnb.count > QST_LN_BATCH_MAX) return QST_ERR_UNSUPPORTED;
         QST_TRY(qst_ln_bwd_reduce_batch(&lnb, st));
@@ -842,4 +918,17 @@ extern "C" int qst_clip_adamw_step(const qst_encoder* e, float* params, float* g
     if (!e) return QST_ERR_BAD_ARG;
     return qst_adamw_launch(params, grads, exp_avg, exp_avg_sq, e->chunk_decay, e->lay.total, lr, beta1, beta2, eps,
                             weight_decay, max_grad_norm, grad_scale, step, norm_out, scratch, (hipStream_t)stream);
+}
+
+extern "C" int64_t qst_abi_sizeof(int which) {
+    switch (which) {
+        case 0: return sizeof(QstGemmArgs);
+        case 1: return sizeof(QstLnEpi);
+        case 2: return sizeof(QstFfnArgs);
+        case 3: return sizeof(QstTnGroup);
+        case 4: return sizeof(QstLnReduceBatch);
+        case 5: return sizeof(QstDrop);
+        case 6: return sizeof(QstAttnDesc);
+        default: return QST_ERR_BAD_ARG;
+    }
 }

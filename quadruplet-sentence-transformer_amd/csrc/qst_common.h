@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/qst.h"
+#include "../../include/qst_kernels.h"
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -159,3 +160,30 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 }
 
 static inline int64_t qst_align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------- dropout masks (include/qst_kernels.h: QstDrop)
+__device__ __forceinline__ uint32_t qst_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+struct DropCtx { uint32_t key, thr; float scale; };          // thr == 0: no dropout
+__device__ __forceinline__ DropCtx drop_ctx(const QstDrop& d) {
+    DropCtx c;
+    c.thr = d.state ? d.thr16 : 0u; c.key = 0u; c.scale = 1.f;
+    if (c.thr) {
+        const uint32_t s0 = d.state[0], s1 = d.state[1], step = d.state[2];           // uniform: scalar loads
+        c.key = qst_hash32(s0 ^ qst_hash32(step * 0x9E3779B9u + d.site) ^ ((s1 << 16) | (s1 >> 16)));
+        c.scale = 65536.0f / (float)(65536u - c.thr);
+    }
+    return c;
+}
+// the 2 x 16 random bits of elements idx_even and idx_even + 1
+__device__ __forceinline__ uint32_t drop_bits(const DropCtx& c, uint32_t idx_even) { return qst_hash32((idx_even >> 1) ^ c.key); }
+__device__ __forceinline__ bool drop_keep_lo(const DropCtx& c, uint32_t bits) { return (bits & 0xFFFFu) >= c.thr; }
+__device__ __forceinline__ bool drop_keep_hi(const DropCtx& c, uint32_t bits) { return (bits >> 16) >= c.thr; }
+// multipliers (0 or scale) of elements idx_even and idx_even + 1
+__device__ __forceinline__ void drop_pair(const DropCtx& c, uint32_t idx_even, float& m0, float& m1) {
+    const uint32_t b = drop_bits(c, idx_even);
+    m0 = drop_keep_lo(c, b) ? c.scale : 0.f;
+    m1 = drop_keep_hi(c, b) ? c.scale : 0.f;
+}

@@ -25,7 +25,8 @@ template <int VPL>
 __device__ __forceinline__ void ln_row_finish(const f32x2 (&v)[VPL], int lane, int H, int row,
                                               const float* gamma, const float* beta, float eps,
                                               float* y, bf16* yb, bf16* xh, float* rstd_out,
-                                              uint8_t* yq = nullptr, uint8_t* ys = nullptr, int M = 0) {
+                                              uint8_t* yq = nullptr, uint8_t* ys = nullptr, int M = 0,
+                                              DropCtx dc = DropCtx{0u, 0u, 1.f}) {
     const int nv = H >> 1;
     float s = 0.f;
 #pragma unroll
@@ -52,6 +53,11 @@ __device__ __forceinline__ void ln_row_finish(const f32x2 (&v)[VPL], int lane, i
             f32x2 o;
             o[0] = h0 * g[0] + b[0];
             o[1] = h1 * g[1] + b[1];
+            if (dc.thr) {                                   // dropout of the LayerNorm output (embeddings); xhat stays undropped
+                float m0, m1;
+                drop_pair(dc, (uint32_t)(base + 2 * c), m0, m1);
+                o[0] *= m0; o[1] *= m1;
+            }
             *(f32x2*)(y + base + 2 * c) = o;
             if (yb) *(uint32_t*)(yb + base + 2 * c) = pack_bf16x2(o[0], o[1]);
             if (xh) *(uint32_t*)(xh + base + 2 * c) = pack_bf16x2(h0, h1);
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, c
                                                            const float* pos, const float* type,
                                                            const float* gamma, const float* beta, float eps,
                                                            int M, int H, float* y, bf16* yb, bf16* xh, float* rstd,
-                                                           uint8_t* yq, uint8_t* ys) {
+                                                           uint8_t* yq, uint8_t* ys, QstDrop drop) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, c
             v[i][1] = w[1] + p[1];
         } else { v[i][0] = 0.f; v[i][1] = 0.f; }
     }
-    ln_row_finish<VPL>(v, lane, H, row, gamma, beta, eps, y, yb, xh, rstd, yq, ys, M);
+    ln_row_finish<VPL>(v, lane, H, row, gamma, beta, eps, y, yb, xh, rstd, yq, ys, M, drop_ctx(drop));
 }
 
 template <int VPL>
@@ -142,7 +148,8 @@ constexpr int LN_BWD_ROWS_PER_WAVE = 8;
 template <int VPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const bf16* xh, const float* rstd,
                                                      const float* gamma, int M, int H, float* ds, bf16* dsb,
-                                                     float* dgamma, float* dbeta, float* partials) {
+                                                     float* dgamma, float* dbeta, float* partials,
+                                                     QstDrop drop_in, QstDrop drop_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [4 waves][2][H] floats
     float* sh = (float*)smem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -156,6 +163,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const bf16
         ag[i][0] = ag[i][1] = ab[i][0] = ab[i][1] = 0.f;
     }
     const int row0 = (blockIdx.x * 4 + wave) * LN_BWD_ROWS_PER_WAVE;
+    const DropCtx dci = drop_ctx(drop_in), dco = drop_ctx(drop_out);
     // software pipeline: the loads of row r+1 are in flight while row r is reduced and stored
     f32x2 dn[VPL];
     uint32_t xn[VPL];
@@ -182,6 +190,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const bf16
         const float rs = rsn;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) { d[i] = dn[i]; x[i][0] = bf16lo(xn[i]); x[i][1] = bf16hi(xn[i]); }
+        if (dci.thr) {                   // the dropout that followed this LayerNorm: its mask on the incoming gradient
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                float m0, m1;
+                drop_pair(dci, (uint32_t)(base + 2 * (lane + 64 * i)), m0, m1);
+                d[i][0] *= m0; d[i][1] *= m1;
+            }
+        }
         if (rr + 1 < LN_BWD_ROWS_PER_WAVE && row + 1 < M) fetch(row + 1);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -204,7 +220,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const bf16
                 o[0] = rs * (d[i][0] - m1 - x[i][0] * m2);
                 o[1] = rs * (d[i][1] - m1 - x[i][1] * m2);
                 *(f32x2*)(ds + base + 2 * c) = o;
-                if (dsb) *(uint32_t*)(dsb + base + 2 * c) = pack_bf16x2(o[0], o[1]);
+                if (dsb) {
+                    if (dco.thr) {       // ds_bf16 = gradient of the dropped projection output; ds = of the residual
+                        float m0, m1;
+                        drop_pair(dco, (uint32_t)(base + 2 * c), m0, m1);
+                        o[0] *= m0; o[1] *= m1;
+                    }
+                    *(uint32_t*)(dsb + base + 2 * c) = pack_bf16x2(o[0], o[1]);
+                }
             }
         }
     }
@@ -553,18 +576,33 @@ extern "C" int qst_embed_ln_fwd_mx(const int64_t* ids, const int64_t* type_ids, 
                                    const float* word_emb, const float* pos_emb, const float* type_emb,
                                    const float* gamma, const float* beta, float eps, int M, int H,
                                    float* y, void* y_bf16, void* yq, void* ys, void* stream);
+static const QstDrop kNoDrop = {nullptr, 0u, 0u};
+static int drop_ok(const QstDrop* d, int64_t elems) {
+    if (!d) return QST_OK;
+    if (d->thr16 > 65535u) return QST_ERR_BAD_ARG;
+    if (d->thr16 && d->state && elems >= (int64_t)1 << 32) return QST_ERR_UNSUPPORTED;       // 32-bit element counters
+    return QST_OK;
+}
+extern "C" int qst_embed_ln_fwd_drop(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
+                                     const float* word_emb, const float* pos_emb, const float* type_emb,
+                                     const float* gamma, const float* beta, float eps, int M, int H,
+                                     float* y, void* y_bf16, void* xhat_bf16, float* rstd, const QstDrop* drop, void* stream) {
+    if (!ids || !pos_ids || !word_emb || !pos_emb || !gamma || !beta || !y || M <= 0 || H <= 0 || (H & 1))
+        return QST_ERR_BAD_ARG;
+    if (int rc = drop_ok(drop, (int64_t)M * H)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    QST_VPL_DISPATCH(H, (embed_ln_fwd_kernel<VPL><<<(M + 3) / 4, 256, 0, st>>>(
+                            ids, type_ids, pos_ids, word_emb, pos_emb, type_emb, gamma, beta, eps, M, H, y,
+                            (bf16*)y_bf16, (bf16*)xhat_bf16, rstd, nullptr, nullptr, drop ? *drop : kNoDrop)));
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
 extern "C" int qst_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
                                 const float* word_emb, const float* pos_emb, const float* type_emb,
                                 const float* gamma, const float* beta, float eps, int M, int H,
                                 float* y, void* y_bf16, void* xhat_bf16, float* rstd, void* stream) {
-    if (!ids || !pos_ids || !word_emb || !pos_emb || !gamma || !beta || !y || M <= 0 || H <= 0 || (H & 1))
-        return QST_ERR_BAD_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    QST_VPL_DISPATCH(H, (embed_ln_fwd_kernel<VPL><<<(M + 3) / 4, 256, 0, st>>>(
-                            ids, type_ids, pos_ids, word_emb, pos_emb, type_emb, gamma, beta, eps, M, H, y,
-                            (bf16*)y_bf16, (bf16*)xhat_bf16, rstd, nullptr, nullptr)));
-    QST_LAUNCH_CHECK();
-    return QST_OK;
+    return qst_embed_ln_fwd_drop(ids, type_ids, pos_ids, word_emb, pos_emb, type_emb, gamma, beta, eps, M, H, y, y_bf16,
+                                 xhat_bf16, rstd, nullptr, stream);
 }
 
 extern "C" int qst_embed_ln_fwd_mx(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
@@ -576,7 +614,7 @@ extern "C" int qst_embed_ln_fwd_mx(const int64_t* ids, const int64_t* type_ids, 
     hipStream_t st = (hipStream_t)stream;
     QST_VPL_DISPATCH(H, (embed_ln_fwd_kernel<VPL><<<(M + 3) / 4, 256, 0, st>>>(
                             ids, type_ids, pos_ids, word_emb, pos_emb, type_emb, gamma, beta, eps, M, H, y,
-                            (bf16*)y_bf16, nullptr, nullptr, (uint8_t*)yq, (uint8_t*)ys)));
+                            (bf16*)y_bf16, nullptr, nullptr, (uint8_t*)yq, (uint8_t*)ys, kNoDrop)));
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
@@ -639,6 +677,13 @@ extern "C" size_t qst_ln_bwd_scratch_bytes(int M, int H) {
 
 extern "C" int qst_ln_bwd(const float* dy, const void* xhat_bf16, const float* rstd, const float* gamma, int M, int H,
                           float* ds, void* ds_bf16, float* dgamma, float* dbeta, float* scratch, void* stream) {
+    return qst_ln_bwd_drop(dy, xhat_bf16, rstd, gamma, M, H, ds, ds_bf16, dgamma, dbeta, scratch, nullptr, nullptr, stream);
+}
+extern "C" int qst_ln_bwd_drop(const float* dy, const void* xhat_bf16, const float* rstd, const float* gamma, int M, int H,
+                               float* ds, void* ds_bf16, float* dgamma, float* dbeta, float* scratch,
+                               const QstDrop* drop_in, const QstDrop* drop_out, void* stream) {
+    if (int rc = drop_ok(drop_in, (int64_t)M * H)) return rc;
+    if (int rc = drop_ok(drop_out, (int64_t)M * H)) return rc;
     // dgamma == dbeta == NULL with a scratch buffer: only write the per-block partials; the caller reduces them later
     // with qst_ln_bwd_reduce_batch (one launch for many LayerNorms)
     const bool deferred = !dgamma && !dbeta && scratch;
@@ -649,7 +694,8 @@ extern "C" int qst_ln_bwd(const float* dy, const void* xhat_bf16, const float* r
     const int grid = (M + rows_per_block - 1) / rows_per_block;
     const size_t lds = (size_t)8 * H * sizeof(float);
     QST_VPL_DISPATCH(H, (ln_bwd_kernel<VPL><<<grid, 256, lds, st>>>(dy, (const bf16*)xhat_bf16, rstd, gamma, M, H, ds,
-                                                                   (bf16*)ds_bf16, dgamma, dbeta, scratch)));
+                                                                   (bf16*)ds_bf16, dgamma, dbeta, scratch,
+                                                                   drop_in ? *drop_in : kNoDrop, drop_out ? *drop_out : kNoDrop)));
     QST_LAUNCH_CHECK();
     if (scratch && !deferred) {
         ln_bwd_reduce_kernel<<<dim3((2 * H + 255) / 256, 32), 256, 0, st>>>(scratch, grid, H, dgamma, dbeta);
@@ -750,6 +796,40 @@ extern "C" int qst_shadow_matrix(const float* src, int rows, int cols, void* dst
     if (!src || rows <= 0 || cols <= 0) return QST_ERR_BAD_ARG;
     shadow_kernel<<<dim3((cols + 31) / 32, (rows + 31) / 32), 256, 0, (hipStream_t)stream>>>(
         src, rows, cols, (bf16*)dst_bf16, (bf16*)dstT_bf16);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+// ---------------------------------------------------------------- dropout state (include/qst.h, qst_kernels.h: QstDrop)
+namespace {
+__global__ void drop_init_kernel(uint32_t* st, uint32_t lo, uint32_t hi) { st[0] = lo; st[1] = hi; st[2] = 0u; st[3] = 0u; }
+__global__ void drop_advance_kernel(uint32_t* st) { st[2] += 1u; }
+__global__ __launch_bounds__(256) void drop_mult_kernel(QstDrop d, int64_t n, float* out) {
+    const DropCtx c = drop_ctx(d);
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i >= n) return;
+    float m0 = 1.f, m1 = 1.f;
+    if (c.thr) drop_pair(c, (uint32_t)i, m0, m1);
+    out[i] = m0;
+    if (i + 1 < n) out[i + 1] = m1;
+}
+}  // namespace
+extern "C" int qst_dropout_init(uint32_t* state_dev, uint64_t seed, void* stream) {
+    if (!state_dev) return QST_ERR_BAD_ARG;
+    drop_init_kernel<<<1, 1, 0, (hipStream_t)stream>>>(state_dev, (uint32_t)seed, (uint32_t)(seed >> 32));
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+extern "C" int qst_dropout_advance(uint32_t* state_dev, void* stream) {
+    if (!state_dev) return QST_ERR_BAD_ARG;
+    drop_advance_kernel<<<1, 1, 0, (hipStream_t)stream>>>(state_dev);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+extern "C" int qst_dropout_multipliers(const QstDrop* d, int64_t n, float* out, void* stream) {
+    if (!d || !out || n <= 0) return QST_ERR_BAD_ARG;
+    if (int rc = drop_ok(d, n)) return rc;
+    drop_mult_kernel<<<(unsigned)((n / 2 + 256) / 256), 256, 0, (hipStream_t)stream>>>(*d, n, out);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }

@@ -36,6 +36,9 @@ class HipEncoder:
         h = _lib.vp()
         _lib.check(self.lib.qst_encoder_create(self.ccfg, h), "qst_encoder_create")
         self.handle = h
+        self.dropout = None           # (p_hidden, p_attn, seed) once set_dropout() switched it on
+        self.dropout_step = 0
+        self.drop_state = None
         self.handle_x3 = None         # QST_PREC_BF16X3 handle over the SAME arenas, created on first use
         self.handle_fp8 = None        # QST_PREC_FP8W handle (fp8 e4m3 weights + row scales, inference), on first use
         self.handle_mx = None         # QST_PREC_FP8 handle (MXFP8 weights and activations on the fp8 matrix cores, inference)
@@ -101,6 +104,31 @@ class HipEncoder:
         if self.exp_avg is None:
             self.exp_avg = torch.zeros_like(self.params)
             self.exp_avg_sq = torch.zeros_like(self.params)
+
+    # ------------------------------------------------------------------ dropout
+    def set_dropout(self, p_hidden: float = 0.0, p_attn: float = 0.0, seed: int = 0) -> None:
+        """Dropout for training forwards/backwards (HF hidden_dropout_prob / attention_probs_dropout_prob; the reference's
+        fit() trains in train() mode with 0.1 / 0.1). Masks are counter-based -- a function of (seed, step, tensor, element)
+        recomputed by the backward kernels, never stored; `dropout_step` counts the training forwards run since this call
+        (the device-side counter the kernels read). 0 / 0 switches dropout off. Inference forwards never drop."""
+        if not (0.0 <= p_hidden < 1.0 and 0.0 <= p_attn < 1.0):
+            raise ValueError("dropout probabilities must be in [0, 1)")
+        on = p_hidden > 0.0 or p_attn > 0.0
+        if on:
+            if getattr(self, "drop_state", None) is None:
+                self.drop_state = torch.zeros(4, dtype=torch.int32, device=self.device)
+            _lib.check(self.lib.qst_dropout_init(self.drop_state.data_ptr(), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                                 _lib.current_stream_ptr()), "qst_dropout_init")
+        _lib.check(self.lib.qst_encoder_set_dropout(self.handle, float(p_hidden), float(p_attn),
+                                                    self.drop_state.data_ptr() if on else None), "qst_encoder_set_dropout")
+        self.dropout = (float(p_hidden), float(p_attn), int(seed)) if on else None
+        self.dropout_step = 0
+
+    def set_dropout_step(self, step: int) -> None:
+        """Continue the mask stream at `step` training forwards (checkpoint resume)."""
+        if self.dropout is not None:
+            self.drop_state[2] = int(step)
+            self.dropout_step = int(step)
 
     def refresh_shadow8(self) -> None:
         """Quantise every Linear weight to fp8 e4m3 with one fp32 scale per output row (QST_PREC_FP8W)."""
@@ -201,6 +229,8 @@ class HipEncoder:
             handle, ids.data_ptr(), mask.data_ptr(), _lib.ptr(type_ids), n, L, self.params.data_ptr(),
             shadow.data_ptr(), emb.data_ptr(), _lib.ptr(tok), saved.data_ptr(), saved.numel(), int(training),
             _lib.current_stream_ptr()), "qst_encoder_forward")
+        if training and self.dropout is not None and handle is self.handle:
+            self.dropout_step += 1           # mirrors the device counter (tests rebuild this step's masks from it)
         return emb, tok, saved
 
     def backward(self, ids, mask, type_ids, grad_emb: torch.Tensor, saved: torch.Tensor) -> None:

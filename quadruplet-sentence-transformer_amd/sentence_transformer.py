@@ -189,16 +189,19 @@ class SentenceTransformer(nn.Module):
         self._model_card_name = model_name_or_path
         arena = None
         tok_dir = None
+        self._dropout_config = (0.1, 0.1)        # HF defaults; a loaded config.json overrides (fit(dropout="config"))
         if config is not None:
             cfg = config
         elif model_name_or_path is not None and os.path.isdir(str(model_name_or_path)):
             cfg, arena, tok_dir = _load_model_dir(str(model_name_or_path))
+            self._dropout_config = _dropout_from_config(str(model_name_or_path))
         else:
             full = str(model_name_or_path or "all-MiniLM-L6-v2")
             name = full.split("/")[-1]
             found = _find_cached_model(full, cache_folder)
             if found is not None:
                 cfg, arena, tok_dir = _load_model_dir(found)
+                self._dropout_config = _dropout_from_config(found)
             else:
                 if name not in PRESETS:
                     raise ValueError(f"unknown model '{model_name_or_path}': pass a local model directory or one of "
@@ -368,7 +371,7 @@ class SentenceTransformer(nn.Module):
             callback: Callable[[float, int, int], None] = None, show_progress_bar: bool = True,
             checkpoint_path: str = None, checkpoint_save_steps: int = 500, checkpoint_save_total_limit: int = 0,
             resume_from_checkpoint: str = None, data_parallel: Optional[str] = None, process_group=None,
-            overlap_grad_reduce: bool = True):
+            overlap_grad_reduce: bool = True, dropout="config", dropout_seed: int = 0):
         """Same keyword set as sentence-transformers 2.2.2 `fit` (the reference passes all of them,
         training/main.py:128-148) plus `resume_from_checkpoint`: a checkpoint directory written by this method
         (weights + Adam moments + step counters; the reference's checkpoints hold weights only)
@@ -388,9 +391,11 @@ class SentenceTransformer(nn.Module):
         Files (evaluator CSVs, best model, checkpoints) are written by rank 0 only; the evaluator itself runs on every
         rank so that score-driven control flow (early stopping) stays in step.
 
-        Dropout: this path trains with dropout = 0. The reference's fit() runs HF modules in train() mode
-        (hidden_dropout_prob = attention_probs_dropout_prob = 0.1), so a run here is regularised differently and a
-        step does slightly less work; bench.py states "dropout off" in its workload string."""
+        Dropout: the reference's fit() runs the HF modules in train() mode, i.e. with the checkpoint config's
+        hidden_dropout_prob / attention_probs_dropout_prob (HF default 0.1 / 0.1; training/main.py:128). `dropout`:
+        "config" (default) = those values (0.1 / 0.1 when the model was built without a config.json), a float p or a pair
+        (p_hidden, p_attn), 0 / None = off. Masks come from the library's counter-based generator (include/qst_kernels.h:
+        QstDrop; same distribution as torch's, another random stream), seeded with dropout_seed + rank."""
         optimizer_params = dict(optimizer_params or {"lr": 2e-5})
         if optimizer_class not in (torch.optim.AdamW,):
             raise NotImplementedError(f"fit() drives the fused HIP AdamW; optimizer_class={optimizer_class} is not supported")
@@ -423,6 +428,11 @@ class SentenceTransformer(nn.Module):
         enc = self._enc
         enc.ensure_train_state()
         enc.grads.zero_()
+        if dropout == "config":
+            dropout = getattr(self, "_dropout_config", (0.1, 0.1))
+        if dropout is None or dropout == 0:
+            dropout = (0.0, 0.0)
+        p_hidden, p_attn = (float(dropout), float(dropout)) if isinstance(dropout, (int, float)) else map(float, dropout)
         # ---- data parallelism
         import torch.distributed as dist
         world, rank = 1, 0
@@ -435,9 +445,11 @@ class SentenceTransformer(nn.Module):
                                             "overlap": bool(overlap_grad_reduce)}
         self._dp_works, self._dp_reduced, self._live_graphs = [], False, 0
         is_main = rank == 0
+        enc.set_dropout(p_hidden, p_attn, int(dropout_seed) + rank)
         global_step = 0
         if resume_from_checkpoint is not None:
             global_step = self._load_training_state(resume_from_checkpoint)
+            enc.set_dropout_step(self._resume_dropout_step)     # the mask stream continues where the checkpoint left it
         self._fit_meta = {"scheduler": sched, "lr": lr, "warmup_steps": int(warmup_steps), "t_total": t_total}
         iters = [iter(dl) for dl in dataloaders]
         if global_step > 0:
@@ -491,6 +503,7 @@ class SentenceTransformer(nn.Module):
             self._eval_during_training(evaluator, output_path if is_main else None, save_best_model and is_main, epoch, -1,
                                        callback)
         self._dp = None
+        enc.set_dropout(0.0, 0.0)
         if evaluator is None and output_path is not None and is_main:
             self.save(output_path)
         if checkpoint_path is not None and is_main:
@@ -528,7 +541,8 @@ class SentenceTransformer(nn.Module):
                    "exp_avg_sq": st["exp_avg_sq"].detach().cpu().contiguous()},
                   os.path.join(path, "training_state.safetensors"))
         meta = dict(getattr(self, "_fit_meta", {}))
-        meta.update({"global_step": int(step), "opt_step": int(self._enc.opt_step), "best_score": float(self.best_score)})
+        meta.update({"global_step": int(step), "opt_step": int(self._enc.opt_step), "best_score": float(self.best_score),
+                     "dropout_step": int(self._enc.dropout_step)})
         with open(os.path.join(path, "training_state.json"), "w") as f:
             json.dump(meta, f, indent=2)
         if checkpoint_save_total_limit is not None and checkpoint_save_total_limit > 0:
@@ -553,6 +567,7 @@ class SentenceTransformer(nn.Module):
         st["opt_step"] = torch.tensor([int(meta["opt_step"])], dtype=torch.int64)
         self._enc.load_optimizer_state(st)
         self.best_score = float(meta.get("best_score", self.best_score))
+        self._resume_dropout_step = int(meta.get("dropout_step", 0))
         return int(meta["global_step"])
 
     # ---- save / load: ST model-directory layout (modules.json, config.json, model.safetensors, 1_Pooling/...)
@@ -569,7 +584,8 @@ class SentenceTransformer(nn.Module):
               "num_attention_heads": cfg.num_heads, "intermediate_size": cfg.intermediate_size,
               "max_position_embeddings": cfg.max_position, "type_vocab_size": cfg.type_vocab_size,
               "layer_norm_eps": cfg.layer_norm_eps, "hidden_act": "gelu", "pad_token_id": cfg.pad_token_id,
-              "relative_attention_num_buckets": cfg.rel_buckets}
+              "relative_attention_num_buckets": cfg.rel_buckets,
+              "hidden_dropout_prob": self._dropout_config[0], "attention_probs_dropout_prob": self._dropout_config[1]}
         json.dump(hf, open(os.path.join(path, "config.json"), "w"), indent=2)
         json.dump({"max_seq_length": self.max_seq_length, "do_lower_case": False},
                   open(os.path.join(path, "sentence_bert_config.json"), "w"), indent=2)
@@ -643,6 +659,15 @@ def _find_cached_model(name: str, cache_folder: Optional[str] = None) -> Optiona
                 os.path.isfile(os.path.join(c, f)) for f in ("model.safetensors", "pytorch_model.bin")):
             return c
     return None
+
+
+def _dropout_from_config(path: str):
+    """(hidden_dropout_prob, attention_probs_dropout_prob) of a model directory's config.json, HF defaults 0.1 / 0.1."""
+    try:
+        hf = json.load(open(os.path.join(path, "config.json")))
+    except (OSError, ValueError):
+        return (0.1, 0.1)
+    return (float(hf.get("hidden_dropout_prob", 0.1)), float(hf.get("attention_probs_dropout_prob", 0.1)))
 
 
 def _load_model_dir(path: str):

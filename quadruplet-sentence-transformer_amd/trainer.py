@@ -111,12 +111,18 @@ class QuadrupletTrainer:
                  lr: float = 2e-5, weight_decay: float = 0.01, max_grad_norm: float = 1.0,
                  betas=(0.9, 0.999), eps: float = 1e-8, warmup_steps: int = 0, total_steps: int = 0,
                  process_group=None, world_size: int = 1, overlap: bool = True, encoder: Optional[HipEncoder] = None,
-                 use_graph: bool = False):
+                 use_graph: bool = False, dropout=None, dropout_seed: int = 0):
+        """dropout: None / 0 = off; a float p = HF's hidden_dropout_prob = attention_probs_dropout_prob = p; a pair
+        (p_hidden, p_attn). The reference's fit() trains with 0.1 (HF config defaults, train() mode). Ranks of a
+        data-parallel job should pass different dropout_seed values (fit() adds the rank)."""
         self.cfg = cfg
         self.enc = encoder if encoder is not None else HipEncoder(cfg, device=device)
         if arena is not None:
             self.enc.load_arena(arena)
         self.enc.ensure_train_state()
+        if dropout is not None:
+            ph, pa = (dropout, dropout) if isinstance(dropout, (int, float)) else dropout
+            self.enc.set_dropout(float(ph), float(pa), int(dropout_seed))
         self.loss_args = (gamma, margin_pos_neg, margin_pos_part, margin_part_neg, p, swap)
         self.lr, self.wd, self.max_grad_norm, self.betas, self.eps = lr, weight_decay, max_grad_norm, betas, eps
         self.warmup_steps, self.total_steps = warmup_steps, total_steps

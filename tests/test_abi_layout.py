@@ -1,6 +1,7 @@
 """CPU: libqst.so loads without a GPU, exports every symbol the public headers declare, and its arena layout
 agrees with the Python side. No compute entry point is called here."""
 import ctypes
+import ctypes as C
 import os
 import re
 
@@ -32,6 +33,15 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in a header but not exported by libqst.so"
     # and the ctypes table binds exactly those
     assert set(_lib.SIGNATURES) == decl
+
+
+def test_ctypes_structs_have_the_compiled_sizes():
+    """The ctypes mirrors of the argument structs must match what the library was compiled with, field for field; sizes
+    catch a forgotten or misplaced field (every struct ends in the fields added last)."""
+    lib = _lib.load()
+    for which, cls in enumerate([_lib.QstGemmArgs, _lib.QstLnEpi, _lib.QstFfnArgs, _lib.QstTnGroup, _lib.QstLnReduceBatch,
+                                 _lib.QstDrop, _lib.QstAttnDesc]):
+        assert lib.qst_abi_sizeof(which) == C.sizeof(cls), cls.__name__
 
 
 def test_public_headers_are_self_contained_c(tmp_path):

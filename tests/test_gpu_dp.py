@@ -161,7 +161,7 @@ def _fit_worker(rank, world, port, out_dir):
               evaluation_steps=0, output_path=os.path.join(out_dir, f"model_w{world}"), save_best_model=True,
               max_grad_norm=1.0, use_amp=False, callback=None, show_progress_bar=False,
               checkpoint_path=os.path.join(out_dir, f"ckpt_w{world}"), checkpoint_save_steps=2,
-              checkpoint_save_total_limit=1)
+              checkpoint_save_total_limit=1, dropout=0)      # (masks are per rank: only the dropout-free run is rank-count invariant)
     torch.cuda.synchronize()
     np.save(os.path.join(out_dir, f"fit_w{world}_r{rank}.npy"), model._enc.params.cpu().numpy())
     if world > 1:

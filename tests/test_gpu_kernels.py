@@ -473,7 +473,7 @@ def from_head_major(t, n, L, A, d):
 @pytest.mark.parametrize("n,L,A,d,use_rel", [(2, 32, 2, 32, False), (3, 128, 12, 32, False), (2, 160, 2, 64, True),
                                               (2, 256, 3, 64, False), (2, 64, 2, 32, True), (5, 96, 3, 32, False)])
 def test_attention_head_major_equals_token_major(lib, n, L, A, d, use_rel):
-    """The _hm entry points run the same kernels on the other layout: results must be bit-identical (the split
+    """QstAttnDesc.head_major runs the same kernels on the other layout: results must be bit-identical (the split
     backward of long sequences accumulates dK / dV in another order only through float atomics on drel)."""
     H = A * d
     g = torch.Generator().manual_seed(7 * n * L + A + d)
@@ -486,16 +486,17 @@ def test_attention_head_major_equals_token_major(lib, n, L, A, d, use_rel):
     qd, qh = dev(qkv), dev(to_head_major(qkv, n, L, A, d))
     outs = []
     for hm, q in ((False, qd), (True, qh)):
-        fwd = lib.qst_attention_fwd_hm if hm else lib.qst_attention_fwd
-        bwd = lib.qst_attention_bwd_hm if hm else lib.qst_attention_bwd
         ctx = torch.empty(n * L, H, dtype=torch.bfloat16, device="cuda")
         lse = torch.empty(n, A, L, device="cuda")
-        _lib.check(fwd(q.data_ptr(), md.data_ptr(), _lib.ptr(reld), n, L, A, d, ctx.data_ptr(), lse.data_ptr(), stream()))
         dq = torch.full((n * L * 3 * H,), float("nan"), dtype=torch.bfloat16, device="cuda")
         drel = torch.zeros(A, 2 * L, device="cuda") if use_rel else None
         delta = torch.empty(n, A, L, device="cuda")
-        _lib.check(bwd(q.data_ptr(), ctx.data_ptr(), dcd.data_ptr(), lse.data_ptr(), md.data_ptr(), _lib.ptr(reld), n, L, A, d,
-                       dq.data_ptr(), _lib.ptr(drel), delta.data_ptr(), stream()))
+        a = _lib.QstAttnDesc()
+        a.qkv, a.mask, a.rel_pos, a.nseq, a.L, a.A, a.d = q.data_ptr(), md.data_ptr(), _lib.ptr(reld), n, L, A, d
+        a.ctx, a.lse, a.head_major = ctx.data_ptr(), lse.data_ptr(), int(hm)
+        a.dctx, a.dqkv, a.drel, a.delta_scratch = dcd.data_ptr(), dq.data_ptr(), _lib.ptr(drel), delta.data_ptr()
+        _lib.check(lib.qst_attention_fwd_ex(a, stream()))
+        _lib.check(lib.qst_attention_bwd_ex(a, stream()))
         torch.cuda.synchronize()
         outs.append((ctx, lse, from_head_major(dq, n, L, A, d) if hm else dq.view(n * L, 3 * H), drel))
     (c0, l0, d0, r0), (c1, l1, d1, r1) = outs
