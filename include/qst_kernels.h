@@ -24,7 +24,8 @@ enum {
  * random bits -- the low (i even) or high (i odd) half of hash32((i >> 1) ^ key), key = hash32(seed lo ^
  * hash32(step * 0x9E3779B9 + site) ^ rotl16(seed hi)), hash32 = x ^= x >> 16; x *= 0x7feb352d; x ^= x >> 15;
  * x *= 0x846ca68b; x ^= x >> 16 -- are < thr16; kept elements are multiplied by 65536 / (65536 - thr16). So the
- * effective rate is thr16 / 65536 (p = 0.1: thr16 = 6554). oracle/dropout_ref.py restates this in numpy.
+ * effective rate is thr16 / 65536 (p = 0.1: thr16 = 6554). oracle/dropout_ref.py restates this (and the 8-bit form the
+ * attention probabilities use, below) in numpy.
  * Flat indices: hidden states [M, H]: m * H + n; attention probabilities: ((seq * A + head) * L + query) * L + key. */
 typedef struct {
     const uint32_t* state;   /* NULL = no dropout */
@@ -35,8 +36,13 @@ typedef struct {
 #define QST_DROP_SITE_ATTN_OUT(layer) (4u * (uint32_t)(layer) + 0u)    /* output of the attention projection, [M, H]  */
 #define QST_DROP_SITE_FFN_OUT(layer) (4u * (uint32_t)(layer) + 1u)     /* output of the second feed-forward GEMM      */
 #define QST_DROP_SITE_PROBS(layer) (4u * (uint32_t)(layer) + 2u)       /* softmax probabilities, [nseq, A, L, L]      */
-/* test / debug: out[i] = multiplier (0 or 65536 / (65536 - thr16)) of element i, i < n */
-int qst_dropout_multipliers(const QstDrop* d, int64_t n, float* out, void* stream);
+/* The attention probabilities (QST_DROP_SITE_PROBS) use a cheaper form of the same generator, 8 random bits per element and
+ * four elements per hash word: byte b of hash32((i >> 2) ^ key) belongs to element (i & ~3) + b, dropped when byte < thr8 =
+ * min(255, (thr16 + 128) >> 8), kept ones multiplied by 256 / (256 - thr8): their rate is quantised to 1/256 (p = 0.1 ->
+ * 26/256 = 0.1016, with the scale that matches it exactly). That tensor is 4 A L / H times the size of a hidden state and its
+ * mask is rebuilt in the forward, dQ and dK/dV kernels; hashing per pair cost the fused backward 37 us on 60.
+ * test / debug: out[i] = multiplier of element i, i < n (probs != 0: the 8-bit form). */
+int qst_dropout_multipliers(const QstDrop* d, int probs, int64_t n, float* out, void* stream);
 
 typedef struct {
     const void* A;        // bf16

@@ -12,6 +12,9 @@ itself is checked in tests/test_dropout_host.py. Only tests/ may import this mod
     key       = hash32(seed_lo ^ hash32(step * 0x9E3779B9 + site) ^ rotl16(seed_hi))
     element i: 16 bits = the low (i even) / high (i odd) half of hash32((i >> 1) ^ key); dropped iff bits < thr16,
                thr16 = round(p * 65536); multiplier of a kept element = 65536 / (65536 - thr16)
+    attention probabilities (the largest masked tensor, rebuilt in three kernels) use the cheaper 8-bit form: byte i & 3 of
+               hash32((i >> 2) ^ key), dropped iff byte < thr8 = min(255, (thr16 + 128) >> 8), multiplier 256 / (256 - thr8):
+               p = 0.1 becomes 26/256 = 0.1016 with the scale that matches it.
 """
 import numpy as np
 
@@ -65,6 +68,22 @@ def multipliers(seed, step, site, n, p):
     return np.where(bits >= thr, scale, np.float32(0.0)).astype(np.float32)
 
 
+def thr8_of(p):
+    return min(255, (thr16_of(p) + 128) >> 8)
+
+
+def multipliers8(seed, step, site, n, p):
+    """The 8-bit / four-elements-per-word form used for attention probabilities."""
+    thr = thr8_of(p)
+    if thr16_of(p) == 0 or thr == 0:
+        return np.ones(n, dtype=np.float32)
+    i = np.arange(n, dtype=np.uint64)
+    h = hash32((i >> np.uint64(2)).astype(np.uint32) ^ mask_key(seed, step, site))
+    byte = (h >> (np.uint32(8) * (i & np.uint64(3)).astype(np.uint32))) & np.uint32(0xFF)
+    scale = np.float32(256.0) / np.float32(256 - thr)
+    return np.where(byte >= thr, scale, np.float32(0.0)).astype(np.float32)
+
+
 class Masks:
     """The masks of one training step, in the shapes oracle/torch_ref.encoder_forward multiplies by.
     step = the number of training forwards the HIP handle has run, this one included (the counter advances first)."""
@@ -86,4 +105,5 @@ class Masks:
         return self._t(site_ffn_out(layer), (n, L, H), self.p_hidden)
 
     def probs(self, layer, n, A, L):
-        return self._t(site_probs(layer), (n, A, L, L), self.p_attn)
+        import torch
+        return torch.from_numpy(multipliers8(self.seed, self.step, site_probs(layer), n * A * L * L, self.p_attn).reshape(n, A, L, L))

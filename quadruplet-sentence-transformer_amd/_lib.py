@@ -135,7 +135,7 @@ SIGNATURES = {
     "qst_attention_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "qst_attention_fwd_ex": (C.c_int, [C.POINTER(QstAttnDesc), vp]),
     "qst_attention_bwd_ex": (C.c_int, [C.POINTER(QstAttnDesc), vp]),
-    "qst_dropout_multipliers": (C.c_int, [C.POINTER(QstDrop), C.c_int64, vp, vp]),
+    "qst_dropout_multipliers": (C.c_int, [C.POINTER(QstDrop), C.c_int, C.c_int64, vp, vp]),
     "qst_abi_sizeof": (C.c_int64, [C.c_int]),
     "qst_dropout_init": (C.c_int, [vp, C.c_uint64, vp]),
     "qst_dropout_advance": (C.c_int, [vp, vp]),

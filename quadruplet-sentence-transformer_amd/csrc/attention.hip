@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
     float m = -INFINITY, l = 0.f;
-    const DropCtx dc = DROP ? drop_ctx(a.drop) : DropCtx{0u, 0u, 1.f};
+    const DropCtx dc = DROP ? drop_ctx8(a.drop) : DropCtx{0u, 0u, 1.f};
     const uint32_t drow = ((uint32_t)(seq * a.A + head) * a.L + qi) * a.L;      // this lane's query row of the mask
 
     const int nchunk = (a.L + 127) / 128;
@@ -217,12 +217,14 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs
             m = mn;
             if (DROP && dc.thr) {
                 // dropped probabilities leave the P.V product only: l stays the full softmax denominator, the 1/(1-p)
-                // scale joins 1/l at the end. Registers r, r+1 (r even) are keys j, j+1 of one random word.
+                // scale joins 1/l at the end. Registers 4g .. 4g+3 are four consecutive keys: the bytes of one random word.
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const uint32_t b2 = drop_bits(dc, drow + j0 + acc_row(r, h));
-                    if (!drop_keep_lo(dc, b2)) s[r] = 0.f;
-                    if (!drop_keep_hi(dc, b2)) s[r + 1] = 0.f;
+                for (int r = 0; r < 16; r += 4) {
+                    const uint32_t w = drop_word4(dc, drow + j0 + acc_row(r, h));
+                    if (!drop_keep_byte<0>(dc, w)) s[r] = 0.f;
+                    if (!drop_keep_byte<1>(dc, w)) s[r + 1] = 0.f;
+                    if (!drop_keep_byte<2>(dc, w)) s[r + 2] = 0.f;
+                    if (!drop_keep_byte<3>(dc, w)) s[r + 3] = 0.f;
                 }
             }
 #pragma unroll
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dq_kernel(AttnA
     for (int b = 0; b < DB; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[b][r] = 0.f;
-    const DropCtx dc = DROP ? drop_ctx(a.drop) : DropCtx{0u, 0u, 1.f};
+    const DropCtx dc = DROP ? drop_ctx8(a.drop) : DropCtx{0u, 0u, 1.f};
     const uint32_t drow = ((uint32_t)(seq * a.A + head) * a.L + qi) * a.L;
 
     const int nchunk = (a.L + 127) / 128;
@@ -342,10 +344,12 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dq_kernel(AttnA
             if (DROP && dc.thr) {
                 // dP = mask * dP~ (dp holds the gradient of the DROPPED probabilities); delta = dO.O is unchanged
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const uint32_t b2 = drop_bits(dc, drow + j0 + acc_row(r, h));
-                    dp[r] *= drop_keep_lo(dc, b2) ? dc.scale : 0.f;
-                    dp[r + 1] *= drop_keep_hi(dc, b2) ? dc.scale : 0.f;
+                for (int r = 0; r < 16; r += 4) {
+                    const uint32_t w = drop_word4(dc, drow + j0 + acc_row(r, h));
+                    dp[r] *= drop_keep_byte<0>(dc, w) ? dc.scale : 0.f;
+                    dp[r + 1] *= drop_keep_byte<1>(dc, w) ? dc.scale : 0.f;
+                    dp[r + 2] *= drop_keep_byte<2>(dc, w) ? dc.scale : 0.f;
+                    dp[r + 3] *= drop_keep_byte<3>(dc, w) ? dc.scale : 0.f;
                 }
             }
 #pragma unroll
@@ -424,8 +428,11 @@ __global__ __launch_bounds__(256, (D == 32 && !DROP) ? 4 : 2) void attn_bwd_dkv_
     for (int b = 0; b < DB; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[b][r] = 0.f; dv[b][r] = 0.f; }
-    const DropCtx dc = DROP ? drop_ctx(a.drop) : DropCtx{0u, 0u, 1.f};
+    const DropCtx dc = DROP ? drop_ctx8(a.drop) : DropCtx{0u, 0u, 1.f};
     const uint32_t dhead = (uint32_t)(seq * a.A + head) * a.L;            // mask row of query i: (dhead + i) * L
+    // S orientation: the lane's key kj is byte kj & 3 (= lane & 3) of the word that the four lanes of its quad share, one
+    // word per query row. Lane q of a quad hashes the rows 4g + q, the others fetch them by DPP: 4 hashes per 16 rows.
+    const uint32_t dsh = 8u * (uint32_t)(lane & 3);
 
     const int nchunk = (a.L + 127) / 128;
     for (int c = 0; c < nchunk; ++c) {
@@ -463,6 +470,11 @@ __global__ __launch_bounds__(256, (D == 32 && !DROP) ? 4 : 2) void attn_bwd_dkv_
                 // accumulator registers 4g..4g+3 are query rows 8g + 4h + (0..3): one 16-byte LDS read per constant
                 const int il = it * 32 + 8 * g + 4 * h;
                 const f32x4 l4 = *(const f32x4*)(lse_s + il), d4 = *(const f32x4*)(del_s + il);
+                uint32_t wq[4] = {0u, 0u, 0u, 0u};
+                if (DROP && dc.thr) {
+                    const uint32_t mine = drop_word4(dc, (dhead + (uint32_t)(i0 + 8 * g + 4 * h + (lane & 3))) * a.L + (uint32_t)(kj & ~3));
+                    wq[0] = quad_bcast<0>(mine); wq[1] = quad_bcast<1>(mine); wq[2] = quad_bcast<2>(mine); wq[3] = quad_bcast<3>(mine);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g + e;
@@ -472,11 +484,7 @@ __global__ __launch_bounds__(256, (D == 32 && !DROP) ? 4 : 2) void attn_bwd_dkv_
                     v += madd;
                     const float pr = __expf(v - l4[e]);
                     float mk = 1.f;
-                    if (DROP && dc.thr) {
-                        // this lane's key is one half of the random word of (query i, keys kj & ~1, kj | 1)
-                        const uint32_t b2 = drop_bits(dc, (dhead + (uint32_t)i) * a.L + (uint32_t)(kj & ~1));
-                        mk = ((kj & 1) ? drop_keep_hi(dc, b2) : drop_keep_lo(dc, b2)) ? dc.scale : 0.f;
-                    }
+                    if (DROP && dc.thr) mk = (((wq[e] >> dsh) & 0xFFu) >= dc.thr) ? dc.scale : 0.f;
                     const float dsr = pr * (dp[r] * mk - d4[e]);               // dS (unscaled) = d(score)
                     p[r] = pr * mk;                                            // dV takes the dropped probabilities
                     s[r] = REL ? dsr : dsr * a.scale;                          // REL: unscaled until the bias gradient is taken
@@ -627,7 +635,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
     const int nunits = paired ? nitems / 2 : nitems;
     auto item_of = [&](int unit) { return paired ? 2 * unit + bsub : unit; };
     int unit = bp, iter = 0;
-    const DropCtx dc = DROP ? drop_ctx(a.drop) : DropCtx{0u, 0u, 1.f};
+    const DropCtx dc = DROP ? drop_ctx8(a.drop) : DropCtx{0u, 0u, 1.f};
+    const uint32_t dsh = 8u * (uint32_t)(lane & 3);       // this lane's byte of its quad's random words (see the dK/dV kernel)
     if (unit < nunits) prefetch(item_of(unit), -1);
     for (; unit < nunits; unit += stride, ++iter) {
         const int item = item_of(unit);
@@ -704,6 +713,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
                 for (int g = 0; g < 4; ++g) {
                     const int il = it * 32 + 8 * g + 4 * h;     // accumulator registers 4g..4g+3 = query rows il..il+3
                     const f32x4 l4 = *(const f32x4*)(lse_s + il), d4 = *(const f32x4*)(del_s + il);
+                    uint32_t wq[4] = {0u, 0u, 0u, 0u};
+                    if (DROP && dc.thr) {
+                        const uint32_t mine = drop_word4(dc, (dhead + (uint32_t)(il + (lane & 3))) * a.L + (uint32_t)(kj & ~3));
+                        wq[0] = quad_bcast<0>(mine); wq[1] = quad_bcast<1>(mine); wq[2] = quad_bcast<2>(mine); wq[3] = quad_bcast<3>(mine);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; e += 2) {
                         const int r = 4 * g + e;
@@ -721,13 +735,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
                         pr[0] = __builtin_amdgcn_exp2f(v[0]);
                         pr[1] = __builtin_amdgcn_exp2f(v[1]);
                         if (DROP && dc.thr) {
-                            // dP = mask * dP~ and dV takes the dropped probabilities; this lane's key is one half of the
-                            // random word of (query, keys kj & ~1, kj | 1)
-                            const uint32_t e0 = (dhead + (uint32_t)(il + e)) * a.L + (uint32_t)(kj & ~1);
-                            const uint32_t b0 = drop_bits(dc, e0), b1 = drop_bits(dc, e0 + a.L);
+                            // dP = mask * dP~ and dV takes the dropped probabilities
                             f32x2 mk;
-                            mk[0] = ((kj & 1) ? drop_keep_hi(dc, b0) : drop_keep_lo(dc, b0)) ? dc.scale : 0.f;
-                            mk[1] = ((kj & 1) ? drop_keep_hi(dc, b1) : drop_keep_lo(dc, b1)) ? dc.scale : 0.f;
+                            mk[0] = (((wq[e] >> dsh) & 0xFFu) >= dc.thr) ? dc.scale : 0.f;
+                            mk[1] = (((wq[e + 1] >> dsh) & 0xFFu) >= dc.thr) ? dc.scale : 0.f;
                             dpv *= mk;
                             const f32x2 dsd = pr * (dpv - dv2);
                             if (REL && a.drel) { diag_add(dsd[0], r, lane, dlo, dhi); diag_add(dsd[1], r + 1, lane, dlo, dhi); }

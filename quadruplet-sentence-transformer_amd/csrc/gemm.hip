@@ -757,8 +757,9 @@ constexpr int LN_N = 384, LN_LD = 388;               // slab row stride 1552 B: 
 constexpr int LN_RING = 2 * (128 + LN_N) * NBK * 2;  // the K-loop ring (128 KB); the epilogue slabs reuse 99 KB of it
 constexpr int LN_LDS = LN_RING + 3 * LN_N * 4;       // + bias / gamma / beta, loaded before the K loop
 
-template <int MODE, bool DROP = false>
+template <int MODE, int DROPW = 0>        // DROPW: QstGemmArgs.drop_where as a compile-time constant (0 = no dropout)
 __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLnEpi e) {
+    constexpr bool DROP = DROPW != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -825,7 +826,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
     // result (2) or the incoming gradient (3). Masks are recomputed from (state, site, m * 384 + n), never stored.
     // (a separate instantiation: the backward epilogue has no registers to spare -- 252 of 256 without it)
     const DropCtx dc = DROP ? drop_ctx(g.drop) : DropCtx{0u, 0u, 1.f};
-    const int dwhere = (DROP && dc.thr) ? g.drop_where : 0;
+    constexpr int dwhere = DROPW;
 
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -841,8 +842,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
             }
         __syncthreads();                                     // slab complete
         LN_STAMP(3 + 2 * i);
-        if (i == 0 && !(DROP && MODE == 1)) LN_PREFETCH(1);  // pass 1's rows travel while pass 0 is normalised and stored
-        if (i == 1 && DROP && MODE == 1) LN_PREFETCH(1);     // (the masked backward variant cannot hold both passes' rows)
+        if (i == 0) LN_PREFETCH(1);                          // pass 1's rows travel while pass 0 is normalised and stored
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int row = wn * 8 + k;
@@ -1315,13 +1315,15 @@ extern "C" int qst_gemm_nt_ln(const QstGemmArgs* a, const QstLnEpi* ln, int mode
         if (a->drop.thr16 > 65535u || (int64_t)a->M * a->N >= ((int64_t)1 << 32)) return QST_ERR_UNSUPPORTED;
         if (mode == 0 ? a->drop_where != 1 : (a->drop_where != 2 && a->drop_where != 3)) return QST_ERR_BAD_ARG;
     }
-    static QstLdsAttr attr0, attr1, attr0d, attr1d;
+    static QstLdsAttr attr0, attr1, attr01, attr12, attr13;
     const int ntm = (a->M + 127) / 128;
     if (a->drop.thr16 && a->drop.state) {
-        if (int rc = qst_ensure_lds(attr0d, (const void*)gemm_nt_ln_kernel<0, true>, LN_LDS)) return rc;
-        if (int rc = qst_ensure_lds(attr1d, (const void*)gemm_nt_ln_kernel<1, true>, LN_LDS)) return rc;
-        if (mode == 0) gemm_nt_ln_kernel<0, true><<<dim3(ntm), dim3(512), LN_LDS, (hipStream_t)stream>>>(*a, *ln);
-        else gemm_nt_ln_kernel<1, true><<<dim3(ntm), dim3(512), LN_LDS, (hipStream_t)stream>>>(*a, *ln);
+        if (int rc = qst_ensure_lds(attr01, (const void*)gemm_nt_ln_kernel<0, 1>, LN_LDS)) return rc;
+        if (int rc = qst_ensure_lds(attr12, (const void*)gemm_nt_ln_kernel<1, 2>, LN_LDS)) return rc;
+        if (int rc = qst_ensure_lds(attr13, (const void*)gemm_nt_ln_kernel<1, 3>, LN_LDS)) return rc;
+        if (mode == 0) gemm_nt_ln_kernel<0, 1><<<dim3(ntm), dim3(512), LN_LDS, (hipStream_t)stream>>>(*a, *ln);
+        else if (a->drop_where == 2) gemm_nt_ln_kernel<1, 2><<<dim3(ntm), dim3(512), LN_LDS, (hipStream_t)stream>>>(*a, *ln);
+        else gemm_nt_ln_kernel<1, 3><<<dim3(ntm), dim3(512), LN_LDS, (hipStream_t)stream>>>(*a, *ln);
         QST_LAUNCH_CHECK();
         return QST_OK;
     }

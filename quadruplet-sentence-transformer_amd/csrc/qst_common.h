@@ -187,3 +187,24 @@ __device__ __forceinline__ void drop_pair(const DropCtx& c, uint32_t idx_even, f
     m0 = drop_keep_lo(c, b) ? c.scale : 0.f;
     m1 = drop_keep_hi(c, b) ? c.scale : 0.f;
 }
+
+// Attention probabilities ([nseq, A, L, L], the largest masked tensor by far, regenerated in three kernels): 8 random bits
+// per element, FOUR elements (keys 4t .. 4t+3 of one query) per hash word -- byte b of hash32((idx >> 2) ^ key) belongs to
+// element (idx & ~3) + b, dropped when byte < thr8 = (thr16 + 128) >> 8, kept ones scaled by 256 / (256 - thr8). So the
+// rate is quantised to 1/256 (p = 0.1 -> 26/256 = 0.1016, the scale matching it exactly); a quarter of the hashing.
+__device__ __forceinline__ DropCtx drop_ctx8(const QstDrop& d) {
+    DropCtx c = drop_ctx(d);
+    if (c.thr) {
+        c.thr = min(255u, (c.thr + 128u) >> 8);
+        c.scale = 256.0f / (float)(256u - c.thr);
+    }
+    return c;
+}
+__device__ __forceinline__ uint32_t drop_word4(const DropCtx& c, uint32_t idx4) { return qst_hash32((idx4 >> 2) ^ c.key); }
+template <int BYTE> __device__ __forceinline__ bool drop_keep_byte(const DropCtx& c, uint32_t w) {
+    return ((w >> (8 * BYTE)) & 0xFFu) >= c.thr;
+}
+// value of `v` in lane (lane & ~3) + SRC of this lane's quad
+template <int SRC> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, SRC | (SRC << 2) | (SRC << 4) | (SRC << 6), 0xf, 0xf, true);
+}

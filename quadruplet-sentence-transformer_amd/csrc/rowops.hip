@@ -804,14 +804,22 @@ extern "C" int qst_shadow_matrix(const float* src, int rows, int cols, void* dst
 namespace {
 __global__ void drop_init_kernel(uint32_t* st, uint32_t lo, uint32_t hi) { st[0] = lo; st[1] = hi; st[2] = 0u; st[3] = 0u; }
 __global__ void drop_advance_kernel(uint32_t* st) { st[2] += 1u; }
-__global__ __launch_bounds__(256) void drop_mult_kernel(QstDrop d, int64_t n, float* out) {
-    const DropCtx c = drop_ctx(d);
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+__global__ __launch_bounds__(256) void drop_mult_kernel(QstDrop d, int probs, int64_t n, float* out) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
-    float m0 = 1.f, m1 = 1.f;
-    if (c.thr) drop_pair(c, (uint32_t)i, m0, m1);
-    out[i] = m0;
-    if (i + 1 < n) out[i + 1] = m1;
+    float m[4] = {1.f, 1.f, 1.f, 1.f};
+    if (probs) {
+        const DropCtx c = drop_ctx8(d);
+        if (c.thr) {
+            const uint32_t w = drop_word4(c, (uint32_t)i);
+            m[0] = drop_keep_byte<0>(c, w) ? c.scale : 0.f; m[1] = drop_keep_byte<1>(c, w) ? c.scale : 0.f;
+            m[2] = drop_keep_byte<2>(c, w) ? c.scale : 0.f; m[3] = drop_keep_byte<3>(c, w) ? c.scale : 0.f;
+        }
+    } else {
+        const DropCtx c = drop_ctx(d);
+        if (c.thr) { drop_pair(c, (uint32_t)i, m[0], m[1]); drop_pair(c, (uint32_t)i + 2, m[2], m[3]); }
+    }
+    for (int k = 0; k < 4 && i + k < n; ++k) out[i + k] = m[k];
 }
 }  // namespace
 extern "C" int qst_dropout_init(uint32_t* state_dev, uint64_t seed, void* stream) {
@@ -826,10 +834,10 @@ extern "C" int qst_dropout_advance(uint32_t* state_dev, void* stream) {
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
-extern "C" int qst_dropout_multipliers(const QstDrop* d, int64_t n, float* out, void* stream) {
+extern "C" int qst_dropout_multipliers(const QstDrop* d, int probs, int64_t n, float* out, void* stream) {
     if (!d || !out || n <= 0) return QST_ERR_BAD_ARG;
     if (int rc = drop_ok(d, n)) return rc;
-    drop_mult_kernel<<<(unsigned)((n / 2 + 256) / 256), 256, 0, (hipStream_t)stream>>>(*d, n, out);
+    drop_mult_kernel<<<(unsigned)((n / 4 + 256) / 256), 256, 0, (hipStream_t)stream>>>(*d, probs, n, out);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }

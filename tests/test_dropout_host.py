@@ -32,6 +32,22 @@ def test_rate_and_unbiasedness():
         assert abs(float(m.mean()) - 1.0) < 3e-3                                 # E[mask] = 1
 
 
+def test_eight_bit_form_of_the_attention_masks():
+    assert D.thr8_of(0.1) == 26 and D.thr8_of(0.5) == 128 and D.thr8_of(0.0) == 0
+    n = 1 << 20
+    m = D.multipliers8(99, 5, D.site_probs(0), n, 0.1)
+    assert set(np.unique(m)) == {np.float32(0.0), np.float32(256.0 / 230.0)}
+    rate = float((m == 0).mean())
+    assert abs(rate - 26 / 256) < 4 * np.sqrt(0.1 * 0.9 / n)
+    assert abs(float(m.mean()) - 1.0) < 3e-3
+    z = m == 0
+    for k in (1, 2, 3):                                       # the four bytes of one word are independent of each other
+        assert abs(float((z[0::4] & z[k::4]).mean()) - (26 / 256) ** 2) < 2e-3
+    assert abs(float((z[:-4] & z[4:]).mean()) - (26 / 256) ** 2) < 1.5e-3
+    other = D.multipliers8(99, 6, D.site_probs(0), n, 0.1) == 0
+    assert abs(float((z & other).mean()) - (26 / 256) ** 2) < 1.5e-3
+
+
 def test_streams_are_independent():
     n = 1 << 18
     base = D.multipliers(5, 1, D.site_attn_out(0), n, 0.1) == 0

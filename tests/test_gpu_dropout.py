@@ -56,8 +56,10 @@ def mult(seed, step, site, shape, p):
 def test_mask_words_equal_the_oracle(lib, seed, step, site, n, p):
     st = make_state(lib, seed, step)
     out = torch.empty(n, device="cuda")
-    _lib.check(lib.qst_dropout_multipliers(drop(st, site, p), n, out.data_ptr(), stream()))
+    _lib.check(lib.qst_dropout_multipliers(drop(st, site, p), 0, n, out.data_ptr(), stream()))
     assert np.array_equal(out.cpu().numpy(), D.multipliers(seed, step, site, n, p))
+    _lib.check(lib.qst_dropout_multipliers(drop(st, site, p), 1, n, out.data_ptr(), stream()))      # the attention-probability form
+    assert np.array_equal(out.cpu().numpy(), D.multipliers8(seed, step, site, n, p))
     assert st.cpu().tolist()[2] == step
 
 
@@ -185,7 +187,7 @@ def test_attention_with_dropped_probabilities(lib, n, L, A, d, use_rel, hm):
     g = torch.Generator().manual_seed(n * L + A + d)
     seed, step, p, site = 31337, 4, 0.1, D.site_probs(1)
     st = make_state(lib, seed, step)
-    pm = mult(seed, step, site, (n, A, L, L), p)
+    pm = torch.from_numpy(D.multipliers8(seed, step, site, n * A * L * L, p).reshape(n, A, L, L))
     qkv = bfr(torch.randn(n * L, 3 * H, generator=g))
     lens = torch.randint(max(1, L // 8), L + 1, (n,), generator=g); lens[0] = L
     mask = (torch.arange(L)[None, :] < lens[:, None]).long()
