@@ -251,13 +251,27 @@ def time_kernels(trainer, n, L, reps, batches):
         t_ffn1 += ev[1].elapsed_time(ev[2])
         t_chain += ev[2].elapsed_time(ev[3])
     wflops = 2.0 * M * (H * I + I * H + H * H + 3 * H * H)
+    # algorithmic HBM bytes per launch (finding 7): every operand once, every output once
+    nparam = H * I + I * H + H * H + 3 * H * H
+    wbytes = 2.0 * M * (8 * H + 2 * I) + 8 * 4.0 * nparam            # bf16 dY and X of the four products + 8 fp32 partial sums
+    f1bytes = 2.0 * M * H + 2.0 * I * H + 2 * 2.0 * M * I            # A, W, then gelu'(u) and h
+    chbytes = 2.0 * M * H + 4.0 * I * H + 4.0 * M * H + M * H * (4 + 2 + 2)     # A, W1+W2, resid; y fp32, y bf16, xhat
     third = None if chain is None else {
         "kernel": "ffn_chain_kernel<0, false> (FFN-1 + GELU + FFN-2 + LayerNorm in one launch; inference forward)",
-        "ms": t_chain / reps, "flops_per_launch": 4.0 * M * I * H, "shape": [M, I, H]}
+        "ms": t_chain / reps, "flops_per_launch": 4.0 * M * I * H, "bytes_per_launch": chbytes, "shape": [M, I, H]}
     return ({"kernel": "gemm_tn_group_kernel (all 4 wgrads of one layer: dW2, dW1, dWo, dWqkv + bias grads)",
-             "ms": t_wgrad / reps, "flops_per_launch": wflops, "shape": [M, H, I]},
+             "ms": t_wgrad / reps, "flops_per_launch": wflops, "bytes_per_launch": wbytes, "shape": [M, H, I]},
             {"kernel": "gemm_nt_kernel<2, 2, 2> (FFN1 fwd, bias+GELU epilogue)", "ms": t_ffn1 / reps,
-             "flops_per_launch": 2.0 * M * I * H, "shape": [M, I, H]}, third)
+             "flops_per_launch": 2.0 * M * I * H, "bytes_per_launch": f1bytes, "shape": [M, I, H]}, third)
+
+
+def hbm_side(dk):
+    """The same launch against the HBM roofline: these kernels' arithmetic intensity (170-290 FLOP/B) is below the chip's
+    balance point (2.5 PF / 8 TB/s = 312), so the byte floor is the longer one."""
+    gbs = dk["bytes_per_launch"] / (dk["ms"] * 1e-3) / 1e9
+    return {"algorithmic_bytes": int(dk["bytes_per_launch"]), "floor_us": round(dk["bytes_per_launch"] / (PEAK_HBM_GBS * 1e9) * 1e6, 1),
+            "achieved_GBps": round(gbs, 1), "peak_GBps": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4),
+            "flop_per_byte": round(dk["flops_per_launch"] / dk["bytes_per_launch"], 1)}
 
 
 def time_fwd_only(trainer, batches, steps, precision="bf16"):
@@ -434,10 +448,12 @@ def main():
             "step_mfma_frac": round(step_tflops / (PEAK_BF16_TFLOPS * world), 4),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": dk["kernel"], "avg_launch_ms": round(dk["ms"], 5), "shape_M_H_I": dk["shape"]},
+                         "kernel": dk["kernel"], "avg_launch_ms": round(dk["ms"], 5), "shape_M_H_I": dk["shape"],
+                         "hbm_side": hbm_side(dk)},
             "roofline_ffn1_fwd": {"bound": "mfma", "achieved": round(achieved2, 2), "peak": PEAK_BF16_TFLOPS,
                                   "unit": "TFLOP/s", "frac": round(achieved2 / PEAK_BF16_TFLOPS, 4), "traffic": traffic2,
-                                  "kernel": dk2["kernel"], "avg_launch_ms": round(dk2["ms"], 5), "shape_MNK": dk2["shape"]},
+                                  "kernel": dk2["kernel"], "avg_launch_ms": round(dk2["ms"], 5), "shape_MNK": dk2["shape"],
+                                  "hbm_side": hbm_side(dk2)},
         }
         if dk3 is not None:
             a3 = dk3["flops_per_launch"] / (dk3["ms"] * 1e-3) / 1e12
