@@ -145,8 +145,13 @@ typedef struct {
     int32_t ranges_per_xcd;       /* filled by the library */
     int32_t tiles[QST_TN_MAX_PROB];
     QstGemmArgs prob[QST_TN_MAX_PROB];
+    /* Optional scratch of qst_gemm_tn_slab_bytes(grp) bytes (f32, 16-byte aligned): partial tiles are then written with plain
+     * stores and summed into C by a second kernel in a fixed order (reproducible bit for bit) instead of float atomics.
+     * NULL = atomics. The library falls back to atomics by itself when the shape does not fit the slab scheme. */
+    float* slabs;
 } QstTnGroup;
 int qst_gemm_tn_group(const QstTnGroup* grp, void* stream);
+size_t qst_gemm_tn_slab_bytes(const QstTnGroup* grp);
 
 /* Embedding gather + LayerNorm (BertEmbeddings / MPNetEmbeddings forward).
  * pos_ids: int32 [M] position row per token. type_emb may be NULL. Outputs: y f32, y bf16, xhat bf16, rstd f32. */

@@ -67,7 +67,7 @@ class QstLnReduceBatch(C.Structure):
 class QstTnGroup(C.Structure):
     _fields_ = [("nprob", C.c_int32), ("splits", C.c_int32), ("total_tiles", C.c_int32), ("ranges_per_xcd", C.c_int32),
                 ("tiles", C.c_int32 * 8),
-                ("prob", QstGemmArgs * 8)]
+                ("prob", QstGemmArgs * 8), ("slabs", vp)]
 
 
 # name -> (restype, argtypes). Every symbol the two public headers declare.
@@ -137,6 +137,7 @@ SIGNATURES = {
     "qst_attention_bwd_ex": (C.c_int, [C.POINTER(QstAttnDesc), vp]),
     "qst_dropout_multipliers": (C.c_int, [C.POINTER(QstDrop), C.c_int, C.c_int64, vp, vp]),
     "qst_abi_sizeof": (C.c_int64, [C.c_int]),
+    "qst_gemm_tn_slab_bytes": (C.c_size_t, [C.POINTER(QstTnGroup)]),
     "qst_dropout_init": (C.c_int, [vp, C.c_uint64, vp]),
     "qst_dropout_advance": (C.c_int, [vp, vp]),
     "qst_encoder_set_dropout": (C.c_int, [vp, C.c_float, C.c_float, vp]),

@@ -966,6 +966,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
 // LDS image per operand stage: [32 m-rows][192 bf16] = 384-byte rows (24 chunks of 16 B); chunk c of row r sits at
 // chunk position c ^ (((r >> 1) & 1) << 2): the 4 rows x 64 B that one half-wave reads land in 16 distinct 16-B slots.
 constexpr int TT = 192, TBK = 32, TSTAGES = 6;            // 6-slot ring: one stage being read, up to five in flight
+constexpr int TN_MAX_PIECES = 2;                          // slab flush: stage pieces a leftover tile may be cut into
 constexpr int TT_TILE = TBK * TT * 2;                // 12 KB per operand per stage
 constexpr int TT_STAGE = 2 * TT_TILE;                // 24 KB
 constexpr int TT_LDS = TSTAGES * TT_STAGE;           // 144 KB: one workgroup (4 MFMA + 4 loader waves) per CU
@@ -986,6 +987,7 @@ __device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
 // = a*W + b, every workgroup reduces `a` whole tiles and then one stage-piece of a leftover tile (task list in the
 // kernel), so all CUs finish together instead of 1.5 tiles per CU being rounded up to 2; split tiles simply receive
 // several partial sums through the fp32 atomics.
+template <bool SLAB>
 __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1142,6 +1144,26 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
         __builtin_amdgcn_s_barrier();                      // end of piece: the loaders may refill the ring while we flush
 
         float* C = (float*)g.C;
+        if (SLAB) {
+            // slab flush: this task's partial tile goes out as plain stores into its own [192][192] slot (tile-local
+            // layout, whole tile incl. padding rows / columns, which hold zeros); tn_reduce_kernel sums the slots of a
+            // tile into C afterwards. Float atomics execute at the memory side at ~1.3 TB/s chip-wide: the 75 MB of
+            // partial sums of a MiniLM layer cost 43 us of the launch that way.
+            const int tile_g = (task < a_full) ? task * W + jr : a_full * W + jr / pieces;      // index over all problems
+            const int pc = (task < a_full) ? 0 : jr % pieces;
+            float* S = grp.slabs + ((size_t)(range * TN_MAX_PIECES + pc) * T + tile_g) * (TT * TT) +
+                       (wm * 96 + 4 * fh) * TT + wn * 96 + fr;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                __builtin_amdgcn_sched_barrier(0);       // one 32-row band's addresses at a time (144 at once spill)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float* row = S + (i * 32 + (r & 3) + 8 * (r >> 2)) * TT;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) row[j * 32] = acc[i][j][r];
+                }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int k = k0 + wn * 96 + j * 32 + fr;
@@ -1155,6 +1177,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
                 }
             }
         }
+        }
         if (do_bias) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -1163,6 +1186,43 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
                 if (fh == 0 && n < g.N) atomicAdd(&g.colsum[n], t);
             }
         }
+    }
+}
+
+// Second half of the slab flush: C[n][k] += sum over the slots that hold a partial sum of that tile (every M-range's
+// slot 0 for a tile reduced whole; the pieces that exist for a leftover tile). One workgroup per (tile, 16-row band),
+// 16-byte accesses along k; the order of the sum is fixed, so the weight gradients are reproducible bit for bit.
+__global__ __launch_bounds__(256) void tn_reduce_kernel(QstTnGroup grp, int nranges, int W, int per) {
+    const int T = grp.total_tiles;
+    const int tile_g = blockIdx.x / (TT / 16), band = blockIdx.x % (TT / 16);
+    int tile = tile_g, pi = 0;
+    while (pi + 1 < grp.nprob && tile >= grp.tiles[pi]) { tile -= grp.tiles[pi]; ++pi; }
+    const QstGemmArgs& g = grp.prob[pi];
+    const int ntk = (g.K + TT - 1) / TT;
+    const int n0 = (tile / ntk) * TT, k0 = (tile % ntk) * TT;
+    const int a_full = T / W, b_left = T % W;
+    const int pieces = b_left > 0 ? max(1, W / b_left) : 1;
+    const bool leftover = tile_g >= a_full * W;
+    const int M = grp.prob[0].M;
+    float* C = (float*)g.C;
+    for (int e = threadIdx.x; e < 16 * (TT / 4); e += 256) {
+        const int nl = band * 16 + e / (TT / 4), kl = (e % (TT / 4)) * 4;
+        const int n = n0 + nl, k = k0 + kl;
+        if (n >= g.N || k >= g.K) continue;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < nranges; ++r) {
+            int npc = 1;
+            if (leftover) {                                                  // pieces of this range with at least one stage
+                const int S = (min(M, (r + 1) * per) - r * per + TBK - 1) / TBK;
+                const int per_piece = (S + pieces - 1) / pieces;
+                npc = min(pieces, (S + per_piece - 1) / per_piece);
+            }
+            for (int pc = 0; pc < npc; ++pc)
+                a += *(const f32x4*)(grp.slabs + ((size_t)(r * TN_MAX_PIECES + pc) * T + tile_g) * (TT * TT) + nl * TT + kl);
+        }
+        float* dst = C + (size_t)n * g.ldc + k;
+        if (k + 4 <= g.K) { *(f32x4*)dst = *(const f32x4*)dst + a; }
+        else for (int q = 0; q < 4 && k + q < g.K; ++q) dst[q] += a[q];
     }
 }
 
@@ -1363,11 +1423,33 @@ extern "C" int qst_gemm_tn_group(const QstTnGroup* grp_in, void* stream) {
     const int64_t work = (int64_t)g.total_tiles * stages;
     if (wg_per_range > work) wg_per_range = work < 1 ? 1 : work;
     const int grid = (int)(8 * g.ranges_per_xcd * wg_per_range);
-    static QstLdsAttr attr;
-    if (int rc = qst_ensure_lds(attr, (const void*)gemm_tn_group_kernel, TT_LDS)) return rc;
-    gemm_tn_group_kernel<<<dim3(grid), dim3(512), TT_LDS, (hipStream_t)stream>>>(g);
+    // slab flush (g.slabs: qst_gemm_tn_slab_bytes of scratch): only when every range has rows, a leftover tile is cut into
+    // at most TN_MAX_PIECES pieces and the outputs are 16-byte aligned; float atomics otherwise
+    const int W = (int)wg_per_range, T = g.total_tiles, b_left = T % W;
+    bool slab_ok = g.slabs != nullptr && (b_left == 0 || W / b_left <= TN_MAX_PIECES) && (int64_t)(g.splits - 1) * stages * TBK < M;
+    for (int i = 0; i < g.nprob && slab_ok; ++i)
+        slab_ok = g.prob[i].ldc % 4 == 0 && ((uintptr_t)g.prob[i].C & 15) == 0;
+    if (!slab_ok) g.slabs = nullptr;
+    static QstLdsAttr attr, attr_s;
+    if (int rc = qst_ensure_lds(attr, (const void*)gemm_tn_group_kernel<false>, TT_LDS)) return rc;
+    if (int rc = qst_ensure_lds(attr_s, (const void*)gemm_tn_group_kernel<true>, TT_LDS)) return rc;
+    if (g.slabs) gemm_tn_group_kernel<true><<<dim3(grid), dim3(512), TT_LDS, (hipStream_t)stream>>>(g);
+    else gemm_tn_group_kernel<false><<<dim3(grid), dim3(512), TT_LDS, (hipStream_t)stream>>>(g);
     QST_LAUNCH_CHECK();
+    if (g.slabs) {
+        tn_reduce_kernel<<<dim3(T * (TT / 16)), dim3(256), 0, (hipStream_t)stream>>>(g, g.splits, W, (int)(stages * TBK));
+        QST_LAUNCH_CHECK();
+    }
     return QST_OK;
+}
+
+extern "C" size_t qst_gemm_tn_slab_bytes(const QstTnGroup* grp) {
+    if (!grp || grp->nprob <= 0 || grp->nprob > QST_TN_MAX_PROB) return 0;
+    size_t tiles = 0;
+    for (int i = 0; i < grp->nprob; ++i)
+        tiles += (size_t)((grp->prob[i].N + TT - 1) / TT) * ((grp->prob[i].K + TT - 1) / TT);
+    const int splits = grp->splits <= 0 ? 8 : (grp->splits + 7) / 8 * 8;
+    return (size_t)splits * TN_MAX_PIECES * tiles * TT * TT * sizeof(float);
 }
 
 extern "C" int qst_gemm_tn(const QstGemmArgs* a, void* stream) {

@@ -298,7 +298,13 @@ MxPlan plan_mx(const qst_config& c, int nseq, int L) {
     return p;
 }
 
-struct BwdPlan { size_t dxa, dxb, ds, dsb, dsb1, du, dctx, dqkv, drel, lnred, lnred_stride, delta, total; };
+struct BwdPlan { size_t dxa, dxb, ds, dsb, dsb1, du, dctx, dqkv, drel, lnred, lnred_stride, delta, slabs, total; };
+// Flush of the grouped wgrad launch: float atomics (default) or plain stores into per-range slots + a reduce kernel
+// (QstTnGroup.slabs; reproducible sums). Measured on the c2 step, same process: 4.851 ms with slabs against 4.827 with
+// atomics -- the 75 MB of partial sums cost the same written and re-read as they do added at the memory side.
+// qst_debug_wgrad_slabs(1) selects the slab flush (set it before the workspace size is asked for).
+static int g_wgrad_slabs = 0;
+extern "C" void qst_debug_wgrad_slabs(int on) { g_wgrad_slabs = on; }
 BwdPlan plan_bwd(const qst_config& c, int nseq, int L) {
     BwdPlan p;
     const size_t M = (size_t)nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads;
@@ -311,6 +317,14 @@ BwdPlan plan_bwd(const qst_config& c, int nseq, int L) {
     p.lnred_stride = (qst_ln_bwd_scratch_bytes((int)M, (int)H) + 255) / 256 * 256;
     p.lnred = take(p.lnred_stride * (size_t)(2 * c.num_layers + 1));
     p.delta = take((size_t)nseq * A * L * 4);
+    {
+        // partial-sum slots of one layer's grouped wgrad launch (qst_gemm_tn_slab_bytes)
+        QstTnGroup grp{};
+        grp.nprob = 4;
+        const int shp[4][2] = {{(int)H, (int)I}, {(int)I, (int)H}, {(int)H, (int)H}, {(int)(3 * H), (int)H}};
+        for (int i = 0; i < 4; ++i) { grp.prob[i].N = shp[i][0]; grp.prob[i].K = shp[i][1]; }
+        p.slabs = g_wgrad_slabs ? take(qst_gemm_tn_slab_bytes(&grp)) : 0;
+    }
     p.total = off;
     return p;
 }
@@ -785,6 +799,7 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
         set(2, dsb1, H, sv + a.ctx, H, b + W_O, b + B_O);          // dWo [H, H]
         set(3, dqkv, 3 * H, xin_b, H, b + W_QKV, b + B_QKV);       // dWqkv [3H, H]
         if (hm) { grp.prob[3].a_head_L = L; grp.prob[3].a_head_d = d; }
+        if (g_wgrad_slabs) grp.slabs = (float*)(ws + w.slabs);
         return qst_gemm_tn_group(&grp, st);
     };
     if (wgrad_only) {

@@ -154,10 +154,13 @@ def test_gemm_tn_wgrad(lib, M, N, K):
     torch.testing.assert_close(C.cpu(), 2 * ref, rtol=1e-3, atol=2e-3 * scale)
 
 
-def test_gemm_tn_group_matches_individual(lib):
-    """All four weight gradients of a MiniLM-shaped layer in one grouped launch."""
-    M, H, I = 1000, 384, 1536
-    g = torch.Generator().manual_seed(5)
+@pytest.mark.parametrize("M,slab", [(1000, False), (1000, True), (4096, True), (32 * 70 + 32, True), (96, True)])
+def test_gemm_tn_group_matches_individual(lib, M, slab):
+    """All four weight gradients of a MiniLM-shaped layer in one grouped launch; slab: partial tiles flushed with plain
+    stores into per-range slots and summed by a second kernel in a fixed order (bit-reproducible) instead of float
+    atomics -- incl. a last M-range shorter than the others and M too small for eight ranges (falls back to atomics)."""
+    H, I = 384, 1536
+    g = torch.Generator().manual_seed(5 + M)
     shapes = [(H, I), (I, H), (H, H), (3 * H, H)]
     grp = _lib.QstTnGroup()
     grp.nprob, grp.splits = 4, 0
@@ -166,18 +169,31 @@ def test_gemm_tn_group_matches_individual(lib):
         A = bfr(torch.randn(M, N, generator=g))
         B = bfr(torch.randn(M, K, generator=g))
         Ad, Bd = dev(A.to(torch.bfloat16)), dev(B.to(torch.bfloat16))
-        C = torch.zeros(N, K, device="cuda")
+        C = torch.ones(N, K, device="cuda")                    # accumulation semantics: C += A^T.B
         cs = torch.zeros(N, device="cuda")
         q = grp.prob[i]
         q.A, q.B, q.C, q.colsum = Ad.data_ptr(), Bd.data_ptr(), C.data_ptr(), cs.data_ptr()
         q.M, q.N, q.K, q.lda, q.ldb, q.ldc = M, N, K, N, K, K
         keep += [Ad, Bd]
-        refs.append((A.t() @ B, A.sum(0)))
+        refs.append((A.t() @ B + 1.0, A.sum(0)))
         outs.append((C, cs))
+    if slab:
+        sl = torch.full((lib.qst_gemm_tn_slab_bytes(grp) // 4,), float("nan"), device="cuda")
+        grp.slabs = sl.data_ptr()
     _lib.check(lib.qst_gemm_tn_group(grp, stream()))
+    torch.cuda.synchronize()
     for (C, cs), (rC, rcs) in zip(outs, refs):
         torch.testing.assert_close(C.cpu(), rC, rtol=1e-3, atol=1e-3 * math.sqrt(M))
         torch.testing.assert_close(cs.cpu(), rcs, rtol=1e-3, atol=1e-3 * math.sqrt(M))
+    if slab and M >= 256:
+        first = [C.clone() for C, _ in outs]
+        for C, _ in outs:
+            C.fill_(1.0)
+        sl.fill_(float("nan"))
+        _lib.check(lib.qst_gemm_tn_group(grp, stream()))
+        torch.cuda.synchronize()
+        for a, (C, _) in zip(first, outs):
+            assert torch.equal(a, C)                              # fixed summation order
 
 
 # ------------------------------------------------------------------ LayerNorm
