@@ -35,7 +35,7 @@ def _dp_case(name):
     return PRESETS[name], 4, 32
 
 
-def _worker(rank, world, port, overlap, out_dir, case="tiny-bert"):
+def _worker(rank, world, port, overlap, out_dir, case="tiny-bert", dropout=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -44,7 +44,8 @@ def _worker(rank, world, port, overlap, out_dir, case="tiny-bert"):
     torch.cuda.set_device(0)
     cfg, B, L = _dp_case(case)
     arena = synthetic_params(cfg, seed=14, std=0.05, bias_std=0.02, ln_jitter=0.05)
-    tr = QuadrupletTrainer(cfg, arena=arena, device="cuda:0", lr=1e-3, world_size=world, overlap=overlap)
+    tr = QuadrupletTrainer(cfg, arena=arena, device="cuda:0", lr=1e-3, world_size=world, overlap=overlap,
+                           dropout=dropout, dropout_seed=100 + rank)           # every rank its own mask stream
     for step in range(2):
         ids, mask, types = synthetic_quadruplets(cfg, world * B, L, seed=14, ragged=True, step=step)
         sl = slice(rank * B, (rank + 1) * B)                  # this rank's shard of the global batch
@@ -79,6 +80,19 @@ def test_two_rank_step_equals_single_rank_on_global_batch(tmp_path, overlap, cas
     bad = np.abs(p0 - ref) > 0.05 * moved
     assert bad.mean() < 1e-3, f"{bad.sum()} of {bad.size} parameters differ"
     assert np.abs(p0 - ref).max() <= 2.1e-3 and np.abs(p0 - ref).mean() < 2e-3 * moved
+
+
+def test_replicas_stay_identical_with_per_rank_dropout(tmp_path):
+    """With dropout every rank draws its own masks (seed + rank), so the ranks' local gradients differ by more than their
+    data -- the reduced gradient, the global-norm clip and the update are still the same everywhere: replicas stay
+    bit-identical, and the masks did something (the result differs from the dropout-free run)."""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), True, str(tmp_path), "tiny-bert", 0.1), nprocs=world, join=True)
+    p0, p1 = np.load(tmp_path / "params_0.npy"), np.load(tmp_path / "params_1.npy")
+    np.testing.assert_array_equal(p0, p1)
+    assert np.isfinite(p0).all()
+    mp.spawn(_worker, args=(world, _free_port(), True, str(tmp_path), "tiny-bert", None), nprocs=world, join=True)
+    assert np.abs(np.load(tmp_path / "params_0.npy") - p0).max() > 1e-5
 
 
 def _grads_after(cfg, arena, batch, mode):

@@ -338,3 +338,22 @@ def test_trainer_steps_with_dropout_and_eval_mode_is_unaffected():
     assert tr.enc.dropout_step == 12
     with pytest.raises(ValueError):
         tr.enc.set_dropout(1.0, 0.0)
+
+
+def test_captured_step_draws_fresh_masks_on_every_replay():
+    """QuadrupletTrainer(use_graph=True): the counter advance and the per-forward snapshot are launches inside the captured
+    step, so every replay uses the next step's masks -- the losses of the graph-replayed run follow those of the eager run
+    with the same seed, step for step."""
+    from quadruplet_sentence_transformer_amd.trainer import QuadrupletTrainer
+    cfg = PRESETS["tiny-bert"]
+    arena = synthetic_params(cfg, seed=14, std=0.05)
+    batches = [[torch.from_numpy(x).cuda() for x in synthetic_quadruplets(cfg, 8, 32, seed=14, step=i)] for i in range(3)]
+    runs = []
+    for use_graph in (False, True):
+        tr = QuadrupletTrainer(cfg, arena=arena, device="cuda:0", lr=1e-3, dropout=0.1, dropout_seed=9, use_graph=use_graph)
+        runs.append([tr.step(*batches[i % 3]).item() for i in range(7)])
+        torch.cuda.synchronize()
+        assert tr.enc.drop_state.cpu().tolist()[2] == 7
+    eager, graph = runs
+    assert len(set(round(v, 6) for v in graph)) == 7
+    np.testing.assert_allclose(graph, eager, rtol=0, atol=2e-4)
