@@ -224,6 +224,10 @@ int qst_topk_scores(const float* queries, const float* corpus, int nq, int nc, i
 size_t qst_score_workspace_bytes(int nq, int nc, int dim);
 int qst_score_matrix(const float* queries, const float* corpus, int nq, int nc, int dim, int mode, float* out,
                      int64_t ld_out, void* workspace, size_t workspace_bytes, void* stream);
+/* torch.nn.functional.normalize(x, p=2, dim=1, eps=1e-12) over the rows of x f32 [n, dim] (contiguous): what
+ * SentenceTransformer.encode(normalize_embeddings=True) applies. out may alias x. */
+int qst_normalize_rows(const float* x, int n, int dim, float* out, void* stream);
+
 
 /* The same with a ceiling: corpus rows scoring above max_score do not take part. This is the reference's negative
  * selection (dataset/quadruplet_dataset.py:185-270: candidates with SBERT cosine <= 0.2 to the reference caption, then

@@ -137,6 +137,7 @@ SIGNATURES = {
     "qst_attention_bwd_ex": (C.c_int, [C.POINTER(QstAttnDesc), vp]),
     "qst_dropout_multipliers": (C.c_int, [C.POINTER(QstDrop), C.c_int, C.c_int64, vp, vp]),
     "qst_abi_sizeof": (C.c_int64, [C.c_int]),
+    "qst_normalize_rows": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "qst_gemm_tn_slab_bytes": (C.c_size_t, [C.POINTER(QstTnGroup)]),
     "qst_dropout_init": (C.c_int, [vp, C.c_uint64, vp]),
     "qst_dropout_advance": (C.c_int, [vp, vp]),

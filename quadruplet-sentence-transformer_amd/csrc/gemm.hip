@@ -6,13 +6,19 @@
 // These replace nn.Linear forward/backward inside BertLayer (transformers modeling_bert.py:154-156,
 // 282-293, 325-351).
 //
-// Structure (both kernels): 128x128 output tile per 256-thread workgroup (4 waves, 2x2, 64x64 per wave = 2x2 MFMA
-// 32x32 tiles); the reduction dimension is streamed in 32-deep stages through a 4-slot LDS ring filled by LDS-DMA
-// (buffer_load_dwordx4 ... lds: no staging registers, hardware range check zero-fills ragged M/N), three stages in
-// flight across ONE raw s_barrier per stage with counted s_waitcnt vmcnt -- the short-K shapes here (K = 384) are
-// latency-bound, not MFMA-bound, so memory-level parallelism is what the loop is built around.
+// Kernels in this file (each is described in detail at its definition):
+//   gemm_nt_kernel<EPI, WAVES_M, WAVES_N, TI>  128x192 tile, 4 waves of 64x96, two workgroups per CU (default); 256x192 with 8
+//                       waves; 256x192 with four waves of 128x96 ("tall", 32-deep stages) for the K >= 768 bf16-output GEMMs.
+//                       K in 64-deep stages by LDS-DMA into a 2-slot XOR-swizzled ring, one raw s_barrier per stage.
+//   gemm_nt_w8_kernel   the same loop on fp8 (e4m3) weights widened to bf16 in registers (QST_PREC_FP8W, inference)
+//   gemm_nt_f8_kernel   both operands MXFP8 on v_mfma_scale_f32_32x32x64_f8f6f4, 128-deep stages (QST_PREC_FP8, inference)
+//   gemm_nt_ln_kernel<MODE, DROPW>  128x384 full-row tile with the LayerNorm (forward) / LayerNorm backward in the epilogue
+//   gemm_tn_group_kernel<SLAB>      all weight gradients of a layer in one launch, 192x192 tiles, one M-range per XCD,
+//                       4 MFMA + 4 loader waves, 6-slot ring of 32-row stages; tn_reduce_kernel for the slab flush
+//   quant_mx_kernel     MXFP8 quantisation of an activation matrix
 // LDS images are XOR-swizzled (applied on the DMA SOURCE address, the destination is lane-linear) so that
-// ds_read_b128 (nt) and ds_read_b64_tr_b16 (tn) fragment reads are bank-conflict-free.
+// ds_read_b128 (nt) and ds_read_b64_tr_b16 (tn) fragment reads are bank-conflict-free; LDS-DMA = buffer_load_dwordx4 ... lds
+// (no staging registers, hardware range check zero-fills ragged M / N).
 #include "qst_common.h"
 #include "qst_kernels.h"
 

@@ -300,3 +300,10 @@ extern "C" int qst_score_matrix(const float* queries, const float* corpus, int n
     }
     return QST_OK;
 }
+
+extern "C" int qst_normalize_rows(const float* x, int n, int dim, float* out, void* stream) {
+    if (!x || !out || n <= 0 || dim <= 0) return QST_ERR_BAD_ARG;
+    prep_rows_kernel<<<(n + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, n, n, dim, 1, out);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}

@@ -348,8 +348,10 @@ class SentenceTransformer(nn.Module):
             for start in range(0, len(sorted_s), batch_size):
                 feats = self.tokenize(sorted_s[start:start + batch_size])
                 emb = self.forward(feats)["sentence_embedding"].detach()
-                if normalize_embeddings:
-                    emb = torch.nn.functional.normalize(emb, p=2, dim=1)
+                if normalize_embeddings and emb.shape[0] > 0:
+                    emb = emb.contiguous()
+                    _lib.check(self._enc.lib.qst_normalize_rows(emb.data_ptr(), emb.shape[0], emb.shape[1], emb.data_ptr(),
+                                                                _lib.current_stream_ptr()), "qst_normalize_rows")
                 chunks.append(emb.cpu() if convert_to_numpy else emb)
         allemb = torch.cat(chunks, 0) if chunks else torch.zeros(0, self.cfg.hidden_size)
         inv = np.argsort(order)

@@ -48,6 +48,19 @@ def test_encode_shapes_order_and_determinism(model):
     np.testing.assert_allclose(t.cpu().numpy(), model.encode(texts, batch_size=32), rtol=0, atol=2e-3)
 
 
+def test_encode_normalize_embeddings_runs_the_library_kernel():
+    """encode(normalize_embeddings=True) on a model WITHOUT the Normalize module (ST auto-wrapped bert-base style):
+    qst_normalize_rows == torch.nn.functional.normalize(p=2, dim=1)."""
+    from dataclasses import replace
+    from quadruplet_sentence_transformer_amd.config import PRESETS
+    m = SentenceTransformer(config=replace(PRESETS["tiny-bert"], normalize=False), device="cuda")
+    texts = [sent(i, 3 + i % 5) for i in range(7)]
+    raw = m.encode(texts, convert_to_tensor=True)
+    assert (raw.norm(dim=1) - 1).abs().max() > 1e-2
+    got = m.encode(texts, normalize_embeddings=True, convert_to_tensor=True)
+    torch.testing.assert_close(got, torch.nn.functional.normalize(raw, p=2, dim=1), rtol=1e-6, atol=1e-7)
+
+
 def test_encode_parity_precision(model):
     texts = [sent(i, 3 + i % 7) for i in range(9)]
     fast = model.encode(texts)
