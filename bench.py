@@ -66,16 +66,29 @@ def cpu_baseline(cfg, arena, seq_len, batch, budget_s=25.0):
         parameter groups) on the same batches, bounded by the time budget;
       * the headline shape (configs[1]: `batch` quadruplets x `seq_len`), one full training step after one warm-up
         forward, for a like-for-like ratio.
-    `value` is the config-1 full-training-step rate; `cores` = torch's intra-op thread count (stated, not tuned)."""
+    `value` is the config-1 full-training-step rate; `cores` = torch's intra-op thread count, chosen by a short
+    calibration (4 forward batches at 8 / 16 / 32 / all threads): at these sizes all 128 threads of the box's host are
+    several times SLOWER than 8-16 (measured 9.8 vs 36 q/s), and the baseline should be the CPU's best."""
     import torch
     from oracle import torch_ref as R
     from quadruplet_sentence_transformer_amd.config import build_layout
     from quadruplet_sentence_transformer_amd.synthetic import synthetic_quadruplets
-    threads = torch.get_num_threads()
     t_begin = time.perf_counter()
     batches = [[torch.from_numpy(x) for x in b] for b in _c1_batches(cfg)]
-    # ---- config 1, forward only
     P = R.arena_to_dict(arena, cfg)
+    max_threads = torch.get_num_threads()
+    tried = {}
+    for nt in sorted({min(max_threads, t) for t in (8, 16, 32, max_threads)}):
+        torch.set_num_threads(nt)
+        with torch.no_grad():
+            R.quadruplet_step(P, cfg, *batches[0], LOSS_KW)
+            t0 = time.perf_counter()
+            for b in batches[:4]:
+                R.quadruplet_step(P, cfg, *b, LOSS_KW)
+            tried[nt] = time.perf_counter() - t0
+    threads = min(tried, key=tried.get)
+    torch.set_num_threads(threads)
+    # ---- config 1, forward only
     losses = []
     with torch.no_grad():
         R.quadruplet_step(P, cfg, *batches[0], LOSS_KW)                       # thread-pool / allocator warm-up
@@ -120,7 +133,8 @@ def cpu_baseline(cfg, arena, seq_len, batch, budget_s=25.0):
             "sample": f"BASELINE configs[0] exactly: MiniLM dims, {nq} quadruplets, seq_len {CONFIG1['seq_len']} ragged, "
                       f"batch {CONFIG1['batch']}, seed {CONFIG1['seed']}; value = full training steps (fwd+loss+bwd+clip+AdamW) "
                       f"over {n_train} quadruplets in {t_train:.1f} s; fp32 torch CPU oracle (oracle/torch_ref.py), "
-                      f"{threads} threads of {os.cpu_count()} logical CPUs",
+                      f"{threads} threads of {os.cpu_count()} logical CPUs (fastest of "
+                      + ", ".join(f"{k}: {4 * CONFIG1['batch'] / v:.0f} q/s fwd" for k, v in sorted(tried.items())) + ")",
             "config1_fwd_only": {"value": round(nq / t_fwd, 2), "unit": "quadruplets/s", "seconds": round(t_fwd, 2),
                                  "mean_loss": round(float(sum(losses) / len(losses)), 6),
                                  "per_batch_loss": [round(x, 6) for x in losses]},
