@@ -138,13 +138,14 @@ class _EncodeFn(torch.autograd.Function):
             emb, _, _ = enc.forward(ids, mask, types, training=False, precision=model.inference_precision)
             return emb
         saved = None
-        if training:
+        if training == 1:
             n, L = ids.shape
             nbytes = enc.lib.qst_encoder_saved_bytes(enc.handle, n, L, 1)
             saved = torch.empty(nbytes, dtype=torch.uint8, device=enc.device)   # one arena per live graph
-        emb, _, saved = enc.forward(ids, mask, types, training=training, saved=saved)
+        # training == 2: a train()-mode pass without autograd (dropout on, nothing to keep): the shared activation arena
+        emb, _, saved = enc.forward(ids, mask, types, training=bool(training), saved=saved)
         ctx.model, ctx.saved, ctx.inputs = model, saved, (ids, mask, types)
-        if training:
+        if training == 1:
             model._live_graphs += 1
         return emb
 
@@ -318,7 +319,10 @@ class SentenceTransformer(nn.Module):
         mask = mask.to(dev, torch.int64)
         types = types.to(dev, torch.int64) if types is not None else None
         ids, mask, types, _ = HipEncoder.pad_inputs(ids, mask, types, self.cfg.pad_token_id)
-        training = torch.is_grad_enabled() and self.training
+        # train() mode = the HF modules drop (while fit() has dropout on), with or without autograd: the reference's
+        # QuadrupletLossEvaluator computes its validation loss inside fit() under torch.no_grad() but never calls eval()
+        # (/root/reference/models/evaluators.py:80-95), so that loss is taken WITH dropout there, and here. 2 = such a pass.
+        training = (1 if torch.is_grad_enabled() else (2 if self._enc.dropout is not None else 0)) if self.training else 0
         with torch.cuda.device(dev):
             emb = _EncodeFn.apply(self._anchor, self, ids, mask, types, training)
         features.update({"sentence_embedding": emb})

@@ -61,6 +61,32 @@ def test_encode_normalize_embeddings_runs_the_library_kernel():
     torch.testing.assert_close(got, torch.nn.functional.normalize(raw, p=2, dim=1), rtol=1e-6, atol=1e-7)
 
 
+def test_train_mode_drops_with_or_without_autograd():
+    """HF modules drop whenever module.training is set: the reference's QuadrupletLossEvaluator takes its validation loss
+    inside fit() under torch.no_grad() without calling eval() (models/evaluators.py:80-95) -- with dropout. eval() and
+    encode() never drop; outside fit() (no dropout configured) train() mode is deterministic."""
+    m = SentenceTransformer("tiny-bert", device="cuda")
+    feats = m.tokenize([sent(i, 4 + i % 5) for i in range(6)])
+    m.train()
+    with torch.no_grad():
+        a = m(dict(feats))["sentence_embedding"].clone()
+        b = m(dict(feats))["sentence_embedding"].clone()
+    assert torch.equal(a, b)                                        # no dropout configured
+    m._enc.set_dropout(0.1, 0.1, 5)
+    try:
+        with torch.no_grad():
+            c = m(dict(feats))["sentence_embedding"].clone()
+            d = m(dict(feats))["sentence_embedding"].clone()
+        assert not torch.equal(c, d) and (c - a).abs().max() > 1e-3   # fresh masks per pass
+        assert m._live_graphs == 0
+        m.eval()
+        with torch.no_grad():
+            e = m(dict(feats))["sentence_embedding"].clone()
+        torch.testing.assert_close(e, a, rtol=0, atol=2e-5)
+    finally:
+        m._enc.set_dropout(0.0, 0.0)
+
+
 def test_encode_parity_precision(model):
     texts = [sent(i, 3 + i % 7) for i in range(9)]
     fast = model.encode(texts)
