@@ -82,6 +82,9 @@ __device__ __forceinline__ uint32_t nt_off(int row, int chunk) {
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // after_first_issue: run once, right after the first stage's DMAs are on their way (work whose own memory latency should
 // overlap that first round trip instead of preceding it)
+// (Tried here and removed: an L2 touch-ahead of the activation operand -- one 4-byte LDS-DMA per lane on the line a row
+// needs three stages later, as csrc/ffn.hip does -- step 4.802 vs 4.825 ms, +3..9% on back-to-back launches: in the step
+// the A operand was written by the previous kernel and is still in the Infinity Cache.)
 template <int WAVES_M, int WAVES_N, typename HOOK = NoHook>
 __device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, int m0, int n0, f32x16 (&acc)[2][3],
                                             HOOK after_first_issue = HOOK()) {
@@ -412,9 +415,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 2 ? 2 : 1) void 
     const int wg = xcd_remap(blockIdx.x, ntm * ntn);
     const int m0 = (wg / ntn) * NBM, n0 = (wg % ntn) * NBN;
     const int fr = lane & 31, fh = lane >> 5;
+    // diagnostic (QstGemmArgs.splits bit 16; g.colsum, unused by NT, = uint64 [workgroup][4]): wall-clock stamps (s_memrealtime,
+    // 100 MHz) of wave 0 at kernel entry, after the K loop, after the epilogue -- one scalar branch each when off
+    const bool stamp_on = (g.splits & 16) && g.colsum != nullptr;
+#define NT_STAMP(k_) do { if (stamp_on && tid == 0) ((unsigned long long*)g.colsum)[blockIdx.x * 4 + (k_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    NT_STAMP(0);
     f32x16 acc[TI][3];
     if constexpr (TI == 4) nt_mainloop_tall<WAVES_M, WAVES_N>(g, smem, m0, n0, acc);
     else nt_mainloop<WAVES_M, WAVES_N>(g, smem, m0, n0, acc);
+    NT_STAMP(1);
 
     float* stg = (float*)smem + wave * (32 * NT_STG_LD);
     float* bias_s = (float*)smem + NW * (32 * NT_STG_LD) + wave * 96;     // this wave's 96 bias values
@@ -425,6 +434,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 2 ? 2 : 1) void 
         }
     }
     nt_epilogue<EPI, TI>(g, acc, stg, bias_s, m0 + wm * (32 * TI), n0 + wn * 96, lane);
+    NT_STAMP(2);
+#undef NT_STAMP
 }
 
 // ---------------------------------------------------------------- NT with fp8 (e4m3) weights (inference)
