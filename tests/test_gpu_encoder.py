@@ -217,6 +217,46 @@ def test_head_major_qkv_layout_is_bit_identical():
         del PRESETS["minilm-2l"]
 
 
+def test_head_major_layout_with_dropout_and_fp8():
+    """The optional layout under the two other options that touch the same kernels: dropout (masks are indexed by
+    (sequence, head, query, key) and by (token, column), not by address) and the fp8 inference path (its QKV epilogue
+    scatters too) -- bit-identical to the token-major runs."""
+    import ctypes as C
+    lib = _lib.load()
+    lib.qst_debug_head_major.argtypes = [C.c_int]
+    cfg = PRESETS["tiny-mpnet"]
+    arena = synthetic_params(cfg, seed=14, std=0.05, bias_std=0.02, ln_jitter=0.05)
+    ids, mask, _ = [torch.from_numpy(x).view(16, 64).cuda() for x in synthetic_quadruplets(cfg, 4, 64, seed=14, ragged=True)]
+    res = []
+    try:
+        for hm in (0, 1):
+            lib.qst_debug_head_major(hm)
+            enc = HipEncoder(cfg)
+            enc.load_arena(arena)
+            enc.ensure_train_state()
+            enc.set_dropout(0.1, 0.2, 31)
+            emb, _, saved = enc.forward(ids, mask, None, training=True)
+            enc.grads.zero_()
+            enc.backward(ids, mask, None, torch.ones_like(emb), saved)
+            torch.cuda.synchronize()
+            res.append((emb.clone(), enc.grads.clone()))
+        assert torch.equal(res[0][0], res[1][0])
+        torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-5, atol=1e-6 * res[0][1].abs().max().item())
+        from dataclasses import replace
+        cfg8 = replace(PRESETS["tiny-bert"], hidden_size=128, num_heads=4, intermediate_size=256)
+        arena8 = synthetic_params(cfg8, seed=3, std=0.05)
+        ids8, mask8, types8 = [torch.from_numpy(x).view(8, 32).cuda() for x in synthetic_quadruplets(cfg8, 2, 32, seed=3, ragged=True)]
+        out = []
+        for hm in (0, 1):
+            lib.qst_debug_head_major(hm)
+            enc = HipEncoder(cfg8)
+            enc.load_arena(arena8)
+            out.append(enc.forward(ids8, mask8, types8, precision="fp8")[0].clone())
+        assert torch.equal(out[0], out[1])
+    finally:
+        lib.qst_debug_head_major(0)
+
+
 def test_minilm_full_dims_ragged():
     run_case("all-MiniLM-L6-v2", 2, 128, True, dict(std=0.02))
 
