@@ -265,6 +265,19 @@ def test_minilm_fused_path_trains_with_dropout():
         del PRESETS["minilm-2l"]
 
 
+def test_fused_path_with_a_ragged_last_tile_and_dropout():
+    """M = 4 * 129 * 32 = 16512 token rows: above the fusion threshold and not a multiple of the 128-row tile of the fused
+    GEMM+LayerNorm kernels (the last workgroup has 0 rows of its second 64-row half), short sequences (L = 32: four
+    sequences per tile), masks on."""
+    from dataclasses import replace
+    PRESETS["minilm-1l"] = replace(PRESETS["all-MiniLM-L6-v2"], num_layers=1, vocab_size=2048)
+    try:
+        run_case("minilm-1l", 129, 32, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), emb_atol_vs_bf16_oracle=1.5e-3,
+                 dropout=(0.1, 0.1, 5))
+    finally:
+        del PRESETS["minilm-1l"]
+
+
 def test_long_sequences_and_wide_heads_train_with_dropout():
     """d = 64 heads with the relative-position bias and L = 256 (dQ and dK/dV kernels), unfused LayerNorms (H = 768)."""
     from dataclasses import replace
