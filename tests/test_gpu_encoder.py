@@ -101,9 +101,12 @@ def run_case(name, B, L, ragged, weights_kw, check_grads=True, emb_atol_vs_bf16_
             #     the smallest batch (M = 256 rows);
             #   b_qkv: 4e-2 [3.0e-2] -- its key third has a mathematically zero gradient (softmax shift invariance), so a
             #     third of the vector is pure rounding noise in both implementations.
+            #   Batches under 2,048 token rows (BASELINE configs[0]: 1,024) average the rounding noise over fewer rows and sit
+            #   closest to the bounds: weights 2e-2 there.
             leaf = s.name.split(".")[-1]
+            w_lim = 2e-2 if 4 * B * L < 2048 else 1.5e-2
             lim = 4e-2 if leaf == "b_qkv" else (3e-2 if (leaf.startswith("b_") or leaf.startswith("ln") or leaf.startswith("emb_ln"))
-                                                else (2e-2 if leaf.endswith("_emb") else 1.5e-2))
+                                                else (2e-2 if leaf.endswith("_emb") else w_lim))
             assert err < lim, f"{name} grad {s.name}: relative L2 error {err:.3e} (ref norm {denom:.3e})"
             errs.append((err, s.name))
         errs.sort(reverse=True)
