@@ -351,8 +351,12 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("QST_DIST_BACKEND", "nccl")      # "nccl" = RCCL over xGMI; "gloo" only to rehearse
         if backend == "nccl":
-            assert ndev >= world, f"{world} ranks need {world} GPUs for RCCL (found {ndev})"
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+            if ndev < world and ndev != 1:          # (1 visible device per rank = a launcher that pins ranks itself: fine)
+                print(f"bench.py: {world} ranks but {ndev} visible GPUs: RCCL refuses ranks that share a device", file=sys.stderr)
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+            except TypeError:                       # a torch without the device_id keyword
+                dist.init_process_group("nccl", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
