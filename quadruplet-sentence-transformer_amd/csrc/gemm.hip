@@ -1261,6 +1261,10 @@ static int check_heads(const QstGemmArgs* a, bool a_ok, bool c_ok, int epi) {
     return QST_OK;
 }
 
+// persistent ping-pong form (gemm_pp.hip)
+extern "C" int qst_gemm_nt_pp_ok(const QstGemmArgs* a, int epi);
+extern "C" int qst_gemm_nt_pp(const QstGemmArgs* a, int epi, void* stream);
+
 template <int EPI, int WAVES_M, int WAVES_N = 2, int TI = 2>
 static int launch_nt(const QstGemmArgs* a, hipStream_t st) {
     constexpr int NBM = 32 * TI * WAVES_M, NBN = 96 * WAVES_N;
@@ -1284,6 +1288,7 @@ extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
         if (a->drop.thr16 > 65535u || (int64_t)a->M * a->N >= ((int64_t)1 << 32)) return QST_ERR_UNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
+    if ((a->splits & 7) == 5 && qst_gemm_nt_pp_ok(a, epi)) return qst_gemm_nt_pp(a, epi, st);    // forced: the persistent ping-pong form
     // Two 128-row workgroups per CU beat one 256-row workgroup on every shape of the step (their MFMA and
     // store phases interleave); a->splits (unused by nt otherwise) can force the tile height: 1 = 128, 2 = 256 rows.
     const bool small = (a->splits & 3) != 2;

@@ -98,13 +98,16 @@ def gemm_args(**kw):
     return g
 
 
-@pytest.mark.parametrize("form", [0, 2, 4], ids=["tiles128", "tiles256", "tall256"])
+@pytest.mark.parametrize("form", [0, 2, 4, 5], ids=["tiles128", "tiles256", "tall256", "pingpong"])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 384), (200, 192, 128), (1000, 1152, 384), (64, 64, 64),
-                                   (4096, 384, 1536), (5000, 1536, 384)])
+                                   (4096, 384, 1536), (5000, 1536, 384), (20000, 1152, 384), (12000, 768, 768),
+                                   (33000, 384, 320)])
 def test_gemm_nt_epilogues(lib, M, N, K, form):
-    """form: QstGemmArgs.splits selects the nt tiling (0 = 128-row tiles, two workgroups per CU; 2 = 256-row tiles, one
-    8-wave workgroup per CU; 4 = 256-row tiles of four waves owning 128 x 96 each, bf16-output epilogues only -- the
-    fp32 one falls back to form 0); all must give the same results."""
+    """form: QstGemmArgs.splits selects the nt tiling (0 = automatic; 1 = 128-row tiles, two workgroups per CU; 2 = 256-row
+    tiles, one 8-wave workgroup per CU; 4 = 256-row tiles of four waves owning 128 x 96 each, bf16-output epilogues only --
+    the fp32 one falls back to form 1; 5 = the persistent ping-pong kernel of gemm_pp.hip: loader waves + two MFMA groups
+    that alternate between a tile's K loop and the previous tile's epilogue -- the last three shapes give its workgroups
+    several tiles each, ragged in M, and a K loop shorter than the six epilogue slices); all must give the same results."""
     g = torch.Generator().manual_seed(M + N + K)
     A = bfr(torch.randn(M, K, generator=g))
     B = bfr(torch.randn(N, K, generator=g) * 0.05)
