@@ -237,7 +237,7 @@ template <int EPI>
 __global__ __launch_bounds__(768, 3) void gemm_nt_pp_kernel(QstGemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef QST_PP_STAMP
-    unsigned long long tk0 = 0, tk1 = 0, tk2 = 0;
+    unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, fs0 = 0, fs1 = 0, fs2 = 0;
     const unsigned long long tk_begin = __builtin_amdgcn_s_memtime();
 #endif
     const int tid = threadIdx.x, lane = tid & 63;
@@ -379,7 +379,10 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_pp_kernel(QstGemmArgs g) {
             PP_T(tb);
             PP_ACC(tk2, ta, tb);
             if (comp) {
+#ifndef QST_PP_NOCOMP
+#if !defined(QST_PP_PRIO) || QST_PP_PRIO == 2
                 __builtin_amdgcn_s_setprio(2);                     // this wave feeds the SIMD's matrix pipe: its LDS reads and MFMAs first
+#endif
                 const char* pa = smem + slot * PSTAGE;
                 const char* pb = pa + PA_BYTES;
                 bf16x8 fa[2][2], fb[2][3];                         // two fragment sets: k-step ks + 1 is read while ks multiplies
@@ -417,7 +420,10 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_pp_kernel(QstGemmArgs g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
 #undef PP_LOAD
 #undef PP_MFMA
+#if !defined(QST_PP_PRIO) || QST_PP_PRIO == 2
                 __builtin_amdgcn_s_setprio(0);
+#endif
+#endif
                 if (kt == 0 && g.bias) {                           // this wave's 96 bias values travel during the K loop
                     const int n = nw + lane;
                     bv0 = n < g.N ? g.bias[n] : 0.f;
@@ -436,6 +442,9 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_pp_kernel(QstGemmArgs g) {
 #endif
             } else if (epi && kt < E) {
 #ifndef QST_PP_NOEPI
+#if defined(QST_PP_PRIO) && QST_PP_PRIO == 3
+                __builtin_amdgcn_s_setprio(3);
+#endif
                 const int s_end = min(6, (kt + 1) * spp);
 #pragma unroll 1
                 for (int s = kt * spp; s < s_end; ++s) {
@@ -443,15 +452,31 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_pp_kernel(QstGemmArgs g) {
                     float* nxt = slabs + ((s + 1) & 1) * PSLAB;
                     if (nk < 6 && s == 0) PP_PUT(0, cur)           // (not written ahead: see above)
                     PpBlk b;
+#if defined(QST_PP_STAMP) && QST_PP_STAMP == 2
+                    PP_T(f0);
+#endif
                     pp_get<EPI>(cur, lane, b);                     // written one super-step ago: no round trip to wait for
                     if (s + 1 < 6) PP_PUT(s + 1, nxt)
+#if defined(QST_PP_STAMP) && QST_PP_STAMP == 2
+                    PP_T(f1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    PP_T(f2);
+                    PP_ACC(fs0, f0, f1); PP_ACC(fs1, f1, f2);
+#endif
                     const int si = s >= 3 ? 1 : 0, sj = s - 3 * si;
                     pp_finish<EPI>(g, rs, b, bias_s, mw, nw, si, sj, lane, pf, dc);
+#if defined(QST_PP_STAMP) && QST_PP_STAMP == 2
+                    PP_T(f3);
+                    PP_ACC(fs2, f2, f3);
+#endif
                     if (s + 1 < 6) {
                         const int ni = s + 1 >= 3 ? 1 : 0, nj = s + 1 - 3 * ni;
                         pp_prefetch<EPI>(g, rs, mw, nw, ni, nj, lane, pf);
                     }
                 }
+#if defined(QST_PP_PRIO) && QST_PP_PRIO == 3
+                __builtin_amdgcn_s_setprio(0);
+#endif
 #endif
                 PP_T(tc); PP_ACC(tk1, tb, tc);
             }
@@ -463,6 +488,9 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_pp_kernel(QstGemmArgs g) {
     if ((tid == 0 || tid == 256) && g.colsum) {
         unsigned long long* o = (unsigned long long*)g.colsum + (size_t)blockIdx.x * 12 + (tid == 0 ? 4 : 8);
         o[0] = tk0; o[1] = tk1; o[2] = tk2; o[3] = __builtin_amdgcn_s_memtime() - tk_begin;
+#if QST_PP_STAMP == 2
+        o[0] = fs0; o[2] = fs1; o[3] = fs2;      // get + put issue | LDS wait | arithmetic + stores (o[1] = whole slices)
+#endif
     }
 #endif
 }
