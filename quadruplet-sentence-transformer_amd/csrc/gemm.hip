@@ -982,10 +982,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
 // (8 adders per element). Operands are consumed straight from row-major [M, *] images with ds_read_b64_tr_b16.
 // LDS image per operand stage: [32 m-rows][192 bf16] = 384-byte rows (24 chunks of 16 B); chunk c of row r sits at
 // chunk position c ^ (((r >> 1) & 1) << 2): the 4 rows x 64 B that one half-wave reads land in 16 distinct 16-B slots.
-constexpr int TT = 192, TBK = 32, TSTAGES = 6;            // 6-slot ring: one stage being read, up to five in flight
+constexpr int TT = 192, TBK = 64, TSTAGES = 3;            // 3-slot ring of 64-row stages: one being read, two in flight
 constexpr int TN_MAX_PIECES = 2;                          // slab flush: stage pieces a leftover tile may be cut into
-constexpr int TT_TILE = TBK * TT * 2;                // 12 KB per operand per stage
-constexpr int TT_STAGE = 2 * TT_TILE;                // 24 KB
+constexpr int TT_TILE = TBK * TT * 2;                // 24 KB per operand per stage
+constexpr int TT_STAGE = 2 * TT_TILE;                // 48 KB
 constexpr int TT_LDS = TSTAGES * TT_STAGE;           // 144 KB: one workgroup (4 MFMA + 4 loader waves) per CU
 __device__ __forceinline__ int tn_swz(int row) { return ((row >> 1) & 1) << 2; }
 __device__ __forceinline__ uint32_t tn_off(int row, int chunk) {
@@ -1072,10 +1072,11 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
             // the next row: those lanes get an out-of-range offset (-> zero fill). (Cutting the stage into three
             // [32][64] sub-images so that every instruction moves 8 whole 128-byte lines changed nothing: 169.2 vs
             // 168.3 us, same-process A/B.)
-            uint32_t vo[6];
+            constexpr int NDMA = TBK * 24 / 64 / 2;       // DMA instructions per loader wave and stage (1 KB each): 12
+            uint32_t vo[NDMA];
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {
-                const int pp = (half * 6 + t) * 64 + lane;
+            for (int t = 0; t < NDMA; ++t) {
+                const int pp = (half * NDMA + t) * 64 + lane;
                 const int row = pp / 24, chunk = (pp % 24) ^ tn_swz(row);
                 vo[t] = (c0 + chunk * 8 < width) ? (uint32_t)row * ld * 2u + chunk * 16u : kOOB;
                 if (hL) {
@@ -1091,7 +1092,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
                     so = __builtin_amdgcn_readfirstlane(((uint32_t)seq * ld * hL + (uint32_t)l0 * hd) * 2u);
                 }
 #pragma unroll
-                for (int t = 0; t < 6; ++t) dma16(rs, st + (half * 6 + t) * 1024, vo[t], so);  // kOOB + so < 2^32: no wrap
+                for (int t = 0; t < NDMA; ++t) dma16(rs, st + (half * NDMA + t) * 1024, vo[t], so);  // kOOB + so < 2^32: no wrap
             };
             // All TSTAGES-1 slots that are not being read are kept in flight (120 KB per CU). Timing experiments on this
             // kernel (same-process A/B): MFMAs compiled out -17%, atomic flush compiled out -16%, constant LDS slot
@@ -1103,9 +1104,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
 #pragma unroll 1
             for (int mt = 0; mt < nm; ++mt) {
                 // stage mt must have landed before this wave arrives at the barrier that releases it to the MFMA waves
-                const int younger = min(AHEAD - 1, nm - 1 - mt);
-                if (younger >= 4) wait_vmcnt_n<24>(); else if (younger == 3) wait_vmcnt_n<18>();
-                else if (younger == 2) wait_vmcnt_n<12>(); else if (younger == 1) wait_vmcnt_n<6>(); else wait_vmcnt_n<0>();
+                const int younger = min(AHEAD - 1, nm - 1 - mt);       // 0 or 1 stages (NDMA = 12 instructions each) stay in flight
+                if (younger >= 1) wait_vmcnt_n<12>(); else wait_vmcnt_n<0>();
                 __builtin_amdgcn_s_barrier();              // MFMA waves are done with stage mt-1 (and older)
                 if (mt + AHEAD < nm) issue(mt + AHEAD);    // into the slot of stage mt-1
             }
@@ -1128,34 +1128,62 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
             __builtin_amdgcn_s_barrier();                  // stage mt landed (the loaders waited for it before arriving)
             const char* pa = smem + (mt % TSTAGES) * TT_STAGE;
             const char* pb = pa + TT_TILE;
+            // One MFMA wave per SIMD: nothing but its own instruction stream hides the LDS latency of its fragment reads. The
+            // fragments of k-step ks + 1 are therefore read into a second register set while the MFMAs of ks issue (hipcc's own
+            // schedule reads a k-step's 12 fragments, waits, multiplies: ~250 exposed cycles per 288 of MFMA, in-kernel stamps
+            // of round 1: 990 cycles per 32-row stage for 576 of MFMA); the order is pinned with sched_group_barrier.
+            bf16x8 fa[2][3], fb[2][3];
+#define TN_LOAD(ks_, set_)                                                                                  \
+    do {                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                     \
+            _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                              \
+                const int row = (ks_) * 16 + 8 * fh + 4 * jj + q;                                           \
+                const int ca = wm * 12 + i * 4 + gsel * 2 + (p >> 1);                                       \
+                const int cb = wn * 12 + i * 4 + gsel * 2 + (p >> 1);                                       \
+                const bf16x4 ta = lds_tr16(pa + tn_off(row, ca) + 8 * (p & 1));                             \
+                const bf16x4 tb = lds_tr16(pb + tn_off(row, cb) + 8 * (p & 1));                             \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) { fa[set_][i][jj * 4 + e] = ta[e]; fb[set_][i][jj * 4 + e] = tb[e]; } \
+            }                                                                                               \
+        }                                                                                                   \
+    } while (0)
+#define TN_MFMA(set_)                                                                                       \
+    do {                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                       \
+            _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                   \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set_][i], fb[set_][j], acc[i][j], 0, 0, 0); \
+        if (do_bias) {   /* lane (n' = lane&31, half h) holds dY[m = 8h .. 8h+7][n']: 8 of the 16 rows of this k-step */ \
+            _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                   \
+                _Pragma("unroll") for (int e = 0; e < 8; ++e) bsum[i] += (float)fa[set_][i][e];             \
+        }                                                                                                   \
+    } while (0)
+            TN_LOAD(0, 0);
+            TN_LOAD(1, 1);
+            TN_MFMA(0);
+            TN_LOAD(2, 0);
+            TN_MFMA(1);
+            TN_LOAD(3, 1);
+            TN_MFMA(0);
+            TN_MFMA(1);
+#undef TN_LOAD
+#undef TN_MFMA
+            if (!do_bias) {
+                // issue order: the 12 reads of k-step 0; then the 12 reads of each later k-step spread behind the 9 MFMAs of the
+                // k-step before it (two behind each of the first three, one behind each of the other six); then the last 9 MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 fa[3], fb[3];
+                for (int rep = 0; rep < 3; ++rep) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
+                    for (int u = 0; u < 3; ++u) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        const int row = ks * 16 + 8 * fh + 4 * jj + q;
-                        const int ca = wm * 12 + i * 4 + gsel * 2 + (p >> 1);
-                        const int cb = wn * 12 + i * 4 + gsel * 2 + (p >> 1);
-                        const bf16x4 ta = lds_tr16(pa + tn_off(row, ca) + 8 * (p & 1));
-                        const bf16x4 tb = lds_tr16(pb + tn_off(row, cb) + 8 * (p & 1));
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { fa[i][jj * 4 + e] = ta[e]; fb[i][jj * 4 + e] = tb[e]; }
+                    for (int u = 0; u < 6; ++u) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
                 }
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-                if (do_bias) {
-                    // lane (n' = lane&31, half h) holds dY[m = 8h .. 8h+7][n']: 8 of the 16 rows of this k-step
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) bsum[i] += (float)fa[i][e];
-                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
             }
         }
         __builtin_amdgcn_s_barrier();                      // end of piece: the loaders may refill the ring while we flush
@@ -1261,10 +1289,6 @@ static int check_heads(const QstGemmArgs* a, bool a_ok, bool c_ok, int epi) {
     return QST_OK;
 }
 
-// persistent ping-pong form (gemm_pp.hip)
-extern "C" int qst_gemm_nt_pp_ok(const QstGemmArgs* a, int epi);
-extern "C" int qst_gemm_nt_pp(const QstGemmArgs* a, int epi, void* stream);
-
 template <int EPI, int WAVES_M, int WAVES_N = 2, int TI = 2>
 static int launch_nt(const QstGemmArgs* a, hipStream_t st) {
     constexpr int NBM = 32 * TI * WAVES_M, NBN = 96 * WAVES_N;
@@ -1288,7 +1312,6 @@ extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
         if (a->drop.thr16 > 65535u || (int64_t)a->M * a->N >= ((int64_t)1 << 32)) return QST_ERR_UNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
-    if ((a->splits & 7) == 5 && qst_gemm_nt_pp_ok(a, epi)) return qst_gemm_nt_pp(a, epi, st);    // forced: the persistent ping-pong form
     // Two 128-row workgroups per CU beat one 256-row workgroup on every shape of the step (their MFMA and
     // store phases interleave); a->splits (unused by nt otherwise) can force the tile height: 1 = 128, 2 = 256 rows.
     const bool small = (a->splits & 3) != 2;
@@ -1426,6 +1449,7 @@ extern "C" int qst_gemm_tn_group(const QstTnGroup* grp_in, void* stream) {
         if (!a.A || !a.B || !a.C || a.M <= 0 || a.N <= 0 || a.K <= 0 || a.M != g.prob[0].M) return QST_ERR_BAD_ARG;
         if (a.lda % 8 != 0 || a.ldb % 8 != 0 || a.N % 8 != 0 || a.K % 8 != 0) return QST_ERR_UNSUPPORTED;
         if (int rc = check_heads(&a, a.lda == a.N && a.N % (a.a_head_d ? a.a_head_d : 1) == 0, false, -1)) return rc;
+        if (a.a_head_L && a.a_head_L % TBK != 0) return QST_ERR_UNSUPPORTED;      // a stage of TBK rows must lie in one sequence
         if ((int64_t)a.M * a.lda * 2 >= 0x7FFFFF00LL || (int64_t)a.M * a.ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
         g.tiles[i] = ((a.N + TT - 1) / TT) * ((a.K + TT - 1) / TT);
         g.total_tiles += g.tiles[i];
