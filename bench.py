@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--kernel-reps", type=int, default=10)
     ap.add_argument("--graph", action="store_true",
                     help="single GPU: replay the step from a captured HIP graph (device-side LR schedule)")
+    ap.add_argument("--profile", action="store_true",
+                    help="profiled runs: with --no-extras, also skip the dropout-off side steps, so that every launch in the "
+                         "trace belongs to the headline step (or is one of the --kernel-reps direct launches)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the forward-only and loss-kernel side measurements (profiled runs: keeps per-step kernel counts clean)")
     return ap.parse_args()
@@ -122,8 +125,10 @@ def cpu_baseline(cfg, arena, seq_len, batch, budget_s=25.0):
     P = R.arena_to_dict(arena, cfg, requires_grad=True)
     batch = min(batch, 16)              # bounded sample: the CPU's per-quadruplet rate does not depend on it at this size
     ids, mask, types = [torch.from_numpy(x) for x in synthetic_quadruplets(cfg, batch, seq_len, seed=14, step=1000)]
-    with torch.no_grad():
-        R.quadruplet_step(P, cfg, ids[:, :2], mask[:, :2], types[:, :2], LOSS_KW)
+    wl, _ = R.quadruplet_step(P, cfg, ids[:, :2], mask[:, :2], types[:, :2], LOSS_KW)     # warm-up: forward AND backward
+    wl.backward()
+    for t_ in P.values():
+        t_.grad = None
     t0 = time.perf_counter()
     loss, _ = R.quadruplet_step(P, cfg, ids, mask, types, LOSS_KW)
     loss.backward()
@@ -139,7 +144,7 @@ def cpu_baseline(cfg, arena, seq_len, batch, budget_s=25.0):
                                  "mean_loss": round(float(sum(losses) / len(losses)), 6),
                                  "per_batch_loss": [round(x, 6) for x in losses]},
             "headline_shape_train_step": {"value": round(batch / t_c2, 3), "unit": "quadruplets/s",
-                                          "what": f"one fwd+loss+bwd of {batch} quadruplets x seq_len {seq_len}",
+                                          "what": f"one fwd+loss+bwd of {batch} quadruplets x seq_len {seq_len} (after a warm-up step of 2)",
                                           "seconds": round(t_c2, 2)}}, losses
 
 
@@ -333,6 +338,74 @@ def time_loss_kernel(D, reps=10, rows=262144):
             "kernel": "quad_loss_kernel fwd+grads", "avg_launch_ms": round(ms, 4), "rows": rows, "D": D}
 
 
+def baseline_config_name(model, B, L, world):
+    """Which entry of BASELINE.json `configs` a (model, quadruplets per GPU, seq_len, GPUs) run corresponds to."""
+    if model == "all-MiniLM-L6-v2" and L == 128 and B == 64:
+        return "BASELINE.json configs[1]" if world == 1 else "BASELINE.json configs[1] per GPU" + (" = configs[3]" if world == 8 else "")
+    if model == "all-mpnet-base-v2" and L == 256 and B == 32 and world == 1:
+        return "BASELINE.json configs[2]"
+    if model == "bert-base-uncased" and L == 384 and B == 128 and world == 1:
+        return "BASELINE.json configs[4] shape, trained with bf16 operands (its fp8 matrix-core path is inference only)"
+    return "not a BASELINE.json configuration"
+
+
+def distinct_gpus_or_exit(rank, world, dev_index):
+    """Ranks of an RCCL job must sit on different physical GPUs. A launcher may pin one GPU per rank (every rank then sees
+    ONE device, index 0), so device indices cannot tell: compare the devices' identities over a TCP store before
+    init_process_group("nccl"), and exit non-zero on every rank if two ranks resolve to the same card -- RCCL would otherwise
+    end in a duplicate-GPU error or a stall."""
+    import torch
+    from torch.distributed import TCPStore
+    props = torch.cuda.get_device_properties(dev_index)
+    ident = str(getattr(props, "uuid", "")) or str(getattr(props, "pci_bus_id", "")) + ":" + str(getattr(props, "pci_device_id", ""))
+    if not ident.strip(":"):
+        return                                       # no identity available from this torch: nothing to compare
+    host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("MASTER_PORT", "29500")) + 1
+    store = TCPStore(host, port, world, rank == 0, timeout=__import__("datetime").timedelta(seconds=120))
+    store.set(f"gpu{rank}", ident)
+    idents = [store.get(f"gpu{r}").decode() for r in range(world)]
+    if len(set(idents)) != world:
+        print(f"bench.py rank {rank}: {world} ranks on {len(set(idents))} physical GPU(s) ({idents}): RCCL needs one GPU per "
+              "rank (QST_DIST_BACKEND=gloo rehearses the step on a shared card)", file=sys.stderr)
+        raise SystemExit(3)
+
+
+def time_dp_rccl_ws1(trainer, cfg, batches, steps, B, ms_dp1):
+    """The data-parallel step on the ONE GPU a test box has: init_process_group("nccl", world_size=1) and the staged backward
+    with its seven asynchronous RCCL all-reduces (one per layer bucket + the embedding bucket) in place -- what every rank of
+    configs[3] executes, minus peers. Reports the step time beside the plain single-GPU step."""
+    import torch
+    import torch.distributed as dist
+    from quadruplet_sentence_transformer_amd.trainer import QuadrupletTrainer
+    try:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dev = torch.device(trainer.enc.device)
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        except TypeError:
+            dist.init_process_group("nccl", rank=0, world_size=1)
+        tr = QuadrupletTrainer(cfg, encoder=trainer.enc, lr=2e-5, weight_decay=0.01, max_grad_norm=1.0, warmup_steps=10000,
+                               total_steps=1000000, world_size=1, overlap=True, force_dp=True)
+        for i in range(3):
+            tr.step(*batches[i % len(batches)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            tr.step(*batches[i % len(batches)])
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        dist.destroy_process_group()
+        return {"value": round(B / ms * 1e3, 1), "unit": "quadruplets/s", "ms_per_step": round(ms, 4),
+                "overhead_vs_dp1_ms": round(ms - ms_dp1, 4),
+                "what": "the same step through the data-parallel path: staged backward + 7 async RCCL all-reduces "
+                        "(world_size 1 on this GPU; the 1 -> 8 GPU curve itself needs an 8-GPU node)"}
+    except Exception as e:                           # RCCL unavailable on this box: say so, do not fail the bench line
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def main():
     args = parse()
     import torch
@@ -351,8 +424,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("QST_DIST_BACKEND", "nccl")      # "nccl" = RCCL over xGMI; "gloo" only to rehearse
         if backend == "nccl":
-            if ndev < world and ndev != 1:          # (1 visible device per rank = a launcher that pins ranks itself: fine)
-                print(f"bench.py: {world} ranks but {ndev} visible GPUs: RCCL refuses ranks that share a device", file=sys.stderr)
+            distinct_gpus_or_exit(rank, world, dev_index)
             try:
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
             except TypeError:                       # a torch without the device_id keyword
@@ -402,7 +474,7 @@ def main():
     final_loss = float(loss.item())
     # side figure: the same step with dropout off (what rounds 1 measured; eager path only -- a captured graph holds its masks' launches)
     no_drop = None
-    if args.dropout > 0 and not args.graph:
+    if args.dropout > 0 and not args.graph and not args.profile:
         trainer.enc.set_dropout(0.0, 0.0)
         for i in range(3):
             trainer.step(*batches[i % nb])
@@ -433,7 +505,7 @@ def main():
         # the profile file names the kernel source it was measured on, and a figure for other code is not reported
         traffic = traffic2 = None
         traffic_src = None
-        prof = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        prof = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
         if os.path.exists(prof) and args.model == "all-MiniLM-L6-v2" and B == 64 and L == 128:
             try:
                 import hashlib
@@ -442,9 +514,9 @@ def main():
                 if pj.get("gemm_hip_sha256") == hashlib.sha256(open(src, "rb").read()).hexdigest():
                     traffic = pj["gemm_tn_group_kernel"]["hbm_bytes_per_launch"]
                     traffic2 = pj.get("gemm_nt_kernel<2>_hbm_bytes_per_launch")
-                    traffic_src = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same gemm.hip)"
+                    traffic_src = "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same gemm.hip)"
                 else:
-                    traffic_src = "stale: profiles/r02_pmc_traffic.json was measured on a different gemm.hip"
+                    traffic_src = "stale: profiles/r03_pmc_traffic.json was measured on a different gemm.hip"
             except Exception:
                 traffic = traffic2 = None
         out = {
@@ -455,8 +527,7 @@ def main():
             "config": {"workload": f"{args.model} dims (random-init), {B} quadruplets/GPU x {world} GPU, seq_len={L}, "
                                    "fwd + gamma-quadruplet loss + bwd + clip + AdamW, "
                                    + (f"dropout {args.dropout:g} on hidden states and attention probabilities as the reference's "
-                                      "train() mode" if args.dropout > 0 else "dropout off") + " (BASELINE.json configs[1]"
-                                   + ("/[3]" if world > 1 else "") + ")",
+                                      "train() mode" if args.dropout > 0 else "dropout off") + f" ({baseline_config_name(args.model, B, L, world)})",
                        "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}",
                        "precision": "bf16 MFMA operands, fp32 accumulate/residual/LN/softmax/loss/optimizer",
                        "launch": "hip graph replay" if (args.graph and world == 1) else "eager"},
@@ -483,9 +554,6 @@ def main():
             out["fwd_only"] = {"value": round(B / t_f, 1), "unit": "quadruplets/s", "ms_per_step": round(t_f * 1e3, 4),
                                "what": "encode 4 columns + loss forward, no backward / saved activations",
                                "mfma_frac": round(B / t_f * fwd_flops_q / 1e12 / PEAK_BF16_TFLOPS, 4)}
-            t_8 = time_fwd_only(trainer, batches, max(5, args.steps // 2), precision="fp8w")
-            out["fwd_only_fp8w"] = {"value": round(B / t_8, 1), "unit": "quadruplets/s", "ms_per_step": round(t_8 * 1e3, 4),
-                                    "what": "same, Linear weights as fp8 e4m3 + per-row scales (QST_PREC_FP8W, inference)"}
             if cfg.hidden_size % 128 == 0 and cfg.intermediate_size % 128 == 0:
                 t_m = time_fwd_only(trainer, batches, max(5, args.steps // 2), precision="fp8")
                 out["fwd_only_fp8"] = {"value": round(B / t_m, 1), "unit": "quadruplets/s", "ms_per_step": round(t_m * 1e3, 4),
@@ -498,6 +566,12 @@ def main():
                                       "what": "same, parity precision (split-bf16 x3 MFMA, fp32 activations): the "
                                               "configuration that meets rtol 1e-3 / atol 1e-4 on embeddings"}
             out["golden_parity"] = golden_parity(os.path.join(ROOT, "tests", "golden", "encoder_golden.npz"))
+            ms_ref = no_drop["ms_per_step"] if no_drop else ms_per_step           # (the RCCL rehearsal runs with dropout off)
+            if args.dropout > 0 and not args.graph:
+                trainer.enc.set_dropout(0.0, 0.0)
+            out["dp_rccl_ws1"] = time_dp_rccl_ws1(trainer, cfg, batches, max(5, args.steps // 2), B, ms_ref)
+            if args.dropout > 0 and not args.graph:
+                trainer.enc.set_dropout(args.dropout, args.dropout, 14 + rank)
             out["roofline_loss_kernel"] = time_loss_kernel(cfg.hidden_size)
         if world == 1 and not args.no_cpu_baseline:
             cpu_losses = None

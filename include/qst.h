@@ -15,10 +15,7 @@
  * operands with fp32 accumulation. precision = QST_PREC_BF16X3 splits every
  * fp32 operand into hi+lo bf16 and issues three MFMAs (fp32-class accuracy,
  * the parity mode); QST_PREC_BF16 rounds operands once (the throughput mode);
- * QST_PREC_FP8W (inference only; BASELINE configs[4] "fp8 weights") keeps every
- * Linear weight as fp8 e4m3 (OCP) with one fp32 scale per output row
- * (qst_refresh_shadow8), bf16 activations, fp32 accumulation.
- * QST_PREC_FP8 (inference only; BASELINE configs[4] "CDNA4 fp8 MFMA GEMMs") runs every Linear on the fp8 matrix
+ * QST_PREC_FP8 (inference only; BASELINE configs[4] "fp8 weights ... CDNA4 fp8 MFMA GEMMs") runs every Linear on the fp8 matrix
  * cores: weights AND activations as OCP MXFP8 (e4m3 elements, one E8M0 scale per 32 input features;
  * v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulation), attention in bf16, residual stream / LayerNorm in fp32.
  */
@@ -42,7 +39,7 @@ typedef enum {
 } qst_status;
 
 enum { QST_ARCH_BERT = 0, QST_ARCH_MPNET = 1 };
-enum { QST_PREC_BF16 = 0, QST_PREC_BF16X3 = 1, QST_PREC_FP8W = 2, QST_PREC_FP8 = 3 };
+enum { QST_PREC_BF16 = 0, QST_PREC_BF16X3 = 1, QST_PREC_FP8 = 3 };   /* 2 was an fp8-weights-only mode (removed) */
 enum { QST_REDUCE_NONE = 0, QST_REDUCE_SUM = 1, QST_REDUCE_MEAN = 2 };
 
 /* Encoder architecture. Mirrors HF BertConfig / MPNetConfig fields that the
@@ -80,7 +77,7 @@ int     qst_arena_segment(const qst_config* cfg, int idx, const char** name_out,
 /* Elements of the bf16 shadow arena: [W | W^T] copies of every GEMM weight. */
 int64_t qst_shadow_elems(const qst_config* cfg);
 
-/* Bytes of the fp8 weight shadow of QST_PREC_FP8W: per GEMM weight the e4m3 matrix and its fp32 row scales. */
+/* Bytes of the MXFP8 weight shadow of QST_PREC_FP8: per GEMM weight the e4m3 matrix and its E8M0 block scales. */
 int64_t qst_shadow8_bytes(const qst_config* cfg);
 
 /* ---- encoder handle ---- */
@@ -96,10 +93,7 @@ size_t qst_encoder_bwd_workspace_bytes(const qst_encoder* enc, int nseq, int L);
 /* Refresh the bf16 shadows (W and W^T of every GEMM weight) from the fp32 arena.
  * Must be called after any parameter update and before forward/backward. */
 int qst_refresh_shadow(const qst_encoder* enc, const float* params, void* shadow_bf16, void* stream);
-/* QST_PREC_FP8W: quantise every GEMM weight of the fp32 arena into the fp8 shadow (per output row: scale = max|w| / 448,
- * round to nearest even). qst_encoder_forward on a QST_PREC_FP8W handle takes this buffer as its `shadow` argument. */
-int qst_refresh_shadow8(const qst_encoder* enc, const float* params, void* shadow_fp8, void* stream);
-/* QST_PREC_FP8: the same buffer size (qst_shadow8_bytes) holds every GEMM weight as MXFP8: e4m3 bytes, then one E8M0
+/* QST_PREC_FP8: a buffer of qst_shadow8_bytes holds every GEMM weight as MXFP8: e4m3 bytes, then one E8M0
  * scale per 32 input features of each output row (qst_quant_mx). qst_encoder_forward on a QST_PREC_FP8 handle takes it
  * as its `shadow` argument. */
 int qst_refresh_shadow_mx(const qst_encoder* enc, const float* params, void* shadow_mx, void* stream);
@@ -128,6 +122,10 @@ int qst_encoder_forward(qst_encoder* enc, const int64_t* ids, const int64_t* mas
  * is ever stored (include/qst_kernels.h: QstDrop). Inference forwards never drop. */
 int qst_encoder_set_dropout(qst_encoder* enc, float p_hidden, float p_attn, uint32_t* state_dev);
 int qst_dropout_init(uint32_t* state_dev, uint64_t seed, void* stream);
+/* Where this handle runs the feed-forward block (dense + GELU + dense + residual + LayerNorm) as ONE kernel instead of two
+ * GEMM launches (H = 384 only, no dropout): bit 0 = inference forward (default), bit 1 = training forward, bit 2 = backward.
+ * Same results to fp32 summation order; the training variants are slower than the two-kernel path. */
+int qst_encoder_set_ffn_chain(qst_encoder* enc, int mask);
 int qst_dropout_advance(uint32_t* state_dev, void* stream);
 
 /*
@@ -152,11 +150,13 @@ int qst_encoder_backward_partial(qst_encoder* enc, const int64_t* ids, const int
                                  void* workspace, size_t workspace_bytes,
                                  int do_head, int layer_hi, int layer_lo, int do_embed, void* stream);
 
-/* The staged backward with flags. QST_BWD_HEAD / QST_BWD_EMBED = do_head / do_embed above. For ONE layer
- * (layer_hi == layer_lo + 1): QST_BWD_SKIP_WGRAD leaves out that layer's weight-gradient launch (its operands stay in
+/* The staged backward with flags. QST_BWD_HEAD / QST_BWD_EMBED = do_head / do_embed above. For LAYER 0 ALONE
+ * (layer_lo == 0, layer_hi == 1): QST_BWD_SKIP_WGRAD leaves out that layer's weight-gradient launch (its operands stay in
  * the workspace) and a later call with QST_BWD_WGRAD_ONLY for the same layer runs just that launch -- a data-parallel
  * step does {layer 0 | SKIP_WGRAD | EMBED}, starts the all-reduce of the embedding gradients (the largest bucket),
- * and runs layer 0's weight gradients underneath it. No other stage may run between the two calls. */
+ * and runs layer 0's weight gradients underneath it. No other stage may run between the two calls. Any other layer range
+ * with either flag is QST_ERR_BAD_ARG: below a layer l > 0 the next stage overwrites the gradients its postponed launch
+ * would read. */
 enum { QST_BWD_HEAD = 1, QST_BWD_EMBED = 2, QST_BWD_SKIP_WGRAD = 4, QST_BWD_WGRAD_ONLY = 8 };
 int qst_encoder_backward_stage(qst_encoder* enc, const int64_t* ids, const int64_t* mask, const int64_t* type_ids,
                                int nseq, int L, const float* params, const void* shadow_bf16,

@@ -56,13 +56,7 @@ typedef struct {
     int32_t M, N, K;
     int32_t lda, ldb, ldc, ldr;
     int32_t splits;       // tn only: reduction splits over M (0 = auto); nt: tile-variant selector (tests / tuning)
-    const float* bscale;  // qst_gemm_nt_w8 only: f32 [N] quantisation scale of each fp8 weight row
-    // Head-major q/k/v tensors (0 = the operand is a plain row-major matrix). A [M, 3H] q|k|v matrix whose rows are tokens
-    // of sequences of L tokens can instead be stored as [M / L][3H / d][L][d] (d = head width, 32 or 64): every
-    // (sequence, q/k/v, head) is a contiguous L x d block, what the attention kernels read and write whole lines of.
-    //   c_head_L, c_head_d: layout of C for QST_EPI_BF16 (the QKV projection writes it); N % d == 0, M % L == 0
-    //   a_head_L, a_head_d: layout of A (the QKV dgrad and wgrad read dqkv); nt: K % 64 == 0 as ever, tn: L % 32 == 0
-    int32_t a_head_L, a_head_d, c_head_L, c_head_d;
+    const void* bscale;   // qst_gemm_nt_f8 only: the E8M0 block scales of B (uint8, layout of qst_quant_mx)
     // Dropout (training; drop.thr16 == 0 / drop.state == NULL = none), element index m * N + n of the [M, N] result:
     //   drop_where 1: the projection output, before the residual: C = (acc + bias) * mask + resid   (QST_EPI_F32_RESID*,
     //                 qst_gemm_nt_ln mode 0) -- BertSelfOutput / BertOutput: LayerNorm(dropout(dense(x)) + input)
@@ -76,9 +70,6 @@ typedef struct {
 
 /* C[M,N] = A[M,K] . B[N,K]^T with epilogue `epi`. K % 64 == 0, lda/ldb % 8 == 0. */
 int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream);
-/* NT GEMM with fp8 (e4m3, OCP) weights: C = (A . Q^T) * bscale[n] (+ epilogue). B = Q: fp8 [N, K] (ldb in bytes,
- * % 16 == 0), bscale f32 [N]. epi: QST_EPI_BF16, QST_EPI_F32_RESID, QST_EPI_GELU. Inference path (QST_PREC_FP8W). */
-int qst_gemm_nt_w8(const QstGemmArgs* a, int epi, void* stream);
 /* NT GEMM on the fp8 matrix cores, both operands MXFP8 (OCP e4m3 elements + one E8M0 power-of-two scale per 32
  * consecutive K elements of a row; v_mfma_scale_f32_32x32x64_f8f6f4): A = e4m3 [M, K] (lda bytes), aux = its scales;
  * B = e4m3 [N, K] (ldb bytes), bscale = its scales (uint8 arrays in the layout qst_quant_mx writes). K % 128 == 0.
@@ -90,9 +81,6 @@ int qst_gemm_nt_f8(const QstGemmArgs* a, int epi, void* stream);
  * ((kb / 4) * rows + r) * 4 + kb % 4, ceil(K / 128) * rows * 4 bytes in all -- the four scales a GEMM stage (128 K) needs
  * from a row are one aligned dword, and 32 consecutive rows one 128-byte line. K % 32 == 0. */
 int qst_quant_mx(const void* src, int src_is_bf16, int64_t rows, int K, void* q, void* scales, void* stream);
-/* Per-row symmetric quantisation of a [rows, cols] f32 matrix to fp8 e4m3: scale[r] = max|row| / 448 (1 for an
- * all-zero row), dst = round-to-nearest-even(src / scale). cols % 4 == 0. */
-int qst_quant_rows_fp8(const float* src, int rows, int cols, void* dst_fp8, float* scales, void* stream);
 /* NT GEMM with a LayerNorm fused into the epilogue (one 128 x 384 tile spans whole rows: N must be 384;
  * qst_gemm_nt_ln_supported(N) tells). xhat is bf16 [M, 384] contiguous, rstd f32 [M].
  *  mode 0 (forward):  v = A.B^T + bias + resid ; y = LayerNorm(v) -> C (f32), C2 (bf16, nullable);
@@ -131,6 +119,8 @@ typedef struct {
     float* C;
     void* C2;
     int32_t M, H, I;
+    int32_t diag;          /* 0. Timing experiments only (tools/ffn_diag.py): 1 = drop the A loads, 2 = drop the weight loads
+                              (both give wrong results), 4 = no L2 touch-ahead of the next weight slice */
 } QstFfnArgs;
 int qst_ffn_chain_supported(int H, int I);
 int qst_ffn_chain(const QstFfnArgs* a, const QstLnEpi* ln, int mode, void* stream);
@@ -145,13 +135,8 @@ typedef struct {
     int32_t ranges_per_xcd;       /* filled by the library */
     int32_t tiles[QST_TN_MAX_PROB];
     QstGemmArgs prob[QST_TN_MAX_PROB];
-    /* Optional scratch of qst_gemm_tn_slab_bytes(grp) bytes (f32, 16-byte aligned): partial tiles are then written with plain
-     * stores and summed into C by a second kernel in a fixed order (reproducible bit for bit) instead of float atomics.
-     * NULL = atomics. The library falls back to atomics by itself when the shape does not fit the slab scheme. */
-    float* slabs;
 } QstTnGroup;
 int qst_gemm_tn_group(const QstTnGroup* grp, void* stream);
-size_t qst_gemm_tn_slab_bytes(const QstTnGroup* grp);
 
 /* Embedding gather + LayerNorm (BertEmbeddings / MPNetEmbeddings forward).
  * pos_ids: int32 [M] position row per token. type_emb may be NULL. Outputs: y f32, y bf16, xhat bf16, rstd f32. */
@@ -221,16 +206,14 @@ int qst_attention_fwd(const void* qkv, const int64_t* mask, const float* rel_pos
 int qst_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, const int64_t* mask,
                       const float* rel_bias, int nseq, int L, int A, int d, void* dqkv, float* drel,
                       float* delta_scratch, void* stream);
-/* The same two kernels with options: head_major != 0: qkv and dqkv are bf16 [nseq][3][A][L][d] (every (sequence, q/k/v,
- * head) a contiguous L x d block; what QST_EPI_BF16 writes with QstGemmArgs.c_head_L set; ctx / dctx stay [nseq*L, H]);
- * drop: dropout of the softmax probabilities (BertSelfAttention: dropout(softmax(s)) . v), element index
+/* The same two kernels taking a description; drop: dropout of the softmax probabilities (BertSelfAttention: dropout(softmax(s)) . v), element index
  * ((seq * A + head) * L + query) * L + key. lse stays the log-sum-exp of the undropped scores. */
 typedef struct {
     const void* qkv; const int64_t* mask; const float* rel_pos;
     int32_t nseq, L, A, d;
     void* ctx; float* lse;                       /* forward: outputs; backward: inputs */
     const void* dctx; void* dqkv; float* drel; float* delta_scratch;       /* backward only */
-    int32_t head_major;
+    int32_t force_split;   /* backward: != 0 takes the dQ + dK/dV kernel pair even where the single-workgroup kernel applies */
     QstDrop drop;
 } QstAttnDesc;
 int qst_attention_fwd_ex(const QstAttnDesc* a, void* stream);

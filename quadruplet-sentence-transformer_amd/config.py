@@ -68,6 +68,10 @@ PRESETS: Dict[str, EncoderConfig] = {
         arch=ARCH_MPNET, vocab_size=128, hidden_size=128, num_layers=2, num_heads=2,
         intermediate_size=256, max_position=66, type_vocab_size=0, layer_norm_eps=1e-5,
         max_seq_length=64, pad_token_id=1),
+    # MiniLM layer dimensions on two layers and a 4,096-word vocabulary: the fixture that reaches the flagship kernels
+    # (GEMM + LayerNorm fused, 8-range grouped wgrad, single-workgroup attention backward: M >= 16384 token rows) while
+    # staying cheap for the HF reference on the CPU (tests/golden/encoder_golden.npz: minilm2l_fused)
+    "minilm-2l": EncoderConfig(num_layers=2, vocab_size=4096),
 }
 
 

@@ -114,18 +114,16 @@ struct AttnArgs {
     const bf16* qkv; const bf16* ctx; const bf16* dctx; const float* lse_in; const int64_t* mask;
     const float* rel; bf16* out; bf16* dqkv; float* lse_out; float* drel; float* delta;
     int nseq, L, A, H; float scale;
-    // q / k / v (and their gradients) of one (sequence, head) are [L] rows of `ld` elements starting at qkv_base(); the k
-    // and v parts follow at + woff and + 2 woff. Token-major [M, 3H] (q | k | v, heads concatenated): ld = 3H, woff = H,
-    // a head's rows are 2d-byte slices of 6H-byte rows (d = 32: half a cache line each). Head-major [nseq][3][A][L][d]
-    // (written by the QKV epilogue, QstGemmArgs.c_head_L): ld = d, woff = A L d, a head's q, k and v are contiguous
-    // L x d blocks -- every load and store of these kernels moves whole lines.
-    int ld; int64_t woff; int head_major;
+    // q / k / v (and their gradients) of one (sequence, head) are [L] rows of `ld` = 3H elements of the token-major
+    // [M, 3H] tensor (q | k | v, heads concatenated) starting at qkv_base(); the k and v parts follow at + woff = H and
+    // + 2 woff. A head's rows are 2d-byte slices of 6H-byte rows (d = 32: half a cache line each).
+    int ld; int64_t woff;
     // dropout of the probabilities (training): element ((seq * A + head) * L + query) * L + key of QstDrop's counter space;
     // kernels instantiated with DROP recompute the mask wherever P or dP appears (nothing is stored)
     QstDrop drop;
 };
 __device__ __forceinline__ size_t qkv_base(const AttnArgs& a, int seq, int head, int D) {
-    return a.head_major ? ((size_t)seq * 3 * a.A + head) * a.L * D : (size_t)seq * a.L * a.ld + (size_t)head * D;
+    return (size_t)seq * a.L * a.ld + (size_t)head * D;
 }
 
 // ------------------------------------------------------------------ forward
@@ -550,14 +548,38 @@ constexpr int DS_IMG = 128 * 128 * 2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ uint32_t ds_off(int row, int byte) { return (uint32_t)(row * 256 + (byte ^ ((row & 3) << 6))); }
 
+// tr_frag on a ROW-READ image of 64-byte rows (rr_off<32>: 16-byte chunk c of row r sits at c ^ ((r >> 2) & 3)). The four
+// rows a half-wave reads (row0 + 4h + q, q = 0..3) share r >> 2, so each is still read whole, 256 contiguous bytes per
+// half-wave: no bank conflict, and the separate transposed copies of Q and dO (two more 16-byte LDS stores per thread and
+// tensor) are not needed.
+__device__ __forceinline__ bf16x8 tr_frag_rr32(const char* img, int row0, int lane) {
+    const int li = lane & 15, q = li >> 2, p = li & 3, gsel = (lane >> 4) & 1, h = lane >> 5;
+    const int ra = row0 + 4 * h + q, rb = ra + 8;
+    const int chunk = 2 * gsel + (p >> 1), rem = 8 * (p & 1);
+    const bf16x4 a = lds_tr(img + ra * 64 + ((chunk ^ ((ra >> 2) & 3)) << 4) + rem);
+    const bf16x4 b = lds_tr(img + rb * 64 + ((chunk ^ ((rb >> 2) & 3)) << 4) + rem);
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[e] = a[e]; f[4 + e] = b[e]; }
+    return f;
+}
+
+// A-operand fragment that carries one fp32 value per row into a 32 x 32 accumulator tile: row (lane & 31) holds
+// x = hi + lo (two bf16) at k = 0, 1; every other k is zero. Multiplied by a B fragment of ones at k = 0, 1.
+__device__ __forceinline__ bf16x8 row_frag(float x, int h) {
+    const float hi = bf16lo(pack_bf16x2(x, 0.f));
+    u32x4 u = {h == 0 ? pack_bf16x2(x, x - hi) : 0u, 0u, 0u, 0u};
+    return __builtin_bit_cast(bf16x8, u);
+}
+
 template <int D, bool REL, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = D / 16, DB = D / 32, IMG = 128 * D * 2, CPR = D / 8, PER = 128 * CPR / 256;
-    char* qimg = smem;                  // Q rows   (S = Q.K^T)
-    char* qtr = smem + IMG;             // Q^T      (dK^T = Q^T.dS)
-    char* dimg = smem + 2 * IMG;        // dO rows  (dP = dO.V^T)
-    char* dtr = smem + 3 * IMG;         // dO^T     (dV^T = dO^T.P)
+    static_assert(D == 32, "one image per operand: the transposing reads below assume 64-byte rows");
+    char* qimg = smem;                  // Q rows   (S = Q.K^T) and, read transposed, Q^T (dK^T = Q^T.dS)
+    char* dimg = smem + 2 * IMG;        // dO rows  (dP = dO.V^T) and dO^T (dV^T = dO^T.P)
+                                        // (slots 1 and 3 are only the output staging's)
     char* ktr = smem + 4 * IMG;         // K^T      (dQ^T = K^T.dS^T)
     char* dsimg = smem + 5 * IMG;       // dS [key][query] bf16
     float* lse_s = (float*)(smem + 5 * IMG + DS_IMG);   // [128]
@@ -570,59 +592,72 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
     const bool active = j0 < rows;
     const int kj = j0 + fr;
     const int nitems = a.nseq * a.A;
-    const float sc2 = a.scale * kLog2e;
+    const float sc2 = a.scale * kLog2e, inv_scale = 1.0f / a.scale;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    u32x4 ones_u = {h == 0 ? 0x3F803F80u : 0u, 0u, 0u, 0u};          // B fragment: 1.0 at k = 0, 1 (held by the lanes of half 0)
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
     // Persistent over (sequence, head) items: the global loads of item n+1 are in flight (in registers) while item n
     // is computed -- a workgroup per item spent most of its life waiting for its own loads at two workgroups per CU.
     u32x4 pq[PER], pd[PER], po[PER], pk[PER], pv[PER];
-    float nmadd = 0.f, nlse = 0.f;
+    int64_t nmask = 1;                                   // raw mask word of this lane's key: no use before the next item
+    float nlse = 0.f;
     // part 0..3: a quarter of the next item's loads each. Issued between the score tiles so that the CU's address
     // unit sees them spread over the compute phase (issued as one burst, with all eight waves of the CU doing the same,
     // the ten loads took 3700 cycles to get through it while nothing else ran); part < 0 issues everything.
+    // Buffer loads: one descriptor per tensor, a per-lane byte offset that never changes (rows past the sequence: an offset
+    // that fails the range check, the lane reads zeros -- no branch around the load) and the item's position as the scalar
+    // offset. A quarter is then 2-4 instructions with no address arithmetic; as flat loads each one carried two 64-bit adds
+    // per lane and an exec-mask branch.
+    constexpr uint32_t kOob = 0x7FFFFFF0u;
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(a.qkv, (uint32_t)((size_t)a.nseq * a.L * ld * 2));
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(a.dctx, (uint32_t)((size_t)a.nseq * a.L * a.H * 2));
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(a.ctx, (uint32_t)((size_t)a.nseq * a.L * a.H * 2));
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.dqkv, (uint32_t)((size_t)a.nseq * a.L * ld * 2));
+    uint32_t vq[PER], vc[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int idx = tid + 256 * k, row = idx / CPR, c = idx % CPR;
+        vq[k] = row < rows ? (uint32_t)(row * ld + c * 8) * 2u : kOob;
+        vc[k] = row < rows ? (uint32_t)(row * a.H + c * 8) * 2u : kOob;
+    }
     auto prefetch = [&](int item, int part) {
         const int head = item % a.A, seq = item / a.A;
-        const bf16* base = a.qkv + qkv_base(a, seq, head, D);
-        const bf16* dbase = a.dctx + (size_t)seq * a.L * a.H + head * D;
-        const bf16* obase = a.ctx + (size_t)seq * a.L * a.H + head * D;
-        const u32x4 z = {0, 0, 0, 0};
+        const uint32_t sq = (uint32_t)(qkv_base(a, seq, head, D) * 2);                       // scalar byte offsets
+        const uint32_t sc = (uint32_t)(((size_t)seq * a.L * a.H + head * D) * 2);
+        const uint32_t wb = (uint32_t)(a.woff * 2);
         if (part < 0 || part == 0) {
 #pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const int idx = tid + 256 * k, row = idx / CPR, c = idx % CPR;
-                pq[k] = row < rows ? *(const u32x4*)(base + (size_t)row * ld + c * 8) : z;
-            }
-            if (active) nmadd = a.mask[(size_t)seq * a.L + kj] ? 0.f : kMaskMin;
+            for (int k = 0; k < PER; ++k) pq[k] = __builtin_amdgcn_raw_buffer_load_b128(rq, (int)vq[k], (int)sq, 0);
+            nmask = a.mask[(size_t)seq * a.L + (active ? kj : 0)];      // (unconditional: a branch here makes the value
+                                                                        //  a phi that is waited for at the end of the tiles)
         }
         if (part < 0 || part == 1) {
 #pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const int idx = tid + 256 * k, row = idx / CPR, c = idx % CPR;
-                pk[k] = row < rows ? *(const u32x4*)(base + (size_t)row * ld + a.woff + c * 8) : z;
-            }
-            if (tid < rows) nlse = a.lse_in[((size_t)seq * a.A + head) * a.L + tid];
+            for (int k = 0; k < PER; ++k) pk[k] = __builtin_amdgcn_raw_buffer_load_b128(rq, (int)vq[k], (int)(sq + wb), 0);
+            nlse = a.lse_in[((size_t)seq * a.A + head) * a.L + (tid < rows ? tid : 0)];
         }
         if (part < 0 || part == 2) {
 #pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const int idx = tid + 256 * k, row = idx / CPR, c = idx % CPR;
-                pv[k] = row < rows ? *(const u32x4*)(base + (size_t)row * ld + 2 * a.woff + c * 8) : z;
-            }
+            for (int k = 0; k < PER; ++k) pv[k] = __builtin_amdgcn_raw_buffer_load_b128(rq, (int)vq[k], (int)(sq + 2 * wb), 0);
         }
         if (part < 0 || part == 3) {
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
-                const int idx = tid + 256 * k, row = idx / CPR, c = idx % CPR;
-                pd[k] = row < rows ? *(const u32x4*)(dbase + (size_t)row * a.H + c * 8) : z;
-                po[k] = row < rows ? *(const u32x4*)(obase + (size_t)row * a.H + c * 8) : z;
+                pd[k] = __builtin_amdgcn_raw_buffer_load_b128(rd, (int)vc[k], (int)sc, 0);
+                po[k] = __builtin_amdgcn_raw_buffer_load_b128(ro, (int)vc[k], (int)sc, 0);
             }
         }
     };
 
 #ifdef QST_STAMP_ATTN
-    // diagnostic build: s_memtime at the phase boundaries of the third item, wave 0 -> a.delta as uint64 [block][8]
-#define QST_STAMP(k) do { if (iter == 2 && tid == 0) ((unsigned long long*)a.delta)[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+    // diagnostic build: s_memtime at the phase boundaries of the third item (8 ..: inside its second tile), wave 0 -> a.delta
+    // as uint64 [block][16]
+#define QST_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (iter == 2 && tid == 0) ((unsigned long long*)a.delta)[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define QST_STAMP_ONCE(k) do { if (tid == 0) ((unsigned long long*)a.delta)[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define QST_STAMP(k) do {} while (0)
+#define QST_STAMP_ONCE(k) do {} while (0)
 #endif
     // Item order: d = 32 head slices are 64 bytes, so heads 2k and 2k+1 of a token share every 128-byte line.
     // Workgroups b and b + grid/2 sit on the same XCD (grid/2 is a multiple of 8) and walk the two heads of the same
@@ -637,15 +672,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
     int unit = bp, iter = 0;
     const DropCtx dc = DROP ? drop_ctx8(a.drop) : DropCtx{0u, 0u, 1.f};
     const uint32_t dsh = 8u * (uint32_t)(lane & 3);       // this lane's byte of its quad's random words (see the dK/dV kernel)
+    const uint32_t dlane = (uint32_t)(4 * h + (lane & 3)) * a.L + (uint32_t)(kj & ~3);   // (see dbase below)
+    QST_STAMP_ONCE(13);
     if (unit < nunits) prefetch(item_of(unit), -1);
     for (; unit < nunits; unit += stride, ++iter) {
         const int item = item_of(unit);
         const int head = item % a.A, seq = item / a.A;
-        const uint32_t dhead = (uint32_t)(seq * a.A + head) * a.L;       // mask row of query i: (dhead + i) * L
+        // mask element (query i, key j) of this item: dbase + i * L + j. Split into a per-item scalar, a per-tile scalar and
+        // a per-lane constant: a per-element multiply compiles to v_mad_u64_u32, whose undefined upper addend register
+        // aliased a pending prefetch destination and made every tile wait for vmcnt(0).
+        const uint32_t dbase = (uint32_t)(seq * a.A + head) * a.L * a.L;
         __syncthreads();                                 // the previous item's readers of the images are done
         QST_STAMP(0);
-        const float madd2 = nmadd * kLog2e;              // 0 or -inf
-        if (tid < rows) lse_s[tid] = -nlse * kLog2e;
+        const float madd2 = nmask ? 0.f : -INFINITY;     // kMaskMin in log2 units
+        // -lse / scale enters the score accumulator (see the tile loop): q.k - lse / scale. A sequence of padding only has
+        // lse ~ -2e38 (every key carries the finite mask constant of the forward): clamped, so that the value stays finite
+        // through the bf16 hi/lo split; with every key masked the probabilities are exp2(-inf) = 0 whatever it is.
+        if (tid < rows) lse_s[tid] = fminf(-nlse * inv_scale, 1.0e30f);
         if (REL)
             for (int t = tid; t < 2 * a.L; t += 256) {
                 relv[t] = kLog2e * a.rel[(size_t)head * 2 * a.L + t];
@@ -661,11 +704,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
 #pragma unroll
             for (int o = 1; o < CPR; o <<= 1) part += __shfl_xor(part, o);
             const int idx = tid + 256 * k, row = idx / CPR, c = idx % CPR;
-            if (c == 0) del_s[row] = part;
-            *(u32x4*)(qimg + rr_off<D>(row, c)) = pq[k];
-            *(u32x4*)(qtr + tr_off<D>(row, c * 16)) = pq[k];
-            *(u32x4*)(dimg + rr_off<D>(row, c)) = pd[k];
-            *(u32x4*)(dtr + tr_off<D>(row, c * 16)) = pd[k];
+            if (c == 0) del_s[row] = -part;
+            *(u32x4*)(qimg + rr_off<D>(row, c)) = pq[k];             // one image each serves the row reads AND the
+            *(u32x4*)(dimg + rr_off<D>(row, c)) = pd[k];             // transposing reads (tr_frag_rr32)
             *(u32x4*)(ktr + tr_off<D>(row, c * 16)) = pk[k];
             *(u32x4*)(dsimg + ds_off(row, c * 16)) = pv[k];          // V rows borrow the head of the dS image rows
         }
@@ -681,21 +722,39 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
         for (int b = 0; b < DB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dk[b][r] = 0.f; dv[b][r] = 0.f; }
-        if (active) {
+        {
             // this wave's K / V operand fragments (lane = key row). Image rows of a wave's own keys are touched by no
             // other wave before the next barrier, so the V rows parked in the dS image are read before this wave's
             // first dS tile overwrites them (program order).
             bf16x8 kf[KS], vf[KS];
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                kf[s] = *(const bf16x8*)(ktr + tr_off<D>(kj, (16 * s + 8 * h) * 2));
-                vf[s] = *(const bf16x8*)(dsimg + ds_off(kj, (16 * s + 8 * h) * 2));
+                kf[s] = *(const bf16x8*)(ktr + tr_off<D>(active ? kj : 0, (16 * s + 8 * h) * 2));
+                vf[s] = *(const bf16x8*)(dsimg + ds_off(active ? kj : 0, (16 * s + 8 * h) * 2));
             }
-            for (int it = 0; it < rows / 32; ++it) {
-                if (more) prefetch(next_item, it);
-                f32x16 s, dp;
+            // Unrolled over the (at most four) query tiles, prefetch quarter `it` issued by EVERY wave at one place in the
+            // code: `it` is a constant in each copy and each prefetch register has a single definition, so the loads go
+            // straight into their registers and nothing waits for them before the next item's staging. As a loop (and
+            // with a second copy of the prefetch for waves without keys) the compiler routed the loads through temporaries
+            // and phi copies behind vmcnt(0): three of the four quarters exposed a full HBM round trip per item -- 2,700
+            // cycles per tile for 256 cycles of MFMA (in-kernel stamps).
+            const int nit = active ? rows / 32 : 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            for (int it = 0; it < 4; ++it) {
+                if (it == 1) QST_STAMP(8);
+                if (more) prefetch(next_item, it);
+                if (it == 1) QST_STAMP(9);
+                if (it >= nit) continue;
+                // The per-query constants enter through the ACCUMULATORS: -lse_i / scale and -delta_i are split into
+                // bf16 hi + lo (16 mantissa bits; the products with 1.0 are exact in the fp32 accumulator) and a
+                // one-k-step MFMA against a fragment of ones lays them out as [query row][any key] -- the layout the score
+                // tile has. Reading them as per-row scalars cost 8 ds_read_b128 per tile (half-wave broadcasts, 45% of the
+                // kernel's LDS traffic, and the LDS pipe shared by the CU's 8 waves is what bounds this kernel) plus 8 packed
+                // adds; this way it is 2 ds_read_b32 and 2 of the idle matrix core's cycles.
+                const bf16x8 la = row_frag(lse_s[it * 32 + fr], h), da = row_frag(del_s[it * 32 + fr], h);
+                f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la, ones, zero16, 0, 0, 0);
+                f32x16 nd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, ones, zero16, 0, 0, 0);
+                f32x16 dp = DROP ? zero16 : nd;                     // dropout: mask * dP~ - delta needs -delta on its own
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const bf16x8 qf = *(const bf16x8*)(qimg + rr_off<D>(it * 32 + fr, 2 * ks + h));
@@ -703,30 +762,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
                     s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], s, 0, 0, 0);      // rows i, col j
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], dp, 0, 0, 0);
                 }
-                // Elementwise part, trimmed because it (not the MFMAs) bounds this kernel: log2(e), the softmax scale,
-                // the key mask and -lse are folded into one packed fma feeding v_exp_f32 directly; dS stays unscaled
-                // (dK and dQ are scaled once at the end); P and dS are rounded to bf16 once and the packed words serve
-                // both as MFMA fragments and as the dS image rows.
+                if (it == 1) QST_STAMP(10);
+                // Elementwise part, trimmed because it and the LDS pipe (not the MFMAs) bound this kernel: s already holds
+                // q.k - lse / scale, so one packed fma (softmax scale * log2(e), key mask) feeds v_exp_f32 directly; dS
+                // stays unscaled (dK and dQ are scaled once at the end); P and dS are rounded to bf16 once and the packed
+                // words serve both as MFMA fragments and as the dS image rows.
                 uint32_t pw[4][2], sw[4][2];
                 float dlo = 0.f, dhi = 0.f;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int il = it * 32 + 8 * g + 4 * h;     // accumulator registers 4g..4g+3 = query rows il..il+3
-                    const f32x4 l4 = *(const f32x4*)(lse_s + il), d4 = *(const f32x4*)(del_s + il);
                     uint32_t wq[4] = {0u, 0u, 0u, 0u};
-                    if (DROP && dc.thr) {
-                        const uint32_t mine = drop_word4(dc, (dhead + (uint32_t)(il + (lane & 3))) * a.L + (uint32_t)(kj & ~3));
+                    if (DROP) {
+                        const uint32_t mine = drop_word4(dc, dbase + (uint32_t)(it * 32 + 8 * g) * a.L + dlane);
                         wq[0] = quad_bcast<0>(mine); wq[1] = quad_bcast<1>(mine); wq[2] = quad_bcast<2>(mine); wq[3] = quad_bcast<3>(mine);
                     }
 #pragma unroll
                     for (int e = 0; e < 4; e += 2) {
                         const int r = 4 * g + e;
-                        f32x2 sv, cv, dpv, dv2;
+                        f32x2 sv, dpv;
                         sv[0] = s[r]; sv[1] = s[r + 1];
-                        cv[0] = l4[e] + madd2; cv[1] = l4[e + 1] + madd2;
                         dpv[0] = dp[r]; dpv[1] = dp[r + 1];
-                        dv2[0] = d4[e]; dv2[1] = d4[e + 1];
-                        f32x2 v = sv * sc2 + cv;                                  // log2 of the probability
+                        f32x2 v = sv * sc2 + madd2;                               // log2 of the probability
                         if (REL) {
                             v[0] += relv[kj - (il + e) + a.L];
                             v[1] += relv[kj - (il + e + 1) + a.L];
@@ -734,22 +791,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
                         f32x2 pr;
                         pr[0] = __builtin_amdgcn_exp2f(v[0]);
                         pr[1] = __builtin_amdgcn_exp2f(v[1]);
-                        if (DROP && dc.thr) {
+                        if (DROP) {
                             // dP = mask * dP~ and dV takes the dropped probabilities
-                            f32x2 mk;
+                            f32x2 mk, ndv;
                             mk[0] = (((wq[e] >> dsh) & 0xFFu) >= dc.thr) ? dc.scale : 0.f;
                             mk[1] = (((wq[e + 1] >> dsh) & 0xFFu) >= dc.thr) ? dc.scale : 0.f;
-                            dpv *= mk;
-                            const f32x2 dsd = pr * (dpv - dv2);
-                            if (REL && a.drel) { diag_add(dsd[0], r, lane, dlo, dhi); diag_add(dsd[1], r + 1, lane, dlo, dhi); }
-                            pr *= mk;
+                            ndv[0] = nd[r]; ndv[1] = nd[r + 1];
+                            dpv = dpv * mk + ndv;
+                            pw[g][e >> 1] = pack_bf16x2(pr[0] * mk[0], pr[1] * mk[1]);
+                        } else {
                             pw[g][e >> 1] = pack_bf16x2(pr[0], pr[1]);
-                            sw[g][e >> 1] = pack_bf16x2(dsd[0], dsd[1]);
-                            continue;
                         }
-                        const f32x2 dsr = pr * (dpv - dv2);                       // dS (unscaled) = d(score)
+                        const f32x2 dsr = pr * dpv;                               // dS (unscaled) = d(score)
                         if (REL && a.drel) { diag_add(dsr[0], r, lane, dlo, dhi); diag_add(dsr[1], r + 1, lane, dlo, dhi); }
-                        pw[g][e >> 1] = pack_bf16x2(pr[0], pr[1]);
                         sw[g][e >> 1] = pack_bf16x2(dsr[0], dsr[1]);
                     }
                     u32x2 pkd;
@@ -757,6 +811,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
                     *(u32x2*)(dsimg + ds_off(kj, il * 2)) = pkd;
                 }
                 if (REL && a.drel) diag_store(drel_s + wave * 2 * a.L, a.L, j0, it * 32, lane, dlo, dhi);
+                if (it == 1) QST_STAMP(11);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     u32x4 pu, su;
@@ -765,20 +820,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
                     const bf16x8 pf = __builtin_bit_cast(bf16x8, pu), sf = __builtin_bit_cast(bf16x8, su);
 #pragma unroll
                     for (int b = 0; b < DB; ++b) {
-                        const bf16x8 dt = tr_frag<D>(dtr, it * 32 + 16 * ks, b, lane);
-                        const bf16x8 qt = tr_frag<D>(qtr, it * 32 + 16 * ks, b, lane);
+                        const bf16x8 dt = tr_frag_rr32(dimg, it * 32 + 16 * ks, lane);
+                        const bf16x8 qt = tr_frag_rr32(qimg, it * 32 + 16 * ks, lane);
                         dv[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt, pf, dv[b], 0, 0, 0);
                         dk[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, sf, dk[b], 0, 0, 0);
                     }
                 }
+                if (it == 1) QST_STAMP(12);
             }
 #pragma unroll
             for (int b = 0; b < DB; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dk[b][r] *= a.scale;
         }
-        if (more)
-            for (int part = active ? rows / 32 : 0; part < 4; ++part) prefetch(next_item, part);
         QST_STAMP(3);
         __syncthreads();                                 // every wave's dS tiles are in the image
         QST_STAMP(4);
@@ -830,18 +884,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
                     *(u32x2*)(stg + 2 * 32 * D * 2 + off) = o2;
                 }
             // wave-private staging: no workgroup barrier, the LDS queue is in order within a wave
-            bf16* obase2 = a.dqkv + qkv_base(a, seq, head, D) + (size_t)j0 * ld;
+            const uint32_t so = (uint32_t)((qkv_base(a, seq, head, D) + (size_t)j0 * ld) * 2);
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
                 for (int k = 0; k < 32 * CPR / 64; ++k) {
                     const int idx = lane + 64 * k, row = idx / CPR, c = idx % CPR;
                     const u32x4 v = *(const u32x4*)(stg + t * 32 * D * 2 + rr_off<D>(row, c));
-                    *(u32x4*)(obase2 + (size_t)row * ld + t * a.woff + c * 8) = v;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rw, (int)((uint32_t)(row * ld + c * 8) * 2u),
+                                                           (int)(so + (uint32_t)t * (uint32_t)(a.woff * 2)), 0);
                 }
             QST_STAMP(6);
         }
     }
+    QST_STAMP_ONCE(14);
 }
 
 template <typename K>
@@ -852,7 +908,6 @@ int set_lds(K kern, size_t bytes) {
 
 }  // namespace
 
-static int g_attn_force_split = 0;      // diagnostic switch (qst_debug_attn_force_split): always use the two-kernel path
 static int check_attn(int nseq, int L, int A, int d) {
     if (nseq <= 0 || L <= 0 || A <= 0) return QST_ERR_BAD_ARG;
     if ((d != 32 && d != 64) || (L % 32) != 0 || L > 512) return QST_ERR_UNSUPPORTED;
@@ -864,8 +919,7 @@ static int fill_args(const QstAttnDesc* q, AttnArgs& a) {
     if (int rc = check_attn(q->nseq, q->L, q->A, q->d)) return rc;
     a.qkv = (const bf16*)q->qkv; a.mask = q->mask; a.rel = q->rel_pos;
     a.nseq = q->nseq; a.L = q->L; a.A = q->A; a.H = q->A * q->d; a.scale = 1.0f / sqrtf((float)q->d);
-    if (q->head_major) { a.ld = q->d; a.woff = (int64_t)q->A * q->L * q->d; a.head_major = 1; }
-    else { a.ld = 3 * a.H; a.woff = a.H; a.head_major = 0; }
+    a.ld = 3 * a.H; a.woff = a.H;
     a.drop = q->drop;
     if (a.drop.thr16 > 65535u) return QST_ERR_BAD_ARG;
     if (!a.drop.state) a.drop.thr16 = 0u;
@@ -908,7 +962,9 @@ extern "C" int qst_attention_bwd_ex(const QstAttnDesc* q, void* stream) {
     const size_t lds_kv = (size_t)4 * 128 * d * 2 + 256 * 4 + (rel ? (size_t)10 * L * 4 : 0);
     hipStream_t st = (hipStream_t)stream;
 #define QST_RUN(K_, G_, LDS_) do { if ((rc = set_lds(K_, LDS_))) return rc; K_<<<G_, 256, LDS_, st>>>(a); QST_LAUNCH_CHECK(); } while (0)
-    if (L <= 128 && d == 32 && !g_attn_force_split) {
+    // (the single-workgroup kernel addresses q/k/v through 32-bit buffer offsets)
+    const bool fits32 = (int64_t)nseq * L * 3 * A * d * 2 < 0x7FFFFF00LL;
+    if (L <= 128 && d == 32 && !q->force_split && fits32) {
         // one workgroup per (sequence, head) computes dQ, dK and dV from a single evaluation of the score tile
         const size_t lds_f = (size_t)5 * 128 * d * 2 + DS_IMG + 256 * 4 + (rel ? (size_t)10 * L * 4 : 0);
         const int gf = min(nseq * A, 512);                                            // two per CU, persistent
@@ -943,8 +999,6 @@ extern "C" int qst_attention_bwd(const void* qkv, const void* ctx, const void* d
     q.lse = (float*)lse; q.dctx = dctx; q.dqkv = dqkv; q.drel = drel; q.delta_scratch = delta_scratch;
     return qst_attention_bwd_ex(&q, stream);
 }
-
-extern "C" void qst_debug_attn_force_split(int on) { g_attn_force_split = on; }
 
 // Diagnostic (not declared in the public headers): resident workgroups per CU the runtime reports for the d=32 kernels.
 extern "C" int qst_debug_attn_occupancy(int which, int lds_bytes) {

@@ -69,7 +69,7 @@ struct FfnArgs {
     const bf16* aux; bf16* save_gp; bf16* save_h;
     float* C; bf16* C2;
     int M, I;
-    int diag;        // timing experiments (qst_debug_ffn_diag): 1 = drop the A loads, 2 = drop the weight loads, 4 = L2 touch-ahead
+    int diag;        // timing experiments (QstFfnArgs.diag): 1 = drop the A loads, 2 = drop the weight loads, 4 = L2 touch-ahead
 };
 
 template <int MODE, bool SAVE>
@@ -442,9 +442,6 @@ __global__ __launch_bounds__(512, 1) void ffn_chain_kernel(FfnArgs g, QstLnEpi e
 
 }  // namespace
 
-static int g_ffn_diag = 4;
-extern "C" void qst_debug_ffn_diag(int bits) { g_ffn_diag = bits; }
-
 extern "C" int qst_ffn_chain_supported(int H, int I) { return (H == FH && I > 0 && I % FIC == 0 && I <= 4096) ? 1 : 0; }
 
 extern "C" int qst_ffn_chain(const QstFfnArgs* a, const QstLnEpi* ln, int mode, void* stream) {
@@ -458,7 +455,7 @@ extern "C" int qst_ffn_chain(const QstFfnArgs* a, const QstLnEpi* ln, int mode, 
     g.A = (const bf16*)a->A; g.B1 = (const bf16*)a->B1; g.B2 = (const bf16*)a->B2;
     g.bias1 = a->bias1; g.bias2 = a->bias2; g.resid = a->resid;
     g.aux = (const bf16*)a->aux; g.save_gp = (bf16*)a->save_gp; g.save_h = (bf16*)a->save_h;
-    g.C = a->C; g.C2 = (bf16*)a->C2; g.M = a->M; g.I = a->I; g.diag = g_ffn_diag;
+    g.C = a->C; g.C2 = (bf16*)a->C2; g.M = a->M; g.I = a->I; g.diag = (a->diag & 3) | ((a->diag & 4) ? 0 : 4);
     const int lds = F_VEC + (a->I + 3 * FH) * 4 + 8 * 256;
     if (lds > 160 * 1024) return QST_ERR_UNSUPPORTED;
     const int ntm = (a->M + FBM - 1) / FBM;

@@ -10,11 +10,10 @@
 //   gemm_nt_kernel<EPI, WAVES_M, WAVES_N, TI>  128x192 tile, 4 waves of 64x96, two workgroups per CU (default); 256x192 with 8
 //                       waves; 256x192 with four waves of 128x96 ("tall", 32-deep stages) for the K >= 768 bf16-output GEMMs.
 //                       K in 64-deep stages by LDS-DMA into a 2-slot XOR-swizzled ring, one raw s_barrier per stage.
-//   gemm_nt_w8_kernel   the same loop on fp8 (e4m3) weights widened to bf16 in registers (QST_PREC_FP8W, inference)
 //   gemm_nt_f8_kernel   both operands MXFP8 on v_mfma_scale_f32_32x32x64_f8f6f4, 128-deep stages (QST_PREC_FP8, inference)
 //   gemm_nt_ln_kernel<MODE, DROPW>  128x384 full-row tile with the LayerNorm (forward) / LayerNorm backward in the epilogue
-//   gemm_tn_group_kernel<SLAB>      all weight gradients of a layer in one launch, 192x192 tiles, one M-range per XCD,
-//                       4 MFMA + 4 loader waves, 6-slot ring of 32-row stages; tn_reduce_kernel for the slab flush
+//   gemm_tn_group_kernel            all weight gradients of a layer in one launch, 192x192 tiles, one M-range per XCD,
+//                       4 MFMA + 4 loader waves, 3-slot ring of 64-row stages, float-atomic flush
 //   quant_mx_kernel     MXFP8 quantisation of an activation matrix
 // LDS images are XOR-swizzled (applied on the DMA SOURCE address, the destination is lane-linear) so that
 // ds_read_b128 (nt) and ds_read_b64_tr_b16 (tn) fragment reads are bank-conflict-free; LDS-DMA = buffer_load_dwordx4 ... lds
@@ -98,10 +97,9 @@ __device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, in
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
     const int rows_a = min(NBM, g.M - m0), rows_b = min(NBN, g.N - n0);
-    const bool a_heads = g.a_head_L != 0;            // A is a head-major q|k|v tensor (QstGemmArgs): absolute offsets
-    const bf16* Ab = (const bf16*)g.A + (a_heads ? (size_t)0 : (size_t)m0 * g.lda);
+    const bf16* Ab = (const bf16*)g.A + (size_t)m0 * g.lda;
     const bf16* Bb = (const bf16*)g.B + (size_t)n0 * g.ldb;
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc(Ab, a_heads ? (uint32_t)g.M * g.lda * 2u : (uint32_t)rows_a * g.lda * 2u);
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(Ab, (uint32_t)rows_a * g.lda * 2u);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(Bb, (uint32_t)rows_b * g.ldb * 2u);
 
     // DMA map: one wave-instruction = 1 KB = 8 rows x 128 B. LDS position p (16-B units) = q*64 + lane -> row p/8,
@@ -112,23 +110,6 @@ __device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, in
         const int row = (wave * A_PER_WAVE + t) * 8 + (lane >> 3);
         va[t] = (uint32_t)row * g.lda * 2u + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
     }
-    // Head-major A: element (m, k) of the [M, K] matrix sits at ((m / L) * (K / d) + k / d) * L * d + (m % L) * d + k % d.
-    // A stage is 64 consecutive k = 64 / d whole heads, so stages are 64 * L elements apart and a row's 128 stage bytes
-    // become 64 / d pieces of 2d bytes; the 8 rows of one DMA instruction never straddle a sequence (L % 32 == 0).
-    uint32_t ka_stride = NBK * 2;
-    if (a_heads) {
-        const int L = g.a_head_L, d = g.a_head_d, dsh = 31 - __builtin_clz(d);
-        ka_stride = (uint32_t)NBK * L * 2u;
-#pragma unroll
-        for (int t = 0; t < A_PER_WAVE; ++t) {
-            const int row8 = (wave * A_PER_WAVE + t) * 8;
-            const int mb = m0 + row8, seq = mb / L, l = mb - seq * L + (lane >> 3);
-            const int row = row8 + (lane >> 3);
-            const int kc = ((lane & 7) ^ ((row >> 1) & 7)) * 8;                  // first k of this lane's chunk
-            const uint32_t e = ((uint32_t)seq * (g.K >> dsh) + (kc >> dsh)) * L * d + (uint32_t)l * d + (kc & (d - 1));
-            va[t] = (row < rows_a) ? e * 2u : kOOB;
-        }
-    }
 #pragma unroll
     for (int t = 0; t < B_PER_WAVE; ++t) {
         const int row = (wave * B_PER_WAVE + t) * 8 + (lane >> 3);
@@ -136,9 +117,9 @@ __device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, in
     }
     auto issue = [&](int kt) {
         char* st = smem + (kt & 1) * NT_STAGE;
-        const uint32_t ko = (uint32_t)kt * (NBK * 2), koa = (uint32_t)kt * ka_stride;
+        const uint32_t ko = (uint32_t)kt * (NBK * 2);
 #pragma unroll
-        for (int t = 0; t < A_PER_WAVE; ++t) dma16(ra, st + (wave * A_PER_WAVE + t) * 1024, va[t], koa);
+        for (int t = 0; t < A_PER_WAVE; ++t) dma16(ra, st + (wave * A_PER_WAVE + t) * 1024, va[t], ko);
 #pragma unroll
         for (int t = 0; t < B_PER_WAVE; ++t) dma16(rb, st + NT_A_BYTES + (wave * B_PER_WAVE + t) * 1024, vb[t], ko);
     };
@@ -257,11 +238,9 @@ __device__ __forceinline__ void nt_mainloop_tall(const QstGemmArgs& g, char* sme
 // with loads and stores interleaved per row the compiler must keep them in order (C may alias resid), and in-kernel
 // stamps showed the epilogue then costing 2-4x the whole K loop in exposed load latency.
 // bias_s: this wave's 96 bias values in LDS (written by the caller, same wave).
-// scale_s: optional per-column factors applied to the accumulator before the bias (fp8-weight GEMM: the weight row's
-// quantisation scale), 96 values in LDS like bias_s, or nullptr.
 template <int EPI, int TI>
 __device__ __forceinline__ void nt_epilogue(const QstGemmArgs& g, f32x16 (&acc)[TI][3], float* stg, const float* bias_s,
-                                            int m_base, int n_base, int lane, const float* scale_s = nullptr) {
+                                            int m_base, int n_base, int lane) {
     const int fr = lane & 31, fh = lane >> 5;
     constexpr bool kF32Out = (EPI == QST_EPI_F32_RESID || EPI == QST_EPI_F32_RESID_BF16);
     DropCtx dc = DropCtx{0u, 0u, 1.f};               // dropout of the projection output, before the residual (QstGemmArgs)
@@ -298,7 +277,6 @@ __device__ __forceinline__ void nt_epilogue(const QstGemmArgs& g, f32x16 (&acc)[
                 const int n = n_base + c4 * 4;
                 if (m >= g.M || n >= g.N) continue;
                 f32x4 v = *(const f32x4*)(stg + row * NT_STG_LD + c4 * 4);
-                if (scale_s) v *= *(const f32x4*)(scale_s + c4 * 4);
                 if (g.bias) v += *(const f32x4*)(bias_s + c4 * 4);
                 if (dc.thr) {
                     const uint32_t e = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
@@ -352,24 +330,12 @@ __device__ __forceinline__ void nt_epilogue(const QstGemmArgs& g, f32x16 (&acc)[
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
                 }
-                if (scale_s) {
-                    const f32x4 lo = *(const f32x4*)(scale_s + c8 * 8), hi = *(const f32x4*)(scale_s + c8 * 8 + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] *= lo[e]; v[4 + e] *= hi[e]; }
-                }
                 if (g.bias) {
                     const f32x4 lo = *(const f32x4*)(bias_s + c8 * 8), hi = *(const f32x4*)(bias_s + c8 * 8 + 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[e] += lo[e]; v[4 + e] += hi[e]; }
                 }
-                size_t o = (size_t)m * g.ldc + n;
-                if (EPI == QST_EPI_BF16 && g.c_head_L) {
-                    // head-major q|k|v output (QstGemmArgs): the 32 rows of this pass lie in one sequence (L % 32 == 0),
-                    // 8 consecutive columns in one head
-                    const int L = g.c_head_L, d = g.c_head_d, dsh = 31 - __builtin_clz(d);
-                    const int mb = m_base + i * 32, seq = mb / L, l = mb - seq * L + row;
-                    o = ((size_t)seq * (g.N >> dsh) + (n >> dsh)) * L * d + (size_t)l * d + (n & (d - 1));
-                }
+                const size_t o = (size_t)m * g.ldc + n;
                 // N % 8 != 0 tails fall back to two 8-byte halves (N % 4 == 0 is required)
                 const bool full = n + 8 <= g.N;
                 u32x4 pk;
@@ -436,98 +402,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 2 ? 2 : 1) void 
     nt_epilogue<EPI, TI>(g, acc, stg, bias_s, m0 + wm * (32 * TI), n0 + wn * 96, lane);
     NT_STAMP(2);
 #undef NT_STAMP
-}
-
-// ---------------------------------------------------------------- NT with fp8 (e4m3) weights (inference)
-// C = (A . Q^T) * scale[n] + epilogue: A bf16 activations, Q = fp8 weights quantised per output row (scale = row amax /
-// 448, qst_quant_rows_fp8). The K loop is the 128 x 192 one with the weight tile at half the bytes (12 instead of 24 KB
-// per 64-deep stage: 28 KB per stage against 40 -- the loop runs at the rate operands arrive, DESIGN.md finding 4);
-// fragments are widened to bf16 in registers (e4m3 values are exact in bf16) and go through the same bf16 MFMA, the row
-// scale is applied to the fp32 accumulator in the epilogue. BASELINE configs[4] "fp8 weights"; SURVEY.md 7 step 9.
-__device__ __forceinline__ bf16x8 fp8x8_to_bf16(u32x2 w) {
-    const auto a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[0], false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[0], true);
-    const auto c = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[1], false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[1], true);
-    bf16x8 f;
-    f[0] = (bf16)a[0]; f[1] = (bf16)a[1]; f[2] = (bf16)b[0]; f[3] = (bf16)b[1];
-    f[4] = (bf16)c[0]; f[5] = (bf16)c[1]; f[6] = (bf16)d[0]; f[7] = (bf16)d[1];
-    return f;
-}
-
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_w8_kernel(QstGemmArgs g) {
-    constexpr int NBM = 128, NBN = 192;
-    constexpr int A_BYTES = NBM * NBK * 2, B_BYTES = NBN * NBK, STAGE = A_BYTES + B_BYTES;      // 16 + 12 KB
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int ntn = (g.N + NBN - 1) / NBN, ntm = (g.M + NBM - 1) / NBM;
-    const int wg = xcd_remap(blockIdx.x, ntm * ntn);
-    const int m0 = (wg / ntn) * NBM, n0 = (wg % ntn) * NBN;
-    const int fr = lane & 31, fh = lane >> 5;
-
-    const int rows_a = min(NBM, g.M - m0), rows_b = min(NBN, g.N - n0);
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc((const bf16*)g.A + (size_t)m0 * g.lda, (uint32_t)rows_a * g.lda * 2u);
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc((const uint8_t*)g.B + (size_t)n0 * g.ldb, (uint32_t)rows_b * g.ldb);
-    uint32_t va[4], vb[3];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {                     // A: 8 rows of 128 B per DMA instruction
-        const int row = (wave * 4 + t) * 8 + (lane >> 3);
-        va[t] = (uint32_t)row * g.lda * 2u + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
-    }
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {                     // B: 16 rows of 64 B (64 fp8) per DMA instruction
-        const int row = (wave * 3 + t) * 16 + (lane >> 2);
-        vb[t] = (uint32_t)row * g.ldb + (uint32_t)(((lane & 3) ^ ((row >> 2) & 3)) * 16);
-    }
-    auto issue = [&](int kt) {
-        char* st = smem + (kt & 1) * STAGE;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) dma16(ra, st + (wave * 4 + t) * 1024, va[t], (uint32_t)kt * (NBK * 2));
-#pragma unroll
-        for (int t = 0; t < 3; ++t) dma16(rb, st + A_BYTES + (wave * 3 + t) * 1024, vb[t], (uint32_t)kt * NBK);
-    };
-    f32x16 acc[2][3];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int nk = g.K / NBK;
-    issue(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (kt + 1 < nk) issue(kt + 1);
-        const char* pa = smem + (kt & 1) * STAGE;
-        const char* pb = pa + A_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 fa[2], fb[3];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *(const bf16x8*)(pa + nt_off(wm * 64 + i * 32 + fr, ks * 2 + fh));
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                fb[j] = fp8x8_to_bf16(*(const u32x2*)(pb + nt_off32(wn * 96 + j * 32 + fr, ks) + 8 * fh));
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-        }
-    }
-    __builtin_amdgcn_s_barrier();
-
-    float* stg = (float*)smem + wave * (32 * NT_STG_LD);
-    float* bias_s = (float*)smem + 4 * (32 * NT_STG_LD) + wave * 96;
-    float* scale_s = bias_s + 4 * 96;
-    for (int c = lane; c < 96; c += 64) {
-        const int n = n0 + wn * 96 + c;
-        bias_s[c] = (g.bias && n < g.N) ? g.bias[n] : 0.f;
-        scale_s[c] = n < g.N ? g.bscale[n] : 0.f;
-    }
-    nt_epilogue<EPI, 2>(g, acc, stg, bias_s, m0 + wm * 64, n0 + wn * 96, lane, scale_s);
 }
 
 // ---------------------------------------------------------------- NT on the fp8 matrix cores (MXFP8, inference)
@@ -983,7 +857,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
 // LDS image per operand stage: [32 m-rows][192 bf16] = 384-byte rows (24 chunks of 16 B); chunk c of row r sits at
 // chunk position c ^ (((r >> 1) & 1) << 2): the 4 rows x 64 B that one half-wave reads land in 16 distinct 16-B slots.
 constexpr int TT = 192, TBK = 64, TSTAGES = 3;            // 3-slot ring of 64-row stages: one being read, two in flight
-constexpr int TN_MAX_PIECES = 2;                          // slab flush: stage pieces a leftover tile may be cut into
 constexpr int TT_TILE = TBK * TT * 2;                // 24 KB per operand per stage
 constexpr int TT_STAGE = 2 * TT_TILE;                // 48 KB
 constexpr int TT_LDS = TSTAGES * TT_STAGE;           // 144 KB: one workgroup (4 MFMA + 4 loader waves) per CU
@@ -1004,7 +877,6 @@ __device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
 // = a*W + b, every workgroup reduces `a` whole tiles and then one stage-piece of a leftover tile (task list in the
 // kernel), so all CUs finish together instead of 1.5 tiles per CU being rounded up to 2; split tiles simply receive
 // several partial sums through the fp32 atomics.
-template <bool SLAB>
 __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1059,13 +931,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
             const bool isA = wave < 6;
             const int half = wave & 1;
             const int ld = isA ? g.lda : g.ldb, c0 = isA ? n0 : k0, width = isA ? g.N : g.K;
-            // head-major dY (QstGemmArgs.a_head_L: the q|k|v gradient as the attention backward writes it): absolute
-            // offsets; a 32-row stage lies in one sequence (ranges start at multiples of 32 rows, L % 32 == 0)
-            const int hL = isA ? g.a_head_L : 0, hd = isA ? g.a_head_d : 1, hsh = 31 - __builtin_clz(hd);
-            const bf16* base = (const bf16*)(isA ? g.A : g.B) + (hL ? (size_t)0 : (size_t)row0 * ld + c0);
+            const bf16* base = (const bf16*)(isA ? g.A : g.B) + (size_t)row0 * ld + c0;
             // range = rows [row0, mend); the last row's tail past the allocation reads as zero
-            const uint32_t bytes = hL ? (uint32_t)((size_t)M * ld * 2u)        // (offsets span whole sequence blocks)
-                                      : (uint32_t)min((size_t)(mend - row0) * ld * 2u - (size_t)c0 * 2u, (size_t)0x7FFFFF00u);
+            const uint32_t bytes = (uint32_t)min((size_t)(mend - row0) * ld * 2u - (size_t)c0 * 2u, (size_t)0x7FFFFF00u);
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, bytes);
             // an operand stage is 768 chunks = 12 wave-instructions of 1 KB. LDS position p = q*64 + lane -> row p/24,
             // chunk position p%24 -> logical chunk = pos ^ swz(row). Columns beyond the matrix width must not alias
@@ -1079,18 +947,10 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
                 const int pp = (half * NDMA + t) * 64 + lane;
                 const int row = pp / 24, chunk = (pp % 24) ^ tn_swz(row);
                 vo[t] = (c0 + chunk * 8 < width) ? (uint32_t)row * ld * 2u + chunk * 16u : kOOB;
-                if (hL) {
-                    const int n = c0 + chunk * 8;
-                    vo[t] = (n < width) ? (((uint32_t)(n >> hsh) * hL + row) * hd + (n & (hd - 1))) * 2u : kOOB;
-                }
             }
             auto issue = [&](int mt) {
                 char* st = smem + (mt % TSTAGES) * TT_STAGE + (isA ? 0 : TT_TILE);
-                uint32_t so = (uint32_t)mt * TBK * ld * 2u;
-                if (hL) {
-                    const int m = row0 + mt * TBK, seq = m / hL, l0 = m - seq * hL;
-                    so = __builtin_amdgcn_readfirstlane(((uint32_t)seq * ld * hL + (uint32_t)l0 * hd) * 2u);
-                }
+                const uint32_t so = (uint32_t)mt * TBK * ld * 2u;
 #pragma unroll
                 for (int t = 0; t < NDMA; ++t) dma16(rs, st + (half * NDMA + t) * 1024, vo[t], so);  // kOOB + so < 2^32: no wrap
             };
@@ -1189,26 +1049,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
         __builtin_amdgcn_s_barrier();                      // end of piece: the loaders may refill the ring while we flush
 
         float* C = (float*)g.C;
-        if (SLAB) {
-            // slab flush: this task's partial tile goes out as plain stores into its own [192][192] slot (tile-local
-            // layout, whole tile incl. padding rows / columns, which hold zeros); tn_reduce_kernel sums the slots of a
-            // tile into C afterwards. Float atomics execute at the memory side at ~1.3 TB/s chip-wide: the 75 MB of
-            // partial sums of a MiniLM layer cost 43 us of the launch that way.
-            const int tile_g = (task < a_full) ? task * W + jr : a_full * W + jr / pieces;      // index over all problems
-            const int pc = (task < a_full) ? 0 : jr % pieces;
-            float* S = grp.slabs + ((size_t)(range * TN_MAX_PIECES + pc) * T + tile_g) * (TT * TT) +
-                       (wm * 96 + 4 * fh) * TT + wn * 96 + fr;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                __builtin_amdgcn_sched_barrier(0);       // one 32-row band's addresses at a time (144 at once spill)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float* row = S + (i * 32 + (r & 3) + 8 * (r >> 2)) * TT;
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) row[j * 32] = acc[i][j][r];
-                }
-            }
-        } else {
+        // Partial tiles are combined with float atomics (executed at the memory side, ~1.3 TB/s chip-wide: the 75 MB of
+        // partial sums of a MiniLM layer cost 43 us of the launch). A plain-store flush into per-range slots plus a
+        // fixed-order reduce kernel was built in round 2 and removed in round 3: same time, 75 MB more scratch.
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int k = k0 + wn * 96 + j * 32 + fr;
@@ -1222,7 +1065,6 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
                 }
             }
         }
-        }
         if (do_bias) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -1234,60 +1076,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
     }
 }
 
-// Second half of the slab flush: C[n][k] += sum over the slots that hold a partial sum of that tile (every M-range's
-// slot 0 for a tile reduced whole; the pieces that exist for a leftover tile). One workgroup per (tile, 16-row band),
-// 16-byte accesses along k; the order of the sum is fixed, so the weight gradients are reproducible bit for bit.
-__global__ __launch_bounds__(256) void tn_reduce_kernel(QstTnGroup grp, int nranges, int W, int per) {
-    const int T = grp.total_tiles;
-    const int tile_g = blockIdx.x / (TT / 16), band = blockIdx.x % (TT / 16);
-    int tile = tile_g, pi = 0;
-    while (pi + 1 < grp.nprob && tile >= grp.tiles[pi]) { tile -= grp.tiles[pi]; ++pi; }
-    const QstGemmArgs& g = grp.prob[pi];
-    const int ntk = (g.K + TT - 1) / TT;
-    const int n0 = (tile / ntk) * TT, k0 = (tile % ntk) * TT;
-    const int a_full = T / W, b_left = T % W;
-    const int pieces = b_left > 0 ? max(1, W / b_left) : 1;
-    const bool leftover = tile_g >= a_full * W;
-    const int M = grp.prob[0].M;
-    float* C = (float*)g.C;
-    for (int e = threadIdx.x; e < 16 * (TT / 4); e += 256) {
-        const int nl = band * 16 + e / (TT / 4), kl = (e % (TT / 4)) * 4;
-        const int n = n0 + nl, k = k0 + kl;
-        if (n >= g.N || k >= g.K) continue;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        for (int r = 0; r < nranges; ++r) {
-            int npc = 1;
-            if (leftover) {                                                  // pieces of this range with at least one stage
-                const int S = (min(M, (r + 1) * per) - r * per + TBK - 1) / TBK;
-                const int per_piece = (S + pieces - 1) / pieces;
-                npc = min(pieces, (S + per_piece - 1) / per_piece);
-            }
-            for (int pc = 0; pc < npc; ++pc)
-                a += *(const f32x4*)(grp.slabs + ((size_t)(r * TN_MAX_PIECES + pc) * T + tile_g) * (TT * TT) + nl * TT + kl);
-        }
-        float* dst = C + (size_t)n * g.ldc + k;
-        if (k + 4 <= g.K) { *(f32x4*)dst = *(const f32x4*)dst + a; }
-        else for (int q = 0; q < 4 && k + q < g.K; ++q) dst[q] += a[q];
-    }
-}
-
 }  // namespace
-
-// head-major operand descriptions of QstGemmArgs: which kernels take which, and the shapes they assume
-static int check_heads(const QstGemmArgs* a, bool a_ok, bool c_ok, int epi) {
-    if (a->a_head_L) {
-        const int L = a->a_head_L, d = a->a_head_d;
-        if (!a_ok) return QST_ERR_UNSUPPORTED;
-        if (L <= 0 || L % 32 != 0 || (d != 32 && d != 64) || a->M % L != 0) return QST_ERR_BAD_ARG;
-        if ((int64_t)a->M * a->lda * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
-    }
-    if (a->c_head_L) {
-        const int L = a->c_head_L, d = a->c_head_d;
-        if (!c_ok || epi != QST_EPI_BF16) return QST_ERR_UNSUPPORTED;
-        if (L <= 0 || L % 32 != 0 || (d != 32 && d != 64) || a->M % L != 0 || a->N % d != 0) return QST_ERR_BAD_ARG;
-    }
-    return QST_OK;
-}
 
 template <int EPI, int WAVES_M, int WAVES_N = 2, int TI = 2>
 static int launch_nt(const QstGemmArgs* a, hipStream_t st) {
@@ -1306,7 +1095,6 @@ extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
     if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
     if (a->K % NBK != 0 || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->N % 4 != 0 || a->ldc % 4 != 0) return QST_ERR_UNSUPPORTED;
     if ((int64_t)256 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)384 * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
-    if (int rc = check_heads(a, a->lda == a->K, true, epi)) return rc;
     if (a->drop.thr16 && a->drop.state) {
         if (a->drop_where != 1 || (epi != QST_EPI_F32_RESID && epi != QST_EPI_F32_RESID_BF16)) return QST_ERR_BAD_ARG;
         if (a->drop.thr16 > 65535u || (int64_t)a->M * a->N >= ((int64_t)1 << 32)) return QST_ERR_UNSUPPORTED;
@@ -1322,7 +1110,7 @@ extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
     const bool tall_ok = epi == QST_EPI_BF16 || epi == QST_EPI_GELU || epi == QST_EPI_GELU_BWD;
     const int64_t tall_tiles = (int64_t)((a->M + 255) / 256) * ((a->N + 191) / 192);
     const bool tall_auto = (a->splits & 7) == 0 && a->K >= 768 && a->N >= 1536 && tall_tiles >= 1024;
-    if (tall_ok && !a->a_head_L && ((a->splits & 7) == 4 || tall_auto)) {       // (the tall K loop reads plain A only)
+    if (tall_ok && ((a->splits & 7) == 4 || tall_auto)) {
         switch (epi) {
             case QST_EPI_BF16: return launch_nt<QST_EPI_BF16, 2, 2, 4>(a, st);
             case QST_EPI_GELU: return launch_nt<QST_EPI_GELU, 2, 2, 4>(a, st);
@@ -1342,31 +1130,6 @@ extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
 }
 
 template <int EPI>
-static int launch_nt_w8(const QstGemmArgs* a, hipStream_t st) {
-    constexpr int lds = 2 * (128 * NBK * 2 + 192 * NBK);        // 56 KB ring; staging + bias + scales (54.3 KB) fit inside
-    static QstLdsAttr attr;
-    if (int rc = qst_ensure_lds(attr, (const void*)gemm_nt_w8_kernel<EPI>, lds)) return rc;
-    const int ntm = (a->M + 127) / 128, ntn = (a->N + 191) / 192;
-    gemm_nt_w8_kernel<EPI><<<dim3(ntm * ntn), dim3(256), lds, st>>>(*a);
-    QST_LAUNCH_CHECK();
-    return QST_OK;
-}
-
-extern "C" int qst_gemm_nt_w8(const QstGemmArgs* a, int epi, void* stream) {
-    if (!a || !a->A || !a->B || !a->C || !a->bscale || a->M <= 0 || a->N <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
-    if (a->K % NBK != 0 || a->lda % 8 != 0 || a->ldb % 16 != 0 || a->N % 4 != 0 || a->ldc % 4 != 0) return QST_ERR_UNSUPPORTED;
-    if ((int64_t)128 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)192 * a->ldb >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
-    if (int rc = check_heads(a, false, true, epi)) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    switch (epi) {
-        case QST_EPI_BF16: return launch_nt_w8<QST_EPI_BF16>(a, st);
-        case QST_EPI_F32_RESID: return launch_nt_w8<QST_EPI_F32_RESID>(a, st);
-        case QST_EPI_GELU: return launch_nt_w8<QST_EPI_GELU>(a, st);
-        default: return QST_ERR_BAD_ARG;
-    }
-}
-
-template <int EPI>
 static int launch_nt_f8(const QstGemmArgs* a, hipStream_t st) {
     constexpr int lds = 2 * (128 + 192) * 128;                  // 80 KB ring; the epilogue staging (52.7 KB) fits inside
     static QstLdsAttr attr;
@@ -1382,7 +1145,6 @@ extern "C" int qst_gemm_nt_f8(const QstGemmArgs* a, int epi, void* stream) {
     if (a->K % 128 != 0 || a->lda % 16 != 0 || a->ldb % 16 != 0 || a->N % 8 != 0) return QST_ERR_UNSUPPORTED;
     if (epi == QST_EPI_GELU_MX && a->ldc != a->N) return QST_ERR_UNSUPPORTED;          // stage-major scales: one matrix, no sub-views
     if ((int64_t)128 * a->lda >= 0x7FFFFF00LL || (int64_t)192 * a->ldb >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
-    if (int rc = check_heads(a, false, true, epi)) return rc;
     hipStream_t st = (hipStream_t)stream;
     switch (epi) {
         case QST_EPI_BF16: return a->ldc % 4 ? QST_ERR_UNSUPPORTED : launch_nt_f8<QST_EPI_BF16>(a, st);
@@ -1415,7 +1177,6 @@ extern "C" int qst_gemm_nt_ln(const QstGemmArgs* a, const QstLnEpi* ln, int mode
     if (a->N != LN_N || a->K % NBK != 0 || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->ldc % 2 != 0 || (a->resid && a->ldr % 2 != 0))
         return QST_ERR_UNSUPPORTED;
     if ((int64_t)128 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)LN_N * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
-    if (int rc = check_heads(a, a->lda == a->K, false, -1)) return rc;
     if (a->drop.thr16 && a->drop.state) {
         if (a->drop.thr16 > 65535u || (int64_t)a->M * a->N >= ((int64_t)1 << 32)) return QST_ERR_UNSUPPORTED;
         if (mode == 0 ? a->drop_where != 1 : (a->drop_where != 2 && a->drop_where != 3)) return QST_ERR_BAD_ARG;
@@ -1448,8 +1209,6 @@ extern "C" int qst_gemm_tn_group(const QstTnGroup* grp_in, void* stream) {
         const QstGemmArgs& a = g.prob[i];
         if (!a.A || !a.B || !a.C || a.M <= 0 || a.N <= 0 || a.K <= 0 || a.M != g.prob[0].M) return QST_ERR_BAD_ARG;
         if (a.lda % 8 != 0 || a.ldb % 8 != 0 || a.N % 8 != 0 || a.K % 8 != 0) return QST_ERR_UNSUPPORTED;
-        if (int rc = check_heads(&a, a.lda == a.N && a.N % (a.a_head_d ? a.a_head_d : 1) == 0, false, -1)) return rc;
-        if (a.a_head_L && a.a_head_L % TBK != 0) return QST_ERR_UNSUPPORTED;      // a stage of TBK rows must lie in one sequence
         if ((int64_t)a.M * a.lda * 2 >= 0x7FFFFF00LL || (int64_t)a.M * a.ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
         g.tiles[i] = ((a.N + TT - 1) / TT) * ((a.K + TT - 1) / TT);
         g.total_tiles += g.tiles[i];
@@ -1469,33 +1228,11 @@ extern "C" int qst_gemm_tn_group(const QstTnGroup* grp_in, void* stream) {
     const int64_t work = (int64_t)g.total_tiles * stages;
     if (wg_per_range > work) wg_per_range = work < 1 ? 1 : work;
     const int grid = (int)(8 * g.ranges_per_xcd * wg_per_range);
-    // slab flush (g.slabs: qst_gemm_tn_slab_bytes of scratch): only when every range has rows, a leftover tile is cut into
-    // at most TN_MAX_PIECES pieces and the outputs are 16-byte aligned; float atomics otherwise
-    const int W = (int)wg_per_range, T = g.total_tiles, b_left = T % W;
-    bool slab_ok = g.slabs != nullptr && (b_left == 0 || W / b_left <= TN_MAX_PIECES) && (int64_t)(g.splits - 1) * stages * TBK < M;
-    for (int i = 0; i < g.nprob && slab_ok; ++i)
-        slab_ok = g.prob[i].ldc % 4 == 0 && ((uintptr_t)g.prob[i].C & 15) == 0;
-    if (!slab_ok) g.slabs = nullptr;
-    static QstLdsAttr attr, attr_s;
-    if (int rc = qst_ensure_lds(attr, (const void*)gemm_tn_group_kernel<false>, TT_LDS)) return rc;
-    if (int rc = qst_ensure_lds(attr_s, (const void*)gemm_tn_group_kernel<true>, TT_LDS)) return rc;
-    if (g.slabs) gemm_tn_group_kernel<true><<<dim3(grid), dim3(512), TT_LDS, (hipStream_t)stream>>>(g);
-    else gemm_tn_group_kernel<false><<<dim3(grid), dim3(512), TT_LDS, (hipStream_t)stream>>>(g);
+    static QstLdsAttr attr;
+    if (int rc = qst_ensure_lds(attr, (const void*)gemm_tn_group_kernel, TT_LDS)) return rc;
+    gemm_tn_group_kernel<<<dim3(grid), dim3(512), TT_LDS, (hipStream_t)stream>>>(g);
     QST_LAUNCH_CHECK();
-    if (g.slabs) {
-        tn_reduce_kernel<<<dim3(T * (TT / 16)), dim3(256), 0, (hipStream_t)stream>>>(g, g.splits, W, (int)(stages * TBK));
-        QST_LAUNCH_CHECK();
-    }
     return QST_OK;
-}
-
-extern "C" size_t qst_gemm_tn_slab_bytes(const QstTnGroup* grp) {
-    if (!grp || grp->nprob <= 0 || grp->nprob > QST_TN_MAX_PROB) return 0;
-    size_t tiles = 0;
-    for (int i = 0; i < grp->nprob; ++i)
-        tiles += (size_t)((grp->prob[i].N + TT - 1) / TT) * ((grp->prob[i].K + TT - 1) / TT);
-    const int splits = grp->splits <= 0 ? 8 : (grp->splits + 7) / 8 * 8;
-    return (size_t)splits * TN_MAX_PIECES * tiles * TT * TT * sizeof(float);
 }
 
 extern "C" int qst_gemm_tn(const QstGemmArgs* a, void* stream) {

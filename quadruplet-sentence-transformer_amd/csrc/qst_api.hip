@@ -13,13 +13,6 @@ extern "C" int qst_adamw_launch(float*, float*, float*, float*, const uint8_t*, 
                                 float, float, float, int64_t, float*, float*, hipStream_t);
 
 static thread_local int g_last_hip_error = 0;
-// Where the one-kernel feed-forward block (csrc/ffn.hip) is used: bit 0 = inference forward (default: the [M, I] tensor
-// never leaves the chip, 121 vs 144 us per layer at M = 32768), bit 1 = training forward, bit 2 = backward. The training
-// variants are correct and tested but measured SLOWER than the two-kernel path (178 vs 144 us and 157 vs 125 us): their
-// side outputs (gelu'(u), h / du: 100-200 MB per call) are stored by the same waves that wait on the LDS-DMA stream, and
-// stores and DMAs retire through one in-order counter. qst_debug_fuse_ffn sets the mask (tests, experiments).
-static int g_fuse_ffn = 1;
-extern "C" void qst_debug_fuse_ffn(int mask) { g_fuse_ffn = mask; }
 extern "C" int qst_set_hip_error(int code) { g_last_hip_error = code; return code; }
 extern "C" int qst_last_hip_error(void) { return g_last_hip_error; }
 extern "C" int qst_version(void) { return 100; }
@@ -118,6 +111,18 @@ struct qst_encoder {
     // caller's device counter {seed lo, seed hi, step, 0} that every training forward advances
     uint32_t drop_hidden = 0, drop_attn = 0;
     uint32_t* drop_state = nullptr;
+    // What the last training forwards did with dropout, by activation arena: a backward regenerates the masks of the forward
+    // that FILLED `saved` -- with that forward's thresholds, whatever qst_encoder_set_dropout has been told since (fit() and
+    // bench.py switch dropout on live encoders; several forwards may be alive before their backwards run).
+    struct FwdRec { const void* saved = nullptr; uint32_t hidden = 0, attn = 0; };
+    FwdRec fwd_recs[16];
+    int fwd_next = 0;
+    // Where the one-kernel feed-forward block (csrc/ffn.hip) is used (qst_encoder_set_ffn_chain): bit 0 = inference forward
+    // (default: the [M, I] tensor never leaves the chip, 121 vs 144 us per layer at M = 32768), bit 1 = training forward,
+    // bit 2 = backward. The training variants are correct and tested but measured SLOWER than the two-kernel path (178 vs
+    // 144 us and 157 vs 125 us): their side outputs (gelu'(u), h / du: 100-200 MB per call) are stored by the same waves
+    // that wait on the LDS-DMA stream, and stores and DMAs retire through one in-order counter.
+    int ffn_chain = 1;
 };
 
 extern "C" int64_t qst_arena_elems(const qst_config* cfg) { return cfg_ok(cfg) ? build_layout(cfg).total : QST_ERR_BAD_ARG; }
@@ -166,8 +171,7 @@ extern "C" int qst_encoder_create(const qst_config* cfg, qst_encoder** out) {
     if (cfg->hidden_size % cfg->num_heads != 0 || (d != 32 && d != 64)) return QST_ERR_UNSUPPORTED;
     if (cfg->hidden_size % 64 != 0 || cfg->intermediate_size % 64 != 0 || cfg->hidden_size > 1024) return QST_ERR_UNSUPPORTED;
     if (cfg->type_vocab_size > 2) return QST_ERR_UNSUPPORTED;
-    if (cfg->precision != QST_PREC_BF16 && cfg->precision != QST_PREC_BF16X3 && cfg->precision != QST_PREC_FP8W &&
-        cfg->precision != QST_PREC_FP8)
+    if (cfg->precision != QST_PREC_BF16 && cfg->precision != QST_PREC_BF16X3 && cfg->precision != QST_PREC_FP8)
         return QST_ERR_UNSUPPORTED;
     if (cfg->precision == QST_PREC_FP8 && (cfg->hidden_size % 128 != 0 || cfg->intermediate_size % 128 != 0))
         return QST_ERR_UNSUPPORTED;                      // the fp8 K loop takes 128-deep stages
@@ -298,13 +302,7 @@ MxPlan plan_mx(const qst_config& c, int nseq, int L) {
     return p;
 }
 
-struct BwdPlan { size_t dxa, dxb, ds, dsb, dsb1, du, dctx, dqkv, drel, lnred, lnred_stride, delta, slabs, total; };
-// Flush of the grouped wgrad launch: float atomics (default) or plain stores into per-range slots + a reduce kernel
-// (QstTnGroup.slabs; reproducible sums). Measured on the c2 step, same process: 4.851 ms with slabs against 4.827 with
-// atomics -- the 75 MB of partial sums cost the same written and re-read as they do added at the memory side.
-// qst_debug_wgrad_slabs(1) selects the slab flush (set it before the workspace size is asked for).
-static int g_wgrad_slabs = 0;
-extern "C" void qst_debug_wgrad_slabs(int on) { g_wgrad_slabs = on; }
+struct BwdPlan { size_t dxa, dxb, ds, dsb, dsb1, du, dctx, dqkv, drel, lnred, lnred_stride, delta, total; };
 BwdPlan plan_bwd(const qst_config& c, int nseq, int L) {
     BwdPlan p;
     const size_t M = (size_t)nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads;
@@ -317,14 +315,6 @@ BwdPlan plan_bwd(const qst_config& c, int nseq, int L) {
     p.lnred_stride = (qst_ln_bwd_scratch_bytes((int)M, (int)H) + 255) / 256 * 256;
     p.lnred = take(p.lnred_stride * (size_t)(2 * c.num_layers + 1));
     p.delta = take((size_t)nseq * A * L * 4);
-    {
-        // partial-sum slots of one layer's grouped wgrad launch (qst_gemm_tn_slab_bytes)
-        QstTnGroup grp{};
-        grp.nprob = 4;
-        const int shp[4][2] = {{(int)H, (int)I}, {(int)I, (int)H}, {(int)H, (int)H}, {(int)(3 * H), (int)H}};
-        for (int i = 0; i < 4; ++i) { grp.prob[i].N = shp[i][0]; grp.prob[i].K = shp[i][1]; }
-        p.slabs = g_wgrad_slabs ? take(qst_gemm_tn_slab_bytes(&grp)) : 0;
-    }
     p.total = off;
     return p;
 }
@@ -345,36 +335,32 @@ int nt3(const float* A, int lda, const float* B, int ldb, float* C, int ldc, con
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
     return qst_gemm_nt_x3(&g, epi, st);
 }
-// Optional head-major q/k/v ([nseq][3A][L][d], QstGemmArgs / AttnArgs): the QKV projection writes that layout, attention
-// reads and writes whole L x d blocks, the QKV dgrad and wgrad read it back. Built to give d = 32 heads whole 128-byte
-// lines, measured (MiniLM c2 step, same-process A/B and rocprofv3 per kernel): attention forward 29.2 -> 28.2 us, fused
-// backward 61.9 -> 60.0 us, but the scattered QKV epilogue +3.6 us: step 4.765 vs 4.763 ms, forward-only 1.645 vs
-// 1.632 ms -- the attention kernels are latency-bound, not line-bound. So the default stays token-major [M, 3H];
-// qst_debug_head_major(1) selects the other layout (tests run both). The GEMM helpers below take the layout of their next
-// call from this one-shot description (set by heads_c / heads_a right before the call).
-struct HeadLayout { int aL, ad, cL, cd; };
-static thread_local HeadLayout t_heads = {0, 0, 0, 0};
-static int g_head_major = 0;
-// ... and the dropout mask of their next call the same way (drop_next; QstGemmArgs.drop / drop_where)
+// The GEMM helpers below take the dropout mask of their next call from a one-shot description (drop_next;
+// QstGemmArgs.drop / drop_where), set right before the call.
 struct DropNext { QstDrop d; int where; };
 static thread_local DropNext t_drop = {{nullptr, 0u, 0u}, 0};
 // `state` = the counter copy inside the activation arena of the forward at hand: several training forwards may be live
 // before their backwards run (fit() encodes the four columns one after the other), each with its own step value
-static QstDrop drop_of(const qst_encoder* e, const void* state, bool attn, uint32_t site) {
+// thresholds in force for one pass: the handle's current ones (forward) or the recorded ones of the forward a backward undoes
+struct DropThr { uint32_t hidden, attn; };
+static QstDrop drop_of(const DropThr& t, const void* state, bool attn, uint32_t site) {
     QstDrop d = {nullptr, site, 0u};
-    const uint32_t thr = attn ? e->drop_attn : e->drop_hidden;
-    if (e->drop_state && thr) { d.state = (const uint32_t*)state; d.thr16 = thr; }
+    const uint32_t thr = attn ? t.attn : t.hidden;
+    if (state && thr) { d.state = (const uint32_t*)state; d.thr16 = thr; }
     return d;
 }
-static void drop_next(const qst_encoder* e, const void* state, bool on, uint32_t site, int where) {
+static void drop_next(const DropThr& t, const void* state, bool on, uint32_t site, int where) {
     t_drop = DropNext{{nullptr, 0u, 0u}, 0};
-    if (on && e->drop_state && e->drop_hidden) t_drop = DropNext{drop_of(e, state, false, site), where};
+    if (on && t.hidden) t_drop = DropNext{drop_of(t, state, false, site), where};
 }
-static void take_heads(QstGemmArgs& g) {
-    g.a_head_L = t_heads.aL; g.a_head_d = t_heads.ad; g.c_head_L = t_heads.cL; g.c_head_d = t_heads.cd;
-    t_heads = HeadLayout{0, 0, 0, 0};
+static void take_drop(QstGemmArgs& g) {
     g.drop = t_drop.d; g.drop_where = t_drop.where;
     t_drop = DropNext{{nullptr, 0u, 0u}, 0};
+}
+extern "C" int qst_encoder_set_ffn_chain(qst_encoder* e, int mask) {
+    if (!e || mask < 0 || mask > 7) return QST_ERR_BAD_ARG;
+    e->ffn_chain = mask;
+    return QST_OK;
 }
 extern "C" int qst_encoder_set_dropout(qst_encoder* e, float p_hidden, float p_attn, uint32_t* state_dev) {
     if (!e || !(p_hidden >= 0.f && p_hidden < 1.f) || !(p_attn >= 0.f && p_attn < 1.f)) return QST_ERR_BAD_ARG;
@@ -385,25 +371,14 @@ extern "C" int qst_encoder_set_dropout(qst_encoder* e, float p_hidden, float p_a
     e->drop_state = (e->drop_hidden || e->drop_attn) ? state_dev : nullptr;
     return QST_OK;
 }
-static void heads_c(bool on, int L, int d) { if (on) { t_heads.cL = L; t_heads.cd = d; } }
-static void heads_a(bool on, int L, int d) { if (on) { t_heads.aL = L; t_heads.ad = d; } }
-extern "C" void qst_debug_head_major(int on) { g_head_major = on; }
 
 int nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* C2, const void* aux, const float* bias,
        const float* resid, int ldr, int M, int N, int K, int epi, hipStream_t st) {
     QstGemmArgs g{};
     g.A = A; g.B = B; g.C = C; g.C2 = C2; g.aux = aux; g.bias = bias; g.resid = resid;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
-    take_heads(g);
+    take_drop(g);
     return qst_gemm_nt(&g, epi, st);
-}
-int nt_w8(const void* A, int lda, const void* B8, const float* bscale, int ldb, void* C, int ldc, void* C2, const float* bias,
-          const float* resid, int ldr, int M, int N, int K, int epi, hipStream_t st) {
-    QstGemmArgs g{};
-    g.A = A; g.B = B8; g.C = C; g.C2 = C2; g.bias = bias; g.resid = resid; g.bscale = bscale;
-    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
-    take_heads(g);
-    return qst_gemm_nt_w8(&g, epi, st);
 }
 // GEMM with the following LayerNorm (mode 0) / LayerNorm backward (mode 1) fused into its epilogue (N = H = 384)
 int nt_ln(const void* A, int lda, const void* B, int ldb, float* C, void* C2, const float* bias, const float* resid,
@@ -412,7 +387,7 @@ int nt_ln(const void* A, int lda, const void* B, int ldb, float* C, void* C2, co
     QstGemmArgs g{};
     g.A = A; g.B = B; g.C = C; g.C2 = C2; g.bias = bias; g.resid = resid;
     g.M = M; g.N = H; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = H; g.ldr = H;
-    take_heads(g);
+    take_drop(g);
     QstLnEpi e{};
     e.gamma = gamma; e.beta = beta; e.eps = eps; e.xhat = xhat; e.rstd = rstd; e.partials = partials;
     return qst_gemm_nt_ln(&g, &e, mode, st);
@@ -459,18 +434,6 @@ extern "C" int qst_refresh_shadow(const qst_encoder* e, const float* params, voi
     return qst_shadow_all(params, shadow, e->shadow_tab, e->shadow_nseg, e->shadow_blocks, stream);
 }
 
-extern "C" int qst_refresh_shadow8(const qst_encoder* e, const float* params, void* shadow8, void* stream) {
-    if (!e || !params || !shadow8) return QST_ERR_BAD_ARG;
-    for (const Seg& s : e->lay.segs) {
-        if (!s.gemm) continue;
-        uint8_t* w8 = (uint8_t*)shadow8 + s.shadow_off;
-        float* sc = (float*)((uint8_t*)shadow8 + s.shadow_off + qst_align_up(s.numel, kAlign));
-        int rc = qst_quant_rows_fp8(params + s.off, s.rows, s.cols, w8, sc, stream);
-        if (rc != QST_OK) return rc;
-    }
-    return QST_OK;
-}
-
 // QST_PREC_FP8: every GEMM weight as MXFP8 -- e4m3 bytes at the segment's shadow offset, E8M0 block scales (one per 32
 // input features of an output row) behind them at shadow_off + align(numel); the buffer is qst_shadow8_bytes() long.
 extern "C" int qst_refresh_shadow_mx(const qst_encoder* e, const float* params, void* shadow_mx, void* stream) {
@@ -506,7 +469,7 @@ static int forward_mx(qst_encoder* e, const int64_t* ids, const int64_t* mask, c
         QstGemmArgs g{};
         g.A = Aq; g.aux = As; g.B = WQ(wseg); g.bscale = (const float*)WS(wseg); g.C = Cout; g.C2 = C2; g.bias = P(bseg); g.resid = resid;
         g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.ldr = N;
-        take_heads(g);
+        take_drop(g);
         return qst_gemm_nt_f8(&g, epi, st);
     };
     int32_t* pos_ids = (int32_t*)(sv + p.pos_ids);
@@ -521,16 +484,14 @@ static int forward_mx(qst_encoder* e, const int64_t* ids, const int64_t* mask, c
     }
     float* s = (float*)(sv + p.s);
     float* y1 = (float*)(sv + p.y1);
-    const bool hm = g_head_major != 0;
     for (int l = 0; l < c.num_layers; ++l) {
         const int b = lay.layer0[l];
         float* xn = (float*)(sv + p.x[(l + 1) & 1]);
-        heads_c(hm, L, d);
         QST_TRY(gemm(sv + p.xq, sv + p.xs, H, b + W_QKV, sv + p.qkv, nullptr, 3 * H, b + B_QKV, nullptr, QST_EPI_BF16));
         {
             QstAttnDesc q{};
             q.qkv = sv + p.qkv; q.mask = mask; q.rel_pos = rel; q.nseq = nseq; q.L = L; q.A = A; q.d = d;
-            q.ctx = sv + p.ctx; q.head_major = hm;
+            q.ctx = sv + p.ctx;
             QST_TRY(qst_attention_fwd_ex(&q, st));
         }
         QST_TRY(qst_quant_mx(sv + p.ctx, 1, M, H, sv + p.cq, sv + p.cs, st));
@@ -599,8 +560,6 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     if (c.precision == QST_PREC_FP8)
         return training ? QST_ERR_UNSUPPORTED
                         : forward_mx(e, ids, mask, type_ids, nseq, L, params, shadow, out_emb, out_tok, saved, saved_bytes, (hipStream_t)stream);
-    const bool w8 = c.precision == QST_PREC_FP8W;       // fp8 weights (shadow = qst_refresh_shadow8's buffer): inference only
-    if (w8 && training) return QST_ERR_UNSUPPORTED;
     const ActPlan p = plan_acts(c, nseq, L, training != 0);
     if (saved_bytes < p.total) return QST_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -610,13 +569,7 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     const Layout& lay = e->lay;
     auto P = [&](int seg) { return params + lay.segs[seg].off; };
     auto W = [&](int seg) { return sh + lay.segs[seg].shadow_off; };
-    auto W8 = [&](int seg) { return (const uint8_t*)shadow + lay.segs[seg].shadow_off; };
-    auto S8 = [&](int seg) {
-        return (const float*)((const uint8_t*)shadow + lay.segs[seg].shadow_off + qst_align_up(lay.segs[seg].numel, kAlign));
-    };
-    // one Linear: bf16 shadow weights, or fp8 weights + row scales (same epilogues)
     auto linear = [&](const void* Ain, int K, int wseg, void* Cout, int N, void* C2, int bseg, const float* resid, int epi) {
-        if (w8) return nt_w8(Ain, K, W8(wseg), S8(wseg), K, Cout, N, C2, P(bseg), resid, N, M, N, K, epi, st);
         return nt(Ain, K, W(wseg), K, Cout, N, C2, nullptr, P(bseg), resid, N, M, N, K, epi, st);
     };
 
@@ -625,12 +578,19 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     // dropout: training forwards of a handle that has it on; the step counter moves first, backward reuses its value
     const bool dropping = training && e->drop_state != nullptr;
     const void* dst8 = sv + p.dropst;
+    const DropThr thr = dropping ? DropThr{e->drop_hidden, e->drop_attn} : DropThr{0u, 0u};
     if (dropping) {
         QST_TRY(qst_dropout_advance(e->drop_state, st));
         QST_HIP_CHECK(hipMemcpyAsync(sv + p.dropst, e->drop_state, 16, hipMemcpyDeviceToDevice, st));
     }
+    if (training) {                                   // remember what this forward did, for the backward over the same arena
+        qst_encoder::FwdRec* rec = nullptr;
+        for (auto& r : e->fwd_recs) if (r.saved == saved) rec = &r;
+        if (!rec) { rec = &e->fwd_recs[e->fwd_next]; e->fwd_next = (e->fwd_next + 1) % 16; }
+        *rec = qst_encoder::FwdRec{saved, thr.hidden, thr.attn};
+    }
     {
-        const QstDrop de = drop_of(e, dst8, false, QST_DROP_SITE_EMBED);
+        const QstDrop de = drop_of(thr, dst8, false, QST_DROP_SITE_EMBED);
         QST_TRY(qst_embed_ln_fwd_drop(ids, type_ids, pos_ids, P(lay.word), P(lay.pos), lay.type >= 0 ? P(lay.type) : nullptr,
                                       P(lay.eg), P(lay.eb), c.layer_norm_eps, M, H, (float*)(sv + p.x0), sv + p.x0b,
                                       sv + p.xh0, (float*)(sv + p.rs0), dropping ? &de : nullptr, st));
@@ -646,25 +606,22 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     // H = 384: the LayerNorm after each projection runs inside that GEMM's epilogue (full-row tiles) -- from M = 16384
     // token rows on: one 128-row tile per workgroup gives a small batch too few workgroups (measured: the unfused pair
     // is 5-25% faster up to M = 8192, equal at 16384, 25% slower at 32768)
-    const bool fuse_ln = !w8 && qst_gemm_nt_ln_supported(H) != 0 && M >= kFuseLnMinRows;
-    t_heads = HeadLayout{0, 0, 0, 0};
+    const bool fuse_ln = qst_gemm_nt_ln_supported(H) != 0 && M >= kFuseLnMinRows;
     // ... and the whole feed-forward block (FFN-1, GELU, FFN-2, LayerNorm) is ONE kernel: h never returns from HBM, and
     // an inference forward does not write it at all
-    const bool fuse_ffn = fuse_ln && !dropping && (g_fuse_ffn & (training ? 2 : 1)) && qst_ffn_chain_supported(H, I) != 0;
-    const bool hm = g_head_major != 0;
+    const bool fuse_ffn = fuse_ln && !dropping && (e->ffn_chain & (training ? 2 : 1)) && qst_ffn_chain_supported(H, I) != 0;
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerAct& a = p.layers[l];
         const int b = lay.layer0[l];
-        heads_c(hm, L, d);
         QST_TRY(linear(xb, H, b + W_QKV, sv + a.qkv, 3 * H, nullptr, b + B_QKV, nullptr, QST_EPI_BF16));
         {
             QstAttnDesc q{};
             q.qkv = sv + a.qkv; q.mask = mask; q.rel_pos = rel; q.nseq = nseq; q.L = L; q.A = A; q.d = d;
-            q.ctx = sv + a.ctx; q.lse = (float*)(sv + a.lse); q.head_major = hm;
-            if (dropping) q.drop = drop_of(e, dst8, true, QST_DROP_SITE_PROBS(l));
+            q.ctx = sv + a.ctx; q.lse = (float*)(sv + a.lse);
+            if (dropping) q.drop = drop_of(thr, dst8, true, QST_DROP_SITE_PROBS(l));
             QST_TRY(qst_attention_fwd_ex(&q, st));
         }
-        drop_next(e, dst8, dropping, QST_DROP_SITE_ATTN_OUT(l), 1);
+        drop_next(thr, dst8, dropping, QST_DROP_SITE_ATTN_OUT(l), 1);
         if (fuse_ln) {
             QST_TRY(nt_ln(sv + a.ctx, H, W(b + W_O), H, (float*)(sv + a.y1), sv + a.y1b, P(b + B_O), x, M, H, H, 0,
                           P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, sv + a.xh1, (float*)(sv + a.rs1), nullptr, st));
@@ -683,7 +640,7 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
             continue;
         }
         QST_TRY(linear(sv + a.y1b, H, b + W_1, sv + a.u, I, sv + a.hact, b + B_1, nullptr, QST_EPI_GELU));
-        drop_next(e, dst8, dropping, QST_DROP_SITE_FFN_OUT(l), 1);
+        drop_next(thr, dst8, dropping, QST_DROP_SITE_FFN_OUT(l), 1);
         if (fuse_ln) {
             QST_TRY(nt_ln(sv + a.hact, I, W(b + W_2), I, (float*)(sv + a.x), sv + a.xb, P(b + B_2),
                           (const float*)(sv + a.y1), M, H, I, 0, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, sv + a.xh2,
@@ -718,6 +675,9 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
     const int do_head = (flags & QST_BWD_HEAD) != 0, do_embed = (flags & QST_BWD_EMBED) != 0;
     const bool skip_wgrad = (flags & QST_BWD_SKIP_WGRAD) != 0, wgrad_only = (flags & QST_BWD_WGRAD_ONLY) != 0;
     if (wgrad_only && (skip_wgrad || do_head || do_embed)) return QST_ERR_BAD_ARG;
+    // postponing a layer's weight gradients is sound for layer 0 only: the stage of layer l - 1 overwrites the gradients
+    // (ds / dsb / du / dqkv in the workspace) that layer l's launch reads
+    if ((skip_wgrad || wgrad_only) && (layer_lo != 0 || layer_hi != 1)) return QST_ERR_BAD_ARG;
     if (!e || !ids || !mask || !params || !shadow || !grads || !saved || !workspace) return QST_ERR_BAD_ARG;
     if (e->cfg.precision != QST_PREC_BF16) return QST_ERR_UNSUPPORTED;      // training runs the bf16 path
     if (do_head && !grad_emb) return QST_ERR_BAD_ARG;
@@ -753,16 +713,17 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
     // H = 384: every LayerNorm backward except the top one (whose input comes from the pooling head, not from a GEMM)
     // runs inside the epilogue of the dgrad GEMM that produces its input; those write one partial row per 128-row tile
     const bool fuse_ln = qst_gemm_nt_ln_supported(H) != 0 && M >= kFuseLnMinRows;
-    const bool hm = g_head_major != 0;
-    t_heads = HeadLayout{0, 0, 0, 0};
-    // dropout on: the masks of the forward that filled `saved` are recomputed from the same (seed, step) -- see QstDrop
-    const bool dropping = e->drop_state != nullptr;
+    // dropout: the masks of the forward that filled `saved` are recomputed from its (seed, step) snapshot in the arena and
+    // ITS thresholds (recorded by that forward); an arena this handle has no record of falls back on the current settings
+    DropThr thr = {e->drop_state ? e->drop_hidden : 0u, e->drop_state ? e->drop_attn : 0u};
+    for (const auto& r : e->fwd_recs) if (r.saved == saved) thr = DropThr{r.hidden, r.attn};
+    const bool dropping = thr.hidden != 0 || thr.attn != 0;
     const void* dst8 = sv + p.dropst;
-    const bool fuse_ffn = fuse_ln && !dropping && (g_fuse_ffn & 4) && qst_ffn_chain_supported(H, I) != 0;
+    const bool fuse_ffn = fuse_ln && !dropping && (e->ffn_chain & 4) && qst_ffn_chain_supported(H, I) != 0;
     const int fused_rows = (M + 127) / 128;
     auto hdrop = [&](uint32_t site, QstDrop& d) -> const QstDrop* {          // hidden-state mask of `site`, or none
-        if (!dropping || !e->drop_hidden) return nullptr;
-        d = drop_of(e, dst8, false, site);
+        if (!dropping || !thr.hidden) return nullptr;
+        d = drop_of(thr, dst8, false, site);
         return &d;
     };
     auto ln_slot = [&](int slot, float* dg, float* db, int nrows = 0) {
@@ -798,8 +759,6 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
         set(1, du, I, sv + a.y1b, H, b + W_1, b + B_1);            // dW1 [I, H]
         set(2, dsb1, H, sv + a.ctx, H, b + W_O, b + B_O);          // dWo [H, H]
         set(3, dqkv, 3 * H, xin_b, H, b + W_QKV, b + B_QKV);       // dWqkv [3H, H]
-        if (hm) { grp.prob[3].a_head_L = L; grp.prob[3].a_head_d = d; }
-        if (g_wgrad_slabs) grp.slabs = (float*)(ws + w.slabs);
         return qst_gemm_tn_group(&grp, st);
     };
     if (wgrad_only) {
@@ -831,7 +790,7 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
                               ln_slot(2 * l, G(b + LN1_G), G(b + LN1_B), fused_rows), st));
             ds1 = dxb;
         } else if (fuse_ln) {
-            drop_next(e, dst8, dropping, QST_DROP_SITE_ATTN_OUT(l), 2);
+            drop_next(thr, dst8, dropping, QST_DROP_SITE_ATTN_OUT(l), 2);
             QST_TRY(nt_ln(du, I, WT(b + W_1), I, dxb, dsb1, nullptr, ds, M, H, I, 1, P(b + LN1_G), nullptr, 0.f, sv + a.xh1,
                           (float*)(sv + a.rs1), ln_slot(2 * l, G(b + LN1_G), G(b + LN1_B), fused_rows), st));
             ds1 = dxb;
@@ -847,16 +806,15 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
             QstAttnDesc q{};
             q.qkv = sv + a.qkv; q.mask = mask; q.rel_pos = rel; q.nseq = nseq; q.L = L; q.A = A; q.d = d;
             q.ctx = sv + a.ctx; q.lse = (float*)(sv + a.lse); q.dctx = dctx; q.dqkv = dqkv; q.drel = drel;
-            q.delta_scratch = (float*)(ws + w.delta); q.head_major = hm;
-            if (dropping) q.drop = drop_of(e, dst8, true, QST_DROP_SITE_PROBS(l));
+            q.delta_scratch = (float*)(ws + w.delta);
+            if (dropping) q.drop = drop_of(thr, dst8, true, QST_DROP_SITE_PROBS(l));
             QST_TRY(qst_attention_bwd_ex(&q, st));
         }
         if (!skip_wgrad) QST_TRY(wgrad(l));
         // QKV projection dgrad + residual: dx_in = dqkv . Wqkv + ds1. Fused mode: followed in the same kernel by the
         // backward of the LayerNorm that produced this layer's input (LN2 of layer l-1, or the embedding LayerNorm)
-        heads_a(hm, L, d);
-        if (fuse_ln && l > 0) drop_next(e, dst8, dropping, QST_DROP_SITE_FFN_OUT(l - 1), 2);   // dsb = d(FFN-2 output of layer l-1)
-        else if (fuse_ln) drop_next(e, dst8, dropping, QST_DROP_SITE_EMBED, 3);                // embedding dropout follows its LN
+        if (fuse_ln && l > 0) drop_next(thr, dst8, dropping, QST_DROP_SITE_FFN_OUT(l - 1), 2);   // dsb = d(FFN-2 output of layer l-1)
+        else if (fuse_ln) drop_next(thr, dst8, dropping, QST_DROP_SITE_EMBED, 3);                // embedding dropout follows its LN
         if (fuse_ln && l > 0) {
             const LayerAct& lo = p.layers[l - 1];
             const int bl = lay.layer0[l - 1];

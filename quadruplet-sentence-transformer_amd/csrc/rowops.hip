@@ -475,32 +475,6 @@ __global__ void rel_pos_bwd_kernel(const float* drelpos, const int32_t* lut, int
     if (threadIdx.x == 0) dtable[b * A + a] += red[0] + red[1] + red[2] + red[3];
 }
 
-// fp8 (e4m3, OCP) weight shadow for the QST_PREC_FP8W inference path: one wave per row, scale = amax / 448 (the largest
-// e4m3 magnitude), round-to-nearest-even by v_cvt_pk_fp8_f32.
-__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const float* src, int rows, int cols, uint8_t* dst, float* scales) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const f32x4* s4 = (const f32x4*)(src + (size_t)row * cols);
-    const int n4 = cols >> 2;
-    float amax = 0.f;
-    for (int c = lane; c < n4; c += 64) {
-        const f32x4 v = s4[c];
-        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-    }
-    amax = wave_max(amax);
-    const float scale = amax > 0.f ? amax / 448.0f : 1.0f;
-    if (lane == 0) scales[row] = scale;
-    uint32_t* d4 = (uint32_t*)(dst + (size_t)row * cols);
-    for (int c = lane; c < n4; c += 64) {
-        const f32x4 v = s4[c];
-        uint32_t p = 0;
-        p = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] / scale, v[1] / scale, p, false);
-        p = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] / scale, v[3] / scale, p, true);
-        d4[c] = p;
-    }
-}
-
 // bf16 shadow of a [rows, cols] fp32 matrix and its transpose, via a 32x32 LDS tile
 __global__ __launch_bounds__(256) void shadow_kernel(const float* src, int rows, int cols, bf16* dst, bf16* dstT) {
     __shared__ float tile[32][33];
@@ -773,14 +747,6 @@ extern "C" int qst_rel_pos_bwd(const float* drel_pos, const int32_t* lut, int bu
                                void* stream) {
     if (!drel_pos || !lut || !dtable || A <= 0 || L <= 0 || L > 512 || buckets <= 0) return QST_ERR_BAD_ARG;
     rel_pos_bwd_kernel<<<buckets * A, 256, 0, (hipStream_t)stream>>>(drel_pos, lut, buckets, A, L, dtable);
-    QST_LAUNCH_CHECK();
-    return QST_OK;
-}
-
-extern "C" int qst_quant_rows_fp8(const float* src, int rows, int cols, void* dst_fp8, float* scales, void* stream) {
-    if (!src || !dst_fp8 || !scales || rows <= 0 || cols <= 0) return QST_ERR_BAD_ARG;
-    if (cols % 4 != 0) return QST_ERR_UNSUPPORTED;
-    quant_rows_fp8_kernel<<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(src, rows, cols, (uint8_t*)dst_fp8, scales);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }

@@ -285,7 +285,6 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(AttnX3Args a) {
 }  // namespace
 
 extern "C" int qst_gemm_nt_x3(const QstGemmArgs* a, int epi, void* stream) {
-    if (a && (a->a_head_L || a->c_head_L)) return QST_ERR_UNSUPPORTED;     // plain row-major operands only
     if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
     if (a->K % XBK != 0 || a->lda % 4 != 0 || a->ldb % 4 != 0 || a->N % 4 != 0 || a->ldc % 4 != 0) return QST_ERR_UNSUPPORTED;
     const int grid = ((a->M + 127) / 128) * ((a->N + 127) / 128);

@@ -40,9 +40,7 @@ class HipEncoder:
         self.dropout_step = 0
         self.drop_state = None
         self.handle_x3 = None         # QST_PREC_BF16X3 handle over the SAME arenas, created on first use
-        self.handle_fp8 = None        # QST_PREC_FP8W handle (fp8 e4m3 weights + row scales, inference), on first use
         self.handle_mx = None         # QST_PREC_FP8 handle (MXFP8 weights and activations on the fp8 matrix cores, inference)
-        self.shadow8: Optional[torch.Tensor] = None
         self.shadow_mx: Optional[torch.Tensor] = None
         self.shadow_mx_stale = True
         self.params = torch.zeros(self.total, dtype=torch.float32, device=self.device)
@@ -51,7 +49,6 @@ class HipEncoder:
         self.exp_avg_sq: Optional[torch.Tensor] = None
         self.shadow = torch.zeros(self.lib.qst_shadow_elems(self.ccfg), dtype=torch.bfloat16, device=self.device)
         self.shadow_stale = True
-        self.shadow8_stale = True
         self._saved: Optional[torch.Tensor] = None
         self._ws: Optional[torch.Tensor] = None
         self._scratch = torch.zeros(2048, dtype=torch.float32, device=self.device)
@@ -61,7 +58,7 @@ class HipEncoder:
 
     def __del__(self):
         try:
-            for attr in ("handle", "handle_x3", "handle_fp8", "handle_mx"):
+            for attr in ("handle", "handle_x3", "handle_mx"):
                 if getattr(self, attr, None):
                     self.lib.qst_encoder_destroy(getattr(self, attr))
                     setattr(self, attr, None)
@@ -75,7 +72,6 @@ class HipEncoder:
             raise ValueError(f"arena has {t.numel()} elements, expected {self.total}")
         self.params.copy_(t.to(self.device))
         self.shadow_stale = True
-        self.shadow8_stale = True
         self.shadow_mx_stale = True
 
     def named_views(self) -> Dict[str, torch.Tensor]:
@@ -124,17 +120,16 @@ class HipEncoder:
         self.dropout = (float(p_hidden), float(p_attn), int(seed)) if on else None
         self.dropout_step = 0
 
+    def set_ffn_chain(self, mask: int) -> None:
+        """Where the feed-forward block runs as one kernel (include/qst.h qst_encoder_set_ffn_chain): bit 0 inference
+        forward (default), bit 1 training forward, bit 2 backward."""
+        _lib.check(self.lib.qst_encoder_set_ffn_chain(self.handle, int(mask)), "qst_encoder_set_ffn_chain")
+
     def set_dropout_step(self, step: int) -> None:
         """Continue the mask stream at `step` training forwards (checkpoint resume)."""
         if self.dropout is not None:
             self.drop_state[2] = int(step)
             self.dropout_step = int(step)
-
-    def refresh_shadow8(self) -> None:
-        """Quantise every Linear weight to fp8 e4m3 with one fp32 scale per output row (QST_PREC_FP8W)."""
-        _lib.check(self.lib.qst_refresh_shadow8(self.handle_fp8, self.params.data_ptr(), self.shadow8.data_ptr(),
-                                                _lib.current_stream_ptr()), "qst_refresh_shadow8")
-        self.shadow8_stale = False
 
     def refresh_shadow_mx(self) -> None:
         """Quantise every Linear weight to MXFP8 (e4m3 + one E8M0 scale per 32 input features; QST_PREC_FP8)."""
@@ -172,14 +167,6 @@ class HipEncoder:
     def _handle_for(self, precision: str):
         if precision in ("bf16", 0, None):
             return self.handle
-        if precision in ("fp8w", 2):
-            if self.handle_fp8 is None:
-                h = _lib.vp()
-                _lib.check(self.lib.qst_encoder_create(_lib.make_config(self.cfg, 2), h), "qst_encoder_create(fp8w)")
-                self.handle_fp8 = h
-                self.shadow8 = torch.zeros(self.lib.qst_shadow8_bytes(self.ccfg), dtype=torch.uint8, device=self.device)
-                self.shadow8_stale = True
-            return self.handle_fp8
         if precision in ("fp8", 3):
             if self.handle_mx is None:
                 h = _lib.vp()
@@ -189,7 +176,7 @@ class HipEncoder:
                 self.shadow_mx_stale = True
             return self.handle_mx
         if precision not in ("bf16x3", 1):
-            raise ValueError(f"unknown precision {precision!r} (bf16 | bf16x3 | fp8w | fp8)")
+            raise ValueError(f"unknown precision {precision!r} (bf16 | bf16x3 | fp8)")
         if self.handle_x3 is None:
             h = _lib.vp()
             _lib.check(self.lib.qst_encoder_create(_lib.make_config(self.cfg, 1), h), "qst_encoder_create(x3)")
@@ -200,8 +187,8 @@ class HipEncoder:
                 training: bool = False, want_tokens: bool = False, saved: Optional[torch.Tensor] = None,
                 precision: str = "bf16"):
         """ids/mask int64 [n, L] on this device, L % 32 == 0. Returns (emb [n,H], tok [n,L,H] or None, saved).
-        precision="bf16x3" runs the fp32-class parity path, "fp8w" the fp8-weight path, "fp8" the fp8 matrix-core path
-        (MXFP8 weights and activations) -- all three forward only."""
+        precision="bf16x3" runs the fp32-class parity path, "fp8" the fp8 matrix-core path (MXFP8 weights and
+        activations) -- both forward only."""
         assert ids.dtype == torch.int64 and mask.dtype == torch.int64 and ids.is_cuda and ids.is_contiguous()
         n, L = ids.shape
         handle = self._handle_for(precision)
@@ -210,10 +197,6 @@ class HipEncoder:
         if handle is not self.handle and training:
             raise _lib.QstError(f"precision={precision!r} is forward-only; training runs the bf16 path")
         shadow = self.shadow
-        if handle is self.handle_fp8 and handle is not None:
-            if self.shadow8_stale:
-                self.refresh_shadow8()
-            shadow = self.shadow8
         if handle is self.handle_mx and handle is not None:
             if self.shadow_mx_stale:
                 self.refresh_shadow_mx()
@@ -255,7 +238,6 @@ class HipEncoder:
             self.opt_step, self.grad_norm.data_ptr(), self._scratch.data_ptr(), _lib.current_stream_ptr()),
             "qst_clip_adamw_step")
         self.shadow_stale = True
-        self.shadow8_stale = True
         self.shadow_mx_stale = True
 
 
@@ -292,7 +274,6 @@ class HipEncoder:
             int(warmup_steps), int(total_steps), self._step_dev.data_ptr(), self.grad_norm.data_ptr(),
             self._scratch.data_ptr(), _lib.current_stream_ptr()), "qst_clip_adamw_step_sched")
         self.shadow_stale = True
-        self.shadow8_stale = True
         self.shadow_mx_stale = True
 
 

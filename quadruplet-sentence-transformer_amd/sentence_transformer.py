@@ -18,6 +18,7 @@ import logging
 import math
 import os
 import shutil
+import tempfile
 import zlib
 from collections import OrderedDict
 from typing import Callable, Dict, Iterable, List, Optional, Tuple, Type, Union
@@ -30,7 +31,7 @@ from . import _lib
 from .config import ARCH_BERT, ARCH_MPNET, PRESETS, EncoderConfig, hf_param_views
 from .encoder import HipEncoder
 from .synthetic import synthetic_params
-from .trainer import gradient_buckets, staged_backward, warmup_linear_lr
+from .trainer import allreduce_ranges, gradient_buckets, staged_backward, staged_reduce_order, warmup_linear_lr
 
 logger = logging.getLogger(__name__)
 
@@ -451,6 +452,14 @@ class SentenceTransformer(nn.Module):
                                             "overlap": bool(overlap_grad_reduce)}
         self._dp_works, self._dp_reduced, self._live_graphs = [], False, 0
         is_main = rank == 0
+        # The evaluator runs on every rank (score-driven control flow must stay in step) and the reference's evaluators write
+        # under output_path unconditionally (models/evaluators.py:81 joins it with a file name): ranks other than 0 get a
+        # scratch directory of their own, removed when fit() returns -- never None.
+        scratch_dir = None
+        eval_out = output_path
+        if not is_main and evaluator is not None and output_path is not None:
+            scratch_dir = tempfile.mkdtemp(prefix=f"qst_eval_rank{rank}_")
+            eval_out = scratch_dir
         enc.set_dropout(p_hidden, p_attn, int(dropout_seed) + rank)
         global_step = 0
         if resume_from_checkpoint is not None:
@@ -489,8 +498,13 @@ class SentenceTransformer(nn.Module):
                         loss_value = lm(features, labels)
                         (loss_value if weight == 1.0 else loss_value * weight).backward()
                     if world > 1:
-                        if not self._dp_reduced:          # empty shard, or a loss model that bypassed _EncodeFn
-                            dist.all_reduce(enc.grads, op=dist.ReduceOp.SUM, group=process_group)
+                        if not self._dp_reduced:
+                            # empty shard (the last batch had fewer rows than ranks), or a loss model that bypassed
+                            # _EncodeFn: take part in the SAME sequence of all-reduces the other ranks issue from inside
+                            # staged_backward -- per-layer slices in its order, or one arena-wide reduce without overlap
+                            self._dp_works += allreduce_ranges(
+                                enc.grads, staged_reduce_order(self._dp["buckets"], enc.total, self._dp["overlap"]),
+                                process_group, async_op=self._dp["overlap"])
                         for w in self._dp_works:
                             w.wait()
                         self._dp_works, self._dp_reduced, self._live_graphs = [], False, 0
@@ -499,15 +513,15 @@ class SentenceTransformer(nn.Module):
                 training_steps += 1
                 global_step += 1
                 if evaluation_steps > 0 and training_steps % evaluation_steps == 0:
-                    self._eval_during_training(evaluator, output_path if is_main else None, save_best_model and is_main,
-                                               epoch, training_steps, callback)
+                    self._eval_during_training(evaluator, eval_out, save_best_model and is_main, epoch, training_steps, callback)
                     for lm in loss_models:
                         lm.train()
                 if checkpoint_path is not None and checkpoint_save_steps is not None and checkpoint_save_steps > 0 \
                         and global_step % checkpoint_save_steps == 0 and is_main:
                     self._save_checkpoint(checkpoint_path, checkpoint_save_total_limit, global_step)
-            self._eval_during_training(evaluator, output_path if is_main else None, save_best_model and is_main, epoch, -1,
-                                       callback)
+            self._eval_during_training(evaluator, eval_out, save_best_model and is_main, epoch, -1, callback)
+        if scratch_dir is not None:
+            shutil.rmtree(scratch_dir, ignore_errors=True)
         self._dp = None
         enc.set_dropout(0.0, 0.0)
         if evaluator is None and output_path is not None and is_main:

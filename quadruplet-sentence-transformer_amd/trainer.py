@@ -53,6 +53,16 @@ def allreduce_ranges(flat: torch.Tensor, ranges: Sequence[Tuple[int, int]], grou
 BWD_HEAD, BWD_EMBED, BWD_SKIP_WGRAD, BWD_WGRAD_ONLY = 1, 2, 4, 8      # include/qst.h: QST_BWD_*
 
 
+def staged_reduce_order(buckets: Sequence[Tuple[int, int]], total: int, overlap: bool) -> List[Tuple[int, int]]:
+    """The arena ranges staged_backward all-reduces, in the order it issues them. A rank that has nothing to back-propagate
+    in a step (its shard of the last batch is empty) must still take part in exactly this sequence of collectives: a
+    different number or size of all-reduces than its peers' hangs RCCL (gloo raises a size error)."""
+    if not overlap:
+        return [(0, total)]
+    N = len(buckets) - 1
+    return [buckets[k] for k in range(N - 1)] + [buckets[N], buckets[N - 1]]
+
+
 def staged_backward(enc: HipEncoder, ids, mask, types, grad_emb, saved, ws=None, buckets=None, group=None,
                     overlap: bool = True):
     """One backward pass of the encoder with the data-parallel gradient exchange inside it.
@@ -82,18 +92,19 @@ def staged_backward(enc: HipEncoder, ids, mask, types, grad_emb, saved, ws=None,
     if buckets is None:
         stage(BWD_HEAD | BWD_EMBED, N, 0)
         return []
+    order = staged_reduce_order(buckets, enc.total, overlap)          # (the one place that fixes the collective sequence)
     if not overlap:
         stage(BWD_HEAD | BWD_EMBED, N, 0)
-        allreduce_ranges(enc.grads, [(0, enc.total)], group)
+        allreduce_ranges(enc.grads, order, group)
         return []
     works = []
     for k, l in enumerate(range(N - 1, 0, -1)):                        # layers N-1 ... 1
         stage(BWD_HEAD if k == 0 else 0, l + 1, l)
-        works += allreduce_ranges(enc.grads, [buckets[k]], group, async_op=True)
+        works += allreduce_ranges(enc.grads, [order[k]], group, async_op=True)
     stage((BWD_HEAD if N == 1 else 0) | BWD_SKIP_WGRAD | BWD_EMBED, 1, 0)      # layer 0 dgrads + embeddings
-    works += allreduce_ranges(enc.grads, [buckets[N]], group, async_op=True)  # embedding bucket: the big one
+    works += allreduce_ranges(enc.grads, [order[N - 1]], group, async_op=True)   # embedding bucket: the big one
     stage(BWD_WGRAD_ONLY, 1, 0)                                               # layer 0 weight gradients, under it
-    works += allreduce_ranges(enc.grads, [buckets[N - 1]], group, async_op=True)
+    works += allreduce_ranges(enc.grads, [order[N]], group, async_op=True)
     return works
 
 
@@ -111,7 +122,7 @@ class QuadrupletTrainer:
                  lr: float = 2e-5, weight_decay: float = 0.01, max_grad_norm: float = 1.0,
                  betas=(0.9, 0.999), eps: float = 1e-8, warmup_steps: int = 0, total_steps: int = 0,
                  process_group=None, world_size: int = 1, overlap: bool = True, encoder: Optional[HipEncoder] = None,
-                 use_graph: bool = False, dropout=None, dropout_seed: int = 0):
+                 use_graph: bool = False, dropout=None, dropout_seed: int = 0, force_dp: bool = False):
         """dropout: None / 0 = off; a float p = HF's hidden_dropout_prob = attention_probs_dropout_prob = p; a pair
         (p_hidden, p_attn). The reference's fit() trains with 0.1 (HF config defaults, train() mode). Ranks of a
         data-parallel job should pass different dropout_seed values (fit() adds the rank)."""
@@ -128,6 +139,9 @@ class QuadrupletTrainer:
         self.warmup_steps, self.total_steps = warmup_steps, total_steps
         self.sched_step = 0
         self.group, self.world = process_group, world_size
+        # force_dp: run the data-parallel step (staged backward + one asynchronous all-reduce per bucket) even with one rank --
+        # the RCCL code path on a box with a single GPU (bench.py "dp_rccl_ws1", tests)
+        self.force_dp = bool(force_dp)
         self.overlap = overlap
         self.buckets = gradient_buckets(cfg)
         # use_graph: single-GPU steps are captured once per (B, L) into a HIP graph (torch.cuda.CUDAGraph over the
@@ -201,8 +215,8 @@ class QuadrupletTrainer:
         enc = self.enc
         loss, _, g, saved, (ids, mask, types) = self.forward_loss(ids4, mask4, types4, training=True, want_grads=True,
                                                                  saved=saved)
-        for w in staged_backward(enc, ids, mask, types, stacked(g), saved, ws, self.buckets if self.world > 1 else None,
-                                 self.group, self.overlap):
+        for w in staged_backward(enc, ids, mask, types, stacked(g), saved, ws,
+                                 self.buckets if (self.world > 1 or self.force_dp) else None, self.group, self.overlap):
             w.wait()
         if sched_on_device:
             opt0 = enc.opt_step

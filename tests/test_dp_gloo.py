@@ -38,8 +38,14 @@ def _worker(rank, world, port, ret):
     N = cfg.num_layers
     order = list(range(N - 1)) + [N, N - 1]              # staged_backward: layers N-1..1, embeddings, layer 0
     assert sorted(order) == list(range(N + 1))
-    for k in order:
-        works += allreduce_ranges(grads, [bk[k]], None, async_op=True)
+    from quadruplet_sentence_transformer_amd.trainer import staged_reduce_order
+    assert staged_reduce_order(bk, total, True) == [bk[k] for k in order] and staged_reduce_order(bk, total, False) == [(0, total)]
+    if rank == world - 1:
+        # a rank with an empty shard (fit(): fewer rows in the last batch than ranks) issues the whole sequence at once
+        works += allreduce_ranges(grads, staged_reduce_order(bk, total, True), None, async_op=True)
+    else:
+        for k in order:
+            works += allreduce_ranges(grads, [bk[k]], None, async_op=True)
     for w in works:
         w.wait()
     grads *= 1.0 / world                                  # qst_clip_adamw_step's grad_scale

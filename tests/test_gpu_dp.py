@@ -115,10 +115,18 @@ def _grads_after(cfg, arena, batch, mode):
     return enc.grads.clone(), float(loss.item())
 
 
-def _one_rank_group_worker(rank, world, port, out_dir):
+def _one_rank_group_worker(rank, world, port, out_dir, backend="gloo"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":                     # = RCCL on ROCm: the transport configs[3] runs on
+        torch.cuda.set_device(0)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        except TypeError:
+            dist.init_process_group("nccl", rank=rank, world_size=world)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     from quadruplet_sentence_transformer_amd.synthetic import synthetic_params, synthetic_quadruplets
     torch.cuda.set_device(0)
     cfg, B, L = _dp_case("minilm-c4")
@@ -132,13 +140,17 @@ def _one_rank_group_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_staged_backward_matches_one_call_on_the_fused_path(tmp_path):
-    """The staged call order configs[3] relies on -- layer l's stage writes layer l-1's LayerNorm-2 gamma/beta partials and
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_staged_backward_matches_one_call_on_the_fused_path(tmp_path, backend):
+    """backend "nccl": the same through REAL RCCL works on the one GPU a test box has (world_size 1): dist.all_reduce(
+    async_op=True) on RCCL's own stream, ordered against the kernels the C-ABI enqueues on torch's current stream, waited
+    before the comparison -- the mechanism of configs[3], which gloo (a blocking host-staged reduce) never exercises.
+    The staged call order configs[3] relies on -- layer l's stage writes layer l-1's LayerNorm-2 gamma/beta partials and
     reduces them in that call; layer 0 runs without its weight gradients, the embedding stage follows, the postponed
     grouped wgrad comes last -- must produce the gradients of the single call. fp32 atomics make the weight gradients
     order-dependent in the last bits, so equality is per-tensor relative L2 < 1e-5 (two one-call runs differ as much)."""
     from quadruplet_sentence_transformer_amd.config import build_layout
-    mp.spawn(_one_rank_group_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_one_rank_group_worker, args=(1, _free_port(), str(tmp_path), backend), nprocs=1, join=True)
     g1, g2 = np.load(tmp_path / "g_oneshot.npy"), np.load(tmp_path / "g_staged.npy")
     l = np.load(tmp_path / "loss.npy")
     assert l[0] == l[1] and np.isfinite(g1).all() and np.isfinite(g2).all()
@@ -151,7 +163,18 @@ def test_staged_backward_matches_one_call_on_the_fused_path(tmp_path):
         assert float(np.linalg.norm(a - b)) <= 1e-5 * max(na, 1e-12) + 1e-9, s.name
 
 
-def _fit_worker(rank, world, port, out_dir):
+class _FileWritingEvaluator:
+    """Writes under output_path unconditionally, as the reference's QuadrupletLossEvaluator does
+    (/root/reference/models/evaluators.py:81: os.path.join(output_path, "_quadruplet_loss_eval.json"))."""
+
+    def __call__(self, model, output_path=None, epoch=-1, steps=-1):
+        import json
+        with open(os.path.join(output_path, "_quadruplet_loss_eval.json"), "a") as f:
+            json.dump({"epoch": epoch, "steps": steps}, f)
+        return float(-steps)
+
+
+def _fit_worker(rank, world, port, out_dir, n_examples=24, evaluator=None, tag=""):
     """The reference's training call (training/main.py:128-148) on the drop-in, one process per rank."""
     if world > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -165,19 +188,19 @@ def _fit_worker(rank, world, port, out_dir):
     words = "a man rides red horse two dogs play in park woman eats green apple near old bridge small cat sleeps".split()
     rng = np.random.RandomState(3)
     examples = [InputExample(texts=[" ".join(rng.choice(words, size=rng.randint(3, 9))) for _ in range(4)])
-                for _ in range(24)]
+                for _ in range(n_examples)]
     model = SentenceTransformer("tiny-bert", device="cuda:0")
     loss = GammaQuadrupletLoss(gamma=0.6, margin_pos_neg=1.0, margin_pos_part=0.5, margin_part_neg=0.5)
     lm = QuadrupletSentenceTransformerLossModel(st_model=model, quadruplet_loss=loss)
     dl = DataLoader(examples, batch_size=6, shuffle=False)             # 6 rows over 2 ranks: 3 + 3; over 4: 2+2+1+1
-    model.fit(train_objectives=[(dl, lm)], evaluator=None, epochs=1, steps_per_epoch=None, scheduler="WarmupLinear",
+    model.fit(train_objectives=[(dl, lm)], evaluator=evaluator, epochs=1, steps_per_epoch=None, scheduler="WarmupLinear",
               warmup_steps=2, optimizer_class=torch.optim.AdamW, optimizer_params={"lr": 1e-3}, weight_decay=0.01,
-              evaluation_steps=0, output_path=os.path.join(out_dir, f"model_w{world}"), save_best_model=True,
-              max_grad_norm=1.0, use_amp=False, callback=None, show_progress_bar=False,
-              checkpoint_path=os.path.join(out_dir, f"ckpt_w{world}"), checkpoint_save_steps=2,
+              evaluation_steps=2 if evaluator is not None else 0, output_path=os.path.join(out_dir, f"model{tag}_w{world}"),
+              save_best_model=True, max_grad_norm=1.0, use_amp=False, callback=None, show_progress_bar=False,
+              checkpoint_path=os.path.join(out_dir, f"ckpt{tag}_w{world}"), checkpoint_save_steps=2,
               checkpoint_save_total_limit=1, dropout=0)      # (masks are per rank: only the dropout-free run is rank-count invariant)
     torch.cuda.synchronize()
-    np.save(os.path.join(out_dir, f"fit_w{world}_r{rank}.npy"), model._enc.params.cpu().numpy())
+    np.save(os.path.join(out_dir, f"fit{tag}_w{world}_r{rank}.npy"), model._enc.params.cpu().numpy())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -200,3 +223,23 @@ def test_fit_is_data_parallel_under_torch_distributed(tmp_path):
     assert bad.mean() < 2e-3, f"{bad.sum()} of {bad.size} parameters differ"
     assert os.path.isfile(tmp_path / "model_w2" / "model.safetensors")          # evaluator=None: rank 0 saved at the end
     assert sorted(os.listdir(tmp_path / "ckpt_w2")) == ["4"]                     # 4 steps, limit 1
+
+
+def test_fit_dp_with_an_empty_shard_and_a_file_writing_evaluator(tmp_path):
+    """25 examples in batches of 6: the last batch has ONE row, so under two ranks rank 1's shard of it is empty. That rank
+    must still issue the per-layer all-reduces its peer issues from inside the staged backward (it issued one
+    arena-wide reduce instead -- RCCL hangs on that, gloo raises a size mismatch). And the evaluator, which runs on every
+    rank, gets a real directory on the ranks that do not own output_path (the reference's evaluators write there
+    unconditionally); rank 0 alone writes under output_path."""
+    ev = _FileWritingEvaluator()
+    mp.spawn(_fit_worker, args=(1, 0, str(tmp_path), 25, ev, "_e"), nprocs=1, join=True)
+    mp.spawn(_fit_worker, args=(2, _free_port(), str(tmp_path), 25, ev, "_e"), nprocs=2, join=True)
+    single = np.load(tmp_path / "fit_e_w1_r0.npy")
+    r0, r1 = np.load(tmp_path / "fit_e_w2_r0.npy"), np.load(tmp_path / "fit_e_w2_r1.npy")
+    np.testing.assert_array_equal(r0, r1)
+    from quadruplet_sentence_transformer_amd.config import PRESETS
+    from quadruplet_sentence_transformer_amd.synthetic import synthetic_params
+    moved = np.abs(single - synthetic_params(PRESETS["tiny-bert"], seed=14)).max()
+    bad = np.abs(r0 - single) > 0.05 * moved
+    assert bad.mean() < 2e-3, f"{bad.sum()} of {bad.size} parameters differ"
+    assert os.path.isfile(tmp_path / "model_e_w2" / "eval" / "_quadruplet_loss_eval.json")       # rank 0's evaluator output

@@ -93,6 +93,13 @@ def test_hip_encoder_matches_hf_vectors(enc_g, key, preset, B, L, wkw, store):
     else:
         norms = np.array([np.linalg.norm(ga[s.offset:s.offset + s.numel]) for s in segs])
         np.testing.assert_allclose(norms, enc_g[key + "_gradnorms"], rtol=3e-2, atol=1e-6)
+        # ... and the first 64 gradient values of every segment, against HF's
+        for k, s in enumerate(segs):
+            ref = enc_g[key + "_gradslices"][k][:min(64, s.numel)]
+            got = ga[s.offset:s.offset + min(64, s.numel)]
+            if np.linalg.norm(ref) > 1e-3 * max(1e-12, enc_g[key + "_gradnorms"][k]):      # (slices that are not ~all zero)
+                lim = 0.15 if s.name.split(".")[-1].startswith("b_") or s.name.endswith("emb") else 8e-2
+                assert np.linalg.norm(got - ref) <= lim * np.linalg.norm(ref) + 1e-7, (s.name, np.linalg.norm(got - ref), np.linalg.norm(ref))
 
 
 @pytest.mark.parametrize("key,preset,B,L,wkw,store", ENC_CASES + [("minilm_l128", "all-MiniLM-L6-v2", 2, 128, dict(std=0.02), "norms")])

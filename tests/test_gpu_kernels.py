@@ -158,11 +158,10 @@ def test_gemm_tn_wgrad(lib, M, N, K):
     torch.testing.assert_close(C.cpu(), 2 * ref, rtol=1e-3, atol=2e-3 * scale)
 
 
-@pytest.mark.parametrize("M,slab", [(1000, False), (1000, True), (4096, True), (32 * 70 + 32, True), (96, True)])
-def test_gemm_tn_group_matches_individual(lib, M, slab):
-    """All four weight gradients of a MiniLM-shaped layer in one grouped launch; slab: partial tiles flushed with plain
-    stores into per-range slots and summed by a second kernel in a fixed order (bit-reproducible) instead of float
-    atomics -- incl. a last M-range shorter than the others and M too small for eight ranges (falls back to atomics)."""
+@pytest.mark.parametrize("M", [1000, 4096, 32 * 70 + 32, 96])
+def test_gemm_tn_group_matches_individual(lib, M):
+    """All four weight gradients of a MiniLM-shaped layer in one grouped launch -- incl. a last M-range shorter than
+    the others and M too small for eight ranges."""
     H, I = 384, 1536
     g = torch.Generator().manual_seed(5 + M)
     shapes = [(H, I), (I, H), (H, H), (3 * H, H)]
@@ -181,23 +180,11 @@ def test_gemm_tn_group_matches_individual(lib, M, slab):
         keep += [Ad, Bd]
         refs.append((A.t() @ B + 1.0, A.sum(0)))
         outs.append((C, cs))
-    if slab:
-        sl = torch.full((lib.qst_gemm_tn_slab_bytes(grp) // 4,), float("nan"), device="cuda")
-        grp.slabs = sl.data_ptr()
     _lib.check(lib.qst_gemm_tn_group(grp, stream()))
     torch.cuda.synchronize()
     for (C, cs), (rC, rcs) in zip(outs, refs):
         torch.testing.assert_close(C.cpu(), rC, rtol=1e-3, atol=1e-3 * math.sqrt(M))
         torch.testing.assert_close(cs.cpu(), rcs, rtol=1e-3, atol=1e-3 * math.sqrt(M))
-    if slab and M >= 256:
-        first = [C.clone() for C, _ in outs]
-        for C, _ in outs:
-            C.fill_(1.0)
-        sl.fill_(float("nan"))
-        _lib.check(lib.qst_gemm_tn_group(grp, stream()))
-        torch.cuda.synchronize()
-        for a, (C, _) in zip(first, outs):
-            assert torch.equal(a, C)                              # fixed summation order
 
 
 # ------------------------------------------------------------------ LayerNorm
@@ -467,131 +454,15 @@ def test_attention_fwd_bwd(lib, n, L, A, d, use_rel):
         # this shape ran the single-workgroup backward; the two-kernel path must agree with it
         dq2 = torch.empty_like(dq)
         drel2 = torch.zeros(A, 2 * L, device="cuda") if use_rel else None
-        lib.qst_debug_attn_force_split(1)
-        try:
-            _lib.check(lib.qst_attention_bwd(qd.data_ptr(), ctx.data_ptr(), dcd.data_ptr(), lse.data_ptr(),
-                                             md.data_ptr(), _lib.ptr(reld), n, L, A, d, dq2.data_ptr(), _lib.ptr(drel2),
-                                             delta.data_ptr(), stream()))
-            torch.cuda.synchronize()
-        finally:
-            lib.qst_debug_attn_force_split(0)
+        q = _lib.QstAttnDesc()
+        q.qkv, q.mask, q.rel_pos, q.nseq, q.L, q.A, q.d = qd.data_ptr(), md.data_ptr(), _lib.ptr(reld), n, L, A, d
+        q.ctx, q.lse, q.dctx, q.dqkv, q.drel = ctx.data_ptr(), lse.data_ptr(), dcd.data_ptr(), dq2.data_ptr(), _lib.ptr(drel2)
+        q.delta_scratch, q.force_split = delta.data_ptr(), 1
+        _lib.check(lib.qst_attention_bwd_ex(q, stream()))
+        torch.cuda.synchronize()
         torch.testing.assert_close(dq.float(), dq2.float(), rtol=2e-2, atol=2e-2 * max(1.0, gref.abs().max().item()))
         if use_rel:
             torch.testing.assert_close(drel, drel2, rtol=1e-3, atol=1e-3 * max(1.0, drel2.abs().max().item()))
-
-
-# ------------------------------------------------------------------ head-major q/k/v ([nseq][3A][L][d])
-def to_head_major(t, n, L, A, d):
-    """[n*L, 3*A*d] token-major (q | k | v, heads concatenated) -> [n][3A][L][d] flattened (include/qst_kernels.h)."""
-    return t.view(n, L, 3 * A, d).permute(0, 2, 1, 3).contiguous().view(-1)
-
-
-def from_head_major(t, n, L, A, d):
-    return t.view(n, 3 * A, L, d).permute(0, 2, 1, 3).reshape(n * L, 3 * A * d)
-
-
-@pytest.mark.parametrize("n,L,A,d,use_rel", [(2, 32, 2, 32, False), (3, 128, 12, 32, False), (2, 160, 2, 64, True),
-                                              (2, 256, 3, 64, False), (2, 64, 2, 32, True), (5, 96, 3, 32, False)])
-def test_attention_head_major_equals_token_major(lib, n, L, A, d, use_rel):
-    """QstAttnDesc.head_major runs the same kernels on the other layout: results must be bit-identical (the split
-    backward of long sequences accumulates dK / dV in another order only through float atomics on drel)."""
-    H = A * d
-    g = torch.Generator().manual_seed(7 * n * L + A + d)
-    qkv = torch.randn(n * L, 3 * H, generator=g).to(torch.bfloat16)
-    lens = torch.randint(max(1, L // 8), L + 1, (n,), generator=g)
-    lens[0] = L
-    md = dev((torch.arange(L)[None, :] < lens[:, None]).long())
-    reld = dev(0.5 * torch.randn(A, 2 * L, generator=g)) if use_rel else None
-    dcd = dev(torch.randn(n * L, H, generator=g).to(torch.bfloat16))
-    qd, qh = dev(qkv), dev(to_head_major(qkv, n, L, A, d))
-    outs = []
-    for hm, q in ((False, qd), (True, qh)):
-        ctx = torch.empty(n * L, H, dtype=torch.bfloat16, device="cuda")
-        lse = torch.empty(n, A, L, device="cuda")
-        dq = torch.full((n * L * 3 * H,), float("nan"), dtype=torch.bfloat16, device="cuda")
-        drel = torch.zeros(A, 2 * L, device="cuda") if use_rel else None
-        delta = torch.empty(n, A, L, device="cuda")
-        a = _lib.QstAttnDesc()
-        a.qkv, a.mask, a.rel_pos, a.nseq, a.L, a.A, a.d = q.data_ptr(), md.data_ptr(), _lib.ptr(reld), n, L, A, d
-        a.ctx, a.lse, a.head_major = ctx.data_ptr(), lse.data_ptr(), int(hm)
-        a.dctx, a.dqkv, a.drel, a.delta_scratch = dcd.data_ptr(), dq.data_ptr(), _lib.ptr(drel), delta.data_ptr()
-        _lib.check(lib.qst_attention_fwd_ex(a, stream()))
-        _lib.check(lib.qst_attention_bwd_ex(a, stream()))
-        torch.cuda.synchronize()
-        outs.append((ctx, lse, from_head_major(dq, n, L, A, d) if hm else dq.view(n * L, 3 * H), drel))
-    (c0, l0, d0, r0), (c1, l1, d1, r1) = outs
-    assert torch.equal(c0, c1) and torch.equal(l0, l1)
-    assert torch.equal(d0, d1)
-    if use_rel:
-        torch.testing.assert_close(r0, r1, rtol=1e-5, atol=1e-5 * max(1.0, r0.abs().max().item()))
-
-
-@pytest.mark.parametrize("n,L,A,d", [(2, 32, 2, 32), (8, 128, 12, 32), (3, 96, 3, 64), (5, 160, 12, 64), (40, 32, 12, 32)])
-def test_gemms_on_head_major_operands(lib, n, L, A, d):
-    """QKV projection writing head-major (c_head), QKV dgrad (plain and LayerNorm-fused) and wgrad reading it (a_head):
-    each equals the same call on the token-major matrix, element for element (the wgrad up to its float atomics)."""
-    H, M = A * d, n * L
-    g = torch.Generator().manual_seed(M + H)
-    x = dev(torch.randn(M, H, generator=g).to(torch.bfloat16))
-    w = dev((torch.randn(3 * H, H, generator=g) * 0.05).to(torch.bfloat16))
-    bias = dev(torch.randn(3 * H, generator=g))
-    # --- projection: C head-major
-    c_tok = torch.empty(M, 3 * H, dtype=torch.bfloat16, device="cuda")
-    c_hm = torch.full((M * 3 * H,), float("nan"), dtype=torch.bfloat16, device="cuda")
-    for form in (0, 2, 4):
-        _lib.check(lib.qst_gemm_nt(gemm_args(A=x, B=w, C=c_tok, bias=bias, M=M, N=3 * H, K=H, lda=H, ldb=H, ldc=3 * H, splits=form), 0, stream()))
-        c_hm.fill_(float("nan"))
-        _lib.check(lib.qst_gemm_nt(gemm_args(A=x, B=w, C=c_hm, bias=bias, M=M, N=3 * H, K=H, lda=H, ldb=H, ldc=3 * H, splits=form,
-                                             c_head_L=L, c_head_d=d), 0, stream()))
-        assert torch.equal(from_head_major(c_hm, n, L, A, d), c_tok), f"form {form}"
-    # --- dgrad: A head-major, fp32 + residual out
-    dy_tok = dev(torch.randn(M, 3 * H, generator=g).to(torch.bfloat16))
-    dy_hm = dev(to_head_major(dy_tok.cpu(), n, L, A, d))
-    wt = dev((torch.randn(H, 3 * H, generator=g) * 0.05).to(torch.bfloat16))
-    resid = dev(torch.randn(M, H, generator=g))
-    o_tok = torch.empty(M, H, device="cuda")
-    o_hm = torch.empty(M, H, device="cuda")
-    _lib.check(lib.qst_gemm_nt(gemm_args(A=dy_tok, B=wt, C=o_tok, resid=resid, M=M, N=H, K=3 * H, lda=3 * H, ldb=3 * H, ldc=H, ldr=H), 1, stream()))
-    _lib.check(lib.qst_gemm_nt(gemm_args(A=dy_hm, B=wt, C=o_hm, resid=resid, M=M, N=H, K=3 * H, lda=3 * H, ldb=3 * H, ldc=H, ldr=H,
-                                         a_head_L=L, a_head_d=d), 1, stream()))
-    assert torch.equal(o_tok, o_hm)
-    if H == 384:
-        # fused with the LayerNorm backward (mode 1)
-        xhat = dev(torch.randn(M, H, generator=g).to(torch.bfloat16))
-        rstd = dev(torch.rand(M, generator=g) + 0.5)
-        gamma = dev(torch.randn(H, generator=g))
-        res = []
-        for a_hm in (False, True):
-            C = torch.empty(M, H, device="cuda")
-            C2 = torch.empty(M, H, dtype=torch.bfloat16, device="cuda")
-            part = torch.zeros((M + 127) // 128, 2, H, device="cuda")
-            ln = _lib.QstLnEpi()
-            ln.gamma, ln.xhat, ln.rstd, ln.partials = gamma.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), part.data_ptr()
-            ga = gemm_args(A=dy_hm if a_hm else dy_tok, B=wt, C=C, C2=C2, resid=resid, M=M, N=H, K=3 * H, lda=3 * H, ldb=3 * H, ldc=H, ldr=H,
-                           **(dict(a_head_L=L, a_head_d=d) if a_hm else {}))
-            _lib.check(lib.qst_gemm_nt_ln(ga, ln, 1, stream()))
-            torch.cuda.synchronize()
-            res.append((C, C2, part))
-        for t0, t1 in zip(*res):
-            assert torch.equal(t0, t1)
-    # --- wgrad: dY head-major
-    outs = []
-    for a_hm in (False, True):
-        C = torch.zeros(3 * H, H, device="cuda")
-        cs = torch.zeros(3 * H, device="cuda")
-        _lib.check(lib.qst_gemm_tn(gemm_args(A=dy_hm if a_hm else dy_tok, B=x, C=C, colsum=cs, M=M, N=3 * H, K=H, lda=3 * H, ldb=H, ldc=H,
-                                             **(dict(a_head_L=L, a_head_d=d) if a_hm else {})), stream()))
-        torch.cuda.synchronize()
-        outs.append((C, cs))
-    ref = dy_tok.float().t() @ x.float()
-    torch.testing.assert_close(outs[1][0], ref, rtol=1e-3, atol=1e-3 * math.sqrt(M))
-    torch.testing.assert_close(outs[1][0], outs[0][0], rtol=1e-5, atol=1e-5 * ref.abs().max().item())
-    torch.testing.assert_close(outs[1][1], outs[0][1], rtol=1e-5, atol=1e-4)
-    # shapes the layout cannot describe are refused
-    bad = gemm_args(A=x, B=w, C=c_hm, M=M, N=3 * H, K=H, lda=H, ldb=H, ldc=3 * H, c_head_L=L + 8, c_head_d=d)
-    assert lib.qst_gemm_nt(bad, 0, stream()) != 0
-    bad = gemm_args(A=x, B=w, C=o_tok, resid=resid, M=M, N=3 * H, K=H, lda=H, ldb=H, ldc=3 * H, ldr=3 * H, c_head_L=L, c_head_d=d)
-    assert lib.qst_gemm_nt(bad, 1, stream()) != 0
 
 
 def test_rel_pos_vectors_match_the_full_bias_table(lib):

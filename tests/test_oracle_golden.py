@@ -93,7 +93,10 @@ ENC_CASES = [("tinybert_hfinit", "tiny-bert", 2, 32, dict(std=0.02), "full"),
              ("minilm_c1", "all-MiniLM-L6-v2", 8, 32, dict(std=0.04, bias_std=0.02, ln_jitter=0.05), "norms"),
              # an all-padding sequence and left-padded ones (synthetic.mask_edge_cases)
              ("tinybert_maskedge", "tiny-bert", 3, 64, dict(std=0.08, bias_std=0.05, ln_jitter=0.1), "full"),
-             ("tinympnet_maskedge", "tiny-mpnet", 3, 64, dict(std=0.08, bias_std=0.05, ln_jitter=0.1), "full")]
+             ("tinympnet_maskedge", "tiny-mpnet", 3, 64, dict(std=0.08, bias_std=0.05, ln_jitter=0.1), "full"),
+             # 16,384 token rows: the size the fused GEMM + LayerNorm kernels, the 8-range wgrad and the single-workgroup
+             # attention backward run from (the HIP side of this case: tests/test_gpu_golden.py)
+             ("minilm2l_fused", "minilm-2l", 32, 128, dict(std=0.04, bias_std=0.02, ln_jitter=0.05), "norms")]
 
 
 def golden_inputs(key, cfg, B, L):
@@ -127,6 +130,8 @@ def test_encoder_oracles_match_hf(enc_g, key, preset, B, L, wkw, store):
     else:
         norms = np.array([np.linalg.norm(g[s.offset:s.offset + s.numel]) for s in segs])
         np.testing.assert_allclose(norms, enc_g[key + "_gradnorms"], rtol=2e-3, atol=1e-7)
+    if B * L > 2048:
+        return                                        # (the numpy restatement is for the small cases)
     # numpy restatement of the forward
     l2, e2 = NO.quadruplet_forward(NO.arena_to_dict(arena, cfg), cfg, ids, mask, types, **CLI)
     np.testing.assert_allclose(e2, enc_g[key + "_emb"], rtol=1e-3, atol=2e-5)

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Same-process A/B of a library-level switch on the training step and the forward-only pass:
+"""Same-process A/B of an encoder-handle option on the training step and the forward-only pass:
 
-    python tools/ab_switch.py qst_debug_head_major 0 1 [model] [batch] [seq_len] [rounds]
+    python tools/ab_switch.py set_ffn_chain 1 7 [model] [batch] [seq_len] [rounds]
 
-Calls <switch>(v) for each value v in turn, several rounds, and prints ms per step for both; the two settings alternate in
+Calls HipEncoder.<option>(v) for each value v in turn, several rounds, and prints ms per step for both; the two settings alternate in
 one process on one box, so clock / box differences cancel (boxes of the pool differ by +-4%)."""
 import ctypes as C
 import os
@@ -37,12 +37,10 @@ def main():
     B = int(sys.argv[5]) if len(sys.argv) > 5 else 64
     L = int(sys.argv[6]) if len(sys.argv) > 6 else 128
     rounds = int(sys.argv[7]) if len(sys.argv) > 7 else 4
-    lib = _lib.load()
-    sw = getattr(lib, name)
-    sw.argtypes, sw.restype = [C.c_int], None
     cfg = PRESETS[model]
     tr = QuadrupletTrainer(cfg, arena=synthetic_params(cfg, seed=14), device="cuda:0", lr=2e-5, weight_decay=0.01, max_grad_norm=1.0)
     batch = [torch.from_numpy(x).cuda() for x in synthetic_quadruplets(cfg, B, L, seed=14)]
+    sw = getattr(tr.enc, name)
     res = {v0: [[], []], v1: [[], []]}
     for _ in range(rounds):
         for v in (v0, v1):
@@ -53,7 +51,7 @@ def main():
         st, fw = res[v]
         print(f"{name}({v}): step {min(st):.3f} ms (runs {' '.join(f'{x:.3f}' for x in st)})   "
               f"forward-only {min(fw):.3f} ms (runs {' '.join(f'{x:.3f}' for x in fw)})")
-    sw(v1)
+    sw(v0)
 
 
 if __name__ == "__main__":

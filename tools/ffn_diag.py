@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Timing experiments on the fused feed-forward kernel (csrc/ffn.hip) at M = 32768: qst_debug_ffn_diag bits
+"""Timing experiments on the fused feed-forward kernel (csrc/ffn.hip) at M = 32768: QstFfnArgs.diag, shown as the bits
 1 = drop the activation-panel loads, 2 = drop the weight loads (zero-record descriptors: the instruction stream, waits and
 barriers stay, the memory traffic goes), 4 = L2 touch-ahead. Outputs of the drop builds are wrong by construction."""
 import ctypes as C
@@ -16,7 +16,6 @@ from gemm_bench import timeit  # noqa: E402
 
 def main():
     lib = _lib.load()
-    lib.qst_debug_ffn_diag.argtypes = [C.c_int]
     st = _lib.current_stream_ptr()
     M, H, I = int(os.environ.get("M", 32768)), 384, 1536
     dev, bf = "cuda", torch.bfloat16
@@ -44,13 +43,12 @@ def main():
     cases = [("fwd inference", args(0, False), 0), ("fwd training", args(0, True), 0), ("bwd", args(1, True), 1)]
     fl = 4.0 * M * H * I
     for bits in (0, 4, 1, 2, 3, 7):
-        lib.qst_debug_ffn_diag(bits)
         row = []
         for name, f, mode in cases:
+            f.diag = (bits & 3) | (0 if bits & 4 else 4)          # QstFfnArgs.diag: bit 2 switches the touch-ahead OFF
             best = min(timeit(lambda: _lib.check(lib.qst_ffn_chain(f, e, mode, st))) for _ in range(3))
             row.append(f"{name} {best:7.1f} us ({fl / best / 1e6:6.1f} TF)")
         print(f"diag={bits}: " + "   ".join(row))
-    lib.qst_debug_ffn_diag(4)
 
 
 if __name__ == "__main__":

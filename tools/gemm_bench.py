@@ -53,18 +53,7 @@ def main():
         g.splits = 0
         us = timeit(lambda: _lib.check(lib.qst_gemm_nt(g, epi, st)))
         tot += us
-        w8 = ""
-        if epi in (0, 1, 2):          # the same launch with fp8 (e4m3) weights + row scales (inference path)
-            Wf = (torch.randn(N, K, device=dev) * 0.02)
-            q8 = torch.empty(N, K, dtype=torch.uint8, device=dev)
-            sc8 = torch.empty(N, device=dev)
-            _lib.check(lib.qst_quant_rows_fp8(Wf.data_ptr(), N, K, q8.data_ptr(), sc8.data_ptr(), st))
-            g8 = _lib.QstGemmArgs()
-            g8.A, g8.B, g8.C, g8.C2, g8.bias, g8.resid, g8.bscale = (A.data_ptr(), q8.data_ptr(), C.data_ptr(), C2.data_ptr(),
-                                                                      bias.data_ptr(), resid.data_ptr(), sc8.data_ptr())
-            g8.M, g8.N, g8.K, g8.lda, g8.ldb, g8.ldc, g8.ldr = M, N, K, K, K, N, N
-            w8 = f", fp8 weights {timeit(lambda: _lib.check(lib.qst_gemm_nt_w8(g8, epi, st))):.1f} us"
-        print(f"nt {name:31s} {us:8.1f} {2.0 * M * N * K / us / 1e6:8.1f}   (128-row tile {res[0]:.1f} us, 256-row tile {res[1]:.1f} us, 128x384 tile {res[2]:.1f} us, tall 256x192 {res[3]:.1f} us{w8})")
+        print(f"nt {name:31s} {us:8.1f} {2.0 * M * N * K / us / 1e6:8.1f}   (128-row tile {res[0]:.1f} us, 256-row tile {res[1]:.1f} us, 128x384 tile {res[2]:.1f} us, tall 256x192 {res[3]:.1f} us)")
     # fused GEMM + LayerNorm (N = 384 full-row tiles) against the unfused pair
     if lib.qst_gemm_nt_ln_supported(H):
         for name, K, mode in [("out+LN1 fwd", H, 0), ("FFN2+LN2 fwd", I, 0), ("FFN1 dgrad+LN1 bwd", I, 1), ("QKV dgrad+LN2 bwd", 3 * H, 1)]:

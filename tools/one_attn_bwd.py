@@ -40,10 +40,12 @@ def main():
     def run():
         _lib.check(lib.qst_attention_bwd(qkv.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), lse.data_ptr(), mask.data_ptr(),
                                          None, n, L, A, d, dq.data_ptr(), None, delta.data_ptr(), st))
+    q = _lib.QstAttnDesc()
+    q.qkv, q.mask, q.nseq, q.L, q.A, q.d = qkv.data_ptr(), mask.data_ptr(), n, L, A, d
+    q.ctx, q.lse, q.dctx, q.dqkv, q.delta_scratch = ctx.data_ptr(), lse.data_ptr(), dctx.data_ptr(), dq.data_ptr(), delta.data_ptr()
+    q.force_split = 1
     t1 = timeit(run)
-    lib.qst_debug_attn_force_split(1)
-    t2 = timeit(run)
-    lib.qst_debug_attn_force_split(0)
+    t2 = timeit(lambda: _lib.check(lib.qst_attention_bwd_ex(q, st)))
     print(f"attention backward n={n} L={L} A={A} d={d}: single-workgroup {t1:.1f} us, two-kernel {t2:.1f} us")
 
 

@@ -10,7 +10,7 @@ cfg = PRESETS["all-MiniLM-L6-v2"]
 enc = HipEncoder(cfg); enc.load_arena(synthetic_params(cfg, seed=14))
 ids, mask, types = synthetic_quadruplets(cfg, 64, 128, seed=14)
 i, m, t = (torch.from_numpy(x).view(256, 128).cuda() for x in (ids, mask, types))
-for prec in ("bf16", "fp8w", "bf16x3"):
+for prec in ("bf16", "fp8", "bf16x3"):
     for _ in range(3): enc.forward(i, m, t, precision=prec)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): enc.forward(i, m, t, precision=prec)

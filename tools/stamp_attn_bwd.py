@@ -40,12 +40,12 @@ lse = torch.empty(n, A, L, device="cuda")
 assert lib.qst_attention_fwd(qkv.data_ptr(), mask.data_ptr(), None, n, L, A, d, ctx.data_ptr(), lse.data_ptr(), st) == 0
 dctx = torch.randn(n * L, H, device="cuda").to(bf)
 dq = torch.empty(n * L, 3 * H, dtype=bf, device="cuda")
-stamps = torch.zeros(512 * 8, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(512 * 16, dtype=torch.int64, device="cuda")
 for _ in range(3):
     assert lib.qst_attention_bwd(qkv.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), lse.data_ptr(), mask.data_ptr(), None,
                                  n, L, A, d, dq.data_ptr(), None, stamps.data_ptr(), st) == 0
 torch.cuda.synchronize()
-t = stamps.cpu().numpy().reshape(512, 8).astype(np.int64)
+t = stamps.cpu().numpy().reshape(512, 16).astype(np.int64)
 names = ["stage regs->LDS + delta (+ issue next prefetch)", "wait barrier", "4 score tiles (S, dP, exp, dV, dK, dS image)",
          "wait barrier", "dQ from the dS image", "stores"]
 print("cycles per phase, median over 512 workgroups (third item of each):")
@@ -55,3 +55,16 @@ for k, nm in enumerate(names):
 print(f"  {'  of the first phase: regs->LDS + delta':50s} {np.median(t[:, 7] - t[:, 0]):9.0f}")
 print(f"  {'  of the first phase: issuing the next prefetch':50s} {np.median(t[:, 1] - t[:, 7]):9.0f}")
 print(f"  {'whole item':50s} {np.median(t[:, 6] - t[:, 0]):9.0f}")
+print("inside the second score tile:")
+for k, nm in ((8, "issue a quarter of the next item's loads"), (9, "row constants + S / dP MFMAs (issue)"),
+              (10, "elementwise: exp, dS, dS image rows"), (11, "transposed reads + dV / dK MFMAs (issue)")):
+    dlt = t[:, k + 1] - t[:, k]
+    print(f"  {nm:50s} {np.median(dlt):9.0f}   (p10 {np.percentile(dlt, 10):.0f}, p90 {np.percentile(dlt, 90):.0f})")
+life = t[:, 14] - t[:, 13]
+start = t[:, 13] - t[:, 13].min()
+print(f"workgroup life (6 items): median {np.median(life):.0f} cycles, p10 {np.percentile(life, 10):.0f}, p90 {np.percentile(life, 90):.0f}, "
+      f"max {life.max():.0f}; start skew median {np.median(start):.0f}, max {start.max():.0f}; "
+      f"first start -> last end {t[:, 14].max() - t[:, 13].min():.0f}")
+xcd = np.arange(512) % 8
+for x in range(8):
+    print(f"  XCD {x}: median life {np.median(life[xcd == x]):.0f}, max {life[xcd == x].max():.0f}")
