@@ -184,7 +184,8 @@ typedef struct {
     int32_t nblocks_each[QST_LN_BATCH_MAX];   /* per-entry row count of partials; 0 = nblocks */
 } QstLnReduceBatch;
 int qst_ln_bwd_reduce_batch(const QstLnReduceBatch* b, void* stream);
-/* Embedding backward: scatter ds rows into word/pos/type gradient tables. */
+/* Embedding backward: ds f32 [nseq*L, H] rows are ADDED into the word / position / token-type gradient tables (float
+ * atomics for the word rows; one pass over ds). */
 int qst_embed_bwd(const float* ds, const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
                   int nseq, int L, int H, int num_types, float* dword, float* dpos, float* dtype_, void* stream);
 /* MPNet position ids (cumsum of non-pad) or BERT arange -> int32 [nseq*L]. */

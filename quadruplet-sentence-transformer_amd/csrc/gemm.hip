@@ -81,9 +81,11 @@ __device__ __forceinline__ uint32_t nt_off(int row, int chunk) {
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // after_first_issue: run once, right after the first stage's DMAs are on their way (work whose own memory latency should
 // overlap that first round trip instead of preceding it)
-// (Tried here and removed: an L2 touch-ahead of the activation operand -- one 4-byte LDS-DMA per lane on the line a row
-// needs three stages later, as csrc/ffn.hip does -- step 4.802 vs 4.825 ms, +3..9% on back-to-back launches: in the step
-// the A operand was written by the previous kernel and is still in the Infinity Cache.)
+// (Tried here twice and removed: an L2 touch-ahead of the activation operand -- one 4-byte LDS-DMA per lane on the line a
+// row needs three stages later, as csrc/ffn.hip does. Round 2: step 4.802 vs 4.825 ms, +3..9% on back-to-back launches.
+// Round 3, on the LayerNorm-fused kernel with operands flushed from the caches as they are inside the step
+// (tools/mall_probe.py): K = 1536 cold 111 vs 97 us, warm 62 vs 58 -- the cold penalty is not a per-stage latency. Nor is it
+// the access pattern: a tile-blocked A, every stage one contiguous 16 KB read, measured 94 vs 98 us cold.)
 template <int WAVES_M, int WAVES_N, typename HOOK = NoHook>
 __device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, int m0, int n0, f32x16 (&acc)[2][3],
                                             HOOK after_first_issue = HOOK()) {

@@ -92,6 +92,10 @@ __device__ __forceinline__ void ln_row_finish(const f32x2 (&v)[VPL], int lane, i
     }
 }
 
+// EMB_ROWS rows per wave, all their gathers in flight before the first row is normalised. One row per wave (8192
+// workgroups at M = 32768) runs at 3 TB/s, 50 us; four rows per wave measured SLOWER (54.5 us): the chip then holds the
+// whole grid at once and nothing overlaps the waves' reduction / store tails.
+constexpr int EMB_ROWS = 1;
 template <int VPL>
 __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, const int64_t* type_ids,
                                                            const int32_t* pos_ids, const float* word,
@@ -100,27 +104,34 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, c
                                                            int M, int H, float* y, bf16* yb, bf16* xh, float* rstd,
                                                            uint8_t* yq, uint8_t* ys, QstDrop drop) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * EMB_ROWS;
+    if (row0 >= M) return;
     const int nv = H >> 1;
-    const size_t wrow = (size_t)ids[row] * H, prow = (size_t)pos_ids[row] * H;
-    const size_t trow = (size_t)(type_ids ? type_ids[row] : 0) * H;
-    f32x2 v[VPL];
+    f32x2 v[EMB_ROWS][VPL];
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
-            f32x2 w = *(const f32x2*)(word + wrow + 2 * c);
-            if (type) {                                   // HF order: (word + type) + position
-                const f32x2 t = *(const f32x2*)(type + trow + 2 * c);
-                w[0] += t[0]; w[1] += t[1];
-            }
-            const f32x2 p = *(const f32x2*)(pos + prow + 2 * c);
-            v[i][0] = w[0] + p[0];
-            v[i][1] = w[1] + p[1];
-        } else { v[i][0] = 0.f; v[i][1] = 0.f; }
+    for (int r = 0; r < EMB_ROWS; ++r) {
+        const int row = min(row0 + r, M - 1);             // (a clamped duplicate is loaded and dropped)
+        const size_t wrow = (size_t)ids[row] * H, prow = (size_t)pos_ids[row] * H;
+        const size_t trow = (size_t)(type_ids ? type_ids[row] : 0) * H;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                f32x2 w = *(const f32x2*)(word + wrow + 2 * c);
+                if (type) {                                   // HF order: (word + type) + position
+                    const f32x2 t = *(const f32x2*)(type + trow + 2 * c);
+                    w[0] += t[0]; w[1] += t[1];
+                }
+                const f32x2 p = *(const f32x2*)(pos + prow + 2 * c);
+                v[r][i][0] = w[0] + p[0];
+                v[r][i][1] = w[1] + p[1];
+            } else { v[r][i][0] = 0.f; v[r][i][1] = 0.f; }
+        }
     }
-    ln_row_finish<VPL>(v, lane, H, row, gamma, beta, eps, y, yb, xh, rstd, yq, ys, M, drop_ctx(drop));
+    const DropCtx dc = drop_ctx(drop);
+#pragma unroll
+    for (int r = 0; r < EMB_ROWS; ++r)
+        if (row0 + r < M) ln_row_finish<VPL>(v[r], lane, H, row0 + r, gamma, beta, eps, y, yb, xh, rstd, yq, ys, M, dc);
 }
 
 template <int VPL>
@@ -265,38 +276,61 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* partial
     atomicAdd(col < H ? dgamma + col : dbeta + (col - H), acc);
 }
 
-// Embedding backward.
-//  word: row scatter with float atomics (rows are spread over the vocabulary; low contention)
-//  type: every token hits one of <= 2 rows -> per-block register partials, one atomic per column per block
-__global__ __launch_bounds__(256) void embed_bwd_word_type_kernel(const float* ds, const int64_t* ids,
-                                                                  const int64_t* type_ids, int M, int H, int num_types,
-                                                                  float* dword, float* dtype_) {
+// Embedding backward in one pass over ds [M, H] (it used to be read twice: word + type rows, then position rows).
+//  word: row scatter with float atomics. They execute at the memory side at ~1.5 TB/s chip-wide and are the cost of this
+//        kernel (80 us at M = 32768 for 50 MB of adds). Tried and removed: counting the occurrences of every id first and
+//        updating rows whose id occurs once with a plain load-add-store -- only 34% of the rows of a batch of 32768 random
+//        ids are unique, and the count pass cost more than that saved (85.5 vs 80.0 us).
+//  type: every token hits one of <= 2 rows -> per-lane register partials, one atomic per column per block
+//  position: a wave walks ONE position t over a slice of 16 sequences; rows whose position id equals the first one's are
+//        summed in registers (BERT: all of them), atomics only for the irregular rest (MPNet's pad-dependent ids)
+constexpr int EMB_SEQS_PER_WAVE = 16;
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* ds, const int64_t* ids, const int64_t* type_ids,
+                                                        const int32_t* pos_ids, int nseq, int L, int H,
+                                                        int num_types, float* dword, float* dpos, float* dtype_) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [4 waves][2 types][H] floats
     float* sh = (float*)smem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // token-type sums: a row's type is wave-uniform, so each lane keeps its columns' partial sums for both types in
-    // registers (the first version added every element to an LDS array with ds_add_f32, which cost more than the
-    // global scatter itself: 83 us for the whole kernel at M = 32768)
     constexpr int KMAX = 16;                                      // H <= 1024
-    float acc0[KMAX], acc1[KMAX];
+    float acc0[KMAX], acc1[KMAX], accp[KMAX];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) { acc0[k] = 0.f; acc1[k] = 0.f; }
-    const int rows_per_wave = 16;
-    const int row0 = (blockIdx.x * 4 + wave) * rows_per_wave;
-    for (int rr = 0; rr < rows_per_wave; ++rr) {
-        const int row = row0 + rr;
-        if (row >= M) break;
-        const size_t base = (size_t)row * H;
-        const size_t wrow = (size_t)ids[row] * H;
-        const int t = (num_types > 0 && type_ids) ? ((int)type_ids[row] & 1) : 0;
+    for (int k = 0; k < KMAX; ++k) { acc0[k] = 0.f; acc1[k] = 0.f; accp[k] = 0.f; }
+    // block = 4 consecutive positions of one slice of sequences
+    const int tblocks = (L + 3) / 4;
+    const int t = (blockIdx.x % tblocks) * 4 + wave, slice = blockIdx.x / tblocks;
+    const int s0 = slice * EMB_SEQS_PER_WAVE;
+    const bool live = t < L;
+    // lane rr holds what row rr of this wave needs (one round trip for all 16 rows instead of three dependent ones per row)
+    int my_id = 0, my_type = 0, my_pos = 0;
+    if (live && lane < EMB_SEQS_PER_WAVE && s0 + lane < nseq) {
+        const size_t row = (size_t)(s0 + lane) * L + t;
+        my_id = (int)ids[row];
+        my_pos = pos_ids[row];
+        if (num_types > 0 && type_ids) my_type = (int)type_ids[row] & 1;
+    }
+    const int p0 = __builtin_amdgcn_readlane(my_pos, 0);
+    if (live) {
+        for (int rr = 0; rr < EMB_SEQS_PER_WAVE && s0 + rr < nseq; ++rr) {
+            const size_t base = ((size_t)(s0 + rr) * L + t) * H;
+            const size_t wrow = (size_t)__builtin_amdgcn_readlane(my_id, rr) * H;
+            const int ty = __builtin_amdgcn_readlane(my_type, rr);
+            const int p = __builtin_amdgcn_readlane(my_pos, rr);
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int c = lane + 64 * k;
+                if (c < H) {
+                    const float v = ds[base + c];
+                    atomicAdd(dword + wrow + c, v);
+                    if (ty == 0) acc0[k] += v; else acc1[k] += v;       // uniform branches
+                    if (p == p0) accp[k] += v;
+                    else if (v != 0.f) atomicAdd(dpos + (size_t)p * H + c, v);
+                }
+            }
+        }
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             const int c = lane + 64 * k;
-            if (c < H) {
-                const float v = ds[base + c];
-                atomicAdd(dword + wrow + c, v);
-                if (t == 0) acc0[k] += v; else acc1[k] += v;       // uniform branch
-            }
+            if (c < H && accp[k] != 0.f) atomicAdd(dpos + (size_t)p0 * H + c, accp[k]);
         }
     }
     if (num_types <= 0) return;                                  // uniform
@@ -307,30 +341,10 @@ __global__ __launch_bounds__(256) void embed_bwd_word_type_kernel(const float* d
     }
     __syncthreads();
     for (int c = threadIdx.x; c < min(num_types, 2) * H; c += 256) {
-        const int t = c / H, cc = c - t * H;
-        const float v = (sh[(0 * 2 + t) * H + cc] + sh[(1 * 2 + t) * H + cc]) + (sh[(2 * 2 + t) * H + cc] + sh[(3 * 2 + t) * H + cc]);
+        const int ty = c / H, cc = c - ty * H;
+        const float v = (sh[(0 * 2 + ty) * H + cc] + sh[(1 * 2 + ty) * H + cc]) + (sh[(2 * 2 + ty) * H + cc] + sh[(3 * 2 + ty) * H + cc]);
         if (v != 0.f) atomicAdd(dtype_ + c, v);
     }
-}
-//  position: block per (t, column chunk); sum over sequences whose position id equals the block's
-//  first one in registers, atomics only for the irregular rest
-__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const float* ds, const int32_t* pos_ids, int nseq, int L,
-                                                            int H, float* dpos) {
-    // block = (position t, 64-column slab, sequence slice); 4 sequence slices per block run as 4 waves
-    const int t = blockIdx.x;
-    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
-    const int slice = threadIdx.x >> 6, nslice = 4 * gridDim.z, sl = blockIdx.z * 4 + slice;
-    if (c >= H) return;
-    const int p0 = pos_ids[t];
-    float acc = 0.f;
-    for (int s = sl; s < nseq; s += nslice) {
-        const int row = s * L + t;
-        const int p = pos_ids[row];
-        const float v = ds[(size_t)row * H + c];
-        if (p == p0) acc += v;
-        else if (v != 0.f) atomicAdd(dpos + (size_t)p * H + c, v);
-    }
-    atomicAdd(dpos + (size_t)p0 * H + c, acc);
 }
 
 __global__ void position_ids_kernel(const int64_t* ids, int nseq, int L, int arch, int pad_id, int32_t* pos) {
@@ -348,58 +362,99 @@ __global__ void position_ids_kernel(const int64_t* ids, int nseq, int L, int arc
     }
 }
 
-// mean pool + normalise: block per sequence, thread per column (loops when H > 256)
-__global__ __launch_bounds__(256) void pool_norm_fwd_kernel(const float* tok, const int64_t* mask, int L, int H,
-                                                            int normalize, float* emb, float* pooled) {
-    __shared__ float red[4];
+// mean pool + normalise (sentence-transformers Pooling(mean) + Normalize). One workgroup of 8 waves per sequence. A wave takes every 8th token row, a lane two columns per 64 (8-byte accesses,
+// a row is read / written by whole 512-byte wave instructions); rows of padding are not read. (One thread per column
+// walking the L rows one after the other, 256 threads per sequence, ran at 2.2 TB/s.)
+constexpr int POOL_WAVES = 8, POOL_VPL = 8;                // H <= 1024
+__global__ __launch_bounds__(64 * POOL_WAVES) void pool_norm_fwd_kernel(const float* tok, const int64_t* mask, int L, int H,
+                                                                        int normalize, float* emb, float* pooled) {
+    __shared__ float red[POOL_WAVES];
     __shared__ float msk[512];
-    const int s = blockIdx.x;
-    float cnt = 0.f;
-    for (int t = threadIdx.x; t < L; t += 256) msk[t] = (float)mask[(size_t)s * L + t];
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [POOL_WAVES][H] floats
+    float* part = (float*)smem;
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nv = H >> 1;
+    for (int t = tid; t < L; t += 64 * POOL_WAVES) msk[t] = (float)mask[(size_t)s * L + t];
     __syncthreads();
+    float cnt = 0.f;
     for (int t = 0; t < L; ++t) cnt += msk[t];
     const float inv = 1.0f / fmaxf(cnt, 1e-9f);
-    float sq = 0.f;
-    float e[4];
+    f32x2 acc[POOL_VPL];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = threadIdx.x + 256 * k;
+    for (int i = 0; i < POOL_VPL; ++i) { acc[i][0] = 0.f; acc[i][1] = 0.f; }
+    // four rows of this wave in flight at a time
+    for (int t0 = wave; t0 < L; t0 += 4 * POOL_WAVES) {
+        f32x2 v[4][POOL_VPL];
+        float m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * POOL_WAVES;
+            m[u] = t < L ? msk[t] : 0.f;
+            const float* row = tok + ((size_t)s * L + (t < L ? t : 0)) * H;
+#pragma unroll
+            for (int i = 0; i < POOL_VPL; ++i) {
+                const int c = lane + 64 * i;
+                v[u][i][0] = v[u][i][1] = 0.f;
+                if (c < nv && m[u] != 0.f) v[u][i] = *(const f32x2*)(row + 2 * c);       // (m: uniform)
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < POOL_VPL; ++i) { acc[i][0] += v[u][i][0] * m[u]; acc[i][1] += v[u][i][1] * m[u]; }
+    }
+#pragma unroll
+    for (int i = 0; i < POOL_VPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) *(f32x2*)(part + wave * H + 2 * c) = acc[i];
+    }
+    __syncthreads();
+    float sq = 0.f;
+    float e[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = tid + 64 * POOL_WAVES * k;
         e[k] = 0.f;
         if (c < H) {
             float a = 0.f;
-            for (int t = 0; t < L; ++t) a += tok[((size_t)s * L + t) * H + c] * msk[t];
+#pragma unroll
+            for (int w = 0; w < POOL_WAVES; ++w) a += part[w * H + c];
             e[k] = a * inv;
             sq += e[k] * e[k];
             if (pooled) pooled[(size_t)s * H + c] = e[k];
         }
     }
     sq = wave_sum(sq);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+    if (lane == 0) red[wave] = sq;
     __syncthreads();
-    const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < POOL_WAVES; ++w) tot += red[w];
+    const float nrm = sqrtf(tot);
     const float sc = normalize ? 1.0f / fmaxf(nrm, 1e-12f) : 1.0f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = threadIdx.x + 256 * k;
+    for (int k = 0; k < 2; ++k) {
+        const int c = tid + 64 * POOL_WAVES * k;
         if (c < H) emb[(size_t)s * H + c] = e[k] * sc;
     }
 }
 
-__global__ __launch_bounds__(256) void pool_norm_bwd_kernel(const float* demb, const float* pooled, const int64_t* mask,
-                                                            int L, int H, int normalize, float* dtok) {
-    __shared__ float red[8];
+__global__ __launch_bounds__(64 * POOL_WAVES) void pool_norm_bwd_kernel(const float* demb, const float* pooled, const int64_t* mask,
+                                                                        int L, int H, int normalize, float* dtok) {
+    __shared__ float red[2 * POOL_WAVES];
     __shared__ float msk[512];
-    const int s = blockIdx.x;
-    for (int t = threadIdx.x; t < L; t += 256) msk[t] = (float)mask[(size_t)s * L + t];
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [H] floats: the gradient of the mean row
+    float* dps = (float*)smem;
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nv = H >> 1;
+    for (int t = tid; t < L; t += 64 * POOL_WAVES) msk[t] = (float)mask[(size_t)s * L + t];
     __syncthreads();
     float cnt = 0.f;
     for (int t = 0; t < L; ++t) cnt += msk[t];
     const float inv = 1.0f / fmaxf(cnt, 1e-9f);
-    float e[4], g[4];
+    float e[2], g[2];
     float sq = 0.f, dot = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = threadIdx.x + 256 * k;
+    for (int k = 0; k < 2; ++k) {
+        const int c = tid + 64 * POOL_WAVES * k;
         e[k] = g[k] = 0.f;
         if (c < H) {
             e[k] = pooled[(size_t)s * H + c];
@@ -409,14 +464,15 @@ __global__ __launch_bounds__(256) void pool_norm_bwd_kernel(const float* demb, c
         }
     }
     sq = wave_sum(sq); dot = wave_sum(dot);
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = sq; red[4 + (threadIdx.x >> 6)] = dot; }
+    if (lane == 0) { red[wave] = sq; red[POOL_WAVES + wave] = dot; }
     __syncthreads();
-    sq = red[0] + red[1] + red[2] + red[3];
-    dot = red[4] + red[5] + red[6] + red[7];
+    sq = 0.f; dot = 0.f;
+#pragma unroll
+    for (int w = 0; w < POOL_WAVES; ++w) { sq += red[w]; dot += red[POOL_WAVES + w]; }
     const float nrm = sqrtf(sq);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = threadIdx.x + 256 * k;
+    for (int k = 0; k < 2; ++k) {
+        const int c = tid + 64 * POOL_WAVES * k;
         if (c < H) {
             float dp = g[k];
             if (normalize) {
@@ -424,8 +480,24 @@ __global__ __launch_bounds__(256) void pool_norm_bwd_kernel(const float* demb, c
                 if (nrm > 1e-12f) dp = (g[k] - e[k] * dot / sq) / nrm;
                 else dp = g[k] / 1e-12f;
             }
-            dp *= inv;
-            for (int t = 0; t < L; ++t) dtok[((size_t)s * L + t) * H + c] = dp * msk[t];
+            dps[c] = dp * inv;
+        }
+    }
+    __syncthreads();
+    f32x2 d[POOL_VPL];
+#pragma unroll
+    for (int i = 0; i < POOL_VPL; ++i) {
+        const int c = lane + 64 * i;
+        d[i][0] = d[i][1] = 0.f;
+        if (c < nv) d[i] = *(const f32x2*)(dps + 2 * c);
+    }
+    for (int t = wave; t < L; t += POOL_WAVES) {
+        const float m = msk[t];
+        float* row = dtok + ((size_t)s * L + t) * H;
+#pragma unroll
+        for (int i = 0; i < POOL_VPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) { f32x2 o; o[0] = d[i][0] * m; o[1] = d[i][1] * m; *(f32x2*)(row + 2 * c) = o; }
         }
     }
 }
@@ -565,7 +637,7 @@ extern "C" int qst_embed_ln_fwd_drop(const int64_t* ids, const int64_t* type_ids
         return QST_ERR_BAD_ARG;
     if (int rc = drop_ok(drop, (int64_t)M * H)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    QST_VPL_DISPATCH(H, (embed_ln_fwd_kernel<VPL><<<(M + 3) / 4, 256, 0, st>>>(
+    QST_VPL_DISPATCH(H, (embed_ln_fwd_kernel<VPL><<<(M + 4 * EMB_ROWS - 1) / (4 * EMB_ROWS), 256, 0, st>>>(
                             ids, type_ids, pos_ids, word_emb, pos_emb, type_emb, gamma, beta, eps, M, H, y,
                             (bf16*)y_bf16, (bf16*)xhat_bf16, rstd, nullptr, nullptr, drop ? *drop : kNoDrop)));
     QST_LAUNCH_CHECK();
@@ -586,7 +658,7 @@ extern "C" int qst_embed_ln_fwd_mx(const int64_t* ids, const int64_t* type_ids, 
     if (!ids || !pos_ids || !word_emb || !pos_emb || !gamma || !beta || !y || !yq || !ys || M <= 0 || H <= 0) return QST_ERR_BAD_ARG;
     if (H % 64 != 0) return QST_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    QST_VPL_DISPATCH(H, (embed_ln_fwd_kernel<VPL><<<(M + 3) / 4, 256, 0, st>>>(
+    QST_VPL_DISPATCH(H, (embed_ln_fwd_kernel<VPL><<<(M + 4 * EMB_ROWS - 1) / (4 * EMB_ROWS), 256, 0, st>>>(
                             ids, type_ids, pos_ids, word_emb, pos_emb, type_emb, gamma, beta, eps, M, H, y,
                             (bf16*)y_bf16, nullptr, nullptr, (uint8_t*)yq, (uint8_t*)ys, kNoDrop)));
     QST_LAUNCH_CHECK();
@@ -687,10 +759,9 @@ extern "C" int qst_embed_bwd(const float* ds, const int64_t* ids, const int64_t*
     hipStream_t st = (hipStream_t)stream;
     const int M = nseq * L;
     if (H > 1024) return QST_ERR_UNSUPPORTED;
-    embed_bwd_word_type_kernel<<<(M + 63) / 64, 256, (size_t)8 * H * sizeof(float), st>>>(ds, ids, type_ids, M, H,
-                                                                                           num_types, dword, dtype_);
-    QST_LAUNCH_CHECK();
-    embed_bwd_pos_kernel<<<dim3(L, (H + 63) / 64, nseq >= 64 ? 4 : 1), 256, 0, st>>>(ds, pos_ids, nseq, L, H, dpos);
+    const int grid = ((L + 3) / 4) * ((nseq + EMB_SEQS_PER_WAVE - 1) / EMB_SEQS_PER_WAVE);
+    embed_bwd_kernel<<<grid, 256, (size_t)8 * H * sizeof(float), st>>>(ds, ids, type_ids, pos_ids, nseq, L, H,
+                                                                       num_types, dword, dpos, dtype_);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
@@ -707,7 +778,9 @@ extern "C" int qst_pool_norm_fwd(const float* tok, const int64_t* mask, int nseq
                                  float* emb, float* pooled, void* stream) {
     if (!tok || !mask || !emb || nseq <= 0 || L <= 0 || H <= 0) return QST_ERR_BAD_ARG;
     if (L > 512 || H > 1024) return QST_ERR_UNSUPPORTED;
-    pool_norm_fwd_kernel<<<nseq, 256, 0, (hipStream_t)stream>>>(tok, mask, L, H, normalize, emb, pooled);
+    if (H & 1) return QST_ERR_UNSUPPORTED;
+    pool_norm_fwd_kernel<<<nseq, 64 * POOL_WAVES, (size_t)POOL_WAVES * H * sizeof(float), (hipStream_t)stream>>>(tok, mask, L, H, normalize,
+                                                                                                           emb, pooled);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
@@ -716,7 +789,8 @@ extern "C" int qst_pool_norm_bwd(const float* demb, const float* pooled, const i
                                  int normalize, float* dtok, void* stream) {
     if (!demb || !pooled || !mask || !dtok || nseq <= 0 || L <= 0 || H <= 0) return QST_ERR_BAD_ARG;
     if (L > 512 || H > 1024) return QST_ERR_UNSUPPORTED;
-    pool_norm_bwd_kernel<<<nseq, 256, 0, (hipStream_t)stream>>>(demb, pooled, mask, L, H, normalize, dtok);
+    if (H & 1) return QST_ERR_UNSUPPORTED;
+    pool_norm_bwd_kernel<<<nseq, 64 * POOL_WAVES, (size_t)H * sizeof(float), (hipStream_t)stream>>>(demb, pooled, mask, L, H, normalize, dtok);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }

@@ -465,6 +465,42 @@ def test_attention_fwd_bwd(lib, n, L, A, d, use_rel):
             torch.testing.assert_close(drel, drel2, rtol=1e-3, atol=1e-3 * max(1.0, drel2.abs().max().item()))
 
 
+@pytest.mark.parametrize("nseq,L,H,vocab,ntypes,irregular_pos", [
+    (5, 32, 64, 50, 2, False), (19, 32, 384, 3000, 2, False), (7, 96, 768, 200, 0, True), (33, 64, 128, 100000, 1, True),
+    (3, 30, 64, 40, 2, False)])
+def test_embedding_backward_scatter(lib, nseq, L, H, vocab, ntypes, irregular_pos):
+    """qst_embed_bwd: ds rows added into the word / position / token-type tables in one pass, against index_add_; tables
+    start non-zero (accumulation semantics); a heavily repeated id; MPNet-like position ids that differ from row to row; L
+    not a multiple of 4, nseq not a multiple of 16."""
+    g = torch.Generator().manual_seed(nseq * L + H)
+    M = nseq * L
+    ds = torch.randn(M, H, generator=g)
+    ids = torch.randint(0, vocab, (M,), generator=g)
+    ids[: M // 8] = ids[0]                                  # one heavily repeated id next to (for large vocabularies) unique ones
+    types = torch.randint(0, max(1, ntypes), (M,), generator=g) if ntypes else None
+    if irregular_pos:
+        pos = (torch.arange(L)[None, :] + torch.randint(0, 3, (nseq, 1), generator=g)).reshape(-1).to(torch.int32)
+    else:
+        pos = torch.arange(L).repeat(nseq).to(torch.int32)
+    npos = int(pos.max()) + 1
+    w0, p0 = torch.randn(vocab, H, generator=g), torch.randn(npos, H, generator=g)
+    t0 = torch.randn(max(1, ntypes), H, generator=g)
+    want_w = w0.clone().index_add_(0, ids, ds)
+    want_p = p0.clone().index_add_(0, pos.long(), ds)
+    want_t = t0.clone().index_add_(0, types, ds) if ntypes else None
+    dw, dp, dt = dev(w0), dev(p0), dev(t0)
+    dsd, idd, posd, typd = dev(ds), dev(ids), dev(pos), (dev(types) if ntypes else None)
+    _lib.check(lib.qst_embed_bwd(dsd.data_ptr(), idd.data_ptr(), _lib.ptr(typd), posd.data_ptr(), nseq, L, H, ntypes,
+                                 dw.data_ptr(), dp.data_ptr(),
+                                 dt.data_ptr() if ntypes else None, stream()))
+    torch.cuda.synchronize()
+    tol = dict(rtol=1e-5, atol=1e-4 * math.sqrt(M / 8))
+    torch.testing.assert_close(dw.cpu(), want_w, **tol)
+    torch.testing.assert_close(dp.cpu(), want_p, **tol)
+    if ntypes:
+        torch.testing.assert_close(dt.cpu(), want_t, **tol)
+
+
 def test_rel_pos_vectors_match_the_full_bias_table(lib):
     """qst_rel_pos_fwd / qst_rel_pos_bwd (relative-position form used by the bf16 attention kernels) against
     qst_rel_bias_fwd / qst_rel_bias_bwd (the [A, L, L] table of the parity path): same bias, same table gradient."""
