@@ -35,7 +35,8 @@ typedef enum {
     QST_ERR_UNSUPPORTED = -2,  /* dims the kernels are not built for (see qst_encoder_create) */
     QST_ERR_WORKSPACE = -3,    /* workspace/saved arena smaller than qst_*_bytes() says */
     QST_ERR_HIP = -4,          /* a HIP runtime call failed; qst_last_hip_error() has the code */
-    QST_ERR_NO_DEVICE = -5
+    QST_ERR_NO_DEVICE = -5,
+    QST_ERR_COMM = -6          /* RCCL could not be loaded, or one of its calls failed; qst_comm_last_error() has the text */
 } qst_status;
 
 enum { QST_ARCH_BERT = 0, QST_ARCH_MPNET = 1 };
@@ -237,9 +238,27 @@ int qst_topk_scores_capped(const float* queries, const float* corpus, int nq, in
                            float max_score, float* out_scores, int64_t* out_index, void* workspace,
                            size_t workspace_bytes, void* stream);
 
-/* Data parallelism has no entry point here: the gradient arena is one contiguous fp32 buffer, and
- * the host side all-reduces slices of it with torch.distributed (backend "nccl" = RCCL over xGMI) on a side stream,
- * between qst_encoder_backward_partial stages; qst_clip_adamw_step's grad_scale applies the 1/world_size. */
+/* ---- data parallelism (the reference itself is single-process, training/main.py:113) ----
+ * The exchange step of the data-parallel path is a sum of slices of the contiguous fp32 gradient arena between
+ * qst_encoder_backward_stage calls; qst_clip_adamw_step's grad_scale applies the 1/world_size. The Python side of this
+ * build drives it through torch.distributed (backend "nccl" = RCCL over xGMI). A caller without torch uses these: one
+ * process per GPU; rank 0 obtains the id and ships its QST_COMM_ID_BYTES to the other ranks by its own means; every rank
+ * calls qst_comm_init with the HIP device it will use current. RCCL is loaded at run time (the copy already in the
+ * process if there is one), libqst.so has no link dependency on it.
+ *   qst_allreduce_bucket : in-place SUM over all ranks of `count` elements at `ptr` (device), enqueued on `stream` --
+ *                          pass a stream other than the compute stream and order the two with events to overlap the
+ *                          exchange with the next backward stage. dtype: QST_COMM_F32 (the gradient arena) or QST_COMM_BF16.
+ * Status QST_ERR_COMM: qst_comm_last_error() returns RCCL's text. */
+typedef struct qst_comm qst_comm;
+#define QST_COMM_ID_BYTES 128
+enum { QST_COMM_F32 = 0, QST_COMM_BF16 = 1 };
+int qst_comm_unique_id(void* id_out /* QST_COMM_ID_BYTES, host */);
+int qst_comm_init(int rank, int world, const void* unique_id, qst_comm** out);
+int qst_allreduce_bucket(qst_comm* comm, void* ptr, int64_t count, int dtype, void* stream);
+int qst_comm_rank(const qst_comm* comm);
+int qst_comm_world(const qst_comm* comm);
+void qst_comm_destroy(qst_comm* comm);
+const char* qst_comm_last_error(void);
 
 #ifdef __cplusplus
 }

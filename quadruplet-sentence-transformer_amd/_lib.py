@@ -139,6 +139,13 @@ SIGNATURES = {
     "qst_dropout_advance": (C.c_int, [vp, vp]),
     "qst_encoder_set_dropout": (C.c_int, [vp, C.c_float, C.c_float, vp]),
     "qst_encoder_set_ffn_chain": (C.c_int, [vp, C.c_int]),
+    "qst_comm_unique_id": (C.c_int, [vp]),
+    "qst_comm_init": (C.c_int, [C.c_int, C.c_int, vp, C.POINTER(vp)]),
+    "qst_allreduce_bucket": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),
+    "qst_comm_rank": (C.c_int, [vp]),
+    "qst_comm_world": (C.c_int, [vp]),
+    "qst_comm_destroy": (None, [vp]),
+    "qst_comm_last_error": (C.c_char_p, []),
     "qst_rel_bucket_host": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "qst_rel_bias_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
     "qst_rel_bias_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),

@@ -25,6 +25,7 @@ extern "C" const char* qst_strerror(int s) {
         case QST_ERR_WORKSPACE: return "workspace or saved-activation arena too small";
         case QST_ERR_HIP: return "HIP runtime error (see qst_last_hip_error)";
         case QST_ERR_NO_DEVICE: return "no HIP device";
+        case QST_ERR_COMM: return "RCCL error (see qst_comm_last_error)";
         default: return "unknown qst status";
     }
 }

@@ -40,9 +40,16 @@ def gradient_buckets(cfg: EncoderConfig) -> List[Tuple[int, int]]:
 
 
 def allreduce_ranges(flat: torch.Tensor, ranges: Sequence[Tuple[int, int]], group=None, async_op: bool = False):
-    """Sum all-reduce of slices of a flat tensor (device-agnostic: nccl/RCCL on GPU, gloo in CPU tests)."""
-    import torch.distributed as dist
+    """Sum all-reduce of slices of a flat tensor (device-agnostic: nccl/RCCL on GPU, gloo in CPU tests). `group`: a
+    torch.distributed process group (None = the default one) or a comm.NativeComm (libqst.so's own RCCL binding)."""
     works = []
+    if hasattr(group, "all_reduce"):                      # comm.NativeComm
+        for b, e in ranges:
+            w = group.all_reduce(flat[b:e], async_op=async_op)
+            if async_op:
+                works.append(w)
+        return works
+    import torch.distributed as dist
     for b, e in ranges:
         w = dist.all_reduce(flat[b:e], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         if async_op:

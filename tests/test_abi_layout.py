@@ -114,3 +114,20 @@ def test_bad_config_is_rejected_without_a_device():
     c.hidden_size = -1
     assert lib.qst_arena_elems(c) < 0
     assert lib.qst_strerror(-2).decode().startswith("unsupported")
+
+
+def test_communicator_entry_points_check_their_arguments_without_a_gpu():
+    """include/qst.h qst_comm_*: bad arguments are refused before RCCL is touched (no GPU, no RCCL needed)."""
+    import ctypes as C
+    from quadruplet_sentence_transformer_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    ident = C.create_string_buffer(128)
+    assert lib.qst_comm_unique_id(None) == -1
+    assert lib.qst_comm_init(0, 0, ident, C.byref(h)) == -1          # world <= 0
+    assert lib.qst_comm_init(2, 2, ident, C.byref(h)) == -1          # rank outside [0, world)
+    assert lib.qst_comm_init(0, 1, None, C.byref(h)) == -1
+    assert lib.qst_allreduce_bucket(None, None, 4, 0, None) == -1
+    assert lib.qst_comm_rank(None) == -1 and lib.qst_comm_world(None) == -1
+    lib.qst_comm_destroy(None)                                       # no-op
+    assert lib.qst_strerror(-6).decode().startswith("RCCL")

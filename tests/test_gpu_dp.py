@@ -95,7 +95,7 @@ def test_replicas_stay_identical_with_per_rank_dropout(tmp_path):
     assert np.abs(np.load(tmp_path / "params_0.npy") - p0).max() > 1e-5
 
 
-def _grads_after(cfg, arena, batch, mode):
+def _grads_after(cfg, arena, batch, mode, group=None):
     """Gradient arena of one forward + loss + backward on `batch`: mode "oneshot" = qst_encoder_backward in one call,
     "staged" = trainer.staged_backward's call sequence (per-layer stages, layer 0 without its weight gradients, the
     embedding stage, then the postponed weight-gradient launch) with a one-member process group standing in for the
@@ -109,7 +109,7 @@ def _grads_after(cfg, arena, batch, mode):
     if mode == "oneshot":
         enc.backward(ids, mask, types, stacked(g), saved)
     else:
-        for w in staged_backward(enc, ids, mask, types, stacked(g), saved, None, gradient_buckets(cfg), None, True):
+        for w in staged_backward(enc, ids, mask, types, stacked(g), saved, None, gradient_buckets(cfg), group, True):
             w.wait()
     torch.cuda.synchronize()
     return enc.grads.clone(), float(loss.item())
@@ -161,6 +161,53 @@ def test_staged_backward_matches_one_call_on_the_fused_path(tmp_path, backend):
         na = float(np.linalg.norm(a))
         assert na > 0 or "b_qkv" in s.name, s.name
         assert float(np.linalg.norm(a - b)) <= 1e-5 * max(na, 1e-12) + 1e-9, s.name
+
+
+def test_native_communicator_behind_the_c_abi():
+    """include/qst.h qst_comm_unique_id / qst_comm_init / qst_allreduce_bucket (csrc/comm.hip: RCCL bound at run time) on the
+    one GPU a test box has, world size 1: (a) an in-place sum all-reduce of fp32 and bf16 buffers on the communicator's own
+    stream, ordered against the compute stream by events, leaves the data as it was -- after a kernel that was still
+    writing it when the collective was enqueued; (b) the staged backward at the c4 shape with NativeComm as its group
+    equals the one-shot backward; (c) QuadrupletTrainer steps through it track the single-process steps."""
+    from quadruplet_sentence_transformer_amd.comm import NativeComm
+    from quadruplet_sentence_transformer_amd.config import build_layout
+    from quadruplet_sentence_transformer_amd.synthetic import synthetic_params, synthetic_quadruplets
+    from quadruplet_sentence_transformer_amd.trainer import QuadrupletTrainer
+    torch.cuda.set_device(0)
+    comm = NativeComm(0, 1, NativeComm.unique_id())
+    assert comm.lib.qst_comm_rank(comm.handle) == 0 and comm.lib.qst_comm_world(comm.handle) == 1
+    x = torch.zeros(1 << 22, device="cuda")
+    for dt in (torch.float32, torch.bfloat16):
+        y = torch.zeros(1 << 22, device="cuda", dtype=dt)
+        y += 3                                               # still running when the collective is enqueued
+        w = comm.all_reduce(y, async_op=True)
+        w.wait()
+        assert float(y.float().min()) == 3.0 and float(y.float().max()) == 3.0
+    assert comm.lib.qst_allreduce_bucket(comm.handle, x.data_ptr(), 4, 7, 0) == -1          # unknown dtype
+    cfg, B, L = _dp_case("minilm-c4")
+    arena = synthetic_params(cfg, seed=14, std=0.05, bias_std=0.02, ln_jitter=0.05)
+    batch = [torch.from_numpy(t).cuda() for t in synthetic_quadruplets(cfg, B, L, seed=14, ragged=True)]
+    g1, l1 = _grads_after(cfg, arena, batch, "oneshot")
+    g2, l2 = _grads_after(cfg, arena, batch, "staged", group=comm)
+    assert l1 == l2
+    segs, _ = build_layout(cfg)
+    for s_ in segs:
+        a, b = g1[s_.offset:s_.offset + s_.numel], g2[s_.offset:s_.offset + s_.numel]
+        assert float((a - b).norm()) <= 1e-5 * max(float(a.norm()), 1e-12) + 1e-9, s_.name
+    tcfg = _dp_case("tiny-bert")[0]
+    tarena = synthetic_params(tcfg, seed=3, std=0.05)
+    tb = [torch.from_numpy(t).cuda() for t in synthetic_quadruplets(tcfg, 6, 32, seed=3, ragged=True)]
+    kw = dict(arena=tarena, device="cuda:0", lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+    t_ref, t_dp = QuadrupletTrainer(tcfg, **kw), QuadrupletTrainer(tcfg, process_group=comm, world_size=1, force_dp=True, **kw)
+    for _ in range(3):
+        la, lb = t_ref.step(*tb), t_dp.step(*tb)
+    torch.cuda.synchronize()
+    # (AdamW's first updates are lr * g / |g|: the staged path's other atomic order flips that for gradients near zero,
+    #  so parameters agree to a few lr, not to the last bit)
+    assert abs(float(la) - float(lb)) < 1e-3
+    diff = (t_dp.enc.params - t_ref.enc.params).abs()
+    assert float(diff.max()) <= 6.5e-3 and float(diff.mean()) < 1e-4
+    comm.close()
 
 
 class _FileWritingEvaluator:
