@@ -10,7 +10,8 @@ Prints the GEMM's time alone and, for the last two, the time including the extra
 Measured (round 3): K = 1536: warm 58, cold 97, cold+read 72, cold+write 93 us; K = 384: 34 / 56 / 50 / 55. Inside the step the
 launch takes 90 / 42 us: it runs "cold" -- what the previous kernel wrote is not served from the cache. Two remedies tried in
 nt_mainloop and removed: an L2 touch-ahead of A three stages early (cold 111 us, warm 62: worse) and a tile-blocked A layout
-[M/128][K/64][128][64] that makes every stage one contiguous 16 KB read (cold 94 vs 98: the access pattern is not it)."""
+[M/128][K/64][128][64] that makes every stage one contiguous 16 KB read (cold 94 vs 98: the access pattern is not it). A padded row pitch (K + 8 ...
+K + 72 elements) changes nothing (cold 91-99), nor do touches issued by a ninth wave that never waits for them."""
 import os
 import sys
 
