@@ -355,23 +355,30 @@ def baseline_config_name(model, B, L, world):
 
 def distinct_gpus_or_exit(rank, world, dev_index):
     """Ranks of an RCCL job must sit on different physical GPUs. A launcher may pin one GPU per rank (every rank then sees
-    ONE device, index 0), so device indices cannot tell: compare the devices' identities over a TCP store before
-    init_process_group("nccl"), and exit non-zero on every rank if two ranks resolve to the same card -- RCCL would otherwise
-    end in a duplicate-GPU error or a stall."""
+    ONE device, index 0), so device indices alone cannot tell. Before init_process_group("nccl") every rank publishes
+    (device identity, device index, the *_VISIBLE_DEVICES it was started with) over a TCP store; two ranks for which ALL
+    THREE are equal are on the same card -- nothing distinguishes them -- and every rank exits non-zero (RCCL would end in a
+    duplicate-GPU error or a stall). Ranks a launcher pinned differ in the environment part and are never flagged, whatever
+    the identity strings say. The check is advisory: if the store cannot be set up it prints why and lets RCCL decide."""
+    import datetime
     import torch
     from torch.distributed import TCPStore
-    props = torch.cuda.get_device_properties(dev_index)
-    ident = str(getattr(props, "uuid", "")) or str(getattr(props, "pci_bus_id", "")) + ":" + str(getattr(props, "pci_device_id", ""))
-    if not ident.strip(":"):
-        return                                       # no identity available from this torch: nothing to compare
-    host = os.environ.get("MASTER_ADDR", "127.0.0.1")
-    port = int(os.environ.get("MASTER_PORT", "29500")) + 1
-    store = TCPStore(host, port, world, rank == 0, timeout=__import__("datetime").timedelta(seconds=120))
-    store.set(f"gpu{rank}", ident)
-    idents = [store.get(f"gpu{r}").decode() for r in range(world)]
-    if len(set(idents)) != world:
-        print(f"bench.py rank {rank}: {world} ranks on {len(set(idents))} physical GPU(s) ({idents}): RCCL needs one GPU per "
-              "rank (QST_DIST_BACKEND=gloo rehearses the step on a shared card)", file=sys.stderr)
+    try:
+        props = torch.cuda.get_device_properties(dev_index)
+        ident = "|".join(str(getattr(props, k, "")) for k in ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id"))
+        env = "|".join(os.environ.get(k, "") for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+        me = f"{ident}#{dev_index}#{env}"
+        host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(os.environ.get("MASTER_PORT", "29500")) + 1
+        store = TCPStore(host, port, world, rank == 0, timeout=datetime.timedelta(seconds=60))
+        store.set(f"gpu{rank}", me)
+        recs = [store.get(f"gpu{r}").decode() for r in range(world)]
+    except Exception as ex:                               # a busy port, a torch without TCPStore options, ...
+        print(f"bench.py rank {rank}: GPU-identity check skipped ({type(ex).__name__}: {ex})", file=sys.stderr)
+        return
+    if len(set(recs)) != world:
+        print(f"bench.py rank {rank}: {world} ranks but only {len(set(recs))} distinct (GPU, index, visibility) records "
+              f"({recs}): RCCL needs one GPU per rank (QST_DIST_BACKEND=gloo rehearses the step on a shared card)", file=sys.stderr)
         raise SystemExit(3)
 
 
