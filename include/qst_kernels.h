@@ -190,6 +190,11 @@ int qst_embed_bwd(const float* ds, const int64_t* ids, const int64_t* type_ids, 
                   int nseq, int L, int H, int num_types, float* dword, float* dpos, float* dtype_, void* stream);
 /* MPNet position ids (cumsum of non-pad) or BERT arange -> int32 [nseq*L]. */
 int qst_position_ids(const int64_t* ids, int nseq, int L, int arch, int pad_id, int32_t* pos_ids, void* stream);
+/* The same launch as the whole prologue of a training forward with dropout: it also advances the dropout step counter
+ * (qst_dropout_advance) and copies the four state words to drop_snapshot (kept beside that forward's activations; the
+ * backward rebuilds its masks from it). drop_state and drop_snapshot: both device pointers, or both NULL. */
+int qst_forward_prologue(const int64_t* ids, int nseq, int L, int arch, int pad_id, int32_t* pos_ids,
+                         uint32_t* drop_state, uint32_t* drop_snapshot, void* stream);
 
 /* ST Pooling(mean) + optional Normalize. tok f32 [nseq,L,H]; pooled f32 [nseq,H] (pre-normalize, saved). */
 int qst_pool_norm_fwd(const float* tok, const int64_t* mask, int nseq, int L, int H, int normalize,

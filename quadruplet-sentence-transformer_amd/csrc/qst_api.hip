@@ -575,15 +575,13 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     };
 
     int32_t* pos_ids = (int32_t*)(sv + p.pos_ids);
-    QST_TRY(qst_position_ids(ids, nseq, L, c.arch, c.pad_token_id, pos_ids, st));
-    // dropout: training forwards of a handle that has it on; the step counter moves first, backward reuses its value
+    // dropout: training forwards of a handle that has it on; the step counter moves first (in the prologue launch, which
+    // also leaves its snapshot beside the activations), backward reuses its value
     const bool dropping = training && e->drop_state != nullptr;
     const void* dst8 = sv + p.dropst;
     const DropThr thr = dropping ? DropThr{e->drop_hidden, e->drop_attn} : DropThr{0u, 0u};
-    if (dropping) {
-        QST_TRY(qst_dropout_advance(e->drop_state, st));
-        QST_HIP_CHECK(hipMemcpyAsync(sv + p.dropst, e->drop_state, 16, hipMemcpyDeviceToDevice, st));
-    }
+    QST_TRY(qst_forward_prologue(ids, nseq, L, c.arch, c.pad_token_id, pos_ids, dropping ? e->drop_state : nullptr,
+                                 dropping ? (uint32_t*)(sv + p.dropst) : nullptr, st));
     if (training) {                                   // remember what this forward did, for the backward over the same arena
         qst_encoder::FwdRec* rec = nullptr;
         for (auto& r : e->fwd_recs) if (r.saved == saved) rec = &r;

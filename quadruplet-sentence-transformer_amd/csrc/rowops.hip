@@ -347,8 +347,17 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* ds, const i
     }
 }
 
-__global__ void position_ids_kernel(const int64_t* ids, int nseq, int L, int arch, int pad_id, int32_t* pos) {
+// drop_state / drop_snapshot (both or neither): the first thread also advances the dropout step counter and copies the
+// four state words next to the activations of the forward at hand -- a training forward's whole prologue in one launch
+// (they were three: 5 us each, all launch latency)
+__global__ void position_ids_kernel(const int64_t* ids, int nseq, int L, int arch, int pad_id, int32_t* pos,
+                                    uint32_t* drop_state, uint32_t* drop_snapshot) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s == 0 && drop_state) {
+        drop_state[2] += 1u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) drop_snapshot[i] = drop_state[i];
+    }
     if (s >= nseq) return;
     if (arch == QST_ARCH_BERT) {
         for (int t = 0; t < L; ++t) pos[s * L + t] = t;
@@ -768,8 +777,13 @@ extern "C" int qst_embed_bwd(const float* ds, const int64_t* ids, const int64_t*
 
 extern "C" int qst_position_ids(const int64_t* ids, int nseq, int L, int arch, int pad_id, int32_t* pos_ids,
                                 void* stream) {
-    if (!ids || !pos_ids || nseq <= 0 || L <= 0) return QST_ERR_BAD_ARG;
-    position_ids_kernel<<<(nseq + 63) / 64, 64, 0, (hipStream_t)stream>>>(ids, nseq, L, arch, pad_id, pos_ids);
+    return qst_forward_prologue(ids, nseq, L, arch, pad_id, pos_ids, nullptr, nullptr, stream);
+}
+extern "C" int qst_forward_prologue(const int64_t* ids, int nseq, int L, int arch, int pad_id, int32_t* pos_ids,
+                                    uint32_t* drop_state, uint32_t* drop_snapshot, void* stream) {
+    if (!ids || !pos_ids || nseq <= 0 || L <= 0 || ((drop_state == nullptr) != (drop_snapshot == nullptr))) return QST_ERR_BAD_ARG;
+    position_ids_kernel<<<(nseq + 63) / 64, 64, 0, (hipStream_t)stream>>>(ids, nseq, L, arch, pad_id, pos_ids, drop_state,
+                                                                          drop_snapshot);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
