@@ -140,6 +140,13 @@ SIGNATURES = {
     "qst_dropout_advance": (C.c_int, [vp, vp]),
     "qst_encoder_set_dropout": (C.c_int, [vp, C.c_float, C.c_float, vp]),
     "qst_encoder_set_ffn_chain": (C.c_int, [vp, C.c_int]),
+    "qst_transpose_f32": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "qst_gelu_f32": (C.c_int, [vp, C.c_int64, vp, vp]),
+    "qst_gelu_bwd_f32": (C.c_int, [vp, vp, C.c_int64, vp, vp]),
+    "qst_colsum_f32": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "qst_embed_sum_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]),
+    "qst_ln_bwd_f32": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "qst_attention_bwd_f32": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "qst_comm_unique_id": (C.c_int, [vp]),
     "qst_comm_init": (C.c_int, [C.c_int, C.c_int, vp, C.POINTER(vp)]),
     "qst_allreduce_bucket": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),

@@ -284,6 +284,46 @@ X3Plan plan_x3(const qst_config& c, int nseq, int L) {
     return p;
 }
 
+// QST_PREC_BF16X3 TRAINING: every tensor the fp32-class backward needs, kept in fp32 (the parity path: sized for parity
+// runs, 4x the bf16 path's activation bytes). s0 / s1 / s2 are the PRE-norm inputs of the three LayerNorms (the backward
+// recomputes mean and rstd from them), u the pre-GELU tensor.
+struct X3Layer { size_t qkv, ctx, s1, y1, u, h, s2, x; };
+struct X3TrainPlan { size_t pos_ids, s0, x0, pooled, rel, total; std::vector<X3Layer> layers; };
+X3TrainPlan plan_x3_train(const qst_config& c, int nseq, int L) {
+    X3TrainPlan p;
+    const size_t M = (size_t)nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    p.pos_ids = take(M * 4);
+    p.s0 = take(M * H * 4); p.x0 = take(M * H * 4);
+    p.pooled = take((size_t)nseq * H * 4);
+    p.rel = (c.arch == QST_ARCH_MPNET) ? take(A * (size_t)L * L * 4) : 0;
+    p.layers.resize(c.num_layers);
+    for (auto& a : p.layers) {
+        a.qkv = take(M * 3 * H * 4); a.ctx = take(M * H * 4); a.s1 = take(M * H * 4); a.y1 = take(M * H * 4);
+        a.u = take(M * I * 4); a.h = take(M * I * 4); a.s2 = take(M * H * 4); a.x = take(M * H * 4);
+    }
+    p.total = off;
+    return p;
+}
+// its backward's scratch: gradient activations, the transposed copies the x3 GEMM contracts over (dY^T, X^T: [cols, M]) and
+// one transposed weight
+struct X3BwdPlan { size_t dx, dy, ds, dbig, dctx, dqkv, tA, tB, wT, drel, total; };
+X3BwdPlan plan_x3_bwd(const qst_config& c, int nseq, int L) {
+    X3BwdPlan p;
+    const size_t M = (size_t)nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads;
+    const size_t wide = I > 3 * H ? I : 3 * H;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    p.dx = take(M * H * 4); p.dy = take(M * H * 4); p.ds = take(M * H * 4); p.dbig = take(M * I * 4);
+    p.dctx = take(M * H * 4); p.dqkv = take(M * 3 * H * 4);
+    p.tA = take(wide * M * 4); p.tB = take((I > H ? I : H) * M * 4);
+    p.wT = take((H * I > 3 * H * H ? H * I : 3 * H * H) * 4);
+    p.drel = (c.arch == QST_ARCH_MPNET) ? take(A * (size_t)L * L * 4) : 0;
+    p.total = off;
+    return p;
+}
+
 // QST_PREC_FP8 forward (inference): MXFP8 operands for every Linear, bf16 attention, fp32 residual stream / LayerNorm
 struct MxPlan { size_t pos_ids, x[2], xb, xq, xs, qkv, ctx, cq, cs, s, y1, y1b, yq, ys, hq, hs, pooled, rel, total; };
 MxPlan plan_mx(const qst_config& c, int nseq, int L) {
@@ -421,12 +461,13 @@ constexpr int kFuseLnMinRows = 16384;      // token rows from which the fused GE
 
 extern "C" size_t qst_encoder_saved_bytes(const qst_encoder* e, int nseq, int L, int training) {
     if (shape_ok(e, nseq, L) != QST_OK) return 0;
-    if (e->cfg.precision == QST_PREC_BF16X3) return training ? 0 : plan_x3(e->cfg, nseq, L).total;
+    if (e->cfg.precision == QST_PREC_BF16X3) return training ? plan_x3_train(e->cfg, nseq, L).total : plan_x3(e->cfg, nseq, L).total;
     if (e->cfg.precision == QST_PREC_FP8) return training ? 0 : plan_mx(e->cfg, nseq, L).total;
     return plan_acts(e->cfg, nseq, L, training != 0).total;
 }
 extern "C" size_t qst_encoder_bwd_workspace_bytes(const qst_encoder* e, int nseq, int L) {
     if (shape_ok(e, nseq, L) != QST_OK) return 0;
+    if (e->cfg.precision == QST_PREC_BF16X3) return plan_x3_bwd(e->cfg, nseq, L).total;
     return plan_bwd(e->cfg, nseq, L).total;
 }
 
@@ -548,6 +589,109 @@ static int forward_x3(qst_encoder* e, const int64_t* ids, const int64_t* mask, c
     return QST_OK;
 }
 
+// QST_PREC_BF16X3 training forward: the same arithmetic as forward_x3, every intermediate kept (X3TrainPlan)
+static int forward_x3_train(qst_encoder* e, const int64_t* ids, const int64_t* mask, const int64_t* type_ids, int nseq, int L,
+                            const float* params, float* out_emb, float* out_tok, void* saved, size_t saved_bytes, hipStream_t st) {
+    const qst_config& c = e->cfg;
+    const X3TrainPlan p = plan_x3_train(c, nseq, L);
+    if (saved_bytes < p.total) return QST_ERR_WORKSPACE;
+    char* sv = (char*)saved;
+    const int M = nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads, d = H / A;
+    const Layout& lay = e->lay;
+    auto P = [&](int seg) { return params + lay.segs[seg].off; };
+    auto F = [&](size_t o) { return (float*)(sv + o); };
+    int32_t* pos_ids = (int32_t*)(sv + p.pos_ids);
+    QST_TRY(qst_position_ids(ids, nseq, L, c.arch, c.pad_token_id, pos_ids, st));
+    QST_TRY(qst_embed_sum_f32(ids, type_ids, pos_ids, P(lay.word), P(lay.pos), lay.type >= 0 ? P(lay.type) : nullptr, M, H,
+                              F(p.s0), st));
+    QST_TRY(qst_ln_fwd(F(p.s0), P(lay.eg), P(lay.eb), c.layer_norm_eps, M, H, F(p.x0), nullptr, nullptr, nullptr, st));
+    const float* rel = nullptr;
+    if (c.arch == QST_ARCH_MPNET) {
+        QST_TRY(qst_rel_bias_fwd(P(lay.rel), e->rel_lut, A, L, F(p.rel), st));
+        rel = F(p.rel);
+    }
+    const float* x = F(p.x0);
+    for (int l = 0; l < c.num_layers; ++l) {
+        const int b = lay.layer0[l];
+        const X3Layer& a = p.layers[l];
+        QST_TRY(nt3(x, H, P(b + W_QKV), H, F(a.qkv), 3 * H, P(b + B_QKV), nullptr, 0, M, 3 * H, H, 0, st));
+        QST_TRY(qst_attention_fwd_x3(F(a.qkv), mask, rel, nseq, L, A, d, F(a.ctx), st));
+        QST_TRY(nt3(F(a.ctx), H, P(b + W_O), H, F(a.s1), H, P(b + B_O), x, H, M, H, H, 1, st));
+        QST_TRY(qst_ln_fwd(F(a.s1), P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, F(a.y1), nullptr, nullptr, nullptr, st));
+        QST_TRY(nt3(F(a.y1), H, P(b + W_1), H, F(a.u), I, P(b + B_1), nullptr, 0, M, I, H, 0, st));
+        QST_TRY(qst_gelu_f32(F(a.u), (int64_t)M * I, F(a.h), st));
+        QST_TRY(nt3(F(a.h), I, P(b + W_2), I, F(a.s2), H, P(b + B_2), F(a.y1), H, M, H, I, 1, st));
+        QST_TRY(qst_ln_fwd(F(a.s2), P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, M, H, F(a.x), nullptr, nullptr, nullptr, st));
+        x = F(a.x);
+    }
+    QST_TRY(qst_pool_norm_fwd(x, mask, nseq, L, H, c.normalize, out_emb, F(p.pooled), st));
+    if (out_tok) QST_HIP_CHECK(hipMemcpyAsync(out_tok, x, (size_t)M * H * 4, hipMemcpyDeviceToDevice, st));
+    return QST_OK;
+}
+
+// ... and its backward: fp32-class gradients ACCUMULATED into `grads`. Every contraction is a gemm_nt_x3 call: a dgrad
+// against the transposed weight, a wgrad as (dY^T) . (X^T)^T with the token rows as the reduction dimension.
+static int backward_x3(qst_encoder* e, const int64_t* ids, const int64_t* mask, const int64_t* type_ids, int nseq, int L,
+                       const float* params, const float* grad_emb, float* grads, void* saved, size_t saved_bytes,
+                       void* workspace, size_t workspace_bytes, hipStream_t st) {
+    const qst_config& c = e->cfg;
+    const X3TrainPlan p = plan_x3_train(c, nseq, L);
+    const X3BwdPlan w = plan_x3_bwd(c, nseq, L);
+    if (saved_bytes < p.total || workspace_bytes < w.total) return QST_ERR_WORKSPACE;
+    char* sv = (char*)saved;
+    char* ws = (char*)workspace;
+    const int M = nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads, d = H / A;
+    const Layout& lay = e->lay;
+    auto P = [&](int seg) { return params + lay.segs[seg].off; };
+    auto G = [&](int seg) { return grads + lay.segs[seg].off; };
+    auto F = [&](size_t o) { return (float*)(sv + o); };
+    auto Wk = [&](size_t o) { return (float*)(ws + o); };
+    float* dx = Wk(w.dx); float* dy = Wk(w.dy); float* ds = Wk(w.ds); float* dbig = Wk(w.dbig);
+    float* dctx = Wk(w.dctx); float* dqkv = Wk(w.dqkv); float* tA = Wk(w.tA); float* tB = Wk(w.tB); float* wT = Wk(w.wT);
+    // dX[M, in] = dY[M, out] . W[out, in] (+ resid)
+    auto dgrad = [&](const float* dY, int out, int wseg, int in, float* dX, const float* resid) -> int {
+        QST_TRY(qst_transpose_f32(P(wseg), out, in, in, wT, out, st));
+        return nt3(dY, out, wT, out, dX, in, nullptr, resid, in, M, in, out, resid ? 1 : 0, st);
+    };
+    // dW[out, in] += dY^T . X ; db[out] += column sums of dY
+    auto wgrad = [&](const float* dY, int out, const float* X, int in, int wseg, int bseg) -> int {
+        QST_TRY(qst_transpose_f32(dY, M, out, out, tA, M, st));
+        QST_TRY(qst_transpose_f32(X, M, in, in, tB, M, st));
+        QST_TRY(nt3(tA, M, tB, M, G(wseg), in, nullptr, G(wseg), in, out, in, M, 1, st));
+        return qst_colsum_f32(dY, M, out, out, G(bseg), st);
+    };
+    const float* rel = nullptr;
+    float* drel = nullptr;
+    if (c.arch == QST_ARCH_MPNET) {
+        rel = F(p.rel);
+        drel = Wk(w.drel);
+        QST_HIP_CHECK(hipMemsetAsync(drel, 0, (size_t)A * L * L * 4, st));
+    }
+    QST_TRY(qst_pool_norm_bwd(grad_emb, F(p.pooled), mask, nseq, L, H, c.normalize, dx, st));
+    for (int l = c.num_layers - 1; l >= 0; --l) {
+        const int b = lay.layer0[l];
+        const X3Layer& a = p.layers[l];
+        const float* xin = l == 0 ? F(p.x0) : F(p.layers[l - 1].x);
+        QST_TRY(qst_ln_bwd_f32(dx, F(a.s2), P(b + LN2_G), c.layer_norm_eps, M, H, ds, G(b + LN2_G), G(b + LN2_B), st));
+        QST_TRY(dgrad(ds, H, b + W_2, I, dbig, nullptr));                            // dh
+        QST_TRY(wgrad(ds, H, F(a.h), I, b + W_2, b + B_2));
+        QST_TRY(qst_gelu_bwd_f32(dbig, F(a.u), (int64_t)M * I, dbig, st));          // du
+        QST_TRY(dgrad(dbig, I, b + W_1, H, dy, ds));                                 // dy1 = du . W1 + ds2
+        QST_TRY(wgrad(dbig, I, F(a.y1), H, b + W_1, b + B_1));
+        QST_TRY(qst_ln_bwd_f32(dy, F(a.s1), P(b + LN1_G), c.layer_norm_eps, M, H, ds, G(b + LN1_G), G(b + LN1_B), st));
+        QST_TRY(dgrad(ds, H, b + W_O, H, dctx, nullptr));
+        QST_TRY(wgrad(ds, H, F(a.ctx), H, b + W_O, b + B_O));
+        QST_TRY(qst_attention_bwd_f32(F(a.qkv), dctx, mask, rel, nseq, L, A, d, dqkv, drel, st));
+        QST_TRY(dgrad(dqkv, 3 * H, b + W_QKV, H, dx, ds));                           // dx_in = dqkv . Wqkv + ds1
+        QST_TRY(wgrad(dqkv, 3 * H, xin, H, b + W_QKV, b + B_QKV));
+    }
+    QST_TRY(qst_ln_bwd_f32(dx, F(p.s0), P(lay.eg), c.layer_norm_eps, M, H, ds, G(lay.eg), G(lay.eb), st));
+    QST_TRY(qst_embed_bwd(ds, ids, type_ids, (const int32_t*)(sv + p.pos_ids), nseq, L, H, c.type_vocab_size,
+                          G(lay.word), G(lay.pos), lay.type >= 0 ? G(lay.type) : nullptr, st));
+    if (c.arch == QST_ARCH_MPNET) QST_TRY(qst_rel_bias_bwd(drel, e->rel_lut, c.rel_buckets, A, L, G(lay.rel), st));
+    return QST_OK;
+}
+
 extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int64_t* mask, const int64_t* type_ids,
                                    int nseq, int L, const float* params, const void* shadow, float* out_emb,
                                    float* out_tok, void* saved, size_t saved_bytes, int training, void* stream) {
@@ -555,7 +699,7 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     QST_TRY(shape_ok(e, nseq, L));
     const qst_config& c = e->cfg;
     if (c.precision == QST_PREC_BF16X3)
-        return training ? QST_ERR_UNSUPPORTED
+        return training ? forward_x3_train(e, ids, mask, type_ids, nseq, L, params, out_emb, out_tok, saved, saved_bytes, (hipStream_t)stream)
                         : forward_x3(e, ids, mask, type_ids, nseq, L, params, out_emb, out_tok, saved, saved_bytes, (hipStream_t)stream);
     if (!shadow) return QST_ERR_BAD_ARG;
     if (c.precision == QST_PREC_FP8)
@@ -677,8 +821,17 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
     // postponing a layer's weight gradients is sound for layer 0 only: the stage of layer l - 1 overwrites the gradients
     // (ds / dsb / du / dqkv in the workspace) that layer l's launch reads
     if ((skip_wgrad || wgrad_only) && (layer_lo != 0 || layer_hi != 1)) return QST_ERR_BAD_ARG;
-    if (!e || !ids || !mask || !params || !shadow || !grads || !saved || !workspace) return QST_ERR_BAD_ARG;
-    if (e->cfg.precision != QST_PREC_BF16) return QST_ERR_UNSUPPORTED;      // training runs the bf16 path
+    if (!e || !ids || !mask || !params || !grads || !saved || !workspace) return QST_ERR_BAD_ARG;
+    if (e->cfg.precision == QST_PREC_BF16X3) {
+        // the parity path: the whole backward in one call only (no staged exchange, no shadow), L <= 128
+        if (!do_head || !do_embed || skip_wgrad || layer_lo != 0 || layer_hi != e->cfg.num_layers || !grad_emb) return QST_ERR_UNSUPPORTED;
+        if (int rc = shape_ok(e, nseq, L)) return rc;
+        if (L > 128) return QST_ERR_UNSUPPORTED;
+        return backward_x3(e, ids, mask, type_ids, nseq, L, params, grad_emb, grads, saved, saved_bytes, workspace, workspace_bytes,
+                           (hipStream_t)stream);
+    }
+    if (!shadow) return QST_ERR_BAD_ARG;
+    if (e->cfg.precision != QST_PREC_BF16) return QST_ERR_UNSUPPORTED;      // fp8 is inference only
     if (do_head && !grad_emb) return QST_ERR_BAD_ARG;
     if (layer_lo < 0 || layer_hi > e->cfg.num_layers || layer_lo > layer_hi) return QST_ERR_BAD_ARG;
     QST_TRY(shape_ok(e, nseq, L));

@@ -51,6 +51,8 @@ class HipEncoder:
         self.shadow_stale = True
         self._saved: Optional[torch.Tensor] = None
         self._ws: Optional[torch.Tensor] = None
+        self._saved_x3: Optional[torch.Tensor] = None      # activation arena / scratch of the bf16x3 training path
+        self._ws_x3: Optional[torch.Tensor] = None
         self._scratch = torch.zeros(2048, dtype=torch.float32, device=self.device)
         self._step_dev: Optional[torch.Tensor] = None    # device-side optimiser step counter (graph-captured steps)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
@@ -194,8 +196,8 @@ class HipEncoder:
         handle = self._handle_for(precision)
         if handle is self.handle and self.shadow_stale:
             self.refresh_shadow()
-        if handle is not self.handle and training:
-            raise _lib.QstError(f"precision={precision!r} is forward-only; training runs the bf16 path")
+        if training and handle is not self.handle and handle is not self.handle_x3:
+            raise _lib.QstError(f"precision={precision!r} is forward-only; training runs the bf16 path (or bf16x3, the parity path)")
         shadow = self.shadow
         if handle is self.handle_mx and handle is not None:
             if self.shadow_mx_stale:
@@ -205,7 +207,7 @@ class HipEncoder:
         if nbytes == 0:
             raise _lib.QstError(f"unsupported shape nseq={n} L={L} for this encoder (L % 32 == 0, L <= 512)")
         if saved is None:
-            saved = self._arena("_saved", nbytes)
+            saved = self._arena("_saved_x3" if handle is self.handle_x3 and training else "_saved", nbytes)
         emb = torch.empty(n, self.cfg.hidden_size, dtype=torch.float32, device=self.device)
         tok = torch.empty(n, L, self.cfg.hidden_size, dtype=torch.float32, device=self.device) if want_tokens else None
         _lib.check(self.lib.qst_encoder_forward(
@@ -216,14 +218,19 @@ class HipEncoder:
             self.dropout_step += 1           # mirrors the device counter (tests rebuild this step's masks from it)
         return emb, tok, saved
 
-    def backward(self, ids, mask, type_ids, grad_emb: torch.Tensor, saved: torch.Tensor) -> None:
-        """Accumulate d(loss)/d(params) into self.grads given d(loss)/d(emb)."""
+    def backward(self, ids, mask, type_ids, grad_emb: torch.Tensor, saved: torch.Tensor, precision: str = "bf16") -> None:
+        """Accumulate d(loss)/d(params) into self.grads given d(loss)/d(emb). precision="bf16x3": the fp32-class backward
+        of a forward(training=True, precision="bf16x3") (the parity path: L <= 128, no dropout, one call)."""
         self.ensure_train_state()
         n, L = ids.shape
-        ws = self._arena("_ws", self.lib.qst_encoder_bwd_workspace_bytes(self.handle, n, L))
+        handle = self._handle_for(precision)
+        if handle is not self.handle and handle is not self.handle_x3:
+            raise _lib.QstError(f"precision={precision!r} has no backward")
+        nws = self.lib.qst_encoder_bwd_workspace_bytes(handle, n, L)
+        ws = self._arena("_ws_x3" if handle is self.handle_x3 else "_ws", nws)
         grad_emb = grad_emb.contiguous()
         _lib.check(self.lib.qst_encoder_backward(
-            self.handle, ids.data_ptr(), mask.data_ptr(), _lib.ptr(type_ids), n, L, self.params.data_ptr(),
+            handle, ids.data_ptr(), mask.data_ptr(), _lib.ptr(type_ids), n, L, self.params.data_ptr(),
             self.shadow.data_ptr(), grad_emb.data_ptr(), self.grads.data_ptr(), saved.data_ptr(), saved.numel(),
             ws.data_ptr(), ws.numel(), _lib.current_stream_ptr()), "qst_encoder_backward")
 

@@ -139,13 +139,14 @@ class _EncodeFn(torch.autograd.Function):
             emb, _, _ = enc.forward(ids, mask, types, training=False, precision=model.inference_precision)
             return emb
         saved = None
+        prec = model.training_precision if training == 1 else "bf16"
         if training == 1:
             n, L = ids.shape
-            nbytes = enc.lib.qst_encoder_saved_bytes(enc.handle, n, L, 1)
+            nbytes = enc.lib.qst_encoder_saved_bytes(enc._handle_for(prec), n, L, 1)
             saved = torch.empty(nbytes, dtype=torch.uint8, device=enc.device)   # one arena per live graph
         # training == 2: a train()-mode pass without autograd (dropout on, nothing to keep): the shared activation arena
-        emb, _, saved = enc.forward(ids, mask, types, training=bool(training), saved=saved)
-        ctx.model, ctx.saved, ctx.inputs = model, saved, (ids, mask, types)
+        emb, _, saved = enc.forward(ids, mask, types, training=bool(training), saved=saved, precision=prec)
+        ctx.model, ctx.saved, ctx.inputs, ctx.prec = model, saved, (ids, mask, types), prec
         if training == 1:
             model._live_graphs += 1
         return emb
@@ -165,7 +166,7 @@ class _EncodeFn(torch.autograd.Function):
                                                dp["group"], dp["overlap"])
             model._dp_reduced = True
         else:
-            model._enc.backward(ids, mask, types, grad_emb, ctx.saved)
+            model._enc.backward(ids, mask, types, grad_emb, ctx.saved, precision=ctx.prec)
         ctx.saved = None
         return None, None, None, None, None, None
 
@@ -237,6 +238,9 @@ class SentenceTransformer(nn.Module):
             self._synthetic_tokenizer = SyntheticTokenizer(cfg)
         # "bf16" (throughput) or "bf16x3" (fp32-class parity path) for no-grad forwards: encode() and evaluators
         self.inference_precision = "bf16"
+        # "bf16" or "bf16x3" for forwards that keep a graph (fit(precision=...)): the parity path trains with fp32-class
+        # gradients as the reference's fp32 run does (training/main.py:142) -- single process, no dropout, L <= 128
+        self.training_precision = "bf16"
         self._live_graphs = 0          # training forwards whose backward has not run yet
         self._dp = None                # data-parallel state of a running fit(): {"group", "buckets", "overlap"}
         self._dp_works, self._dp_reduced = [], False
@@ -378,11 +382,13 @@ class SentenceTransformer(nn.Module):
             callback: Callable[[float, int, int], None] = None, show_progress_bar: bool = True,
             checkpoint_path: str = None, checkpoint_save_steps: int = 500, checkpoint_save_total_limit: int = 0,
             resume_from_checkpoint: str = None, data_parallel: Optional[str] = None, process_group=None,
-            overlap_grad_reduce: bool = True, dropout="config", dropout_seed: int = 0):
+            overlap_grad_reduce: bool = True, dropout="config", dropout_seed: int = 0, precision: str = "bf16"):
         """Same keyword set as sentence-transformers 2.2.2 `fit` (the reference passes all of them,
         training/main.py:128-148) plus `resume_from_checkpoint`: a checkpoint directory written by this method
         (weights + Adam moments + step counters; the reference's checkpoints hold weights only)
-        from which training continues with the schedule where it stopped.
+        from which training continues with the schedule where it stopped; and `precision`: "bf16" (default) or "bf16x3", the
+        parity path -- forward and backward as split-bf16 x3 products with fp32 activations, gradients within 1e-4 of fp32
+        autograd (the reference trains in fp32, training/main.py:142); single process, dropout=0, seq_len <= 128.
 
         Data parallelism (one process per GPU, e.g. the unchanged training script under
         `python -m torch.distributed.run`): when torch.distributed is initialised with more than one rank, every step's
@@ -460,6 +466,11 @@ class SentenceTransformer(nn.Module):
         if not is_main and evaluator is not None and output_path is not None:
             scratch_dir = tempfile.mkdtemp(prefix=f"qst_eval_rank{rank}_")
             eval_out = scratch_dir
+        if precision not in ("bf16", "bf16x3"):
+            raise ValueError("fit(precision=...) is 'bf16' or 'bf16x3'")
+        if precision == "bf16x3" and (world > 1 or p_hidden > 0 or p_attn > 0):
+            raise ValueError("fit(precision='bf16x3') is the single-process parity path: pass dropout=0 and run one process")
+        self.training_precision = precision
         enc.set_dropout(p_hidden, p_attn, int(dropout_seed) + rank)
         global_step = 0
         if resume_from_checkpoint is not None:
@@ -524,6 +535,7 @@ class SentenceTransformer(nn.Module):
             shutil.rmtree(scratch_dir, ignore_errors=True)
         self._dp = None
         enc.set_dropout(0.0, 0.0)
+        self.training_precision = "bf16"
         if evaluator is None and output_path is not None and is_main:
             self.save(output_path)
         if checkpoint_path is not None and is_main:

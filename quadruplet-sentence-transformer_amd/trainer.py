@@ -129,11 +129,20 @@ class QuadrupletTrainer:
                  lr: float = 2e-5, weight_decay: float = 0.01, max_grad_norm: float = 1.0,
                  betas=(0.9, 0.999), eps: float = 1e-8, warmup_steps: int = 0, total_steps: int = 0,
                  process_group=None, world_size: int = 1, overlap: bool = True, encoder: Optional[HipEncoder] = None,
-                 use_graph: bool = False, dropout=None, dropout_seed: int = 0, force_dp: bool = False):
-        """dropout: None / 0 = off; a float p = HF's hidden_dropout_prob = attention_probs_dropout_prob = p; a pair
+                 use_graph: bool = False, dropout=None, dropout_seed: int = 0, force_dp: bool = False,
+                 precision: str = "bf16"):
+        """precision: "bf16" (the throughput path) or "bf16x3" -- the parity path: fp32 activations, every product as three
+        split-bf16 MFMAs, gradients fp32-class (the reference trains in fp32, training/main.py:142). Single process, no
+        dropout, L <= 128, several times slower.
+        dropout: None / 0 = off; a float p = HF's hidden_dropout_prob = attention_probs_dropout_prob = p; a pair
         (p_hidden, p_attn). The reference's fit() trains with 0.1 (HF config defaults, train() mode). Ranks of a
         data-parallel job should pass different dropout_seed values (fit() adds the rank)."""
         self.cfg = cfg
+        if precision not in ("bf16", "bf16x3"):
+            raise ValueError("training precision is 'bf16' or 'bf16x3'")
+        if precision == "bf16x3" and (world_size > 1 or force_dp or use_graph or dropout):
+            raise ValueError("precision='bf16x3' is the single-process parity path: no data parallelism, graph or dropout")
+        self.precision = precision
         self.enc = encoder if encoder is not None else HipEncoder(cfg, device=device)
         if arena is not None:
             self.enc.load_arena(arena)
@@ -221,9 +230,14 @@ class QuadrupletTrainer:
                     ws: Optional[torch.Tensor] = None) -> torch.Tensor:
         enc = self.enc
         loss, _, g, saved, (ids, mask, types) = self.forward_loss(ids4, mask4, types4, training=True, want_grads=True,
-                                                                 saved=saved)
-        for w in staged_backward(enc, ids, mask, types, stacked(g), saved, ws,
-                                 self.buckets if (self.world > 1 or self.force_dp) else None, self.group, self.overlap):
+                                                                 saved=saved, precision=self.precision)
+        if self.precision == "bf16x3":
+            enc.backward(ids, mask, types, stacked(g), saved, precision="bf16x3")
+            works = []
+        else:
+            works = staged_backward(enc, ids, mask, types, stacked(g), saved, ws,
+                                    self.buckets if (self.world > 1 or self.force_dp) else None, self.group, self.overlap)
+        for w in works:
             w.wait()
         if sched_on_device:
             opt0 = enc.opt_step

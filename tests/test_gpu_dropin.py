@@ -169,6 +169,35 @@ def test_fit_trains_saves_and_reloads(model, tmp_path):
                   optimizer_params={"lr": 1e-4}, output_path=str(tmp_path / "out2"), show_progress_bar=False)
 
 
+def test_fit_at_parity_precision(tmp_path):
+    """fit(precision="bf16x3"): the reference's training call on the fp32-class path (forward AND backward as split-bf16 x3
+    products; the reference trains in fp32, training/main.py:142). Same data, same seed, same schedule as a bf16 fit: both
+    train, and the two end close to each other (they differ by the bf16 path's operand rounding, not in kind); dropout or
+    several ranks are refused for this path."""
+    def run(prec):
+        torch.manual_seed(0)
+        m = SentenceTransformer("tiny-bert", device="cuda")
+        loss = GammaQuadrupletLoss(gamma=0.6, margin_pos_neg=1.0, margin_pos_part=0.5, margin_part_neg=0.5, p=2.0)
+        lm = QuadrupletSentenceTransformerLossModel(m, loss)
+        data = [to_input_example(quad(i)) for i in range(16)]
+        dl = DataLoader(data, batch_size=8, shuffle=False, num_workers=0)
+        ev = CountingEvaluator(lm, data[:8])
+        m.fit(train_objectives=[(dl, lm)], evaluator=ev, epochs=3, scheduler="warmuplinear", warmup_steps=2,
+              optimizer_params={"lr": 2e-3}, evaluation_steps=0, output_path=str(tmp_path / prec), show_progress_bar=False,
+              dropout=0, precision=prec)
+        return m, ev
+    m3, ev3 = run("bf16x3")
+    m1, ev1 = run("bf16")
+    assert ev3.calls[-1][2] < ev3.calls[0][2], "validation loss did not go down on the parity path"
+    assert m3.training_precision == "bf16"                      # restored after fit
+    d = (m3._enc.params - m1._enc.params).abs()
+    moved = (m3._enc.params - SentenceTransformer("tiny-bert", device="cuda")._enc.params).abs().mean()
+    assert float(d.mean()) < 0.25 * float(moved)
+    with pytest.raises(ValueError):
+        m3.fit(train_objectives=[(DataLoader([to_input_example(quad(0))] * 8, batch_size=8), QuadrupletSentenceTransformerLossModel(
+            m3, GammaQuadrupletLoss(gamma=0.6))) ], epochs=1, show_progress_bar=False, dropout=0.1, precision="bf16x3")
+
+
 def test_named_parameters_are_views_with_hf_names(model):
     names = dict(model.named_parameters())
     assert "0.auto_model.embeddings.word_embeddings.weight" in names
