@@ -382,6 +382,33 @@ def distinct_gpus_or_exit(rank, world, dev_index):
         raise SystemExit(3)
 
 
+def time_fp8_training(trainer, cfg, batches, steps, B, ms_bf16_nodrop):
+    """BASELINE configs[4] as a training configuration: the full step with the forward's Linears on the fp8 matrix cores
+    (MXFP8 weights and activations) and the bf16 backward over what that forward kept; no dropout (the path has none)."""
+    import torch
+    from quadruplet_sentence_transformer_amd.trainer import QuadrupletTrainer
+    try:
+        trainer.enc.set_dropout(0.0, 0.0)
+        tr = QuadrupletTrainer(cfg, encoder=trainer.enc, lr=2e-5, weight_decay=0.01, max_grad_norm=1.0, warmup_steps=10000,
+                               total_steps=1000000, precision="fp8")
+        for i in range(3):
+            tr.step(*batches[i % len(batches)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            tr.step(*batches[i % len(batches)])
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        out = {"value": round(B / (ms * 1e-3), 1), "unit": "quadruplets/s", "ms_per_step": round(ms, 4),
+               "what": "the training step with every forward Linear on the fp8 matrix cores (QST_PREC_FP8 training forward) "
+                       "and the bf16 backward; dropout off"}
+        if ms_bf16_nodrop:
+            out["speedup_vs_bf16_step_without_dropout"] = round(ms_bf16_nodrop / ms, 3)
+        return out
+    except Exception as ex:                               # a side figure must not take the bench line down
+        return {"error": f"{type(ex).__name__}: {ex}"}
+
+
 def time_dp_rccl_ws1(trainer, cfg, batches, steps, B, ms_dp1):
     """The data-parallel step on the ONE GPU a test box has: init_process_group("nccl", world_size=1) and the staged backward
     with its seven asynchronous RCCL all-reduces (one per layer bucket + the embedding bucket) in place -- what every rank of
@@ -586,6 +613,8 @@ def main():
                                        "what": "same on the fp8 matrix cores: MXFP8 weights AND activations, block-scaled MFMA "
                                                "(QST_PREC_FP8, inference; BASELINE configs[4])",
                                        "mfma_frac_of_fp8_peak": round(B / t_m * fwd_flops_q / 1e12 / (2 * PEAK_BF16_TFLOPS), 4)}
+                out["train_step_fp8_forward"] = time_fp8_training(trainer, cfg, batches, max(5, args.steps // 2), B,
+                                                                  no_drop["ms_per_step"] if no_drop else None)
             t_3 = time_fwd_only(trainer, batches, max(5, args.steps // 2), precision="bf16x3")
             out["fwd_only_bf16x3"] = {"value": round(B / t_3, 1), "unit": "quadruplets/s", "ms_per_step": round(t_3 * 1e3, 4),
                                       "what": "same, parity precision (split-bf16 x3 MFMA, fp32 activations): the "

@@ -15,7 +15,8 @@
  * operands with fp32 accumulation. precision = QST_PREC_BF16X3 splits every
  * fp32 operand into hi+lo bf16 and issues three MFMAs (fp32-class accuracy,
  * the parity mode); QST_PREC_BF16 rounds operands once (the throughput mode);
- * QST_PREC_FP8 (inference only; BASELINE configs[4] "fp8 weights ... CDNA4 fp8 MFMA GEMMs") runs every Linear on the fp8 matrix
+ * QST_PREC_FP8 (BASELINE configs[4] "fp8 weights ... CDNA4 fp8 MFMA GEMMs"; inference, and with training != 0 the forward
+ * of a training step whose backward is the bf16 one: qst_encoder_backward* on this handle with the bf16 shadows) runs every Linear on the fp8 matrix
  * cores: weights AND activations as OCP MXFP8 (e4m3 elements, one E8M0 scale per 32 input features;
  * v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulation), attention in bf16, residual stream / LayerNorm in fp32.
  */

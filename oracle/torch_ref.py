@@ -231,12 +231,32 @@ def _mx(x: torch.Tensor, via_bf16: bool) -> torch.Tensor:
     return mx_quant(x)[2]
 
 
+class _LinearMxFwdBf16Bwd(torch.autograd.Function):
+    """One Linear of the fp8 TRAINING path (csrc/qst_api.hip forward_mx_train + the bf16 backward): the forward product is
+    taken on MXFP8 operands, the backward is the bf16 path's -- dX = bf16(dY) . bf16(W), dW = bf16(dY)^T . bf16(X), db = column
+    sums of the bf16-rounded dY -- on the UNquantised operands (fp32 master weights; the bf16 copy of the activation)."""
+
+    @staticmethod
+    def forward(ctx, a, w, b, a_via_bf16):
+        ctx.save_for_backward(a.to(torch.bfloat16).to(torch.float32), w.to(torch.bfloat16).to(torch.float32))
+        return F.linear(_mx(a, a_via_bf16), _mx(w, False), b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a16, w16 = ctx.saved_tensors
+        g16 = g.to(torch.bfloat16).to(torch.float32)
+        g2, a2 = g16.reshape(-1, g16.shape[-1]), a16.reshape(-1, a16.shape[-1])
+        return (g16.double() @ w16.double()).float(), (g2.double().t() @ a2.double()).float(), g2.sum(0), None
+
+
 def encoder_forward_mx(P: Dict[str, torch.Tensor], cfg, ids: torch.Tensor, mask: torch.Tensor,
-                       type_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       type_ids: Optional[torch.Tensor] = None, train: bool = False) -> torch.Tensor:
     """QST_PREC_FP8 oracle (inference): encoder_forward with every Linear computed on MXFP8 operands -- weights
     quantised from fp32; the layer input, the attention output and the LayerNorm-1 output quantised from their bf16
     copies; gelu(u) quantised from fp32 (it never exists in another format) -- and attention on bf16 operands, as the
-    HIP pipeline does (csrc/qst_api.hip forward_mx)."""
+    HIP pipeline does (csrc/qst_api.hip forward_mx). train=True: the fp8 TRAINING forward (forward_mx_train) with the bf16
+    path's backward attached to every Linear (_LinearMxFwdBf16Bwd) -- autograd through the result is the oracle of
+    "fp8 forward GEMMs, bf16 dgrad / wgrad"."""
     n, L = ids.shape
     H, A = cfg.hidden_size, cfg.num_heads
     d = H // A
@@ -256,6 +276,8 @@ def encoder_forward_mx(P: Dict[str, torch.Tensor], cfg, ids: torch.Tensor, mask:
     add_mask = (1.0 - mask[:, None, None, :].to(torch.float32)) * neg
 
     def lin(a, w, b, via_bf16):
+        if train:
+            return _LinearMxFwdBf16Bwd.apply(a, w, b, via_bf16)
         return F.linear(_mx(a, via_bf16), _mx(w, False), b)
     for l in range(cfg.num_layers):
         p = f"layer.{l}."
@@ -270,6 +292,6 @@ def encoder_forward_mx(P: Dict[str, torch.Tensor], cfg, ids: torch.Tensor, mask:
         a = lin(ctx, P[p + "w_o"], P[p + "b_o"], True)
         x = F.layer_norm(a + x, (H,), P[p + "ln1_g"], P[p + "ln1_b"], cfg.layer_norm_eps)
         h = F.gelu(lin(x, P[p + "w_1"], P[p + "b_1"], True))
-        o = lin(h, P[p + "w_2"], P[p + "b_2"], False)
+        o = lin(h, P[p + "w_2"], P[p + "b_2"], train)        # (training keeps gelu(u) as bf16 and quantises that copy)
         x = F.layer_norm(o + x, (H,), P[p + "ln2_g"], P[p + "ln2_b"], cfg.layer_norm_eps)
     return x

@@ -1151,6 +1151,7 @@ extern "C" int qst_gemm_nt_f8(const QstGemmArgs* a, int epi, void* stream) {
     switch (epi) {
         case QST_EPI_BF16: return a->ldc % 4 ? QST_ERR_UNSUPPORTED : launch_nt_f8<QST_EPI_BF16>(a, st);
         case QST_EPI_F32_RESID: return a->ldc % 4 ? QST_ERR_UNSUPPORTED : launch_nt_f8<QST_EPI_F32_RESID>(a, st);
+        case QST_EPI_GELU: return (!a->C2 || a->ldc % 4) ? QST_ERR_UNSUPPORTED : launch_nt_f8<QST_EPI_GELU>(a, st);
         case QST_EPI_GELU_MX:
             if (!a->C2 || a->ldc % 32 != 0 || a->N % 32 != 0) return QST_ERR_UNSUPPORTED;
             return launch_nt_f8<QST_EPI_GELU_MX_>(a, st);

@@ -459,10 +459,25 @@ constexpr int kFuseLnMinRows = 16384;      // token rows from which the fused GE
 
 }  // namespace
 
+// (behind the bf16 activation arena of an fp8 TRAINING forward: the MXFP8 operand copies; see forward_mx_train)
+struct MxTrainTmp { size_t xq, xs, cq, cs, yq, ys, hq, hs, total; };
+static MxTrainTmp plan_mx_train_tmp(const qst_config& c, int nseq, int L, size_t base) {
+    MxTrainTmp t;
+    const size_t M = (size_t)nseq * L, H = c.hidden_size, I = c.intermediate_size;
+    size_t off = base;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    t.xq = take(M * H); t.xs = take(M * H / 32 + 1024);
+    t.cq = take(M * H); t.cs = take(M * H / 32 + 1024);
+    t.yq = take(M * H); t.ys = take(M * H / 32 + 1024);
+    t.hq = take(M * I); t.hs = take(M * I / 32 + 1024);
+    t.total = off;
+    return t;
+}
 extern "C" size_t qst_encoder_saved_bytes(const qst_encoder* e, int nseq, int L, int training) {
     if (shape_ok(e, nseq, L) != QST_OK) return 0;
     if (e->cfg.precision == QST_PREC_BF16X3) return training ? plan_x3_train(e->cfg, nseq, L).total : plan_x3(e->cfg, nseq, L).total;
-    if (e->cfg.precision == QST_PREC_FP8) return training ? 0 : plan_mx(e->cfg, nseq, L).total;
+    if (e->cfg.precision == QST_PREC_FP8)
+        return training ? plan_mx_train_tmp(e->cfg, nseq, L, plan_acts(e->cfg, nseq, L, true).total).total : plan_mx(e->cfg, nseq, L).total;
     return plan_acts(e->cfg, nseq, L, training != 0).total;
 }
 extern "C" size_t qst_encoder_bwd_workspace_bytes(const qst_encoder* e, int nseq, int L) {
@@ -543,6 +558,76 @@ static int forward_mx(qst_encoder* e, const int64_t* ids, const int64_t* mask, c
         QST_TRY(gemm(sv + p.hq, sv + p.hs, I, b + W_2, s, nullptr, H, b + B_2, y1, QST_EPI_F32_RESID));
         QST_TRY(qst_ln_fwd_mx(s, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, M, H, xn, nullptr, sv + p.xq, sv + p.xs, st));
         x = xn;
+    }
+    QST_TRY(qst_pool_norm_fwd(x, mask, nseq, L, H, c.normalize, out_emb, (float*)(sv + p.pooled), st));
+    if (out_tok) QST_HIP_CHECK(hipMemcpyAsync(out_tok, x, (size_t)M * H * 4, hipMemcpyDeviceToDevice, st));
+    return QST_OK;
+}
+
+// QST_PREC_FP8 TRAINING forward (BASELINE configs[4] as a fine-tuning configuration): every Linear of the forward runs on
+// the fp8 matrix cores (MXFP8 weights and activations, as forward_mx) and leaves, in the bf16 path's activation arena
+// (ActPlan), exactly what the bf16 backward reads -- bf16 copies of every GEMM input, xhat / rstd of every LayerNorm, the
+// attention statistics, gelu'(u) and h. The backward is then qst_encoder_backward_stage as it is, on the bf16 shadows:
+// fp8 forward GEMMs, bf16 dgrad / wgrad from fp32 master weights. The MXFP8 operand copies live behind the arena.
+static int forward_mx_train(qst_encoder* e, const int64_t* ids, const int64_t* mask, const int64_t* type_ids, int nseq, int L,
+                            const float* params, const void* shadow, float* out_emb, float* out_tok, void* saved,
+                            size_t saved_bytes, hipStream_t st) {
+    const qst_config& c = e->cfg;
+    const ActPlan p = plan_acts(c, nseq, L, true);
+    const MxTrainTmp t = plan_mx_train_tmp(c, nseq, L, p.total);
+    if (saved_bytes < t.total) return QST_ERR_WORKSPACE;
+    char* sv = (char*)saved;
+    const int M = nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads, d = H / A;
+    const Layout& lay = e->lay;
+    auto P = [&](int seg) { return params + lay.segs[seg].off; };
+    auto WQ = [&](int seg) { return (const uint8_t*)shadow + lay.segs[seg].shadow_off; };
+    auto WS = [&](int seg) { return (const uint8_t*)shadow + lay.segs[seg].shadow_off + qst_align_up(lay.segs[seg].numel, kAlign); };
+    auto gemm = [&](const void* Aq, const void* As, int K, int wseg, void* Cout, void* C2, int N, int bseg, const float* resid, int epi) {
+        QstGemmArgs g{};
+        g.A = Aq; g.aux = As; g.B = WQ(wseg); g.bscale = (const float*)WS(wseg); g.C = Cout; g.C2 = C2; g.bias = P(bseg); g.resid = resid;
+        g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.ldr = N;
+        return qst_gemm_nt_f8(&g, epi, st);
+    };
+    // a backward over this arena must not look for dropout masks: record "none" for it
+    {
+        qst_encoder::FwdRec* rec = nullptr;
+        for (auto& r : e->fwd_recs) if (r.saved == saved) rec = &r;
+        if (!rec) { rec = &e->fwd_recs[e->fwd_next]; e->fwd_next = (e->fwd_next + 1) % 16; }
+        *rec = qst_encoder::FwdRec{saved, 0u, 0u};
+    }
+    int32_t* pos_ids = (int32_t*)(sv + p.pos_ids);
+    QST_TRY(qst_position_ids(ids, nseq, L, c.arch, c.pad_token_id, pos_ids, st));
+    QST_TRY(qst_embed_ln_fwd_mx_train(ids, type_ids, pos_ids, P(lay.word), P(lay.pos), lay.type >= 0 ? P(lay.type) : nullptr,
+                                      P(lay.eg), P(lay.eb), c.layer_norm_eps, M, H, (float*)(sv + p.x0), sv + p.x0b, sv + p.xh0,
+                                      (float*)(sv + p.rs0), sv + t.xq, sv + t.xs, st));
+    const float* rel = nullptr;
+    if (c.arch == QST_ARCH_MPNET) {
+        QST_TRY(qst_rel_pos_fwd(P(lay.rel), e->rel_lut, A, L, (float*)(sv + p.rel), st));
+        rel = (const float*)(sv + p.rel);
+    }
+    const float* x = (const float*)(sv + p.x0);
+    float* s = (float*)(sv + p.s_scratch);
+    for (int l = 0; l < c.num_layers; ++l) {
+        const LayerAct& a = p.layers[l];
+        const int b = lay.layer0[l];
+        QST_TRY(gemm(sv + t.xq, sv + t.xs, H, b + W_QKV, sv + a.qkv, nullptr, 3 * H, b + B_QKV, nullptr, QST_EPI_BF16));
+        {
+            QstAttnDesc q{};
+            q.qkv = sv + a.qkv; q.mask = mask; q.rel_pos = rel; q.nseq = nseq; q.L = L; q.A = A; q.d = d;
+            q.ctx = sv + a.ctx; q.lse = (float*)(sv + a.lse);
+            QST_TRY(qst_attention_fwd_ex(&q, st));
+        }
+        QST_TRY(qst_quant_mx(sv + a.ctx, 1, M, H, sv + t.cq, sv + t.cs, st));
+        QST_TRY(gemm(sv + t.cq, sv + t.cs, H, b + W_O, s, nullptr, H, b + B_O, x, QST_EPI_F32_RESID));
+        QST_TRY(qst_ln_fwd_mx_train(s, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, (float*)(sv + a.y1), sv + a.y1b,
+                                    sv + a.xh1, (float*)(sv + a.rs1), sv + t.yq, sv + t.ys, st));
+        // FFN-1: gelu'(u) and h leave as bf16 (the backward's operands); h is quantised for FFN-2 in a pass of its own
+        QST_TRY(gemm(sv + t.yq, sv + t.ys, H, b + W_1, sv + a.u, sv + a.hact, I, b + B_1, nullptr, QST_EPI_GELU));
+        QST_TRY(qst_quant_mx(sv + a.hact, 1, M, I, sv + t.hq, sv + t.hs, st));
+        QST_TRY(gemm(sv + t.hq, sv + t.hs, I, b + W_2, s, nullptr, H, b + B_2, (const float*)(sv + a.y1), QST_EPI_F32_RESID));
+        QST_TRY(qst_ln_fwd_mx_train(s, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, M, H, (float*)(sv + a.x), sv + a.xb,
+                                    sv + a.xh2, (float*)(sv + a.rs2), sv + t.xq, sv + t.xs, st));
+        x = (const float*)(sv + a.x);
     }
     QST_TRY(qst_pool_norm_fwd(x, mask, nseq, L, H, c.normalize, out_emb, (float*)(sv + p.pooled), st));
     if (out_tok) QST_HIP_CHECK(hipMemcpyAsync(out_tok, x, (size_t)M * H * 4, hipMemcpyDeviceToDevice, st));
@@ -703,7 +788,7 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
                         : forward_x3(e, ids, mask, type_ids, nseq, L, params, out_emb, out_tok, saved, saved_bytes, (hipStream_t)stream);
     if (!shadow) return QST_ERR_BAD_ARG;
     if (c.precision == QST_PREC_FP8)
-        return training ? QST_ERR_UNSUPPORTED
+        return training ? forward_mx_train(e, ids, mask, type_ids, nseq, L, params, shadow, out_emb, out_tok, saved, saved_bytes, (hipStream_t)stream)
                         : forward_mx(e, ids, mask, type_ids, nseq, L, params, shadow, out_emb, out_tok, saved, saved_bytes, (hipStream_t)stream);
     const ActPlan p = plan_acts(c, nseq, L, training != 0);
     if (saved_bytes < p.total) return QST_ERR_WORKSPACE;
@@ -831,7 +916,7 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
                            (hipStream_t)stream);
     }
     if (!shadow) return QST_ERR_BAD_ARG;
-    if (e->cfg.precision != QST_PREC_BF16) return QST_ERR_UNSUPPORTED;      // fp8 is inference only
+    // (a QST_PREC_FP8 handle: the bf16 backward over the arena its training forward filled; `shadow` = the bf16 shadows)
     if (do_head && !grad_emb) return QST_ERR_BAD_ARG;
     if (layer_lo < 0 || layer_hi > e->cfg.num_layers || layer_lo > layer_hi) return QST_ERR_BAD_ARG;
     QST_TRY(shape_ok(e, nseq, L));

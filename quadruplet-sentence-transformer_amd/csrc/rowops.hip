@@ -685,6 +685,34 @@ extern "C" int qst_ln_fwd_mx(const float* s, const float* gamma, const float* be
     return QST_OK;
 }
 
+// The same two with everything a backward needs as well (fp8 TRAINING forward: the LayerNorm output goes to the next GEMM as
+// MXFP8 and to the bf16 backward as y_bf16 / xhat / rstd)
+extern "C" int qst_embed_ln_fwd_mx_train(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
+                                         const float* word_emb, const float* pos_emb, const float* type_emb,
+                                         const float* gamma, const float* beta, float eps, int M, int H, float* y,
+                                         void* y_bf16, void* xhat_bf16, float* rstd, void* yq, void* ys, void* stream) {
+    if (!ids || !pos_ids || !word_emb || !pos_emb || !gamma || !beta || !y || !y_bf16 || !xhat_bf16 || !rstd || !yq || !ys ||
+        M <= 0 || H <= 0)
+        return QST_ERR_BAD_ARG;
+    if (H % 64 != 0) return QST_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    QST_VPL_DISPATCH(H, (embed_ln_fwd_kernel<VPL><<<(M + 4 * EMB_ROWS - 1) / (4 * EMB_ROWS), 256, 0, st>>>(
+                            ids, type_ids, pos_ids, word_emb, pos_emb, type_emb, gamma, beta, eps, M, H, y,
+                            (bf16*)y_bf16, (bf16*)xhat_bf16, rstd, (uint8_t*)yq, (uint8_t*)ys, kNoDrop)));
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+extern "C" int qst_ln_fwd_mx_train(const float* s, const float* gamma, const float* beta, float eps, int M, int H, float* y,
+                                   void* y_bf16, void* xhat_bf16, float* rstd, void* yq, void* ys, void* stream) {
+    if (!s || !gamma || !beta || !y || !y_bf16 || !xhat_bf16 || !rstd || !yq || !ys || M <= 0 || H <= 0) return QST_ERR_BAD_ARG;
+    if (H % 64 != 0) return QST_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    QST_VPL_DISPATCH(H, (ln_fwd_kernel<VPL><<<(M + 3) / 4, 256, 0, st>>>(s, gamma, beta, eps, M, H, y, (bf16*)y_bf16,
+                                                                         (bf16*)xhat_bf16, rstd, (uint8_t*)yq, (uint8_t*)ys)));
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
 extern "C" int qst_ln_fwd(const float* s, const float* gamma, const float* beta, float eps, int M, int H,
                           float* y, void* y_bf16, void* xhat_bf16, float* rstd, void* stream) {
     if (!s || !gamma || !beta || !y || M <= 0 || H <= 0 || (H & 1)) return QST_ERR_BAD_ARG;

@@ -190,14 +190,14 @@ class HipEncoder:
                 precision: str = "bf16"):
         """ids/mask int64 [n, L] on this device, L % 32 == 0. Returns (emb [n,H], tok [n,L,H] or None, saved).
         precision="bf16x3" runs the fp32-class parity path, "fp8" the fp8 matrix-core path (MXFP8 weights and
-        activations) -- both forward only."""
+        activations). training=True keeps what the matching backward(precision=...) needs."""
         assert ids.dtype == torch.int64 and mask.dtype == torch.int64 and ids.is_cuda and ids.is_contiguous()
         n, L = ids.shape
         handle = self._handle_for(precision)
-        if handle is self.handle and self.shadow_stale:
-            self.refresh_shadow()
-        if training and handle is not self.handle and handle is not self.handle_x3:
-            raise _lib.QstError(f"precision={precision!r} is forward-only; training runs the bf16 path (or bf16x3, the parity path)")
+        if self.shadow_stale and (handle is self.handle or (training and handle is self.handle_mx)):
+            self.refresh_shadow()                    # (an fp8 training forward: its backward runs on the bf16 shadows)
+        if training and handle is self.handle_mx and self.dropout is not None:
+            raise _lib.QstError("precision='fp8' trains without dropout (set_dropout(0, 0))")
         shadow = self.shadow
         if handle is self.handle_mx and handle is not None:
             if self.shadow_mx_stale:
@@ -207,7 +207,7 @@ class HipEncoder:
         if nbytes == 0:
             raise _lib.QstError(f"unsupported shape nseq={n} L={L} for this encoder (L % 32 == 0, L <= 512)")
         if saved is None:
-            saved = self._arena("_saved_x3" if handle is self.handle_x3 and training else "_saved", nbytes)
+            saved = self._arena("_saved_x3" if handle is not self.handle and training else "_saved", nbytes)
         emb = torch.empty(n, self.cfg.hidden_size, dtype=torch.float32, device=self.device)
         tok = torch.empty(n, L, self.cfg.hidden_size, dtype=torch.float32, device=self.device) if want_tokens else None
         _lib.check(self.lib.qst_encoder_forward(
@@ -220,12 +220,13 @@ class HipEncoder:
 
     def backward(self, ids, mask, type_ids, grad_emb: torch.Tensor, saved: torch.Tensor, precision: str = "bf16") -> None:
         """Accumulate d(loss)/d(params) into self.grads given d(loss)/d(emb). precision="bf16x3": the fp32-class backward
-        of a forward(training=True, precision="bf16x3") (the parity path: L <= 128, no dropout, one call)."""
+        of a forward(training=True, precision="bf16x3") (the parity path: L <= 128, no dropout, one call); "fp8": the bf16
+        backward over what a forward(training=True, precision="fp8") kept (fp8 forward GEMMs, bf16 dgrad / wgrad)."""
         self.ensure_train_state()
         n, L = ids.shape
         handle = self._handle_for(precision)
-        if handle is not self.handle and handle is not self.handle_x3:
-            raise _lib.QstError(f"precision={precision!r} has no backward")
+        if handle is self.handle_mx and self.shadow_stale:
+            self.refresh_shadow()                    # the backward's operands are the bf16 shadows
         nws = self.lib.qst_encoder_bwd_workspace_bytes(handle, n, L)
         ws = self._arena("_ws_x3" if handle is self.handle_x3 else "_ws", nws)
         grad_emb = grad_emb.contiguous()

@@ -131,17 +131,21 @@ class QuadrupletTrainer:
                  process_group=None, world_size: int = 1, overlap: bool = True, encoder: Optional[HipEncoder] = None,
                  use_graph: bool = False, dropout=None, dropout_seed: int = 0, force_dp: bool = False,
                  precision: str = "bf16"):
-        """precision: "bf16" (the throughput path) or "bf16x3" -- the parity path: fp32 activations, every product as three
+        """precision: "bf16" (the throughput path); "fp8" -- BASELINE configs[4]: the forward's Linears on the fp8 matrix
+        cores (MXFP8 weights and activations), dgrad / wgrad in bf16 from the fp32 master weights (H and I multiples of 128,
+        no dropout); or "bf16x3" -- the parity path: fp32 activations, every product as three
         split-bf16 MFMAs, gradients fp32-class (the reference trains in fp32, training/main.py:142). Single process, no
         dropout, L <= 128, several times slower.
         dropout: None / 0 = off; a float p = HF's hidden_dropout_prob = attention_probs_dropout_prob = p; a pair
         (p_hidden, p_attn). The reference's fit() trains with 0.1 (HF config defaults, train() mode). Ranks of a
         data-parallel job should pass different dropout_seed values (fit() adds the rank)."""
         self.cfg = cfg
-        if precision not in ("bf16", "bf16x3"):
-            raise ValueError("training precision is 'bf16' or 'bf16x3'")
+        if precision not in ("bf16", "bf16x3", "fp8"):
+            raise ValueError("training precision is 'bf16', 'bf16x3' or 'fp8'")
         if precision == "bf16x3" and (world_size > 1 or force_dp or use_graph or dropout):
             raise ValueError("precision='bf16x3' is the single-process parity path: no data parallelism, graph or dropout")
+        if precision == "fp8" and (use_graph or dropout):
+            raise ValueError("precision='fp8' (fp8 forward GEMMs, bf16 backward) trains without dropout and without a graph")
         self.precision = precision
         self.enc = encoder if encoder is not None else HipEncoder(cfg, device=device)
         if arena is not None:
@@ -233,6 +237,9 @@ class QuadrupletTrainer:
                                                                  saved=saved, precision=self.precision)
         if self.precision == "bf16x3":
             enc.backward(ids, mask, types, stacked(g), saved, precision="bf16x3")
+            works = []
+        elif self.precision == "fp8" and not (self.world > 1 or self.force_dp):
+            enc.backward(ids, mask, types, stacked(g), saved, precision="fp8")
             works = []
         else:
             works = staged_backward(enc, ids, mask, types, stacked(g), saved, ws,
