@@ -256,8 +256,8 @@ int qst_attention_fwd_x3(const float* qkv, const int64_t* mask, const float* rel
  *   qst_colsum_f32       : out[n] += sum_m x[m, n]
  *   qst_embed_sum_f32    : s[m, :] = (word[ids[m]] + type[type_ids[m]]) + pos[pos_ids[m]]  (pre-norm embedding sum)
  *   qst_ln_bwd_f32       : LayerNorm backward from the pre-norm rows (mean / rstd recomputed): ds; dgamma, dbeta += (atomics)
- *   qst_attention_bwd_f32: qkv [nseq*L, 3H], dctx [nseq*L, H], rel_bias [A, L, L] or NULL -> dqkv [nseq*L, 3H];
- *                          drel_bias [A, L, L] += (or NULL). L <= 128, d in {32, 64}. */
+ *   qst_attention_bwd_f32: qkv [nseq*L, 3H], ctx and dctx [nseq*L, H], rel_bias [A, L, L] or NULL -> dqkv [nseq*L, 3H];
+ *                          drel_bias [A, L, L] += (or NULL). L <= 512, d in {32, 64}. */
 int qst_transpose_f32(const float* src, int R, int C, int ld_src, float* dst, int ld_dst, void* stream);
 int qst_gelu_f32(const float* u, int64_t n, float* h, void* stream);
 int qst_gelu_bwd_f32(const float* dh, const float* u, int64_t n, float* du, void* stream);
@@ -266,8 +266,8 @@ int qst_embed_sum_f32(const int64_t* ids, const int64_t* type_ids, const int32_t
                       const float* pos_emb, const float* type_emb, int M, int H, float* s, void* stream);
 int qst_ln_bwd_f32(const float* dy, const float* prenorm, const float* gamma, float eps, int M, int H, float* ds,
                    float* dgamma, float* dbeta, void* stream);
-int qst_attention_bwd_f32(const float* qkv, const float* dctx, const int64_t* mask, const float* rel_bias, int nseq, int L,
-                          int A, int d, float* dqkv, float* drel_bias, void* stream);
+int qst_attention_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const int64_t* mask, const float* rel_bias,
+                          int nseq, int L, int A, int d, float* dqkv, float* drel_bias, void* stream);
 
 /* k best entries of every row of scores f32 [nrows, ld] (first n columns), sorted by descending score (ties: ascending
  * index). index_map (nullable, int64, same ld) translates column numbers into caller ids -- used to merge the

@@ -149,7 +149,7 @@ SIGNATURES = {
     "qst_colsum_f32": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "qst_embed_sum_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "qst_ln_bwd_f32": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp]),
-    "qst_attention_bwd_f32": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "qst_attention_bwd_f32": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "qst_comm_unique_id": (C.c_int, [vp]),
     "qst_comm_init": (C.c_int, [C.c_int, C.c_int, vp, C.POINTER(vp)]),
     "qst_allreduce_bucket": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),

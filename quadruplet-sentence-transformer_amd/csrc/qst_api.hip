@@ -766,7 +766,7 @@ static int backward_x3(qst_encoder* e, const int64_t* ids, const int64_t* mask, 
         QST_TRY(qst_ln_bwd_f32(dy, F(a.s1), P(b + LN1_G), c.layer_norm_eps, M, H, ds, G(b + LN1_G), G(b + LN1_B), st));
         QST_TRY(dgrad(ds, H, b + W_O, H, dctx, nullptr));
         QST_TRY(wgrad(ds, H, F(a.ctx), H, b + W_O, b + B_O));
-        QST_TRY(qst_attention_bwd_f32(F(a.qkv), dctx, mask, rel, nseq, L, A, d, dqkv, drel, st));
+        QST_TRY(qst_attention_bwd_f32(F(a.qkv), F(a.ctx), dctx, mask, rel, nseq, L, A, d, dqkv, drel, st));
         QST_TRY(dgrad(dqkv, 3 * H, b + W_QKV, H, dx, ds));                           // dx_in = dqkv . Wqkv + ds1
         QST_TRY(wgrad(dqkv, 3 * H, xin, H, b + W_QKV, b + B_QKV));
     }
@@ -908,10 +908,9 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
     if ((skip_wgrad || wgrad_only) && (layer_lo != 0 || layer_hi != 1)) return QST_ERR_BAD_ARG;
     if (!e || !ids || !mask || !params || !grads || !saved || !workspace) return QST_ERR_BAD_ARG;
     if (e->cfg.precision == QST_PREC_BF16X3) {
-        // the parity path: the whole backward in one call only (no staged exchange, no shadow), L <= 128
+        // the parity path: the whole backward in one call only (no staged exchange, no shadow)
         if (!do_head || !do_embed || skip_wgrad || layer_lo != 0 || layer_hi != e->cfg.num_layers || !grad_emb) return QST_ERR_UNSUPPORTED;
         if (int rc = shape_ok(e, nseq, L)) return rc;
-        if (L > 128) return QST_ERR_UNSUPPORTED;
         return backward_x3(e, ids, mask, type_ids, nseq, L, params, grad_emb, grads, saved, saved_bytes, workspace, workspace_bytes,
                            (hipStream_t)stream);
     }

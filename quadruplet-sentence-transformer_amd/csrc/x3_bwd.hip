@@ -5,14 +5,14 @@
 // contraction goes through the split-bf16 x3 GEMM (dgrad: against a transposed copy of the weight; wgrad: dW = dY^T X as an
 // NT product of transposed copies of dY and X, reduction over the token rows), every row kernel works on fp32 and
 // recomputes the LayerNorm statistics from the saved pre-norm tensor, and the attention backward is a plain fp32 kernel
-// (one workgroup per (sequence, head), L <= 128) that recomputes the probabilities row by row.
+// (one workgroup per (sequence, head), L <= 512) that recomputes the probabilities row by row.
 //
 //   qst_transpose_f32    : dst[C, R] = src[R, C]^T
 //   qst_gelu_f32         : h = gelu(u) (exact erf), forward; qst_gelu_bwd_f32: du = dh * gelu'(u)
 //   qst_colsum_f32       : out[n] += sum_m x[m, n]                     (bias gradients)
 //   qst_embed_sum_f32    : s[m, :] = word[ids[m]] + type[...] + pos[...]  (the embedding LayerNorm's pre-norm input)
 //   qst_ln_bwd_f32       : LayerNorm backward from the PRE-NORM tensor (mean / rstd recomputed): ds, dgamma +=, dbeta +=
-//   qst_attention_bwd_f32: dqkv (and the [A, L, L] position-bias gradient) from fp32 qkv and dctx
+//   qst_attention_bwd_f32: dqkv (and the [A, L, L] position-bias gradient) from fp32 qkv, ctx and dctx
 #include "qst_common.h"
 #include "qst_kernels.h"
 
@@ -143,96 +143,136 @@ __global__ __launch_bounds__(256) void ln_bwd_f32_kernel(const float* dy, const 
 }
 
 // ---------------------------------------------------------------- attention backward, fp32
-// One workgroup of 128 threads per (sequence, head); thread j owns key j (its dK / dV rows live in its registers) and the
-// probabilities of the query row at hand are recomputed from q, k (no saved statistics): for row i
-//   s_j = scale * q_i.k_j + rel[i][j] + mask_j ; p = softmax(s) ; dp_j = dO_i.v_j ; delta = sum_j p_j dp_j ;
-//   ds_j = p_j (dp_j - delta) ; dq_i = scale * sum_j ds_j k_j ; dk_j += scale * ds_j q_i ; dv_j += p_j dO_i ; drel[i][j] += ds_j
-// q, k, v, dO of the item sit in LDS as fp32 with padded rows. L <= 128.
+// One workgroup of 256 threads per (sequence, head), L <= 512. The keys of the item sit in LDS as fp32 (padded rows); q, dO,
+// ctx and v rows come from global memory (a row read by every thread is one broadcast line). Nothing was saved by the
+// forward: pass 1 recomputes, row by row, lse_i = logsumexp_j s_ij and delta_i = dO_i . ctx_i; pass 2 walks blocks of 256
+// keys -- thread j owns key j of the block, its v row and its dK / dV rows in registers -- and for every query row i
+//   s_ij = scale * q_i.k_j + rel[i][j] + mask_j ; p = exp(s - lse_i) ; dp = dO_i.v_j ; ds = p (dp - delta_i)
+//   dk_j += scale * ds * q_i ; dv_j += p * dO_i ; drel[i][j] += ds ; dq_i += scale * sum_{j in block} ds_ij k_j
+// (dq accumulates over the key blocks in global memory: one workgroup owns the item, so a plain read-modify-write).
 constexpr float kMaskMinF = -3.4028234663852886e38f;
 struct AttnBwdF32Args {
-    const float* qkv; const float* dctx; const int64_t* mask; const float* rel; float* dqkv; float* drel;
+    const float* qkv; const float* ctx; const float* dctx; const int64_t* mask; const float* rel; float* dqkv; float* drel;
     int nseq, L, A, H; float scale;
 };
-__device__ __forceinline__ float block_max128(float v, float* red, int tid) {
+__device__ __forceinline__ float block_max256(float v, float* red, int tid) {
     v = wave_max(v);
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
-    const float r = fmaxf(red[0], red[1]);
+    const float r = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
     return r;
 }
-__device__ __forceinline__ float block_sum128(float v, float* red, int tid) {
+__device__ __forceinline__ float block_sum256(float v, float* red, int tid) {
     v = wave_sum(v);
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
-    const float r = red[0] + red[1];
+    const float r = (red[0] + red[1]) + (red[2] + red[3]);
     __syncthreads();
     return r;
 }
 template <int D>
-__global__ __launch_bounds__(128) void attn_bwd_f32_kernel(AttnBwdF32Args a) {
+__global__ __launch_bounds__(256) void attn_bwd_f32_kernel(AttnBwdF32Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LD = D + 1;
-    float* qs = (float*)smem;                  // [128][LD]
-    float* ks = qs + 128 * LD;
-    float* vs = ks + 128 * LD;
-    float* ds_ = vs + 128 * LD;                // dO rows
-    float* dsrow = ds_ + 128 * LD;             // [128]
-    float* red = dsrow + 128;                  // [2]
-    const int tid = threadIdx.x, j = tid;
+    const int L = a.L;
+    float* ks = (float*)smem;                  // [L][LD]
+    float* lse = ks + (size_t)L * LD;          // [L]: the row maximum m_i ...
+    float* lz = lse + L;                       // [L]: ... and log sum_j exp(s_ij - m_i), kept apart: a row with every key masked
+                                               //      has m_i = -3.4e38, which would absorb the log of the sum
+    float* delta = lz + L;                     // [L]
+    float* dsrow = delta + L;                  // [256]
+    float* red = dsrow + 256;                  // [4]
+    const int tid = threadIdx.x;
     const int head = blockIdx.x % a.A, seq = blockIdx.x / a.A;
-    const int L = a.L, ld = 3 * a.H;
-    const float* base = a.qkv + (size_t)seq * L * ld + head * D;
+    const int ld = 3 * a.H;
+    const float* qbase = a.qkv + (size_t)seq * L * ld + head * D;
+    const float* kbase = qbase + a.H;
+    const float* vbase = qbase + 2 * a.H;
+    const float* obase = a.ctx + (size_t)seq * L * a.H + head * D;
     const float* dbase = a.dctx + (size_t)seq * L * a.H + head * D;
-    for (int idx = tid; idx < L * D; idx += 128) {
+    for (int idx = tid; idx < L * D; idx += 256) {
         const int r = idx / D, c = idx - r * D;
-        qs[r * LD + c] = base[(size_t)r * ld + c];
-        ks[r * LD + c] = base[(size_t)r * ld + a.H + c];
-        vs[r * LD + c] = base[(size_t)r * ld + 2 * a.H + c];
-        ds_[r * LD + c] = dbase[(size_t)r * a.H + c];
+        ks[r * LD + c] = kbase[(size_t)r * ld + c];
     }
-    const bool live = j < L;
-    const float madd = (live && a.mask[(size_t)seq * L + j]) ? 0.f : kMaskMinF;
-    float dk[D], dv[D];
-#pragma unroll
-    for (int c = 0; c < D; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
+    for (int i = tid; i < L; i += 256) {
+        float acc = 0.f;
+        for (int c = 0; c < D; ++c) acc += dbase[(size_t)i * a.H + c] * obase[(size_t)i * a.H + c];
+        delta[i] = acc;
+    }
     __syncthreads();
+    // ---- pass 1: lse_i
     for (int i = 0; i < L; ++i) {
-        float s = -INFINITY, dp = 0.f;
-        if (live) {
-            float acc = 0.f;
+        float q[D];
 #pragma unroll
-            for (int c = 0; c < D; ++c) { acc += qs[i * LD + c] * ks[j * LD + c]; dp += ds_[i * LD + c] * vs[j * LD + c]; }
-            s = acc * a.scale;
-            if (a.rel) s += a.rel[((size_t)head * L + i) * L + j];
-            s += madd;
-        }
-        const float m = block_max128(s, red, tid);
-        const float e = live ? expf(s - m) : 0.f;
-        const float z = block_sum128(e, red, tid);
-        const float p = e / z;
-        const float delta = block_sum128(p * dp, red, tid);
-        const float dsj = p * (dp - delta);
-        if (live) {
-            if (a.drel) atomicAdd(a.drel + ((size_t)head * L + i) * L + j, dsj);
-            const float dss = dsj * a.scale;
+        for (int c = 0; c < D; ++c) q[c] = qbase[(size_t)i * ld + c];
+        float s[2] = {-INFINITY, -INFINITY};
 #pragma unroll
-            for (int c = 0; c < D; ++c) { dk[c] += dss * qs[i * LD + c]; dv[c] += p * ds_[i * LD + c]; }
+        for (int u = 0; u < 2; ++u) {
+            const int j = tid + 256 * u;
+            if (j < L) {
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < D; ++c) acc += q[c] * ks[j * LD + c];
+                acc *= a.scale;
+                if (a.rel) acc += a.rel[((size_t)head * L + i) * L + j];
+                s[u] = acc + (a.mask[(size_t)seq * L + j] ? 0.f : kMaskMinF);
+            }
         }
-        dsrow[j] = live ? dsj : 0.f;
-        __syncthreads();
-        if (tid < D) {
-            float acc = 0.f;
-            for (int jj = 0; jj < L; ++jj) acc += dsrow[jj] * ks[jj * LD + tid];
-            a.dqkv[((size_t)seq * L + i) * ld + head * D + tid] = acc * a.scale;
-        }
-        __syncthreads();
+        const float m = block_max256(fmaxf(s[0], s[1]), red, tid);
+        const float e = (tid < L ? expf(s[0] - m) : 0.f) + (tid + 256 < L ? expf(s[1] - m) : 0.f);
+        const float z = block_sum256(e, red, tid);
+        if (tid == 0) { lse[i] = m; lz[i] = logf(z); }
     }
-    if (live) {
-        float* ok = a.dqkv + ((size_t)seq * L + j) * ld + a.H + head * D;
-        float* ov = ok + a.H;
+    __syncthreads();
+    // ---- pass 2: key blocks
+    for (int kb = 0; kb * 256 < L; ++kb) {
+        const int j = kb * 256 + tid;
+        const bool live = j < L;
+        float v[D], dk[D], dv[D];
 #pragma unroll
-        for (int c = 0; c < D; ++c) { ok[c] = dk[c]; ov[c] = dv[c]; }
+        for (int c = 0; c < D; ++c) { v[c] = live ? vbase[(size_t)j * ld + c] : 0.f; dk[c] = 0.f; dv[c] = 0.f; }
+        const float madd = (live && a.mask[(size_t)seq * L + j]) ? 0.f : kMaskMinF;
+        for (int i = 0; i < L; ++i) {
+            float dsj = 0.f;
+            if (live) {
+                float acc = 0.f, dp = 0.f;
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    const float qc = qbase[(size_t)i * ld + c], dc = dbase[(size_t)i * a.H + c];
+                    acc += qc * ks[j * LD + c];
+                    dp += dc * v[c];
+                }
+                float s = acc * a.scale;
+                if (a.rel) s += a.rel[((size_t)head * L + i) * L + j];
+                s += madd;
+                const float p = expf((s - lse[i]) - lz[i]);
+                dsj = p * (dp - delta[i]);
+                if (a.drel) atomicAdd(a.drel + ((size_t)head * L + i) * L + j, dsj);
+                const float dss = dsj * a.scale;
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    dk[c] += dss * qbase[(size_t)i * ld + c];
+                    dv[c] += p * dbase[(size_t)i * a.H + c];
+                }
+            }
+            dsrow[tid] = dsj;
+            __syncthreads();
+            if (tid < D) {
+                float acc = 0.f;
+                const int nj = min(256, L - kb * 256);
+                for (int jj = 0; jj < nj; ++jj) acc += dsrow[jj] * ks[(kb * 256 + jj) * LD + tid];
+                float* dq = a.dqkv + ((size_t)seq * L + i) * ld + head * D + tid;
+                *dq = (kb == 0 ? 0.f : *dq) + acc * a.scale;
+            }
+            __syncthreads();
+        }
+        if (live) {
+            float* ok = a.dqkv + ((size_t)seq * L + j) * ld + a.H + head * D;
+            float* ov = ok + a.H;
+#pragma unroll
+            for (int c = 0; c < D; ++c) { ok[c] = dk[c]; ov[c] = dv[c]; }
+        }
     }
 }
 
@@ -279,23 +319,23 @@ extern "C" int qst_ln_bwd_f32(const float* dy, const float* prenorm, const float
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
-extern "C" int qst_attention_bwd_f32(const float* qkv, const float* dctx, const int64_t* mask, const float* rel_bias, int nseq,
-                                     int L, int A, int d, float* dqkv, float* drel_bias, void* stream) {
-    if (!qkv || !dctx || !mask || !dqkv || nseq <= 0 || L <= 0 || A <= 0) return QST_ERR_BAD_ARG;
+extern "C" int qst_attention_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const int64_t* mask,
+                                     const float* rel_bias, int nseq, int L, int A, int d, float* dqkv, float* drel_bias,
+                                     void* stream) {
+    if (!qkv || !ctx || !dctx || !mask || !dqkv || nseq <= 0 || L <= 0 || A <= 0) return QST_ERR_BAD_ARG;
     if (drel_bias && !rel_bias) return QST_ERR_BAD_ARG;
-    if ((d != 32 && d != 64) || L > 128) return QST_ERR_UNSUPPORTED;
+    if ((d != 32 && d != 64) || L > 512) return QST_ERR_UNSUPPORTED;
     AttnBwdF32Args a{};
-    a.qkv = qkv; a.dctx = dctx; a.mask = mask; a.rel = rel_bias; a.dqkv = dqkv; a.drel = drel_bias;
+    a.qkv = qkv; a.ctx = ctx; a.dctx = dctx; a.mask = mask; a.rel = rel_bias; a.dqkv = dqkv; a.drel = drel_bias;
     a.nseq = nseq; a.L = L; a.A = A; a.H = A * d; a.scale = 1.0f / sqrtf((float)d);
-    const size_t lds = ((size_t)4 * 128 * (d + 1) + 128 + 8) * sizeof(float);
+    const size_t lds = ((size_t)L * (d + 1) + 3 * (size_t)L + 256 + 8) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    static QstLdsAttr a32, a64;
     if (d == 32) {
-        if (int rc = qst_ensure_lds(a32, (const void*)attn_bwd_f32_kernel<32>, lds)) return rc;
-        attn_bwd_f32_kernel<32><<<nseq * A, 128, lds, st>>>(a);
+        QST_HIP_CHECK(hipFuncSetAttribute((const void*)attn_bwd_f32_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attn_bwd_f32_kernel<32><<<nseq * A, 256, lds, st>>>(a);
     } else {
-        if (int rc = qst_ensure_lds(a64, (const void*)attn_bwd_f32_kernel<64>, lds)) return rc;
-        attn_bwd_f32_kernel<64><<<nseq * A, 128, lds, st>>>(a);
+        QST_HIP_CHECK(hipFuncSetAttribute((const void*)attn_bwd_f32_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attn_bwd_f32_kernel<64><<<nseq * A, 256, lds, st>>>(a);
     }
     QST_LAUNCH_CHECK();
     return QST_OK;

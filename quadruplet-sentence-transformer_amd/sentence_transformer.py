@@ -239,7 +239,7 @@ class SentenceTransformer(nn.Module):
         # "bf16" (throughput) or "bf16x3" (fp32-class parity path) for no-grad forwards: encode() and evaluators
         self.inference_precision = "bf16"
         # "bf16" or "bf16x3" for forwards that keep a graph (fit(precision=...)): the parity path trains with fp32-class
-        # gradients as the reference's fp32 run does (training/main.py:142) -- single process, no dropout, L <= 128
+        # gradients as the reference's fp32 run does (training/main.py:142) -- single process, no dropout
         self.training_precision = "bf16"
         self._live_graphs = 0          # training forwards whose backward has not run yet
         self._dp = None                # data-parallel state of a running fit(): {"group", "buckets", "overlap"}
@@ -388,7 +388,7 @@ class SentenceTransformer(nn.Module):
         (weights + Adam moments + step counters; the reference's checkpoints hold weights only)
         from which training continues with the schedule where it stopped; and `precision`: "bf16" (default) or "bf16x3", the
         parity path -- forward and backward as split-bf16 x3 products with fp32 activations, gradients within 1e-4 of fp32
-        autograd (the reference trains in fp32, training/main.py:142); single process, dropout=0, seq_len <= 128; or "fp8"
+        autograd (the reference trains in fp32, training/main.py:142); single process, dropout=0; or "fp8"
         (BASELINE configs[4]): the forward's Linears on the fp8 matrix cores, the bf16 backward; dropout=0.
 
         Data parallelism (one process per GPU, e.g. the unchanged training script under

@@ -135,7 +135,7 @@ class QuadrupletTrainer:
         cores (MXFP8 weights and activations), dgrad / wgrad in bf16 from the fp32 master weights (H and I multiples of 128,
         no dropout); or "bf16x3" -- the parity path: fp32 activations, every product as three
         split-bf16 MFMAs, gradients fp32-class (the reference trains in fp32, training/main.py:142). Single process, no
-        dropout, L <= 128, several times slower.
+        dropout, several times slower.
         dropout: None / 0 = off; a float p = HF's hidden_dropout_prob = attention_probs_dropout_prob = p; a pair
         (p_hidden, p_attn). The reference's fit() trains with 0.1 (HF config defaults, train() mode). Ranks of a
         data-parallel job should pass different dropout_seed values (fit() adds the rank)."""
