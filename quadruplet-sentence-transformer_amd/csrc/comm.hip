@@ -14,6 +14,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <mutex>
+
 #include <hip/hip_runtime.h>
 
 #include "qst_common.h"
@@ -41,8 +43,10 @@ struct Rccl {
     int last_error = 0;
 };
 Rccl g_rccl;
+std::mutex g_rccl_mutex;                      // binding happens once, from whichever thread asks first
 
 bool rccl_load() {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.lib) return true;
     const char* names[] = {"librccl.so", "librccl.so.1"};
     void* h = nullptr;
