@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--kernel-reps", type=int, default=10)
     ap.add_argument("--graph", action="store_true",
                     help="single GPU: replay the step from a captured HIP graph (device-side LR schedule)")
+    ap.add_argument("--train-precision", choices=["bf16", "fp8", "bf16x3"], default="bf16",
+                    help="precision of the TIMED training step: bf16 (BASELINE configs[1]); fp8 = BASELINE configs[4]'s 'fp8 "
+                         "MFMA GEMMs': every forward Linear on the fp8 matrix cores, bf16 backward; bf16x3 = the fp32-class "
+                         "parity path. fp8 and bf16x3 train without dropout (--dropout is set to 0)")
     ap.add_argument("--force-dp", action="store_true",
                     help="single GPU: run the TIMED step through the data-parallel path -- init_process_group('nccl', "
                          "world_size=1), staged backward, the seven async RCCL all-reduces of the gradient buckets -- so that "
@@ -342,14 +346,17 @@ def time_loss_kernel(D, reps=10, rows=262144):
             "kernel": "quad_loss_kernel fwd+grads", "avg_launch_ms": round(ms, 4), "rows": rows, "D": D}
 
 
-def baseline_config_name(model, B, L, world):
+def baseline_config_name(model, B, L, world, precision="bf16"):
     """Which entry of BASELINE.json `configs` a (model, quadruplets per GPU, seq_len, GPUs) run corresponds to."""
     if model == "all-MiniLM-L6-v2" and L == 128 and B == 64:
         return "BASELINE.json configs[1]" if world == 1 else "BASELINE.json configs[1] per GPU" + (" = configs[3]" if world == 8 else "")
     if model == "all-mpnet-base-v2" and L == 256 and B == 32 and world == 1:
         return "BASELINE.json configs[2]"
     if model == "bert-base-uncased" and L == 384 and B == 128 and world == 1:
-        return "BASELINE.json configs[4] shape, trained with bf16 operands (its fp8 matrix-core path is inference only)"
+        if precision == "fp8":
+            return "BASELINE.json configs[4]: fp8 MFMA GEMMs in the forward (MXFP8 weights and activations), bf16 backward"
+        return ("BASELINE.json configs[4] shape, trained with bf16 operands (--train-precision fp8 runs the forward on the fp8 "
+                "matrix cores)")
     return "not a BASELINE.json configuration"
 
 
@@ -489,11 +496,15 @@ def main():
 
     cfg = PRESETS[args.model]
     B, L = args.batch, args.seq_len
+    if args.train_precision != "bf16":
+        args.dropout = 0.0                          # neither path has dropout
+        args.graph = False
     arena = synthetic_params(cfg, seed=14)          # same replica on every rank
     trainer = QuadrupletTrainer(cfg, arena=arena, device=f"cuda:{dev_index}", lr=2e-5, weight_decay=0.01,
                                 max_grad_norm=1.0, warmup_steps=10000, total_steps=1000000,
                                 process_group=None, world_size=world, overlap=not args.no_overlap,
                                 use_graph=args.graph and world == 1 and not args.force_dp, force_dp=args.force_dp,
+                                precision=args.train_precision,
                                 dropout=(args.dropout if args.dropout > 0 else None), dropout_seed=14 + rank)
     # a few distinct synthetic batches, resident in HBM before the timed region (rank-offset streams)
     nb = 4
@@ -574,11 +585,12 @@ def main():
             "metric": f"quadruplets/sec (seq_len={L}, {args.model}) training step", "value": round(value, 1),
             "unit": "quadruplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp8": "fp8 (MXFP8 forward GEMMs, bf16 backward)", "bf16x3": "bf16x3 (fp32-class)"}[args.train_precision],
+            "data": "synthetic",
             "config": {"workload": f"{args.model} dims (random-init), {B} quadruplets/GPU x {world} GPU, seq_len={L}, "
                                    "fwd + gamma-quadruplet loss + bwd + clip + AdamW, "
                                    + (f"dropout {args.dropout:g} on hidden states and attention probabilities as the reference's "
-                                      "train() mode" if args.dropout > 0 else "dropout off") + f" ({baseline_config_name(args.model, B, L, world)})",
+                                      "train() mode" if args.dropout > 0 else "dropout off") + f" ({baseline_config_name(args.model, B, L, world, args.train_precision)})",
                        "global_batch": B * world, "seq_len": L,
                        "parallelism": f"dp{world}" + (" through RCCL (world_size 1: staged backward + 7 async all-reduces)" if args.force_dp else ""),
                        "precision": "bf16 MFMA operands, fp32 accumulate/residual/LN/softmax/loss/optimizer",
