@@ -15,7 +15,9 @@ enum {
     QST_EPI_GELU = 2,            // u = acc + bias ; C(bf16) = gelu'(u) (saved for backward) ; C2(bf16) = gelu(u)
     QST_EPI_GELU_BWD = 3,        // C(bf16) = acc * aux   (aux = the gelu'(u) saved by QST_EPI_GELU)
     QST_EPI_F32_RESID_BF16 = 4,  // C(f32) = acc + bias + resid ; C2(bf16) = same
-    QST_EPI_GELU_MX = 5          // qst_gemm_nt_f8 only: gelu(acc + bias) as MXFP8: C = e4m3 [M, ldc], C2 = E8M0 [M, ldc/32]
+    QST_EPI_GELU_MX = 5,         // qst_gemm_nt_f8 only: gelu(acc + bias) as MXFP8: C = e4m3 [M, ldc], C2 = E8M0 [M, ldc/32]
+    QST_EPI_GELU_MX_TRAIN = 6    // qst_gemm_nt_f8 only: C / C2 as QST_EPI_GELU (bf16 gelu'(u), bf16 h) AND the bf16-rounded h as
+                                 // MXFP8: C3 = e4m3 [M, N], C4 = E8M0 scales (fp8 training forward)
 };
 
 /* Dropout masks are a pure function of (state, site, element index): nothing is stored between forward and backward,
@@ -66,6 +68,8 @@ typedef struct {
     //                 sits AFTER its LayerNorm)
     QstDrop drop;
     int32_t drop_where;
+    void* C3;             // QST_EPI_GELU_MX_TRAIN only (see the enum)
+    void* C4;
 } QstGemmArgs;
 
 /* C[M,N] = A[M,K] . B[N,K]^T with epilogue `epi`. K % 64 == 0, lda/ldb % 8 == 0. */

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs
     for (int kk = 0; kk < 32 * CPR / 64; ++kk) {
         const int idx = lane + 64 * kk, row = idx / CPR, c = idx % CPR;
         const u32x4 v = *(const u32x4*)(stg + rr_off<D>(row, c));
-        *(u32x4*)(obase + (size_t)row * a.H + c * 8) = v;
+        st_stream((u32x4*)(obase + (size_t)row * a.H + c * 8), v);
     }
     if (h == 0 && a.lse_out) a.lse_out[((size_t)seq * a.A + head) * a.L + qi] = (m + __log2f(l)) * 0.6931471805599453f;
 }
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dq_kernel(AttnA
             u32x2 pk;
             pk[0] = pack_bf16x2(dq[b][4 * g], dq[b][4 * g + 1]);
             pk[1] = pack_bf16x2(dq[b][4 * g + 2], dq[b][4 * g + 3]);
-            *(u32x2*)(orow + b * 32 + 8 * g + 4 * h) = pk;
+            st_stream((u32x2*)(orow + b * 32 + 8 * g + 4 * h), pk);
         }
 }
 
@@ -521,10 +521,10 @@ __global__ __launch_bounds__(256, (D == 32 && !DROP) ? 4 : 2) void attn_bwd_dkv_
                 u32x2 pk;
                 pk[0] = pack_bf16x2(dk[b][4 * g], dk[b][4 * g + 1]);
                 pk[1] = pack_bf16x2(dk[b][4 * g + 2], dk[b][4 * g + 3]);
-                *(u32x2*)(krow + b * 32 + 8 * g + 4 * h) = pk;
+                st_stream((u32x2*)(krow + b * 32 + 8 * g + 4 * h), pk);
                 pk[0] = pack_bf16x2(dv[b][4 * g], dv[b][4 * g + 1]);
                 pk[1] = pack_bf16x2(dv[b][4 * g + 2], dv[b][4 * g + 3]);
-                *(u32x2*)(vrow + b * 32 + 8 * g + 4 * h) = pk;
+                st_stream((u32x2*)(vrow + b * 32 + 8 * g + 4 * h), pk);
             }
     }
     if (REL && a.drel) {
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
                     const int idx = lane + 64 * k, row = idx / CPR, c = idx % CPR;
                     const u32x4 v = *(const u32x4*)(stg + t * 32 * D * 2 + rr_off<D>(row, c));
                     __builtin_amdgcn_raw_buffer_store_b128(v, rw, (int)((uint32_t)(row * ld + c * 8) * 2u),
-                                                           (int)(so + (uint32_t)t * (uint32_t)(a.woff * 2)), 0);
+                                                           (int)(so + (uint32_t)t * (uint32_t)(a.woff * 2)), QST_STREAM_STORES ? 2 : 0);   // aux bit 1 = nt
                 }
             QST_STAMP(6);
         }

@@ -28,9 +28,11 @@ constexpr uint32_t kOOB = 0x7FFFFFF0u;              // voffset that always fails
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
+template <bool ONCE = false>      // ONCE: no other workgroup reads these lines -> non-temporal (aux bit 1), see st_stream
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* lds_wave_base, uint32_t voff, uint32_t soff) {
     // one wave-instruction writes 64 x 16 B = 1 KB at lds_wave_base + lane*16 (base must be wave-uniform)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds_wave_base, 16, (int)voff, (int)soff, 0,
+                                             (ONCE && QST_STREAM_LOADS) ? 2 : 0);
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -86,7 +88,7 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // Round 3, on the LayerNorm-fused kernel with operands flushed from the caches as they are inside the step
 // (tools/mall_probe.py): K = 1536 cold 111 vs 97 us, warm 62 vs 58 -- the cold penalty is not a per-stage latency. Nor is it
 // the access pattern: a tile-blocked A, every stage one contiguous 16 KB read, measured 94 vs 98 us cold.)
-template <int WAVES_M, int WAVES_N, typename HOOK = NoHook>
+template <int WAVES_M, int WAVES_N, typename HOOK = NoHook, bool A_ONCE = false>
 __device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, int m0, int n0, f32x16 (&acc)[2][3],
                                             HOOK after_first_issue = HOOK()) {
     constexpr int NBM = 64 * WAVES_M, NBN = 96 * WAVES_N, NW = WAVES_M * WAVES_N;
@@ -121,7 +123,7 @@ __device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, in
         char* st = smem + (kt & 1) * NT_STAGE;
         const uint32_t ko = (uint32_t)kt * (NBK * 2);
 #pragma unroll
-        for (int t = 0; t < A_PER_WAVE; ++t) dma16(ra, st + (wave * A_PER_WAVE + t) * 1024, va[t], ko);
+        for (int t = 0; t < A_PER_WAVE; ++t) dma16<A_ONCE>(ra, st + (wave * A_PER_WAVE + t) * 1024, va[t], ko);
 #pragma unroll
         for (int t = 0; t < B_PER_WAVE; ++t) dma16(rb, st + NT_A_BYTES + (wave * B_PER_WAVE + t) * 1024, vb[t], ko);
     };
@@ -259,7 +261,7 @@ __device__ __forceinline__ void nt_epilogue(const QstGemmArgs& g, f32x16 (&acc)[
                 const int m = m_base + i * 32 + row;
                 const int n = n_base + c4 * 4;
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                rv[t] = (m < g.M && n < g.N && g.resid) ? *(const f32x4*)(g.resid + (size_t)m * g.ldr + n) : z;
+                rv[t] = (m < g.M && n < g.N && g.resid) ? ld_stream((const f32x4*)(g.resid + (size_t)m * g.ldr + n)) : z;
             }
 #pragma unroll
             for (int j = 0; j < 3; ++j)
@@ -289,10 +291,10 @@ __device__ __forceinline__ void nt_epilogue(const QstGemmArgs& g, f32x16 (&acc)[
                 }
                 v += rv[t];
                 const size_t o = (size_t)m * g.ldc + n;
-                *(f32x4*)((float*)g.C + o) = v;
+                st_stream((f32x4*)((float*)g.C + o), v);
                 if (EPI == QST_EPI_F32_RESID_BF16) {
                     u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
-                    *(u32x2*)((bf16*)g.C2 + o) = pk;
+                    st_stream((u32x2*)((bf16*)g.C2 + o), pk);
                 }
             }
         } else {
@@ -307,7 +309,7 @@ __device__ __forceinline__ void nt_epilogue(const QstGemmArgs& g, f32x16 (&acc)[
                 const int n = n_base + c8 * 8;
                 const u32x4 z = {0u, 0u, 0u, 0u};
                 if (EPI == QST_EPI_GELU_BWD)
-                    av[t] = (m < g.M && n < g.N) ? *(const u32x4*)((const bf16*)g.aux + (size_t)m * g.ldc + n) : z;
+                    av[t] = (m < g.M && n < g.N) ? ld_stream((const u32x4*)((const bf16*)g.aux + (size_t)m * g.ldc + n)) : z;
             }
 #pragma unroll
             for (int j = 0; j < 3; ++j)
@@ -357,16 +359,16 @@ __device__ __forceinline__ void nt_epilogue(const QstGemmArgs& g, f32x16 (&acc)[
                         pg[e] = pack_bf16x2(gg[0], gg[1]);
                         pk[e] = pack_bf16x2(hh[0], hh[1]);
                     }
-                    if (full) *(u32x4*)((bf16*)g.C + o) = pg;                     // gelu'(u), saved for backward
-                    else { u32x2 h2; h2[0] = pg[0]; h2[1] = pg[1]; *(u32x2*)((bf16*)g.C + o) = h2; }
+                    if (full) st_stream((u32x4*)((bf16*)g.C + o), pg);                     // gelu'(u), saved for backward
+                    else { u32x2 h2; h2[0] = pg[0]; h2[1] = pg[1]; st_stream((u32x2*)((bf16*)g.C + o), h2); }
                 } else {   // QST_EPI_GELU_BWD: acc * gelu'(u)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         pk[e] = pack_bf16x2(v[2 * e] * bf16lo(av[t][e]), v[2 * e + 1] * bf16hi(av[t][e]));
                 }
                 bf16* dst = (EPI == QST_EPI_GELU) ? (bf16*)g.C2 : (bf16*)g.C;
-                if (full) *(u32x4*)(dst + o) = pk;
-                else { u32x2 h2; h2[0] = pk[0]; h2[1] = pk[1]; *(u32x2*)(dst + o) = h2; }
+                if (full) st_stream((u32x4*)(dst + o), pk);
+                else { u32x2 h2; h2[0] = pk[0]; h2[1] = pk[1]; st_stream((u32x2*)(dst + o), h2); }
             }
         }
     }
@@ -444,6 +446,7 @@ __device__ __forceinline__ int mx_exponent(float amax) {
 }
 __device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (uint32_t)(e + 127) << 23); }   // -126 <= e <= 127
 
+constexpr int QST_EPI_GELU_MX_TRAIN_ = 6;    // = QST_EPI_GELU_MX_TRAIN: C / C2 as QST_EPI_GELU (gelu'(u), h as bf16) AND h as MXFP8 in C3 / C4
 constexpr int QST_EPI_GELU_MX_ = 5;          // = QST_EPI_GELU_MX: C = e4m3 of gelu(acc + bias) [M, ldc bytes], C2 = E8M0 [M, ldc / 32]
 
 template <int EPI>
@@ -542,13 +545,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f8_kernel(QstGemmArgs g) {
         const int n = n0 + wn * 96 + c;
         bias_s[c] = (g.bias && n < g.N) ? g.bias[n] : 0.f;
     }
-    if constexpr (EPI != QST_EPI_GELU_MX_) {
+    if constexpr (EPI != QST_EPI_GELU_MX_ && EPI != QST_EPI_GELU_MX_TRAIN_) {
         nt_epilogue<EPI, 2>(g, acc, stg, bias_s, m0 + wm * 64, n0 + wn * 96, lane);
     } else {
+        constexpr bool TRAIN = EPI == QST_EPI_GELU_MX_TRAIN_;
         // h = gelu(acc + bias) leaves as MXFP8 for the second feed-forward product: 8 columns per lane, 4 lanes = one
         // 32-column MX block (aligned quads: 12 lanes per row), block amax by two DPP steps inside the quad
-        uint8_t* Cq = (uint8_t*)g.C;
-        uint8_t* Cs = (uint8_t*)g.C2;
+        // (training: the same launch also leaves gelu'(u) and h as bf16 for the backward, and the MX copy is taken from the
+        //  bf16-rounded h -- what quantising that copy in a pass of its own would give, without the 1.8 GB pass per layer)
+        uint8_t* Cq = (uint8_t*)(TRAIN ? g.C3 : g.C);
+        uint8_t* Cs = (uint8_t*)(TRAIN ? g.C4 : g.C2);
         const int m_base = m0 + wm * 64, n_base = n0 + wn * 96;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -570,11 +576,35 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f8_kernel(QstGemmArgs g) {
                 const f32x4 blo = *(const f32x4*)(bias_s + c8 * 8), bhi = *(const f32x4*)(bias_s + c8 * 8 + 4);
                 float hv[8];
                 float amax = 0.f;
+                if constexpr (TRAIN) {
+                    float gp[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    hv[e] = gelu_erf(lo[e] + blo[e]);
-                    hv[4 + e] = gelu_erf(hi[e] + bhi[e]);
-                    amax = fmaxf(amax, fmaxf(fabsf(hv[e]), fabsf(hv[4 + e])));
+                    for (int e = 0; e < 4; ++e) {
+                        float cdf, pdf;
+                        const float x0 = lo[e] + blo[e], x1 = hi[e] + bhi[e];
+                        gelu_parts(x0, cdf, pdf); hv[e] = x0 * cdf; gp[e] = cdf + x0 * pdf;
+                        gelu_parts(x1, cdf, pdf); hv[4 + e] = x1 * cdf; gp[4 + e] = cdf + x1 * pdf;
+                    }
+                    u32x4 pg, ph;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        pg[e] = pack_bf16x2(gp[2 * e], gp[2 * e + 1]);
+                        ph[e] = pack_bf16x2(hv[2 * e], hv[2 * e + 1]);
+                        hv[2 * e] = bf16lo(ph[e]); hv[2 * e + 1] = bf16hi(ph[e]);          // quantise the bf16-rounded h
+                    }
+                    if (m < g.M && n < g.N) {
+                        st_stream((u32x4*)((bf16*)g.C + (size_t)m * g.ldc + n), pg);
+                        st_stream((u32x4*)((bf16*)g.C2 + (size_t)m * g.ldc + n), ph);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(hv[e]));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hv[e] = gelu_erf(lo[e] + blo[e]);
+                        hv[4 + e] = gelu_erf(hi[e] + bhi[e]);
+                        amax = fmaxf(amax, fmaxf(fabsf(hv[e]), fabsf(hv[4 + e])));
+                    }
                 }
                 amax = fmaxf(amax, dpp_mov<0xB1>(amax));             // quad_perm [1,0,3,2]
                 amax = fmaxf(amax, dpp_mov<0x4E>(amax));             // quad_perm [2,3,0,1]
@@ -587,7 +617,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f8_kernel(QstGemmArgs g) {
                 p1 = __builtin_amdgcn_cvt_pk_fp8_f32(hv[6] * inv, hv[7] * inv, p1, true);
                 if (m < g.M && n < g.N) {
                     u32x2 pk; pk[0] = p0; pk[1] = p1;
-                    *(u32x2*)(Cq + (size_t)m * g.ldc + n) = pk;
+                    st_stream((u32x2*)(Cq + (size_t)m * g.ldc + n), pk);
                     if ((c8 & 3) == 0) Cs[((size_t)(n >> 7) * g.M + m) * 4 + ((n >> 5) & 3)] = (uint8_t)(ex + 127);   // stage-major
                 }
             }
@@ -682,8 +712,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
                 const int c = 2 * (lane + 64 * t);                                                                       \
                 rv[i_][k][t][0] = rv[i_][k][t][1] = 0.f;                                                                 \
                 xv[i_][k][t] = 0u;                                                                                       \
-                if (ok && g.resid) rv[i_][k][t] = *(const f32x2*)(g.resid + (size_t)m * g.ldr + c);                      \
-                if (MODE == 1 && ok) xv[i_][k][t] = *(const uint32_t*)((const bf16*)e.xhat + (size_t)m * LN_N + c);      \
+                if (ok && g.resid) rv[i_][k][t] = ld_stream((const f32x2*)(g.resid + (size_t)m * g.ldr + c)); \
+                if (MODE == 1 && ok) xv[i_][k][t] = ld_stream((const uint32_t*)((const bf16*)e.xhat + (size_t)m * LN_N + c)); \
             }                                                                                                            \
             rs[i_][k] = (MODE == 1 && ok) ? e.rstd[m] : 0.f;                                                             \
         }                                                                                                                \
@@ -708,7 +738,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
         for (int q = 0; q < 3; ++q)
             if (tid + 512 * q < 3 * LN_N) vec_s[tid + 512 * q] = v3[q];
     };
-    nt_mainloop<2, 4>(g, smem, m0, 0, acc, early_loads);
+    nt_mainloop<2, 4, decltype(early_loads), true>(g, smem, m0, 0, acc, early_loads);      // the tile spans whole rows: A is read once
     LN_STAMP(2);
 
     f32x2 ag[3], ab[3];
@@ -776,9 +806,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
                         f32x2 o;
                         o[0] = h0 * ga[0] + be[0];
                         o[1] = h1 * ga[1] + be[1];
-                        if (!(g.splits & 4)) *(f32x2*)((float*)g.C + (size_t)m * g.ldc + c) = o;
-                        if (g.C2 && !(g.splits & 1)) *(uint32_t*)((bf16*)g.C2 + (size_t)m * g.ldc + c) = pack_bf16x2(o[0], o[1]);
-                        if (e.xhat && !(g.splits & 2)) *(uint32_t*)((bf16*)e.xhat + (size_t)m * LN_N + c) = pack_bf16x2(h0, h1);
+                        if (!(g.splits & 4)) st_stream((f32x2*)((float*)g.C + (size_t)m * g.ldc + c), o);
+                        if (g.C2 && !(g.splits & 1)) st_stream((uint32_t*)((bf16*)g.C2 + (size_t)m * g.ldc + c), pack_bf16x2(o[0], o[1]));
+                        if (e.xhat && !(g.splits & 2)) st_stream((uint32_t*)((bf16*)e.xhat + (size_t)m * LN_N + c), pack_bf16x2(h0, h1));
                     }
                 }
             } else {
@@ -809,14 +839,14 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
                         f32x2 o;
                         o[0] = rs[i][k] * (v[t][0] - m1 - x[t][0] * m2);
                         o[1] = rs[i][k] * (v[t][1] - m1 - x[t][1] * m2);
-                        *(f32x2*)((float*)g.C + (size_t)m * g.ldc + c) = o;
+                        st_stream((f32x2*)((float*)g.C + (size_t)m * g.ldc + c), o);
                         if (g.C2) {
                             if (DROP && dwhere == 2) {
                                 float k0, k1;
                                 drop_pair(dc, (uint32_t)m * LN_N + c, k0, k1);
                                 o[0] *= k0; o[1] *= k1;
                             }
-                            *(uint32_t*)((bf16*)g.C2 + (size_t)m * g.ldc + c) = pack_bf16x2(o[0], o[1]);
+                            st_stream((uint32_t*)((bf16*)g.C2 + (size_t)m * g.ldc + c), pack_bf16x2(o[0], o[1]));
                         }
                     }
                 }
@@ -1155,6 +1185,9 @@ extern "C" int qst_gemm_nt_f8(const QstGemmArgs* a, int epi, void* stream) {
         case QST_EPI_GELU_MX:
             if (!a->C2 || a->ldc % 32 != 0 || a->N % 32 != 0) return QST_ERR_UNSUPPORTED;
             return launch_nt_f8<QST_EPI_GELU_MX_>(a, st);
+        case QST_EPI_GELU_MX_TRAIN:
+            if (!a->C2 || !a->C3 || !a->C4 || a->ldc != a->N || a->N % 32 != 0) return QST_ERR_UNSUPPORTED;
+            return launch_nt_f8<QST_EPI_GELU_MX_TRAIN_>(a, st);
         default: return QST_ERR_BAD_ARG;
     }
 }

@@ -621,9 +621,15 @@ static int forward_mx_train(qst_encoder* e, const int64_t* ids, const int64_t* m
         QST_TRY(gemm(sv + t.cq, sv + t.cs, H, b + W_O, s, nullptr, H, b + B_O, x, QST_EPI_F32_RESID));
         QST_TRY(qst_ln_fwd_mx_train(s, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, (float*)(sv + a.y1), sv + a.y1b,
                                     sv + a.xh1, (float*)(sv + a.rs1), sv + t.yq, sv + t.ys, st));
-        // FFN-1: gelu'(u) and h leave as bf16 (the backward's operands); h is quantised for FFN-2 in a pass of its own
-        QST_TRY(gemm(sv + t.yq, sv + t.ys, H, b + W_1, sv + a.u, sv + a.hact, I, b + B_1, nullptr, QST_EPI_GELU));
-        QST_TRY(qst_quant_mx(sv + a.hact, 1, M, I, sv + t.hq, sv + t.hs, st));
+        // FFN-1: gelu'(u) and h leave as bf16 (the backward's operands) and, from the same epilogue, the bf16-rounded h as
+        // MXFP8 for FFN-2
+        {
+            QstGemmArgs g{};
+            g.A = sv + t.yq; g.aux = sv + t.ys; g.B = WQ(b + W_1); g.bscale = (const float*)WS(b + W_1);
+            g.C = sv + a.u; g.C2 = sv + a.hact; g.C3 = sv + t.hq; g.C4 = sv + t.hs; g.bias = P(b + B_1);
+            g.M = M; g.N = I; g.K = H; g.lda = H; g.ldb = H; g.ldc = I; g.ldr = I;
+            QST_TRY(qst_gemm_nt_f8(&g, QST_EPI_GELU_MX_TRAIN, st));
+        }
         QST_TRY(gemm(sv + t.hq, sv + t.hs, I, b + W_2, s, nullptr, H, b + B_2, (const float*)(sv + a.y1), QST_EPI_F32_RESID));
         QST_TRY(qst_ln_fwd_mx_train(s, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, M, H, (float*)(sv + a.x), sv + a.xb,
                                     sv + a.xh2, (float*)(sv + a.rs2), sv + t.xq, sv + t.xs, st));

@@ -100,6 +100,33 @@ __device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, uint32_t b
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)byte_off, 0, 0);
 }
 
+// Store of output bytes that THIS kernel never reads again (epilogue outputs, saved activations, gradients): marked
+// non-temporal so the lines do not displace the operand tiles the same launch re-reads from its XCD's L2.
+#ifndef QST_STREAM_STORES
+#define QST_STREAM_STORES 1
+#endif
+template <typename T>
+__device__ __forceinline__ void st_stream(T* p, const T& v) {
+#if QST_STREAM_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
+// ... and the matching load for bytes a launch reads exactly once (residual rows, saved gelu'(u), normalised rows)
+#ifndef QST_STREAM_LOADS
+#define QST_STREAM_LOADS QST_STREAM_STORES
+#endif
+template <typename T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+#if QST_STREAM_LOADS
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     bf16x2 v;
     v[0] = (bf16)lo;
