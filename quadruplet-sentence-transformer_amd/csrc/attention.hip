@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dq_kernel(AttnA
             u32x2 pk;
             pk[0] = pack_bf16x2(dq[b][4 * g], dq[b][4 * g + 1]);
             pk[1] = pack_bf16x2(dq[b][4 * g + 2], dq[b][4 * g + 3]);
-            st_stream((u32x2*)(orow + b * 32 + 8 * g + 4 * h), pk);
+            *(u32x2*)(orow + b * 32 + 8 * g + 4 * h) = pk;
         }
 }
 
@@ -521,10 +521,10 @@ __global__ __launch_bounds__(256, (D == 32 && !DROP) ? 4 : 2) void attn_bwd_dkv_
                 u32x2 pk;
                 pk[0] = pack_bf16x2(dk[b][4 * g], dk[b][4 * g + 1]);
                 pk[1] = pack_bf16x2(dk[b][4 * g + 2], dk[b][4 * g + 3]);
-                st_stream((u32x2*)(krow + b * 32 + 8 * g + 4 * h), pk);
+                *(u32x2*)(krow + b * 32 + 8 * g + 4 * h) = pk;
                 pk[0] = pack_bf16x2(dv[b][4 * g], dv[b][4 * g + 1]);
                 pk[1] = pack_bf16x2(dv[b][4 * g + 2], dv[b][4 * g + 3]);
-                st_stream((u32x2*)(vrow + b * 32 + 8 * g + 4 * h), pk);
+                *(u32x2*)(vrow + b * 32 + 8 * g + 4 * h) = pk;
             }
     }
     if (REL && a.drel) {

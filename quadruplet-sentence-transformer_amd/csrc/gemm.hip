@@ -28,7 +28,10 @@ constexpr uint32_t kOOB = 0x7FFFFFF0u;              // voffset that always fails
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
-template <bool ONCE = false>      // ONCE: no other workgroup reads these lines -> non-temporal (aux bit 1), see st_stream
+// ONCE: no other workgroup reads these lines -> non-temporal (aux bit 1), see st_stream. Only for the LayerNorm-fused
+// kernel's activation operand: on operands that other workgroups re-read it costs (same-box A/B of the whole step: the
+// plain NT kernels' A tiles 4.60 -> 4.68 ms, the wgrad kernel's operand stages 4.60 -> 4.65 ms).
+template <bool ONCE = false>
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* lds_wave_base, uint32_t voff, uint32_t soff) {
     // one wave-instruction writes 64 x 16 B = 1 KB at lds_wave_base + lane*16 (base must be wave-uniform)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds_wave_base, 16, (int)voff, (int)soff, 0,

@@ -101,7 +101,13 @@ __device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, uint32_t b
 }
 
 // Store of output bytes that THIS kernel never reads again (epilogue outputs, saved activations, gradients): marked
-// non-temporal so the lines do not displace the operand tiles the same launch re-reads from its XCD's L2.
+// non-temporal. Measured on the whole training step, same box, alternating builds (DESIGN.md finding 21): MiniLM
+// 4.91 -> 4.70 ms with the stores, 4.64 with the once-read loads below as well; per kernel the LayerNorm-fused GEMMs gain
+// 8-15% (their consumers' operand rows arrive without the producer's dirty lines still queued behind them), the others
+// move by a few percent either way. ONLY for stores in which one wave-instruction covers whole 64-byte sectors: the
+// attention dQ / dK,dV kernels write 8 bytes per lane on 32 different rows per instruction and became 1.6-1.8x slower
+// with the hint (partial sectors leave L2 one by one), so they keep plain stores; the row kernels of rowops.hip lost
+// 4-12% and keep plain accesses too.
 #ifndef QST_STREAM_STORES
 #define QST_STREAM_STORES 1
 #endif
@@ -113,6 +119,7 @@ __device__ __forceinline__ void st_stream(T* p, const T& v) {
     *p = v;
 #endif
 }
+
 
 // ... and the matching load for bytes a launch reads exactly once (residual rows, saved gelu'(u), normalised rows)
 #ifndef QST_STREAM_LOADS
