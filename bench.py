@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--train-precision", choices=["bf16", "fp8", "bf16x3"], default="bf16",
                     help="precision of the TIMED training step: bf16 (BASELINE configs[1]); fp8 = BASELINE configs[4]'s 'fp8 "
                          "MFMA GEMMs': every forward Linear on the fp8 matrix cores, bf16 backward; bf16x3 = the fp32-class "
-                         "parity path. fp8 and bf16x3 train without dropout (--dropout is set to 0)")
+                         "parity path (trains without dropout: --dropout is set to 0)")
     ap.add_argument("--force-dp", action="store_true",
                     help="single GPU: run the TIMED step through the data-parallel path -- init_process_group('nccl', "
                          "world_size=1), staged backward, the seven async RCCL all-reduces of the gradient buckets -- so that "
@@ -391,7 +391,8 @@ def distinct_gpus_or_exit(rank, world, dev_index):
 
 def time_fp8_training(trainer, cfg, batches, steps, B, ms_bf16_nodrop):
     """BASELINE configs[4] as a training configuration: the full step with the forward's Linears on the fp8 matrix cores
-    (MXFP8 weights and activations) and the bf16 backward over what that forward kept; no dropout (the path has none)."""
+    (MXFP8 weights and activations) and the bf16 backward over what that forward kept; timed without dropout next to the
+    bf16 step without dropout (--train-precision fp8 times it as the headline step, dropout on)."""
     import torch
     from quadruplet_sentence_transformer_amd.trainer import QuadrupletTrainer
     try:
@@ -497,8 +498,9 @@ def main():
     cfg = PRESETS[args.model]
     B, L = args.batch, args.seq_len
     if args.train_precision != "bf16":
-        args.dropout = 0.0                          # neither path has dropout
         args.graph = False
+    if args.train_precision == "bf16x3":
+        args.dropout = 0.0                          # the parity path has no dropout
     arena = synthetic_params(cfg, seed=14)          # same replica on every rank
     trainer = QuadrupletTrainer(cfg, arena=arena, device=f"cuda:{dev_index}", lr=2e-5, weight_decay=0.01,
                                 max_grad_norm=1.0, warmup_steps=10000, total_steps=1000000,

@@ -77,8 +77,9 @@ int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream);
 /* NT GEMM on the fp8 matrix cores, both operands MXFP8 (OCP e4m3 elements + one E8M0 power-of-two scale per 32
  * consecutive K elements of a row; v_mfma_scale_f32_32x32x64_f8f6f4): A = e4m3 [M, K] (lda bytes), aux = its scales;
  * B = e4m3 [N, K] (ldb bytes), bscale = its scales (uint8 arrays in the layout qst_quant_mx writes). K % 128 == 0.
- * epi: QST_EPI_BF16, QST_EPI_F32_RESID, QST_EPI_GELU_MX (inference), QST_EPI_GELU (fp8 training forward: gelu'(u) and h as
- * bf16, what the bf16 backward reads). QST_PREC_FP8, BASELINE configs[4]. */
+ * epi: QST_EPI_BF16, QST_EPI_F32_RESID (with `drop` / drop_where 1: dropout of the projection output, as qst_gemm_nt),
+ * QST_EPI_GELU_MX (inference), QST_EPI_GELU / QST_EPI_GELU_MX_TRAIN (fp8 training forward: gelu'(u) and h as bf16, what the
+ * bf16 backward reads; the latter with h as MXFP8 too). QST_PREC_FP8, BASELINE configs[4]. */
 int qst_gemm_nt_f8(const QstGemmArgs* a, int epi, void* stream);
 /* MXFP8 quantisation of a contiguous [rows, K] matrix (src f32, or bf16 when src_is_bf16): per 32-element block the
  * scale exponent e = the smallest with amax * 2^-e <= 448 (-127 for an all-zero block), elements = RNE(x * 2^-e) to
@@ -172,7 +173,8 @@ int qst_ln_fwd_mx_train(const float* s, const float* gamma, const float* beta, f
 int qst_embed_ln_fwd_mx_train(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
                               const float* word_emb, const float* pos_emb, const float* type_emb,
                               const float* gamma, const float* beta, float eps, int M, int H, float* y,
-                              void* y_bf16, void* xhat_bf16, float* rstd, void* yq, void* ys, void* stream);
+                              void* y_bf16, void* xhat_bf16, float* rstd, void* yq, void* ys,
+                              const QstDrop* drop /* nullable: dropout of the output, as qst_embed_ln_fwd_drop */, void* stream);
 /* LayerNorm backward: ds = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)); dgamma += sum dy*xhat; dbeta += sum dy. */
 /* scratch: qst_ln_bwd_scratch_bytes(M, H) of per-block partial sums reduced in a fixed order (deterministic);
  * NULL falls back to float atomics on dgamma/dbeta. */

@@ -250,13 +250,14 @@ class _LinearMxFwdBf16Bwd(torch.autograd.Function):
 
 
 def encoder_forward_mx(P: Dict[str, torch.Tensor], cfg, ids: torch.Tensor, mask: torch.Tensor,
-                       type_ids: Optional[torch.Tensor] = None, train: bool = False) -> torch.Tensor:
+                       type_ids: Optional[torch.Tensor] = None, train: bool = False, dropout=None) -> torch.Tensor:
     """QST_PREC_FP8 oracle (inference): encoder_forward with every Linear computed on MXFP8 operands -- weights
     quantised from fp32; the layer input, the attention output and the LayerNorm-1 output quantised from their bf16
     copies; gelu(u) quantised from fp32 (it never exists in another format) -- and attention on bf16 operands, as the
     HIP pipeline does (csrc/qst_api.hip forward_mx). train=True: the fp8 TRAINING forward (forward_mx_train) with the bf16
     path's backward attached to every Linear (_LinearMxFwdBf16Bwd) -- autograd through the result is the oracle of
-    "fp8 forward GEMMs, bf16 dgrad / wgrad"."""
+    "fp8 forward GEMMs, bf16 dgrad / wgrad". dropout (training only): an oracle/dropout_ref.Masks, applied at the four
+    places encoder_forward applies it."""
     n, L = ids.shape
     H, A = cfg.hidden_size, cfg.num_heads
     d = H // A
@@ -272,6 +273,8 @@ def encoder_forward_mx(P: Dict[str, torch.Tensor], cfg, ids: torch.Tensor, mask:
         bucket = mpnet_bucket_table(L, cfg.rel_buckets, cfg.rel_max_distance)
         rel = P["rel_bias"][bucket].permute(2, 0, 1)[None]
     x = F.layer_norm(x, (H,), P["emb_ln_g"], P["emb_ln_b"], cfg.layer_norm_eps)
+    if dropout is not None:
+        x = x * dropout.embed(n, L, H)
     neg = torch.finfo(torch.float32).min
     add_mask = (1.0 - mask[:, None, None, :].to(torch.float32)) * neg
 
@@ -288,10 +291,16 @@ def encoder_forward_mx(P: Dict[str, torch.Tensor], cfg, ids: torch.Tensor, mask:
             s = s + rel
         s = s + add_mask
         pr = torch.softmax(s, dim=-1)
+        if dropout is not None:
+            pr = pr * dropout.probs(l, n, A, L)
         ctx = torch.matmul(_r(pr, True), v).transpose(1, 2).reshape(n, L, H)
         a = lin(ctx, P[p + "w_o"], P[p + "b_o"], True)
+        if dropout is not None:
+            a = a * dropout.attn_out(l, n, L, H)
         x = F.layer_norm(a + x, (H,), P[p + "ln1_g"], P[p + "ln1_b"], cfg.layer_norm_eps)
         h = F.gelu(lin(x, P[p + "w_1"], P[p + "b_1"], True))
         o = lin(h, P[p + "w_2"], P[p + "b_2"], train)        # (training keeps gelu(u) as bf16 and quantises that copy)
+        if dropout is not None:
+            o = o * dropout.ffn_out(l, n, L, H)
         x = F.layer_norm(o + x, (H,), P[p + "ln2_g"], P[p + "ln2_b"], cfg.layer_norm_eps)
     return x

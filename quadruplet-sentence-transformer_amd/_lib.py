@@ -121,7 +121,7 @@ SIGNATURES = {
     "qst_embed_ln_fwd_mx": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "qst_ln_fwd_mx_train": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "qst_embed_ln_fwd_mx_train": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp,
-                                            vp]),
+                                            vp, vp]),
     "qst_ln_fwd": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "qst_ln_bwd_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "qst_ln_bwd_reduce_batch": (C.c_int, [vp, vp]),

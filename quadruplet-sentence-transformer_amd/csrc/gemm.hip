@@ -1179,6 +1179,10 @@ extern "C" int qst_gemm_nt_f8(const QstGemmArgs* a, int epi, void* stream) {
     if (!a || !a->A || !a->B || !a->C || !a->aux || !a->bscale || a->M <= 0 || a->N <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
     if (a->K % 128 != 0 || a->lda % 16 != 0 || a->ldb % 16 != 0 || a->N % 8 != 0) return QST_ERR_UNSUPPORTED;
     if (epi == QST_EPI_GELU_MX && a->ldc != a->N) return QST_ERR_UNSUPPORTED;          // stage-major scales: one matrix, no sub-views
+    if (a->drop.thr16 && a->drop.state) {             // dropout of a projection output (fp8 training forward), as qst_gemm_nt
+        if (a->drop_where != 1 || epi != QST_EPI_F32_RESID) return QST_ERR_BAD_ARG;
+        if (a->drop.thr16 > 65535u || (int64_t)a->M * a->N >= ((int64_t)1 << 32)) return QST_ERR_UNSUPPORTED;
+    }
     if ((int64_t)128 * a->lda >= 0x7FFFFF00LL || (int64_t)192 * a->ldb >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     switch (epi) {

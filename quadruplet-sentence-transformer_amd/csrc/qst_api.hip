@@ -406,7 +406,8 @@ extern "C" int qst_encoder_set_ffn_chain(qst_encoder* e, int mask) {
 extern "C" int qst_encoder_set_dropout(qst_encoder* e, float p_hidden, float p_attn, uint32_t* state_dev) {
     if (!e || !(p_hidden >= 0.f && p_hidden < 1.f) || !(p_attn >= 0.f && p_attn < 1.f)) return QST_ERR_BAD_ARG;
     if ((p_hidden > 0.f || p_attn > 0.f) && !state_dev) return QST_ERR_BAD_ARG;
-    if ((p_hidden > 0.f || p_attn > 0.f) && e->cfg.precision != QST_PREC_BF16) return QST_ERR_UNSUPPORTED;   // training path only
+    if ((p_hidden > 0.f || p_attn > 0.f) && e->cfg.precision != QST_PREC_BF16 && e->cfg.precision != QST_PREC_FP8)
+        return QST_ERR_UNSUPPORTED;                                       // the two precisions whose training forward drops
     auto thr = [](float p) { const long t = lroundf(p * 65536.f); return (uint32_t)(t > 65535 ? 65535 : t); };
     e->drop_hidden = thr(p_hidden); e->drop_attn = thr(p_attn);
     e->drop_state = (e->drop_hidden || e->drop_attn) ? state_dev : nullptr;
@@ -582,24 +583,34 @@ static int forward_mx_train(qst_encoder* e, const int64_t* ids, const int64_t* m
     auto P = [&](int seg) { return params + lay.segs[seg].off; };
     auto WQ = [&](int seg) { return (const uint8_t*)shadow + lay.segs[seg].shadow_off; };
     auto WS = [&](int seg) { return (const uint8_t*)shadow + lay.segs[seg].shadow_off + qst_align_up(lay.segs[seg].numel, kAlign); };
-    auto gemm = [&](const void* Aq, const void* As, int K, int wseg, void* Cout, void* C2, int N, int bseg, const float* resid, int epi) {
+    // dropout exactly as the bf16 training forward has it (same sites, same counter-based masks, the same snapshot beside
+    // the activations): the bf16 backward over this arena recomputes the masks from that record
+    const bool dropping = e->drop_state != nullptr;
+    const void* dst8 = sv + p.dropst;
+    const DropThr thr = dropping ? DropThr{e->drop_hidden, e->drop_attn} : DropThr{0u, 0u};
+    auto gemm = [&](const void* Aq, const void* As, int K, int wseg, void* Cout, void* C2, int N, int bseg, const float* resid, int epi,
+                    int64_t drop_site = -1) {             // (site 0 is a real site: layer 0's attention output)
         QstGemmArgs g{};
         g.A = Aq; g.aux = As; g.B = WQ(wseg); g.bscale = (const float*)WS(wseg); g.C = Cout; g.C2 = C2; g.bias = P(bseg); g.resid = resid;
         g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.ldr = N;
+        if (dropping && thr.hidden && drop_site >= 0) { g.drop = drop_of(thr, dst8, false, (uint32_t)drop_site); g.drop_where = 1; }
         return qst_gemm_nt_f8(&g, epi, st);
     };
-    // a backward over this arena must not look for dropout masks: record "none" for it
     {
         qst_encoder::FwdRec* rec = nullptr;
         for (auto& r : e->fwd_recs) if (r.saved == saved) rec = &r;
         if (!rec) { rec = &e->fwd_recs[e->fwd_next]; e->fwd_next = (e->fwd_next + 1) % 16; }
-        *rec = qst_encoder::FwdRec{saved, 0u, 0u};
+        *rec = qst_encoder::FwdRec{saved, thr.hidden, thr.attn};
     }
     int32_t* pos_ids = (int32_t*)(sv + p.pos_ids);
-    QST_TRY(qst_position_ids(ids, nseq, L, c.arch, c.pad_token_id, pos_ids, st));
-    QST_TRY(qst_embed_ln_fwd_mx_train(ids, type_ids, pos_ids, P(lay.word), P(lay.pos), lay.type >= 0 ? P(lay.type) : nullptr,
-                                      P(lay.eg), P(lay.eb), c.layer_norm_eps, M, H, (float*)(sv + p.x0), sv + p.x0b, sv + p.xh0,
-                                      (float*)(sv + p.rs0), sv + t.xq, sv + t.xs, st));
+    QST_TRY(qst_forward_prologue(ids, nseq, L, c.arch, c.pad_token_id, pos_ids, dropping ? e->drop_state : nullptr,
+                                 dropping ? (uint32_t*)(sv + p.dropst) : nullptr, st));
+    {
+        const QstDrop de = drop_of(thr, dst8, false, QST_DROP_SITE_EMBED);
+        QST_TRY(qst_embed_ln_fwd_mx_train(ids, type_ids, pos_ids, P(lay.word), P(lay.pos), lay.type >= 0 ? P(lay.type) : nullptr,
+                                          P(lay.eg), P(lay.eb), c.layer_norm_eps, M, H, (float*)(sv + p.x0), sv + p.x0b, sv + p.xh0,
+                                          (float*)(sv + p.rs0), sv + t.xq, sv + t.xs, dropping ? &de : nullptr, st));
+    }
     const float* rel = nullptr;
     if (c.arch == QST_ARCH_MPNET) {
         QST_TRY(qst_rel_pos_fwd(P(lay.rel), e->rel_lut, A, L, (float*)(sv + p.rel), st));
@@ -615,10 +626,11 @@ static int forward_mx_train(qst_encoder* e, const int64_t* ids, const int64_t* m
             QstAttnDesc q{};
             q.qkv = sv + a.qkv; q.mask = mask; q.rel_pos = rel; q.nseq = nseq; q.L = L; q.A = A; q.d = d;
             q.ctx = sv + a.ctx; q.lse = (float*)(sv + a.lse);
+            if (dropping) q.drop = drop_of(thr, dst8, true, QST_DROP_SITE_PROBS(l));
             QST_TRY(qst_attention_fwd_ex(&q, st));
         }
         QST_TRY(qst_quant_mx(sv + a.ctx, 1, M, H, sv + t.cq, sv + t.cs, st));
-        QST_TRY(gemm(sv + t.cq, sv + t.cs, H, b + W_O, s, nullptr, H, b + B_O, x, QST_EPI_F32_RESID));
+        QST_TRY(gemm(sv + t.cq, sv + t.cs, H, b + W_O, s, nullptr, H, b + B_O, x, QST_EPI_F32_RESID, QST_DROP_SITE_ATTN_OUT(l)));
         QST_TRY(qst_ln_fwd_mx_train(s, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, (float*)(sv + a.y1), sv + a.y1b,
                                     sv + a.xh1, (float*)(sv + a.rs1), sv + t.yq, sv + t.ys, st));
         // FFN-1: gelu'(u) and h leave as bf16 (the backward's operands) and, from the same epilogue, the bf16-rounded h as
@@ -630,7 +642,8 @@ static int forward_mx_train(qst_encoder* e, const int64_t* ids, const int64_t* m
             g.M = M; g.N = I; g.K = H; g.lda = H; g.ldb = H; g.ldc = I; g.ldr = I;
             QST_TRY(qst_gemm_nt_f8(&g, QST_EPI_GELU_MX_TRAIN, st));
         }
-        QST_TRY(gemm(sv + t.hq, sv + t.hs, I, b + W_2, s, nullptr, H, b + B_2, (const float*)(sv + a.y1), QST_EPI_F32_RESID));
+        QST_TRY(gemm(sv + t.hq, sv + t.hs, I, b + W_2, s, nullptr, H, b + B_2, (const float*)(sv + a.y1), QST_EPI_F32_RESID,
+                     QST_DROP_SITE_FFN_OUT(l)));
         QST_TRY(qst_ln_fwd_mx_train(s, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, M, H, (float*)(sv + a.x), sv + a.xb,
                                     sv + a.xh2, (float*)(sv + a.rs2), sv + t.xq, sv + t.xs, st));
         x = (const float*)(sv + a.x);

@@ -74,7 +74,13 @@ __device__ __forceinline__ void ln_row_finish(const f32x2 (&v)[VPL], int lane, i
             if (c < nv) {
                 const float h0 = (v[i][0] - mean) * rstd, h1 = (v[i][1] - mean) * rstd;
                 const f32x2 g = *(const f32x2*)(gamma + 2 * c), b = *(const f32x2*)(beta + 2 * c);
-                const uint32_t pk = pack_bf16x2(h0 * g[0] + b[0], h1 * g[1] + b[1]);
+                float f0 = h0 * g[0] + b[0], f1 = h1 * g[1] + b[1];
+                if (dc.thr) {                                   // (the dropped output, as the bf16 copy above holds it)
+                    float m0, m1;
+                    drop_pair(dc, (uint32_t)(base + 2 * c), m0, m1);
+                    f0 *= m0; f1 *= m1;
+                }
+                const uint32_t pk = pack_bf16x2(f0, f1);
                 o0 = bf16lo(pk); o1 = bf16hi(pk);
             }
             const float amax = row16_max(fmaxf(fabsf(o0), fabsf(o1)));
@@ -690,15 +696,17 @@ extern "C" int qst_ln_fwd_mx(const float* s, const float* gamma, const float* be
 extern "C" int qst_embed_ln_fwd_mx_train(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
                                          const float* word_emb, const float* pos_emb, const float* type_emb,
                                          const float* gamma, const float* beta, float eps, int M, int H, float* y,
-                                         void* y_bf16, void* xhat_bf16, float* rstd, void* yq, void* ys, void* stream) {
+                                         void* y_bf16, void* xhat_bf16, float* rstd, void* yq, void* ys,
+                                         const QstDrop* drop, void* stream) {
     if (!ids || !pos_ids || !word_emb || !pos_emb || !gamma || !beta || !y || !y_bf16 || !xhat_bf16 || !rstd || !yq || !ys ||
         M <= 0 || H <= 0)
         return QST_ERR_BAD_ARG;
     if (H % 64 != 0) return QST_ERR_UNSUPPORTED;
+    if (int rc = drop_ok(drop, (int64_t)M * H)) return rc;
     hipStream_t st = (hipStream_t)stream;
     QST_VPL_DISPATCH(H, (embed_ln_fwd_kernel<VPL><<<(M + 4 * EMB_ROWS - 1) / (4 * EMB_ROWS), 256, 0, st>>>(
                             ids, type_ids, pos_ids, word_emb, pos_emb, type_emb, gamma, beta, eps, M, H, y,
-                            (bf16*)y_bf16, (bf16*)xhat_bf16, rstd, (uint8_t*)yq, (uint8_t*)ys, kNoDrop)));
+                            (bf16*)y_bf16, (bf16*)xhat_bf16, rstd, (uint8_t*)yq, (uint8_t*)ys, drop ? *drop : kNoDrop)));
     QST_LAUNCH_CHECK();
     return QST_OK;
 }

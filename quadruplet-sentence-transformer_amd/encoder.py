@@ -117,8 +117,10 @@ class HipEncoder:
                 self.drop_state = torch.zeros(4, dtype=torch.int32, device=self.device)
             _lib.check(self.lib.qst_dropout_init(self.drop_state.data_ptr(), int(seed) & 0xFFFFFFFFFFFFFFFF,
                                                  _lib.current_stream_ptr()), "qst_dropout_init")
-        _lib.check(self.lib.qst_encoder_set_dropout(self.handle, float(p_hidden), float(p_attn),
-                                                    self.drop_state.data_ptr() if on else None), "qst_encoder_set_dropout")
+        for h in (self.handle, self.handle_mx):          # the fp8 handle's training forward drops at the same places
+            if h is not None:
+                _lib.check(self.lib.qst_encoder_set_dropout(h, float(p_hidden), float(p_attn),
+                                                            self.drop_state.data_ptr() if on else None), "qst_encoder_set_dropout")
         self.dropout = (float(p_hidden), float(p_attn), int(seed)) if on else None
         self.dropout_step = 0
 
@@ -176,6 +178,9 @@ class HipEncoder:
                 self.handle_mx = h
                 self.shadow_mx = torch.zeros(self.lib.qst_shadow8_bytes(self.ccfg), dtype=torch.uint8, device=self.device)
                 self.shadow_mx_stale = True
+                if self.dropout is not None:         # (created after set_dropout: same settings, same device counter)
+                    _lib.check(self.lib.qst_encoder_set_dropout(h, self.dropout[0], self.dropout[1], self.drop_state.data_ptr()),
+                               "qst_encoder_set_dropout")
             return self.handle_mx
         if precision not in ("bf16x3", 1):
             raise ValueError(f"unknown precision {precision!r} (bf16 | bf16x3 | fp8)")
@@ -196,8 +201,6 @@ class HipEncoder:
         handle = self._handle_for(precision)
         if self.shadow_stale and (handle is self.handle or (training and handle is self.handle_mx)):
             self.refresh_shadow()                    # (an fp8 training forward: its backward runs on the bf16 shadows)
-        if training and handle is self.handle_mx and self.dropout is not None:
-            raise _lib.QstError("precision='fp8' trains without dropout (set_dropout(0, 0))")
         shadow = self.shadow
         if handle is self.handle_mx and handle is not None:
             if self.shadow_mx_stale:
@@ -214,7 +217,7 @@ class HipEncoder:
             handle, ids.data_ptr(), mask.data_ptr(), _lib.ptr(type_ids), n, L, self.params.data_ptr(),
             shadow.data_ptr(), emb.data_ptr(), _lib.ptr(tok), saved.data_ptr(), saved.numel(), int(training),
             _lib.current_stream_ptr()), "qst_encoder_forward")
-        if training and self.dropout is not None and handle is self.handle:
+        if training and self.dropout is not None and (handle is self.handle or handle is self.handle_mx):
             self.dropout_step += 1           # mirrors the device counter (tests rebuild this step's masks from it)
         return emb, tok, saved
 

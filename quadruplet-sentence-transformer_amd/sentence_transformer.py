@@ -389,7 +389,7 @@ class SentenceTransformer(nn.Module):
         from which training continues with the schedule where it stopped; and `precision`: "bf16" (default) or "bf16x3", the
         parity path -- forward and backward as split-bf16 x3 products with fp32 activations, gradients within 1e-4 of fp32
         autograd (the reference trains in fp32, training/main.py:142); single process, dropout=0; or "fp8"
-        (BASELINE configs[4]): the forward's Linears on the fp8 matrix cores, the bf16 backward; dropout=0.
+        (BASELINE configs[4]): the forward's Linears on the fp8 matrix cores, the bf16 backward (dropout as in bf16).
 
         Data parallelism (one process per GPU, e.g. the unchanged training script under
         `python -m torch.distributed.run`): when torch.distributed is initialised with more than one rank, every step's
@@ -471,8 +471,6 @@ class SentenceTransformer(nn.Module):
             raise ValueError("fit(precision=...) is 'bf16', 'bf16x3' or 'fp8'")
         if precision == "bf16x3" and (world > 1 or p_hidden > 0 or p_attn > 0):
             raise ValueError("fit(precision='bf16x3') is the single-process parity path: pass dropout=0 and run one process")
-        if precision == "fp8" and (p_hidden > 0 or p_attn > 0):
-            raise ValueError("fit(precision='fp8') (fp8 forward GEMMs, bf16 backward) trains without dropout: pass dropout=0")
         self.training_precision = precision
         enc.set_dropout(p_hidden, p_attn, int(dropout_seed) + rank)
         global_step = 0

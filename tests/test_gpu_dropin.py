@@ -198,6 +198,32 @@ def test_fit_at_parity_precision(tmp_path):
             m3, GammaQuadrupletLoss(gamma=0.6))) ], epochs=1, show_progress_bar=False, dropout=0.1, precision="bf16x3")
 
 
+def test_fit_on_the_fp8_matrix_cores_in_train_mode(tmp_path):
+    """fit(precision="fp8") exactly as the reference calls fit (training/main.py:128-148: train() mode, HF dropout 0.1 from
+    the config): every forward Linear on the fp8 matrix cores, the bf16 backward, the same counter-based dropout masks as the
+    bf16 path. Same data, seed and schedule as a bf16 fit: both train and end close to each other."""
+    def run(prec):
+        torch.manual_seed(0)
+        m = SentenceTransformer("tiny-mpnet", device="cuda")               # H = 128, I = 256: multiples of the 128-deep fp8 stage
+        loss = GammaQuadrupletLoss(gamma=0.6, margin_pos_neg=1.0, margin_pos_part=0.5, margin_part_neg=0.5, p=2.0)
+        lm = QuadrupletSentenceTransformerLossModel(m, loss)
+        data = [to_input_example(quad(i)) for i in range(16)]
+        dl = DataLoader(data, batch_size=8, shuffle=False, num_workers=0)
+        ev = CountingEvaluator(lm, data[:8])
+        m.fit(train_objectives=[(dl, lm)], evaluator=ev, epochs=3, scheduler="warmuplinear", warmup_steps=2,
+              optimizer_params={"lr": 2e-3}, evaluation_steps=0, output_path=str(tmp_path / prec), show_progress_bar=False,
+              dropout=0.1, dropout_seed=3, precision=prec)
+        return m, ev
+    m8, ev8 = run("fp8")
+    m1, ev1 = run("bf16")
+    assert int(m8._enc.drop_state[2]) >= 6                      # the device-side mask counter: six training forwards dropped
+    assert ev8.calls[-1][2] < ev8.calls[0][2], "validation loss did not go down with the forward on the fp8 matrix cores"
+    assert m8.training_precision == "bf16"                      # restored after fit
+    d = (m8._enc.params - m1._enc.params).abs()
+    moved = (m8._enc.params - SentenceTransformer("tiny-mpnet", device="cuda")._enc.params).abs().mean()
+    assert float(d.mean()) < 0.35 * float(moved)
+
+
 def test_named_parameters_are_views_with_hf_names(model):
     names = dict(model.named_parameters())
     assert "0.auto_model.embeddings.word_embeddings.weight" in names
