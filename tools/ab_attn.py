@@ -5,7 +5,7 @@ quadruplet-sentence-transformer_amd/csrc include | tar -x -C /tmp/base && make -
 in-tree libqst.so. Forward and backward, with and without dropout of the probabilities, alternating, best of 5 rounds;
 also checks that the two builds agree (bit for bit unless the arithmetic changed: the max difference is printed).
 
-    python tools/ab_attn.py [nseq] [L]"""
+    python tools/ab_attn.py [nseq] [L] [A] [d]"""
 import ctypes as C
 import os
 import sys
@@ -33,7 +33,8 @@ def timeit(fn, reps=20):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     L = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-    A, d = 12, 32
+    A = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+    d = int(sys.argv[4]) if len(sys.argv) > 4 else 32
     H = A * d
     libs = {"base": C.CDLL(os.path.join(ROOT, "tools", "libqst_base.so")), "new": _lib.load()}
     for lb in libs.values():
@@ -79,7 +80,7 @@ def main():
         out[drop] = (d_ctx, d_dq, ref)
     for drop in (False, True):
         b, nw = res[("base", drop)], res[("new", drop)]
-        print(f"n={n} L={L} dropout={'on ' if drop else 'off'}: forward base {b[0]:6.1f} us new {nw[0]:6.1f} us | "
+        print(f"n={n} L={L} A={A} d={d} dropout={'on ' if drop else 'off'}: forward base {b[0]:6.1f} us new {nw[0]:6.1f} us | "
               f"backward base {b[1]:6.1f} us new {nw[1]:6.1f} us | max |ctx diff| {out[drop][0]:.3g}, "
               f"max |dqkv diff| {out[drop][1]:.3g} (max |dqkv| {out[drop][2]:.3g})")
 
