@@ -163,7 +163,7 @@ class _EncodeFn(torch.autograd.Function):
             # path) runs in stages with each finished layer's gradients handed to the all-reduce; gradients of earlier
             # passes of the same step are already in the arena and travel with them
             model._dp_works += staged_backward(model._enc, ids, mask, types, grad_emb, ctx.saved, None, dp["buckets"],
-                                               dp["group"], dp["overlap"])
+                                               dp["group"], dp["overlap"], precision=ctx.prec)
             model._dp_reduced = True
         else:
             model._enc.backward(ids, mask, types, grad_emb, ctx.saved, precision=ctx.prec)

@@ -71,7 +71,7 @@ def staged_reduce_order(buckets: Sequence[Tuple[int, int]], total: int, overlap:
 
 
 def staged_backward(enc: HipEncoder, ids, mask, types, grad_emb, saved, ws=None, buckets=None, group=None,
-                    overlap: bool = True):
+                    overlap: bool = True, precision: str = "bf16"):
     """One backward pass of the encoder with the data-parallel gradient exchange inside it.
 
     Stages run top-down on the compute stream; after each finished layer its contiguous slice of the gradient arena
@@ -82,17 +82,23 @@ def staged_backward(enc: HipEncoder, ids, mask, types, grad_emb, saved, ws=None,
     followed by layer 0's own (small) bucket. Returns the list of pending works; the caller waits on them before the
     optimiser step (the global-norm clip needs every reduced gradient, so replicas stay bit-identical).
 
-    buckets=None (single process): one call, no exchange."""
+    buckets=None (single process): one call, no exchange.
+    precision: "bf16", or "fp8" when `saved` was filled by forward(training=True, precision="fp8") -- the same bf16 stages,
+    run on THAT handle: it holds the record of what its forward did with dropout (a handle that never saw the arena, or saw
+    it in an earlier bf16 step with other rates, would rebuild the wrong masks)."""
     lib, st = enc.lib, _lib.current_stream_ptr()
     n, L = ids.shape
+    if precision not in ("bf16", "fp8"):
+        raise ValueError("the staged backward runs the bf16 stages (precision 'bf16' or 'fp8')")
+    handle = enc._handle_for(precision)
     if ws is None:
-        ws = enc._arena("_ws", lib.qst_encoder_bwd_workspace_bytes(enc.handle, n, L))
+        ws = enc._arena("_ws", lib.qst_encoder_bwd_workspace_bytes(handle, n, L))
     grad_emb = grad_emb.contiguous()
     N = enc.cfg.num_layers
 
     def stage(flags, hi, lo):
         _lib.check(lib.qst_encoder_backward_stage(
-            enc.handle, ids.data_ptr(), mask.data_ptr(), _lib.ptr(types), n, L, enc.params.data_ptr(),
+            handle, ids.data_ptr(), mask.data_ptr(), _lib.ptr(types), n, L, enc.params.data_ptr(),
             enc.shadow.data_ptr(), grad_emb.data_ptr(), enc.grads.data_ptr(), saved.data_ptr(), saved.numel(),
             ws.data_ptr(), ws.numel(), int(flags), hi, lo, st), "qst_encoder_backward_stage")
 
@@ -243,7 +249,8 @@ class QuadrupletTrainer:
             works = []
         else:
             works = staged_backward(enc, ids, mask, types, stacked(g), saved, ws,
-                                    self.buckets if (self.world > 1 or self.force_dp) else None, self.group, self.overlap)
+                                    self.buckets if (self.world > 1 or self.force_dp) else None, self.group, self.overlap,
+                                    precision=self.precision)
         for w in works:
             w.wait()
         if sched_on_device:

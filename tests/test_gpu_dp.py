@@ -207,6 +207,20 @@ def test_native_communicator_behind_the_c_abi():
     assert abs(float(la) - float(lb)) < 1e-3
     diff = (t_dp.enc.params - t_ref.enc.params).abs()
     assert float(diff.max()) <= 6.5e-3 and float(diff.mean()) < 1e-4
+    # (d) the same through the fp8 training forward in train() mode (dropout on): the staged stages run on the handle whose
+    # forward filled the arena, so both trainers rebuild the same masks (tiny-mpnet: H = 128, I = 256 suit the fp8 stages)
+    mcfg = _dp_case("tiny-mpnet")[0]
+    marena = synthetic_params(mcfg, seed=3, std=0.05)
+    mb = [torch.from_numpy(t).cuda() for t in synthetic_quadruplets(mcfg, 6, 32, seed=3, ragged=True)]
+    kw = dict(arena=marena, device="cuda:0", lr=1e-3, weight_decay=0.01, max_grad_norm=1.0, precision="fp8", dropout=0.1,
+              dropout_seed=9)
+    f_ref, f_dp = QuadrupletTrainer(mcfg, **kw), QuadrupletTrainer(mcfg, process_group=comm, world_size=1, force_dp=True, **kw)
+    for _ in range(3):
+        la, lb = f_ref.step(*mb), f_dp.step(*mb)
+    torch.cuda.synchronize()
+    assert abs(float(la) - float(lb)) < 2e-3
+    diff = (f_dp.enc.params - f_ref.enc.params).abs()
+    assert float(diff.max()) <= 6.5e-3 and float(diff.mean()) < 1e-4
     comm.close()
 
 

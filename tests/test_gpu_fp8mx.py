@@ -294,6 +294,37 @@ def test_fp8_training_step_against_the_mx_oracle(name, B, L, layers, wkw, drop):
 FP8_TRAIN_GRAD_LIMITS = {"w": 7.9e-2, "emb": 6.5e-2, "vec": 8.2e-2, "b_qkv": 8.5e-2}
 
 
+def test_staged_backward_after_an_fp8_forward_rebuilds_that_forwards_masks():
+    """The data-parallel (staged) backward over an arena filled by forward(training=True, precision="fp8") must run on the
+    handle that ran that forward: the bf16 handle may hold a record of the SAME arena from an earlier bf16 step with other
+    dropout rates, and would rebuild those masks. One-call backward(precision="fp8") is the reference."""
+    from dataclasses import replace
+    from quadruplet_sentence_transformer_amd.config import PRESETS
+    from quadruplet_sentence_transformer_amd.encoder import HipEncoder
+    from quadruplet_sentence_transformer_amd.synthetic import synthetic_params, synthetic_quadruplets
+    from quadruplet_sentence_transformer_amd.trainer import staged_backward
+    cfg = replace(PRESETS["all-MiniLM-L6-v2"], num_layers=2, vocab_size=4096)
+    enc = HipEncoder(cfg)
+    enc.load_arena(synthetic_params(cfg, seed=14, std=0.03, bias_std=0.02, ln_jitter=0.05))
+    enc.ensure_train_state()
+    ids, mask, types = [torch.from_numpy(x).cuda().view(32, 64) for x in synthetic_quadruplets(cfg, 8, 64, seed=14, ragged=True)]
+    arena = torch.empty(enc.lib.qst_encoder_saved_bytes(enc._handle_for("fp8"), 32, 64, 1), dtype=torch.uint8, device="cuda")
+    enc.set_dropout(0.3, 0.3, 1)
+    enc.forward(ids, mask, types, training=True, saved=arena)                         # a bf16 step at other rates, same arena
+    enc.set_dropout(0.1, 0.1, 7)
+    emb, _, saved = enc.forward(ids, mask, types, training=True, saved=arena, precision="fp8")
+    g = torch.randn_like(emb)
+    enc.grads.zero_()
+    enc.backward(ids, mask, types, g, saved, precision="fp8")
+    ref = enc.grads.clone()
+    enc.grads.zero_()
+    staged_backward(enc, ids, mask, types, g, saved, None, None, None, True, precision="fp8")
+    assert float((enc.grads - ref).norm() / ref.norm()) < 1e-5
+    enc.grads.zero_()
+    staged_backward(enc, ids, mask, types, g, saved, None, None, None, True)            # the bf16 handle: the stale record
+    assert float((enc.grads - ref).norm() / ref.norm()) > 1e-2
+
+
 def test_fp8_training_trains():
     """QuadrupletTrainer(precision="fp8"): ten steps on one batch (MiniLM dims, 2 layers) next to the same ten steps of the
     bf16 trainer -- the loss goes down and the two trajectories stay within 2e-2 of each other at every step; then the same
