@@ -94,18 +94,30 @@ def run_case(name, B, L, ragged, weights_kw, check_grads=True, emb_atol_vs_bf16_
         worst = 0.0
         errs = []
         cls_max = {}
+        gnorm = float(torch.sqrt(sum((Pb[s.name].grad.double() ** 2).sum() for s in segs)))
+
+        def cls_of(leaf):
+            return ("b_qkv" if leaf == "b_qkv" else "vec" if (leaf.startswith("b_") or leaf.startswith("ln") or leaf.startswith("emb_ln"))
+                    else "emb" if leaf.endswith("_emb") else "w")
+        # a tensor whose gradient nearly cancels (bare bert-base's LAST feed-forward bias: 1/20 .. 1/40 of the other biases'
+        # norm, tools/fuzz_shapes.py case 29) carries the same absolute rounding noise as its peers: it is measured against at
+        # least 5% of the largest gradient norm of its class
+        cls_top = {}
+        for s in segs:
+            c = cls_of(s.name.split(".")[-1])
+            cls_top[c] = max(cls_top.get(c, 0.0), Pb[s.name].grad.norm().item())
         for s in segs:
             ref = Pb[s.name].grad
             got = ga[s.offset:s.offset + s.numel].view(*s.shape)
             denom = ref.norm().item()
-            if denom < 1e-12:
-                assert got.norm().item() < 1e-6, s.name
+            if denom < 1e-5 * gnorm:
+                # a mathematically zero gradient -- e.g. the last LayerNorm's beta of a model WITHOUT the Normalize module (bare
+                # bert-base): it shifts every embedding alike and the loss sees differences only -- is rounding noise on both sides
+                assert got.norm().item() < 1e-4 * gnorm, s.name
                 continue
-            err = ((got - ref).norm() / denom).item()
+            cls = cls_of(s.name.split(".")[-1])
+            err = ((got - ref).norm() / max(denom, 0.05 * cls_top[cls])).item()
             worst = max(worst, err)
-            leaf = s.name.split(".")[-1]
-            cls = ("b_qkv" if leaf == "b_qkv" else "vec" if (leaf.startswith("b_") or leaf.startswith("ln") or leaf.startswith("emb_ln"))
-                   else "emb" if leaf.endswith("_emb") else "w")
             cls_max[cls] = max(cls_max.get(cls, 0.0), err)
             assert err < GRAD_LIMITS[cls], f"{name} grad {s.name}: relative L2 error {err:.3e} (ref norm {denom:.3e})"
             errs.append((err, s.name))
