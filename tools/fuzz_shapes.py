@@ -5,7 +5,10 @@ ragged lengths, dropout on or off. Prints one line per case; stops at the first 
 the maxima over ITS cases x 1.25; random shapes are held to those x 1.5 (one-quadruplet batches put the last layer's
 near-cancelling feed-forward bias gradient a few percent over them: 2.6e-2 against 2.4e-2 at MiniLM, B = 1, L = 352).
 
-    python tools/fuzz_shapes.py [cases] [seed] [first case to run]"""
+With `fp8` as the fourth argument the same shapes go through the fp8 inference forward against the MX oracle
+(tests/test_gpu_fp8mx.py: run_encoder_mx) instead.
+
+    python tools/fuzz_shapes.py [cases] [seed] [first case to run] [fp8]"""
 import os
 import random
 import sys
@@ -17,12 +20,14 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from quadruplet_sentence_transformer_amd.config import PRESETS  # noqa: E402
 import test_gpu_encoder as T  # noqa: E402
+import test_gpu_fp8mx as T8  # noqa: E402
 
 
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    fp8 = len(sys.argv) > 4 and sys.argv[4] == "fp8"
     T.GRAD_LIMITS = {k: 1.5 * v for k, v in T.GRAD_LIMITS.items()}
     for i in range(cases):
         fam = rng.choice(["all-MiniLM-L6-v2", "all-mpnet-base-v2", "bert-base-uncased"])
@@ -38,6 +43,10 @@ def main():
             continue
         print(f"case {i}: {fam} layers={layers} B={B} L={L} dropout={drop}", flush=True)
         t0 = time.time()
+        if fp8:
+            T8.run_encoder_mx(fam, B, L, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), layers=layers, emb_atol=4e-3)
+            print(f"ok {i} (fp8 forward)  ({time.time() - t0:.1f} s)", flush=True)
+            continue
         T.run_case("fuzz", B, L, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), emb_atol_vs_bf16_oracle=1.5e-3,
                    scale_by_emb=not cfg.normalize, dropout=drop)
         print(f"ok {i}: {fam} layers={layers} B={B} L={L} dropout={drop}  ({time.time() - t0:.1f} s)", flush=True)
