@@ -36,6 +36,12 @@ GRAD_LIMITS = {"w": 1.6e-2, "emb": 1.5e-2, "vec": 2.4e-2, "b_qkv": 3.75e-2}     
 LOSS_KW = dict(gamma=0.6, margin_pos_neg=1.0, margin_pos_part=0.5, margin_part_neg=0.5, p=2.0, swap=False)
 
 
+def cls_of(leaf):
+    """Class of a parameter tensor (by the last component of its name) for the gradient bounds."""
+    return ("b_qkv" if leaf == "b_qkv" else "vec" if (leaf.startswith("b_") or leaf.startswith("ln") or leaf.startswith("emb_ln"))
+            else "emb" if leaf.endswith("_emb") else "w")
+
+
 def run_case(name, B, L, ragged, weights_kw, check_grads=True, emb_atol_vs_bf16_oracle=1e-4, scale_by_emb=False,
              mask_edges=False, dropout=None, ffn_chain=None):
     """dropout = (p_hidden, p_attn, seed): the HIP encoder runs its training forward / backward with dropout on, the
@@ -96,9 +102,6 @@ def run_case(name, B, L, ragged, weights_kw, check_grads=True, emb_atol_vs_bf16_
         cls_max = {}
         gnorm = float(torch.sqrt(sum((Pb[s.name].grad.double() ** 2).sum() for s in segs)))
 
-        def cls_of(leaf):
-            return ("b_qkv" if leaf == "b_qkv" else "vec" if (leaf.startswith("b_") or leaf.startswith("ln") or leaf.startswith("emb_ln"))
-                    else "emb" if leaf.endswith("_emb") else "w")
         # a tensor whose gradient nearly cancels (bare bert-base's LAST feed-forward bias: 1/20 .. 1/40 of the other biases'
         # norm, tools/fuzz_shapes.py case 29) carries the same absolute rounding noise as its peers: it is measured against at
         # least 5% of the largest gradient norm of its class
@@ -241,14 +244,20 @@ def test_parity_precision_backward_matches_fp32_autograd(name, B, L, ragged, wkw
     segs, _ = build_layout(cfg)
     ga = enc.grads.cpu()
     worst = (0.0, "")
+    gnorm = float(torch.sqrt(sum((P[s_.name].grad.double() ** 2).sum() for s_ in segs)))
+    cls_top = {}
+    for s_ in segs:
+        c = cls_of(s_.name.split(".")[-1])
+        cls_top[c] = max(cls_top.get(c, 0.0), P[s_.name].grad.norm().item())
     for s_ in segs:
         ref = P[s_.name].grad
         got = ga[s_.offset:s_.offset + s_.numel].view(*s_.shape)
         denom = ref.norm().item()
-        if denom < 1e-12:
-            assert got.norm().item() < 1e-6, s_.name
+        if denom < 1e-5 * gnorm:                 # a mathematically zero gradient (see run_case): rounding noise on both sides
+            assert got.norm().item() < 1e-5 * gnorm, s_.name
             continue
-        err = ((got - ref).norm() / denom).item()
+        # (near-cancelling tensors -- the last LayerNorm's beta, the last feed-forward bias -- on the scale of their class, as run_case)
+        err = ((got - ref).norm() / max(denom, 0.05 * cls_top[cls_of(s_.name.split(".")[-1])])).item()
         worst = max(worst, (err, s_.name))
         assert err < 1e-4, f"{name} grad {s_.name}: relative L2 error {err:.3e} (ref norm {denom:.3e})"     # measured <= 2.1e-5
     print(f"[x3-grad-err] {name} B={B} L={L}: worst {worst[1]} {worst[0]:.2e}")
