@@ -9,7 +9,10 @@ With `fp8` as the fourth argument the same shapes go through the fp8 inference f
 (tests/test_gpu_fp8mx.py: run_encoder_mx) instead; with `x3`, through the parity-precision training check (forward + backward on
 the split-bf16 x3 path against fp32 autograd: embeddings atol 1e-4, gradients 1e-4 relative L2).
 
-    python tools/fuzz_shapes.py [cases] [seed] [first case to run] [fp8 | x3]"""
+With `topk`: random query / corpus sizes, dimensions and k through the retrieval scoring + top-k checks of
+tests/test_gpu_retrieval.py (cosine, dot and the reference's euclidean score against the fp64 ranking).
+
+    python tools/fuzz_shapes.py [cases] [seed] [first case to run] [fp8 | x3 | topk]"""
 import os
 import random
 import re
@@ -31,6 +34,22 @@ def main():
     first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     fp8 = len(sys.argv) > 4 and sys.argv[4] == "fp8"
     x3 = len(sys.argv) > 4 and sys.argv[4] == "x3"
+    if len(sys.argv) > 4 and sys.argv[4] == "topk":
+        import test_gpu_retrieval as TR
+        for i in range(cases):
+            nq, dim = rng.randint(1, 300), 32 * rng.randint(1, 24)
+            k = rng.randint(1, 128)
+            nc = rng.randint(k, 5000)
+            mode = rng.choice(["cos", "dot", "euclid"])
+            if i < first:
+                continue
+            t0 = time.time()
+            if mode == "euclid":
+                TR.test_topk_scores_euclid_matches_fp64_ranking(nq, nc, dim, k)
+            else:
+                TR.test_topk_scores_matches_fp64_ranking(nq, nc, dim, k, mode == "cos")
+            print(f"ok {i}: topk {mode} nq={nq} nc={nc} dim={dim} k={k}  ({time.time() - t0:.1f} s)", flush=True)
+        return
     T.GRAD_LIMITS = {k: 1.5 * v for k, v in T.GRAD_LIMITS.items()}
     for i in range(cases):
         fam = rng.choice(["all-MiniLM-L6-v2", "all-mpnet-base-v2", "bert-base-uncased"])
