@@ -259,7 +259,7 @@ def test_fp8_training_step_against_the_mx_oracle(name, B, L, layers, wkw, drop):
     if drop is None:
         assert float((emb - emb_inf).abs().max()) / sc < 4e-3
     else:
-        assert float((emb - emb_inf).abs().max()) / sc > 2e-2            # (the masks did something)
+        assert float((emb - emb_inf).abs().max()) / sc > 5e-3            # (the masks did something: more than the parity bar)
     e_err = float((emb.cpu().view(4, B, -1) - emb_o.detach()).abs().max()) / sc
     l_err = abs(loss.item() - loss_o.item()) / max(1.0, sc)                # (bare bert-base emits un-normalised embeddings)
     print(f"[fp8-train fwd] {name} drop={drop}: embeddings {e_err:.2e}, loss {l_err:.2e}")

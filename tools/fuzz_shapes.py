@@ -6,13 +6,14 @@ the maxima over ITS cases x 1.25; random shapes are held to those x 1.5 (one-qua
 near-cancelling feed-forward bias gradient a few percent over them: 2.6e-2 against 2.4e-2 at MiniLM, B = 1, L = 352).
 
 With `fp8` as the fourth argument the same shapes go through the fp8 inference forward against the MX oracle
-(tests/test_gpu_fp8mx.py: run_encoder_mx) instead; with `x3`, through the parity-precision training check (forward + backward on
+(tests/test_gpu_fp8mx.py: run_encoder_mx) instead; with `fp8train`, through the fp8 TRAINING step (fp8 forward, bf16 backward,
+dropout as drawn) against the MX oracle's autograd (gradient bounds x 1.5 as above); with `x3`, through the parity-precision training check (forward + backward on
 the split-bf16 x3 path against fp32 autograd: embeddings atol 1e-4, gradients 1e-4 relative L2).
 
 With `topk`: random query / corpus sizes, dimensions and k through the retrieval scoring + top-k checks of
 tests/test_gpu_retrieval.py (cosine, dot and the reference's euclidean score against the fp64 ranking).
 
-    python tools/fuzz_shapes.py [cases] [seed] [first case to run] [fp8 | x3 | topk]"""
+    python tools/fuzz_shapes.py [cases] [seed] [first case to run] [fp8 | fp8train | x3 | topk]"""
 import os
 import random
 import re
@@ -34,6 +35,8 @@ def main():
     first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     fp8 = len(sys.argv) > 4 and sys.argv[4] == "fp8"
     x3 = len(sys.argv) > 4 and sys.argv[4] == "x3"
+    fp8train = len(sys.argv) > 4 and sys.argv[4] == "fp8train"
+    T8.FP8_TRAIN_GRAD_LIMITS = {k: 1.5 * v for k, v in T8.FP8_TRAIN_GRAD_LIMITS.items()}
     if len(sys.argv) > 4 and sys.argv[4] == "topk":
         import test_gpu_retrieval as TR
         for i in range(cases):
@@ -65,6 +68,11 @@ def main():
             continue
         print(f"case {i}: {fam} layers={layers} B={B} L={L} dropout={drop}", flush=True)
         t0 = time.time()
+        if fp8train:
+            T8.test_fp8_training_step_against_the_mx_oracle(fam, B, L, layers, dict(std=0.03, bias_std=0.02, ln_jitter=0.05),
+                                                            None if drop is None else drop[:2])
+            print(f"ok {i} (fp8 training step)  ({time.time() - t0:.1f} s)", flush=True)
+            continue
         if fp8:
             T8.run_encoder_mx(fam, B, L, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), layers=layers, emb_atol=4e-3)
             print(f"ok {i} (fp8 forward)  ({time.time() - t0:.1f} s)", flush=True)
