@@ -28,6 +28,8 @@ accumulated in fp64 and rounded to fp32 once: products of bf16 values are exact 
 fp64 and the sum no longer depends on the BLAS library's reduction order or thread
 count, so the oracle gives the same numbers on every box (a value that sits on a
 bf16 rounding boundary used to flip with the host's BLAS, and the test bounds chased it).
+The BACKWARD of that mode rounds what the kernels round: the gradient entering every product (dY of a Linear, dO / dS of the
+attention products) is a bf16 operand there too, and bias gradients are column sums of the rounded dY (_MmBf16, _LinearBf16).
 """
 from __future__ import annotations
 
@@ -45,18 +47,64 @@ def _r(x: torch.Tensor, on: bool) -> torch.Tensor:
     return x + (x.detach().to(torch.bfloat16).to(torch.float32) - x.detach())
 
 
+def _b16(x: torch.Tensor) -> torch.Tensor:
+    return x.detach().to(torch.bfloat16).to(torch.float64)
+
+
+class _MmBf16(torch.autograd.Function):
+    """a @ b as the HIP path multiplies: both operands rounded to bf16, exact products, fp64 accumulation, one rounding to
+    fp32 (independent of the host's BLAS) -- and the SAME in the backward, where the incoming gradient is a bf16 matrix-core
+    operand too: dA = bf16(g) @ bf16(b)^T, dB = bf16(a)^T @ bf16(g) (the attention backward's dP, dV, dQ, dK products;
+    csrc/attention.hip rounds dO, P and dS once each)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a16, b16 = _b16(a), _b16(b)
+        ctx.save_for_backward(a16, b16)
+        ctx.shapes = (a.shape, b.shape)
+        return torch.matmul(a16, b16).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        a16, b16 = ctx.saved_tensors
+        g16 = _b16(g)
+        ga = torch.matmul(g16, b16.transpose(-1, -2)).sum_to_size(ctx.shapes[0]).float()
+        gb = torch.matmul(a16.transpose(-1, -2), g16).sum_to_size(ctx.shapes[1]).float()
+        return ga, gb
+
+
+class _LinearBf16(torch.autograd.Function):
+    """x @ w^T + b on bf16-rounded operands (fp64 accumulation); backward as the dgrad / wgrad kernels take it: dY rounded
+    to bf16 once, dX = bf16(dY) @ bf16(W), dW = bf16(dY)^T @ bf16(X), db = the column sums of the bf16-ROUNDED dY (the wgrad
+    kernel sums the fragments it already holds, csrc/gemm.hip gemm_tn_group_kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x16, w16 = _b16(x), _b16(w)
+        ctx.save_for_backward(x16, w16)
+        ctx.has_bias = b is not None
+        y = torch.matmul(x16, w16.t()).float()
+        return y if b is None else y + b
+
+    @staticmethod
+    def backward(ctx, g):
+        x16, w16 = ctx.saved_tensors
+        g16 = _b16(g)
+        g2, x2 = g16.reshape(-1, g16.shape[-1]), x16.reshape(-1, x16.shape[-1])
+        return torch.matmul(g16, w16).float(), torch.matmul(g2.t(), x2).float(), (g2.sum(0).float() if ctx.has_bias else None)
+
+
 def _mm(a, b, bf16):
-    """a @ b; with bf16 operands: exact products, fp64 accumulation, one rounding to fp32 (order-independent)."""
+    """a @ b; with bf16 operands: _MmBf16 (forward and backward on bf16-rounded operands)."""
     if not bf16:
         return torch.matmul(a, b)
-    return torch.matmul(_r(a, True).double(), _r(b, True).double()).float()
+    return _MmBf16.apply(a, b)
 
 
 def _linear(x, w, b, bf16):
     if not bf16:
         return F.linear(x, w, b)
-    y = _mm(x, w.t(), True)
-    return y if b is None else y + b
+    return _LinearBf16.apply(x, w, b)
 
 
 def mpnet_position_ids(ids: torch.Tensor, pad: int = 1) -> torch.Tensor:

@@ -21,17 +21,19 @@ from quadruplet_sentence_transformer_amd.synthetic import synthetic_params, synt
 from quadruplet_sentence_transformer_amd import _lib  # noqa: E402
 from oracle import torch_ref as R  # noqa: E402
 
-# Gradient bounds (relative L2 error per parameter tensor) against the oracle that rounds the same GEMM operands to bf16 and
-# accumulates their products in fp64 (oracle/torch_ref.py: independent of the box's BLAS reduction order). Each bound is the
-# maximum measured over every case of this file and of test_gpu_dropout.py x 1.25 ([measured] in brackets):
-#   w      weight matrices, rel_bias -- accumulation order and bf16 roundings of gradient activations (dY is a bf16 GEMM
-#          operand here, fp32 in autograd);
+# Gradient bounds (relative L2 error per parameter tensor) against the oracle that rounds the same GEMM operands to bf16 --
+# in the forward AND in the backward (dY, dO, P, dS enter its products bf16-rounded, as they enter the matrix cores; bias
+# gradients are column sums of the rounded dY) -- and accumulates the products in fp64 (oracle/torch_ref.py: independent of
+# the box's BLAS reduction order). Each bound is the maximum measured over every case of this file and of
+# test_gpu_dropout.py x 1.25 ([measured] in brackets). What is left between the two:
+#   w      weight matrices, rel_bias -- accumulation order, and the saved activations the backward kernels read as bf16
+#          (gelu'(u), the normalised rows) where autograd keeps fp32; largest on the smallest batch through all six layers;
 #   emb    embedding tables -- sums of the gradient that has crossed every layer, over few rows per table row;
-#   vec    bias / LayerNorm vectors -- column sums of the bf16-ROUNDED dY fragments the wgrad kernel already holds (autograd
-#          sums the unrounded fp32 dY), i.e. sqrt(M)-averaged 2^-9 noise, largest on the smallest batch (M = 256 rows);
+#   vec    bias / LayerNorm vectors -- sums over M rows of values that differ in their last bf16 bit between the two
+#          implementations, largest on the smallest batch (M = 256 rows);
 #   b_qkv  its key third has a mathematically zero gradient (softmax shift invariance), so a third of the vector is pure
 #          rounding noise in both implementations.
-GRAD_LIMITS = {"w": 1.6e-2, "emb": 1.5e-2, "vec": 2.4e-2, "b_qkv": 3.75e-2}     # [1.27e-2, 1.21e-2, 1.89e-2, 2.97e-2]
+GRAD_LIMITS = {"w": 1.65e-2, "emb": 1.55e-2, "vec": 2.2e-2, "b_qkv": 3.55e-2}     # [1.31e-2, 1.22e-2, 1.74e-2, 2.83e-2]
 
 LOSS_KW = dict(gamma=0.6, margin_pos_neg=1.0, margin_pos_part=0.5, margin_part_neg=0.5, p=2.0, swap=False)
 
@@ -216,7 +218,7 @@ def test_bert_base_dims_l384():
 def test_parity_precision_backward_matches_fp32_autograd(name, B, L, ragged, wkw):
     """precision="bf16x3" TRAINING (the reference trains in fp32, training/main.py:142): forward(training=True) + backward on
     the split-bf16 x3 path against fp32 torch autograd -- embeddings within the north-star atol 1e-4, loss 1e-5, every
-    gradient tensor within 1e-4 relative L2 (measured 1.2e-5 ... 2.1e-5; the bf16 path's bounds are 1.6e-2 ... 3.75e-2). The loss gradient comes from
+    gradient tensor within 1e-4 relative L2 (measured 1.2e-5 ... 2.1e-5; the bf16 path's bounds are 1.65e-2 ... 3.55e-2). The loss gradient comes from
     the HIP loss kernel on the x3 embeddings. mpnet-2l: mpnet-base dims (d = 64, position bias) at L = 288 -- two key blocks in
     the fp32 attention backward."""
     from dataclasses import replace
