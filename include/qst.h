@@ -121,9 +121,8 @@ int qst_encoder_forward(qst_encoder* enc, const int64_t* ids, const int64_t* mas
  * (the state of a new handle). state_dev: device uint32[4] owned by the caller, initialised with qst_dropout_init; every
  * qst_encoder_forward(training != 0) of a handle with dropout on first advances its step counter (on the stream, so the
  * step can sit inside a captured graph), and the backward of that forward recomputes the same masks from it -- no mask
- * is ever stored (include/qst_kernels.h: QstDrop). Inference forwards never drop. QST_PREC_BF16 and QST_PREC_FP8 handles
- * (the fp8 training forward drops at the same places with the same masks; its backward is the bf16 one); QST_PREC_BF16X3,
- * the parity path, returns QST_ERR_UNSUPPORTED for non-zero rates. */
+ * is ever stored (include/qst_kernels.h: QstDrop). Inference forwards never drop. Every precision: the fp8 training forward
+ * and the parity path (QST_PREC_BF16X3) drop at the same places with the same masks. */
 int qst_encoder_set_dropout(qst_encoder* enc, float p_hidden, float p_attn, uint32_t* state_dev);
 int qst_dropout_init(uint32_t* state_dev, uint64_t seed, void* stream);
 /* Where this handle runs the feed-forward block (dense + GELU + dense + residual + LayerNorm) as ONE kernel instead of two

@@ -255,6 +255,9 @@ int qst_rel_pos_bwd(const float* drel_pos, const int32_t* lut, int buckets, int 
 int qst_gemm_nt_x3(const QstGemmArgs* a, int epi, void* stream);
 int qst_attention_fwd_x3(const float* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A, int d,
                          float* ctx, void* stream);
+/* ... with dropout of the probabilities (drop nullable; QST_DROP_SITE_PROBS, the 8-bit form): parity-precision TRAINING */
+int qst_attention_fwd_x3_drop(const float* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A, int d,
+                              float* ctx, const QstDrop* drop, void* stream);
 /* Parity-precision BACKWARD building blocks (csrc/x3_bwd.hip; the contractions themselves are qst_gemm_nt_x3 calls on
  * transposed copies). All tensors fp32, contiguous unless a leading dimension is given.
  *   qst_transpose_f32    : dst[C, R] (ld_dst) = src[R, C]^T (ld_src)
@@ -274,6 +277,11 @@ int qst_ln_bwd_f32(const float* dy, const float* prenorm, const float* gamma, fl
                    float* dgamma, float* dbeta, void* stream);
 int qst_attention_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const int64_t* mask, const float* rel_bias,
                           int nseq, int L, int A, int d, float* dqkv, float* drel_bias, void* stream);
+int qst_attention_bwd_f32_drop(const float* qkv, const float* ctx, const float* dctx, const int64_t* mask, const float* rel_bias,
+                               int nseq, int L, int A, int d, float* dqkv, float* drel_bias, const QstDrop* drop, void* stream);
+/* out[i] = in[i] * mask multiplier(i) (+ resid[i], nullable), i < n (n % 4 == 0; in may be out): the hidden-state dropout of
+ * the parity-precision training path (element index = flat index, the 16-bit generator of QstDrop). */
+int qst_dropout_apply_f32(const QstDrop* d, const float* in, const float* resid, int64_t n, float* out, void* stream);
 
 /* k best entries of every row of scores f32 [nrows, ld] (first n columns), sorted by descending score (ties: ascending
  * index). index_map (nullable, int64, same ld) translates column numbers into caller ids -- used to merge the

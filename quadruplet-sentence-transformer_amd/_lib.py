@@ -150,6 +150,8 @@ SIGNATURES = {
     "qst_embed_sum_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "qst_ln_bwd_f32": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp]),
     "qst_attention_bwd_f32": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "qst_attention_bwd_f32_drop": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "qst_dropout_apply_f32": (C.c_int, [vp, vp, vp, C.c_int64, vp, vp]),
     "qst_comm_unique_id": (C.c_int, [vp]),
     "qst_comm_init": (C.c_int, [C.c_int, C.c_int, vp, C.POINTER(vp)]),
     "qst_allreduce_bucket": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),
@@ -167,6 +169,7 @@ SIGNATURES = {
     "qst_shadow_all": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     "qst_gemm_nt_x3": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int, vp]),
     "qst_attention_fwd_x3": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "qst_attention_fwd_x3_drop": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -288,13 +288,14 @@ X3Plan plan_x3(const qst_config& c, int nseq, int L) {
 // runs, 4x the bf16 path's activation bytes). s0 / s1 / s2 are the PRE-norm inputs of the three LayerNorms (the backward
 // recomputes mean and rstd from them), u the pre-GELU tensor.
 struct X3Layer { size_t qkv, ctx, s1, y1, u, h, s2, x; };
-struct X3TrainPlan { size_t pos_ids, s0, x0, pooled, rel, total; std::vector<X3Layer> layers; };
+struct X3TrainPlan { size_t pos_ids, dropst, s0, x0, pooled, rel, total; std::vector<X3Layer> layers; };
 X3TrainPlan plan_x3_train(const qst_config& c, int nseq, int L) {
     X3TrainPlan p;
     const size_t M = (size_t)nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     p.pos_ids = take(M * 4);
+    p.dropst = take(16);                               // the dropout state {seed, step} this forward ran under
     p.s0 = take(M * H * 4); p.x0 = take(M * H * 4);
     p.pooled = take((size_t)nseq * H * 4);
     p.rel = (c.arch == QST_ARCH_MPNET) ? take(A * (size_t)L * L * 4) : 0;
@@ -406,8 +407,6 @@ extern "C" int qst_encoder_set_ffn_chain(qst_encoder* e, int mask) {
 extern "C" int qst_encoder_set_dropout(qst_encoder* e, float p_hidden, float p_attn, uint32_t* state_dev) {
     if (!e || !(p_hidden >= 0.f && p_hidden < 1.f) || !(p_attn >= 0.f && p_attn < 1.f)) return QST_ERR_BAD_ARG;
     if ((p_hidden > 0.f || p_attn > 0.f) && !state_dev) return QST_ERR_BAD_ARG;
-    if ((p_hidden > 0.f || p_attn > 0.f) && e->cfg.precision != QST_PREC_BF16 && e->cfg.precision != QST_PREC_FP8)
-        return QST_ERR_UNSUPPORTED;                                       // the two precisions whose training forward drops
     auto thr = [](float p) { const long t = lroundf(p * 65536.f); return (uint32_t)(t > 65535 ? 65535 : t); };
     e->drop_hidden = thr(p_hidden); e->drop_attn = thr(p_attn);
     e->drop_state = (e->drop_hidden || e->drop_attn) ? state_dev : nullptr;
@@ -705,10 +704,34 @@ static int forward_x3_train(qst_encoder* e, const int64_t* ids, const int64_t* m
     auto P = [&](int seg) { return params + lay.segs[seg].off; };
     auto F = [&](size_t o) { return (float*)(sv + o); };
     int32_t* pos_ids = (int32_t*)(sv + p.pos_ids);
-    QST_TRY(qst_position_ids(ids, nseq, L, c.arch, c.pad_token_id, pos_ids, st));
+    // dropout as the bf16 training forward has it (same sites, same counter-based masks, the snapshot beside the activations);
+    // the hidden-state masks are applied by a pass of their own (qst_dropout_apply_f32): speed is not what this path is for
+    const bool dropping = e->drop_state != nullptr;
+    const void* dst8 = sv + p.dropst;
+    const DropThr thr = dropping ? DropThr{e->drop_hidden, e->drop_attn} : DropThr{0u, 0u};
+    QST_TRY(qst_forward_prologue(ids, nseq, L, c.arch, c.pad_token_id, pos_ids, dropping ? e->drop_state : nullptr,
+                                 dropping ? (uint32_t*)(sv + p.dropst) : nullptr, st));
+    {
+        qst_encoder::FwdRec* rec = nullptr;
+        for (auto& r : e->fwd_recs) if (r.saved == saved) rec = &r;
+        if (!rec) { rec = &e->fwd_recs[e->fwd_next]; e->fwd_next = (e->fwd_next + 1) % 16; }
+        *rec = qst_encoder::FwdRec{saved, thr.hidden, thr.attn};
+    }
+    const bool hdrop = dropping && thr.hidden != 0;
+    // out = (A . W^T + bias) * mask(site) + resid   (BertSelfOutput / BertOutput: LayerNorm(dropout(dense(x)) + input))
+    auto proj = [&](const float* Ain, int K, int wseg, int bseg, const float* resid, float* out, uint32_t site) -> int {
+        if (!hdrop) return nt3(Ain, K, P(wseg), K, out, H, P(bseg), resid, H, M, H, K, 1, st);
+        QST_TRY(nt3(Ain, K, P(wseg), K, out, H, P(bseg), nullptr, 0, M, H, K, 0, st));
+        const QstDrop dd = drop_of(thr, dst8, false, site);
+        return qst_dropout_apply_f32(&dd, out, resid, (int64_t)M * H, out, st);
+    };
     QST_TRY(qst_embed_sum_f32(ids, type_ids, pos_ids, P(lay.word), P(lay.pos), lay.type >= 0 ? P(lay.type) : nullptr, M, H,
                               F(p.s0), st));
     QST_TRY(qst_ln_fwd(F(p.s0), P(lay.eg), P(lay.eb), c.layer_norm_eps, M, H, F(p.x0), nullptr, nullptr, nullptr, st));
+    if (hdrop) {
+        const QstDrop de = drop_of(thr, dst8, false, QST_DROP_SITE_EMBED);
+        QST_TRY(qst_dropout_apply_f32(&de, F(p.x0), nullptr, (int64_t)M * H, F(p.x0), st));
+    }
     const float* rel = nullptr;
     if (c.arch == QST_ARCH_MPNET) {
         QST_TRY(qst_rel_bias_fwd(P(lay.rel), e->rel_lut, A, L, F(p.rel), st));
@@ -719,12 +742,15 @@ static int forward_x3_train(qst_encoder* e, const int64_t* ids, const int64_t* m
         const int b = lay.layer0[l];
         const X3Layer& a = p.layers[l];
         QST_TRY(nt3(x, H, P(b + W_QKV), H, F(a.qkv), 3 * H, P(b + B_QKV), nullptr, 0, M, 3 * H, H, 0, st));
-        QST_TRY(qst_attention_fwd_x3(F(a.qkv), mask, rel, nseq, L, A, d, F(a.ctx), st));
-        QST_TRY(nt3(F(a.ctx), H, P(b + W_O), H, F(a.s1), H, P(b + B_O), x, H, M, H, H, 1, st));
+        {
+            const QstDrop dp = drop_of(thr, dst8, true, QST_DROP_SITE_PROBS(l));
+            QST_TRY(qst_attention_fwd_x3_drop(F(a.qkv), mask, rel, nseq, L, A, d, F(a.ctx), dropping ? &dp : nullptr, st));
+        }
+        QST_TRY(proj(F(a.ctx), H, b + W_O, b + B_O, x, F(a.s1), QST_DROP_SITE_ATTN_OUT(l)));
         QST_TRY(qst_ln_fwd(F(a.s1), P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, F(a.y1), nullptr, nullptr, nullptr, st));
         QST_TRY(nt3(F(a.y1), H, P(b + W_1), H, F(a.u), I, P(b + B_1), nullptr, 0, M, I, H, 0, st));
         QST_TRY(qst_gelu_f32(F(a.u), (int64_t)M * I, F(a.h), st));
-        QST_TRY(nt3(F(a.h), I, P(b + W_2), I, F(a.s2), H, P(b + B_2), F(a.y1), H, M, H, I, 1, st));
+        QST_TRY(proj(F(a.h), I, b + W_2, b + B_2, F(a.y1), F(a.s2), QST_DROP_SITE_FFN_OUT(l)));
         QST_TRY(qst_ln_fwd(F(a.s2), P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, M, H, F(a.x), nullptr, nullptr, nullptr, st));
         x = F(a.x);
     }
@@ -771,23 +797,47 @@ static int backward_x3(qst_encoder* e, const int64_t* ids, const int64_t* mask, 
         drel = Wk(w.drel);
         QST_HIP_CHECK(hipMemsetAsync(drel, 0, (size_t)A * L * L * 4, st));
     }
+    // dropout: the masks of the forward that filled `saved` (its thresholds from the handle's record, its (seed, step) from the
+    // snapshot in the arena). ds = d(loss)/d(LayerNorm input) continues down the residual path as it is; the projection
+    // that was dropped sees ds * mask (dsm, in a buffer that is free at that point).
+    DropThr thr = {e->drop_state ? e->drop_hidden : 0u, e->drop_state ? e->drop_attn : 0u};
+    for (const auto& r : e->fwd_recs) if (r.saved == saved) thr = DropThr{r.hidden, r.attn};
+    const void* dst8 = sv + p.dropst;
+    const bool hdrop = thr.hidden != 0, adrop = thr.attn != 0;
+    auto masked = [&](const float* g, uint32_t site, float* tmp, const float** out) -> int {
+        *out = g;
+        if (!hdrop) return QST_OK;
+        const QstDrop dd = drop_of(thr, dst8, false, site);
+        *out = tmp;
+        return qst_dropout_apply_f32(&dd, g, nullptr, (int64_t)M * H, tmp, st);
+    };
     QST_TRY(qst_pool_norm_bwd(grad_emb, F(p.pooled), mask, nseq, L, H, c.normalize, dx, st));
     for (int l = c.num_layers - 1; l >= 0; --l) {
         const int b = lay.layer0[l];
         const X3Layer& a = p.layers[l];
         const float* xin = l == 0 ? F(p.x0) : F(p.layers[l - 1].x);
         QST_TRY(qst_ln_bwd_f32(dx, F(a.s2), P(b + LN2_G), c.layer_norm_eps, M, H, ds, G(b + LN2_G), G(b + LN2_B), st));
-        QST_TRY(dgrad(ds, H, b + W_2, I, dbig, nullptr));                            // dh
-        QST_TRY(wgrad(ds, H, F(a.h), I, b + W_2, b + B_2));
+        const float* dsm = ds;
+        QST_TRY(masked(ds, QST_DROP_SITE_FFN_OUT(l), dctx, &dsm));                   // (dctx is free until the attention part)
+        QST_TRY(dgrad(dsm, H, b + W_2, I, dbig, nullptr));                           // dh
+        QST_TRY(wgrad(dsm, H, F(a.h), I, b + W_2, b + B_2));
         QST_TRY(qst_gelu_bwd_f32(dbig, F(a.u), (int64_t)M * I, dbig, st));          // du
         QST_TRY(dgrad(dbig, I, b + W_1, H, dy, ds));                                 // dy1 = du . W1 + ds2
         QST_TRY(wgrad(dbig, I, F(a.y1), H, b + W_1, b + B_1));
         QST_TRY(qst_ln_bwd_f32(dy, F(a.s1), P(b + LN1_G), c.layer_norm_eps, M, H, ds, G(b + LN1_G), G(b + LN1_B), st));
-        QST_TRY(dgrad(ds, H, b + W_O, H, dctx, nullptr));
-        QST_TRY(wgrad(ds, H, F(a.ctx), H, b + W_O, b + B_O));
-        QST_TRY(qst_attention_bwd_f32(F(a.qkv), F(a.ctx), dctx, mask, rel, nseq, L, A, d, dqkv, drel, st));
+        QST_TRY(masked(ds, QST_DROP_SITE_ATTN_OUT(l), dy, &dsm));                    // (dy has been consumed)
+        QST_TRY(dgrad(dsm, H, b + W_O, H, dctx, nullptr));
+        QST_TRY(wgrad(dsm, H, F(a.ctx), H, b + W_O, b + B_O));
+        {
+            const QstDrop dp = drop_of(thr, dst8, true, QST_DROP_SITE_PROBS(l));
+            QST_TRY(qst_attention_bwd_f32_drop(F(a.qkv), F(a.ctx), dctx, mask, rel, nseq, L, A, d, dqkv, drel, adrop ? &dp : nullptr, st));
+        }
         QST_TRY(dgrad(dqkv, 3 * H, b + W_QKV, H, dx, ds));                           // dx_in = dqkv . Wqkv + ds1
         QST_TRY(wgrad(dqkv, 3 * H, xin, H, b + W_QKV, b + B_QKV));
+    }
+    if (hdrop) {                                       // the embedding dropout sits AFTER its LayerNorm
+        const QstDrop de = drop_of(thr, dst8, false, QST_DROP_SITE_EMBED);
+        QST_TRY(qst_dropout_apply_f32(&de, dx, nullptr, (int64_t)M * H, dx, st));
     }
     QST_TRY(qst_ln_bwd_f32(dx, F(p.s0), P(lay.eg), c.layer_norm_eps, M, H, ds, G(lay.eg), G(lay.eb), st));
     QST_TRY(qst_embed_bwd(ds, ids, type_ids, (const int32_t*)(sv + p.pos_ids), nseq, L, H, c.type_vocab_size,

@@ -911,7 +911,31 @@ __global__ __launch_bounds__(256) void drop_mult_kernel(QstDrop d, int probs, in
     }
     for (int k = 0; k < 4 && i + k < n; ++k) out[i + k] = m[k];
 }
+// out[i] = in[i] * multiplier(i) (+ resid[i]): the hidden-state masks of the fp32 (parity-precision) training path, whose
+// GEMMs have no dropout in their epilogues. in may alias out.
+__global__ __launch_bounds__(256) void drop_apply_kernel(QstDrop d, const float* in, const float* resid, int64_t n, float* out) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const DropCtx c = drop_ctx(d);
+    float m[4] = {1.f, 1.f, 1.f, 1.f};
+    if (c.thr) { drop_pair(c, (uint32_t)i, m[0], m[1]); drop_pair(c, (uint32_t)i + 2, m[2], m[3]); }
+    if (i + 3 < n) {
+        f32x4 v = *(const f32x4*)(in + i);
+        v[0] *= m[0]; v[1] *= m[1]; v[2] *= m[2]; v[3] *= m[3];
+        if (resid) v += *(const f32x4*)(resid + i);
+        *(f32x4*)(out + i) = v;
+    } else {
+        for (int k = 0; k < 4 && i + k < n; ++k) out[i + k] = in[i + k] * m[k] + (resid ? resid[i + k] : 0.f);
+    }
+}
 }  // namespace
+extern "C" int qst_dropout_apply_f32(const QstDrop* d, const float* in, const float* resid, int64_t n, float* out, void* stream) {
+    if (!d || !in || !out || n <= 0 || (n & 3)) return QST_ERR_BAD_ARG;
+    if (int rc = drop_ok(d, n)) return rc;
+    drop_apply_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(*d, in, resid, n, out);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
 extern "C" int qst_dropout_init(uint32_t* state_dev, uint64_t seed, void* stream) {
     if (!state_dev) return QST_ERR_BAD_ARG;
     drop_init_kernel<<<1, 1, 0, (hipStream_t)stream>>>(state_dev, (uint32_t)seed, (uint32_t)(seed >> 32));

@@ -188,6 +188,7 @@ __device__ __forceinline__ void load_frag_x3(const float* p, bf16x8& hi, bf16x8&
 struct AttnX3Args {
     const float* qkv; const int64_t* mask; const float* rel; float* out;
     int nseq, L, A, H; float scale;
+    QstDrop drop;          // dropout of the probabilities (training), the 8-bit generator of the bf16 kernels
 };
 
 template <int D>
@@ -216,6 +217,8 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(AttnX3Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
     float m = -INFINITY, l = 0.f;
+    const DropCtx dc = drop_ctx8(a.drop);
+    const uint32_t drow = ((uint32_t)(seq * a.A + head) * a.L + qi) * a.L;      // this lane's query row of the mask
     const int nchunk = (a.L + 127) / 128;
     for (int c = 0; c < nchunk; ++c) {
         const int rows = min(128, a.L - c * 128);
@@ -253,6 +256,18 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(AttnX3Args a) {
             ps += swap32(ps);
             l = l * alpha + ps;
             m = mn;
+            if (dc.thr) {
+                // dropped probabilities leave the P.V product only (l stays the softmax denominator, the 1 / (1 - p) scale joins
+                // 1 / l at the end); registers 4g .. 4g+3 are four consecutive keys: the bytes of one random word
+#pragma unroll
+                for (int r = 0; r < 16; r += 4) {
+                    const uint32_t w = drop_word4(dc, drow + j0 + 8 * (r >> 2) + 4 * h);
+                    if (!drop_keep_byte<0>(dc, w)) s[r] = 0.f;
+                    if (!drop_keep_byte<1>(dc, w)) s[r + 1] = 0.f;
+                    if (!drop_keep_byte<2>(dc, w)) s[r + 2] = 0.f;
+                    if (!drop_keep_byte<3>(dc, w)) s[r + 3] = 0.f;
+                }
+            }
 #pragma unroll
             for (int b = 0; b < DB; ++b)
 #pragma unroll
@@ -269,7 +284,7 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(AttnX3Args a) {
         }
     }
     if (!active) return;
-    const float inv = 1.0f / l;
+    const float inv = dc.scale / l;
     float* orow = a.out + ((size_t)seq * a.L + qi) * a.H + head * D;
 #pragma unroll
     for (int b = 0; b < DB; ++b)
@@ -302,9 +317,16 @@ extern "C" int qst_gemm_nt_x3(const QstGemmArgs* a, int epi, void* stream) {
 
 extern "C" int qst_attention_fwd_x3(const float* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A,
                                     int d, float* ctx, void* stream) {
+    return qst_attention_fwd_x3_drop(qkv, mask, rel_bias, nseq, L, A, d, ctx, nullptr, stream);
+}
+extern "C" int qst_attention_fwd_x3_drop(const float* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A,
+                                         int d, float* ctx, const QstDrop* drop, void* stream) {
     if (!qkv || !mask || !ctx || nseq <= 0 || L <= 0 || A <= 0) return QST_ERR_BAD_ARG;
     if ((d != 32 && d != 64) || (L % 32) != 0 || L > 512) return QST_ERR_UNSUPPORTED;
+    if (drop && drop->thr16 && drop->state && (drop->thr16 > 65535u || (int64_t)nseq * A * L * L >= ((int64_t)1 << 32)))
+        return QST_ERR_UNSUPPORTED;
     AttnX3Args a{};
+    if (drop && drop->thr16 && drop->state) a.drop = *drop;
     a.qkv = qkv; a.mask = mask; a.rel = rel_bias; a.out = ctx;
     a.nseq = nseq; a.L = L; a.A = A; a.H = A * d; a.scale = 1.0f / sqrtf((float)d);
     const int grid = nseq * A * ((L + 127) / 128);

@@ -154,6 +154,7 @@ constexpr float kMaskMinF = -3.4028234663852886e38f;
 struct AttnBwdF32Args {
     const float* qkv; const float* ctx; const float* dctx; const int64_t* mask; const float* rel; float* dqkv; float* drel;
     int nseq, L, A, H; float scale;
+    QstDrop drop;          // dropout of the probabilities, as the forward applied it (8-bit generator)
 };
 __device__ __forceinline__ float block_max256(float v, float* red, int tid) {
     v = wave_max(v);
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(AttnBwdF32Args a) {
 #pragma unroll
         for (int c = 0; c < D; ++c) { v[c] = live ? vbase[(size_t)j * ld + c] : 0.f; dk[c] = 0.f; dv[c] = 0.f; }
         const float madd = (live && a.mask[(size_t)seq * L + j]) ? 0.f : kMaskMinF;
+        const DropCtx dcx = drop_ctx8(a.drop);
         for (int i = 0; i < L; ++i) {
             float dsj = 0.f;
             if (live) {
@@ -247,13 +249,20 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(AttnBwdF32Args a) {
                 if (a.rel) s += a.rel[((size_t)head * L + i) * L + j];
                 s += madd;
                 const float p = expf((s - lse[i]) - lz[i]);
-                dsj = p * (dp - delta[i]);
+                // dropout: O = sum_j (m_ij P_ij) V_j, so dP_ij = m_ij (dO_i . V_j), dV takes the dropped probabilities, and
+                // delta_i = dO_i . O_i (from the dropped O the forward saved) still equals sum_k P_ik dP_ik
+                float mk = 1.f;
+                if (dcx.thr) {
+                    const uint32_t idx = ((uint32_t)(seq * a.A + head) * L + (uint32_t)i) * L + (uint32_t)j;
+                    mk = (((drop_word4(dcx, idx) >> (8u * (idx & 3u))) & 0xFFu) >= dcx.thr) ? dcx.scale : 0.f;
+                }
+                dsj = p * (dp * mk - delta[i]);
                 if (a.drel) atomicAdd(a.drel + ((size_t)head * L + i) * L + j, dsj);
-                const float dss = dsj * a.scale;
+                const float dss = dsj * a.scale, pm = p * mk;
 #pragma unroll
                 for (int c = 0; c < D; ++c) {
                     dk[c] += dss * qbase[(size_t)i * ld + c];
-                    dv[c] += p * dbase[(size_t)i * a.H + c];
+                    dv[c] += pm * dbase[(size_t)i * a.H + c];
                 }
             }
             dsrow[tid] = dsj;
@@ -322,10 +331,18 @@ extern "C" int qst_ln_bwd_f32(const float* dy, const float* prenorm, const float
 extern "C" int qst_attention_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const int64_t* mask,
                                      const float* rel_bias, int nseq, int L, int A, int d, float* dqkv, float* drel_bias,
                                      void* stream) {
+    return qst_attention_bwd_f32_drop(qkv, ctx, dctx, mask, rel_bias, nseq, L, A, d, dqkv, drel_bias, nullptr, stream);
+}
+extern "C" int qst_attention_bwd_f32_drop(const float* qkv, const float* ctx, const float* dctx, const int64_t* mask,
+                                          const float* rel_bias, int nseq, int L, int A, int d, float* dqkv, float* drel_bias,
+                                          const QstDrop* drop, void* stream) {
     if (!qkv || !ctx || !dctx || !mask || !dqkv || nseq <= 0 || L <= 0 || A <= 0) return QST_ERR_BAD_ARG;
     if (drel_bias && !rel_bias) return QST_ERR_BAD_ARG;
     if ((d != 32 && d != 64) || L > 512) return QST_ERR_UNSUPPORTED;
+    const bool dropping = drop && drop->thr16 && drop->state;
+    if (dropping && (drop->thr16 > 65535u || (int64_t)nseq * A * L * L >= ((int64_t)1 << 32))) return QST_ERR_UNSUPPORTED;
     AttnBwdF32Args a{};
+    if (dropping) a.drop = *drop;
     a.qkv = qkv; a.ctx = ctx; a.dctx = dctx; a.mask = mask; a.rel = rel_bias; a.dqkv = dqkv; a.drel = drel_bias;
     a.nseq = nseq; a.L = L; a.A = A; a.H = A * d; a.scale = 1.0f / sqrtf((float)d);
     const size_t lds = ((size_t)L * (d + 1) + 3 * (size_t)L + 256 + 8) * sizeof(float);

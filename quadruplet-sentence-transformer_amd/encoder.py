@@ -117,7 +117,7 @@ class HipEncoder:
                 self.drop_state = torch.zeros(4, dtype=torch.int32, device=self.device)
             _lib.check(self.lib.qst_dropout_init(self.drop_state.data_ptr(), int(seed) & 0xFFFFFFFFFFFFFFFF,
                                                  _lib.current_stream_ptr()), "qst_dropout_init")
-        for h in (self.handle, self.handle_mx):          # the fp8 handle's training forward drops at the same places
+        for h in (self.handle, self.handle_mx, self.handle_x3):      # every precision's training forward drops at the same places
             if h is not None:
                 _lib.check(self.lib.qst_encoder_set_dropout(h, float(p_hidden), float(p_attn),
                                                             self.drop_state.data_ptr() if on else None), "qst_encoder_set_dropout")
@@ -188,6 +188,9 @@ class HipEncoder:
             h = _lib.vp()
             _lib.check(self.lib.qst_encoder_create(_lib.make_config(self.cfg, 1), h), "qst_encoder_create(x3)")
             self.handle_x3 = h
+            if self.dropout is not None:
+                _lib.check(self.lib.qst_encoder_set_dropout(h, self.dropout[0], self.dropout[1], self.drop_state.data_ptr()),
+                           "qst_encoder_set_dropout")
         return self.handle_x3
 
     def forward(self, ids: torch.Tensor, mask: torch.Tensor, type_ids: Optional[torch.Tensor] = None,
@@ -217,7 +220,7 @@ class HipEncoder:
             handle, ids.data_ptr(), mask.data_ptr(), _lib.ptr(type_ids), n, L, self.params.data_ptr(),
             shadow.data_ptr(), emb.data_ptr(), _lib.ptr(tok), saved.data_ptr(), saved.numel(), int(training),
             _lib.current_stream_ptr()), "qst_encoder_forward")
-        if training and self.dropout is not None and (handle is self.handle or handle is self.handle_mx):
+        if training and self.dropout is not None:
             self.dropout_step += 1           # mirrors the device counter (tests rebuild this step's masks from it)
         return emb, tok, saved
 

@@ -388,7 +388,7 @@ class SentenceTransformer(nn.Module):
         (weights + Adam moments + step counters; the reference's checkpoints hold weights only)
         from which training continues with the schedule where it stopped; and `precision`: "bf16" (default) or "bf16x3", the
         parity path -- forward and backward as split-bf16 x3 products with fp32 activations, gradients within 1e-4 of fp32
-        autograd (the reference trains in fp32, training/main.py:142); single process, dropout=0; or "fp8"
+        autograd (the reference trains in fp32, training/main.py:142), dropout as on the bf16 path; single process; or "fp8"
         (BASELINE configs[4]): the forward's Linears on the fp8 matrix cores, the bf16 backward (dropout as in bf16).
 
         Data parallelism (one process per GPU, e.g. the unchanged training script under
@@ -469,8 +469,8 @@ class SentenceTransformer(nn.Module):
             eval_out = scratch_dir
         if precision not in ("bf16", "bf16x3", "fp8"):
             raise ValueError("fit(precision=...) is 'bf16', 'bf16x3' or 'fp8'")
-        if precision == "bf16x3" and (world > 1 or p_hidden > 0 or p_attn > 0):
-            raise ValueError("fit(precision='bf16x3') is the single-process parity path: pass dropout=0 and run one process")
+        if precision == "bf16x3" and world > 1:
+            raise ValueError("fit(precision='bf16x3') is the single-process parity path: run one process")
         self.training_precision = precision
         enc.set_dropout(p_hidden, p_attn, int(dropout_seed) + rank)
         global_step = 0

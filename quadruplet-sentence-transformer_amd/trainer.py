@@ -140,16 +140,16 @@ class QuadrupletTrainer:
         """precision: "bf16" (the throughput path); "fp8" -- BASELINE configs[4]: the forward's Linears on the fp8 matrix
         cores (MXFP8 weights and activations), dgrad / wgrad in bf16 from the fp32 master weights (H and I multiples of 128;
         dropout as on the bf16 path); or "bf16x3" -- the parity path: fp32 activations, every product as three
-        split-bf16 MFMAs, gradients fp32-class (the reference trains in fp32, training/main.py:142). Single process, no
-        dropout, several times slower.
+        split-bf16 MFMAs, gradients fp32-class (the reference trains in fp32, training/main.py:142). Single process,
+        several times slower.
         dropout: None / 0 = off; a float p = HF's hidden_dropout_prob = attention_probs_dropout_prob = p; a pair
         (p_hidden, p_attn). The reference's fit() trains with 0.1 (HF config defaults, train() mode). Ranks of a
         data-parallel job should pass different dropout_seed values (fit() adds the rank)."""
         self.cfg = cfg
         if precision not in ("bf16", "bf16x3", "fp8"):
             raise ValueError("training precision is 'bf16', 'bf16x3' or 'fp8'")
-        if precision == "bf16x3" and (world_size > 1 or force_dp or use_graph or dropout):
-            raise ValueError("precision='bf16x3' is the single-process parity path: no data parallelism, graph or dropout")
+        if precision == "bf16x3" and (world_size > 1 or force_dp or use_graph):
+            raise ValueError("precision='bf16x3' is the single-process parity path: no data parallelism or graph")
         if precision == "fp8" and use_graph:
             raise ValueError("precision='fp8' (fp8 forward GEMMs, bf16 backward) trains without a graph")
         self.precision = precision

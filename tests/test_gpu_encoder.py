@@ -209,13 +209,17 @@ def test_bert_base_dims_l384():
              scale_by_emb=True)
 
 
-@pytest.mark.parametrize("name,B,L,ragged,wkw", [
-    ("tiny-bert", 3, 64, True, dict(std=0.08, bias_std=0.05, ln_jitter=0.1)),
-    ("tiny-mpnet", 2, 64, True, dict(std=0.08, bias_std=0.05, ln_jitter=0.1)),
-    ("tiny-bert", 2, 32, False, dict(std=0.02)),
-    ("minilm-2l", 2, 128, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05)),
-    ("mpnet-2l", 1, 288, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05))])       # d = 64, two key blocks (256 + 32)
-def test_parity_precision_backward_matches_fp32_autograd(name, B, L, ragged, wkw):
+@pytest.mark.parametrize("name,B,L,ragged,wkw,drop", [
+    ("tiny-bert", 3, 64, True, dict(std=0.08, bias_std=0.05, ln_jitter=0.1), None),
+    ("tiny-mpnet", 2, 64, True, dict(std=0.08, bias_std=0.05, ln_jitter=0.1), None),
+    ("tiny-bert", 2, 32, False, dict(std=0.02), None),
+    ("minilm-2l", 2, 128, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), None),
+    ("mpnet-2l", 1, 288, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), None),      # d = 64, two key blocks (256 + 32)
+    # train() mode, as the reference's fit() runs (fp32 + HF dropout 0.1 / 0.1): the oracle gets the same masks
+    ("tiny-bert", 3, 64, True, dict(std=0.08, bias_std=0.05, ln_jitter=0.1), (0.1, 0.1, 5)),
+    ("minilm-2l", 2, 128, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), (0.1, 0.1, 6)),
+    ("mpnet-2l", 1, 288, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), (0.2, 0.1, 7))])
+def test_parity_precision_backward_matches_fp32_autograd(name, B, L, ragged, wkw, drop):
     """precision="bf16x3" TRAINING (the reference trains in fp32, training/main.py:142): forward(training=True) + backward on
     the split-bf16 x3 path against fp32 torch autograd -- embeddings within the north-star atol 1e-4, loss 1e-5, every
     gradient tensor within 1e-4 relative L2 (measured 1.2e-5 ... 2.1e-5; the bf16 path's bounds are 1.65e-2 ... 3.55e-2). The loss gradient comes from
@@ -227,11 +231,18 @@ def test_parity_precision_backward_matches_fp32_autograd(name, B, L, ragged, wkw
     ids, mask, types = synthetic_quadruplets(cfg, B, L, seed=21, ragged=ragged)
     ids_t, mask_t, types_t = [torch.from_numpy(x) for x in (ids, mask, types)]
     P = R.arena_to_dict(arena, cfg, requires_grad=True)
-    loss32, emb32 = R.quadruplet_step(P, cfg, ids_t, mask_t, types_t if cfg.type_vocab_size else None, LOSS_KW, bf16_operands=False)
+    masks = None
+    if drop is not None:
+        from oracle.dropout_ref import Masks
+        masks = Masks(drop[2], 1, drop[0], drop[1])
+    loss32, emb32 = R.quadruplet_step(P, cfg, ids_t, mask_t, types_t if cfg.type_vocab_size else None, LOSS_KW, bf16_operands=False,
+                                      dropout=masks)
     loss32.backward()
     enc = HipEncoder(cfg)
     enc.load_arena(arena)
     enc.ensure_train_state()
+    if drop is not None:
+        enc.set_dropout(drop[0], drop[1], drop[2])
     n = 4 * B
     idd, mdd, tdd = ids_t.view(n, L).cuda(), mask_t.view(n, L).cuda(), types_t.view(n, L).cuda()
     tdd = tdd if cfg.type_vocab_size else None

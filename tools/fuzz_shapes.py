@@ -80,7 +80,7 @@ def main():
         if x3:
             note = ""
             try:
-                T.test_parity_precision_backward_matches_fp32_autograd("fuzz", B, L, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05))
+                T.test_parity_precision_backward_matches_fp32_autograd("fuzz", B, L, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), drop)
             except AssertionError as ex:
                 # the suite's 1e-4 is ~5x its own cases' maximum; a one-quadruplet batch can put a partly cancelling
                 # vector (the last LayerNorm's beta) a few percent over it: accepted up to 2e-4, and said so
