@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--train-precision", choices=["bf16", "fp8", "bf16x3"], default="bf16",
                     help="precision of the TIMED training step: bf16 (BASELINE configs[1]); fp8 = BASELINE configs[4]'s 'fp8 "
                          "MFMA GEMMs': every forward Linear on the fp8 matrix cores, bf16 backward; bf16x3 = the fp32-class "
-                         "parity path (trains without dropout: --dropout is set to 0)")
+                         "parity path")
     ap.add_argument("--force-dp", action="store_true",
                     help="single GPU: run the TIMED step through the data-parallel path -- init_process_group('nccl', "
                          "world_size=1), staged backward, the seven async RCCL all-reduces of the gradient buckets -- so that "
@@ -499,8 +499,6 @@ def main():
     B, L = args.batch, args.seq_len
     if args.train_precision != "bf16":
         args.graph = False
-    if args.train_precision == "bf16x3":
-        args.dropout = 0.0                          # the parity path has no dropout
     arena = synthetic_params(cfg, seed=14)          # same replica on every rank
     trainer = QuadrupletTrainer(cfg, arena=arena, device=f"cuda:{dev_index}", lr=2e-5, weight_decay=0.01,
                                 max_grad_norm=1.0, warmup_steps=10000, total_steps=1000000,
