@@ -226,7 +226,7 @@ class HipEncoder:
 
     def backward(self, ids, mask, type_ids, grad_emb: torch.Tensor, saved: torch.Tensor, precision: str = "bf16") -> None:
         """Accumulate d(loss)/d(params) into self.grads given d(loss)/d(emb). precision="bf16x3": the fp32-class backward
-        of a forward(training=True, precision="bf16x3") (the parity path: no dropout, one call); "fp8": the bf16
+        of a forward(training=True, precision="bf16x3") (the parity path: one call); "fp8": the bf16
         backward over what a forward(training=True, precision="fp8") kept (fp8 forward GEMMs, bf16 dgrad / wgrad)."""
         self.ensure_train_state()
         n, L = ids.shape

@@ -239,7 +239,7 @@ class SentenceTransformer(nn.Module):
         # "bf16" (throughput) or "bf16x3" (fp32-class parity path) for no-grad forwards: encode() and evaluators
         self.inference_precision = "bf16"
         # "bf16" or "bf16x3" for forwards that keep a graph (fit(precision=...)): the parity path trains with fp32-class
-        # gradients as the reference's fp32 run does (training/main.py:142) -- single process, no dropout
+        # gradients as the reference's fp32 run does (training/main.py:142) -- single process
         self.training_precision = "bf16"
         self._live_graphs = 0          # training forwards whose backward has not run yet
         self._dp = None                # data-parallel state of a running fit(): {"group", "buckets", "overlap"}
