@@ -11,9 +11,11 @@ dropout as drawn) against the MX oracle's autograd (gradient bounds x 1.5 as abo
 the split-bf16 x3 path against fp32 autograd: embeddings atol 1e-4, gradients 1e-4 relative L2).
 
 With `topk`: random query / corpus sizes, dimensions and k through the retrieval scoring + top-k checks of
-tests/test_gpu_retrieval.py (cosine, dot and the reference's euclidean score against the fp64 ranking).
+tests/test_gpu_retrieval.py (cosine, dot and the reference's euclidean score against the fp64 ranking). With `loss`: the fused
+quadruplet-loss kernel at random B, D, p, swap (all three reductions, values and gradients against the oracle); with `gemm`:
+the NT GEMM epilogues at random M, N, K and tilings (tests/test_gpu_kernels.py).
 
-    python tools/fuzz_shapes.py [cases] [seed] [first case to run] [fp8 | fp8train | x3 | topk]"""
+    python tools/fuzz_shapes.py [cases] [seed] [first case to run] [fp8 | fp8train | x3 | topk | loss | gemm]"""
 import os
 import random
 import re
@@ -37,6 +39,28 @@ def main():
     x3 = len(sys.argv) > 4 and sys.argv[4] == "x3"
     fp8train = len(sys.argv) > 4 and sys.argv[4] == "fp8train"
     T8.FP8_TRAIN_GRAD_LIMITS = {k: 1.5 * v for k, v in T8.FP8_TRAIN_GRAD_LIMITS.items()}
+    if len(sys.argv) > 4 and sys.argv[4] in ("loss", "gemm"):
+        import test_gpu_kernels as TK
+        from quadruplet_sentence_transformer_amd import _lib
+        lib = _lib.load()
+        for i in range(cases):
+            if sys.argv[4] == "loss":
+                B, D = rng.randint(1, 300), rng.choice([rng.randint(1, 64), rng.randint(65, 800), rng.randint(801, 2100)])
+                pn, swap = rng.choice([1.0, 2.0, 3.0]), rng.choice([False, True])
+                if i < first:
+                    continue
+                print(f"case {i}: loss B={B} D={D} p={pn} swap={swap}", flush=True)
+                TK.test_loss_matches_oracle(lib, B, D, pn, swap)
+                print(f"ok {i}: loss B={B} D={D} p={pn} swap={swap}", flush=True)
+            else:
+                M, N, K = rng.randint(1, 40000), 4 * rng.randint(1, 800), 64 * rng.randint(1, 48)
+                form = rng.choice([0, 2, 4])
+                if i < first:
+                    continue
+                t0 = time.time()
+                TK.test_gemm_nt_epilogues(lib, M, N, K, form)
+                print(f"ok {i}: gemm M={M} N={N} K={K} form={form}  ({time.time() - t0:.1f} s)", flush=True)
+        return
     if len(sys.argv) > 4 and sys.argv[4] == "topk":
         import test_gpu_retrieval as TR
         for i in range(cases):
