@@ -13,9 +13,10 @@ the split-bf16 x3 path against fp32 autograd: embeddings atol 1e-4, gradients 1e
 With `topk`: random query / corpus sizes, dimensions and k through the retrieval scoring + top-k checks of
 tests/test_gpu_retrieval.py (cosine, dot and the reference's euclidean score against the fp64 ranking). With `loss`: the fused
 quadruplet-loss kernel at random B, D, p, swap (all three reductions, values and gradients against the oracle); with `gemm`:
-the NT GEMM epilogues at random M, N, K and tilings (tests/test_gpu_kernels.py).
+the NT GEMM epilogues at random M, N, K and tilings; with `wgrad`: the TN weight-gradient GEMM; with `attn`: the bf16
+attention forward + backward at random (sequences, L, heads, d, position bias) (tests/test_gpu_kernels.py).
 
-    python tools/fuzz_shapes.py [cases] [seed] [first case to run] [fp8 | fp8train | x3 | topk | loss | gemm]"""
+    python tools/fuzz_shapes.py [cases] [seed] [first case to run] [fp8 | fp8train | x3 | topk | loss | gemm | wgrad | attn]"""
 import os
 import random
 import re
@@ -39,7 +40,7 @@ def main():
     x3 = len(sys.argv) > 4 and sys.argv[4] == "x3"
     fp8train = len(sys.argv) > 4 and sys.argv[4] == "fp8train"
     T8.FP8_TRAIN_GRAD_LIMITS = {k: 1.5 * v for k, v in T8.FP8_TRAIN_GRAD_LIMITS.items()}
-    if len(sys.argv) > 4 and sys.argv[4] in ("loss", "gemm"):
+    if len(sys.argv) > 4 and sys.argv[4] in ("loss", "gemm", "wgrad", "attn"):
         import test_gpu_kernels as TK
         from quadruplet_sentence_transformer_amd import _lib
         lib = _lib.load()
@@ -52,6 +53,21 @@ def main():
                 print(f"case {i}: loss B={B} D={D} p={pn} swap={swap}", flush=True)
                 TK.test_loss_matches_oracle(lib, B, D, pn, swap)
                 print(f"ok {i}: loss B={B} D={D} p={pn} swap={swap}", flush=True)
+            elif sys.argv[4] == "wgrad":
+                M, N, K = rng.randint(1, 40000), 64 * rng.randint(1, 48), 64 * rng.randint(1, 48)
+                if i < first:
+                    continue
+                print(f"case {i}: wgrad M={M} N={N} K={K}", flush=True)
+                TK.test_gemm_tn_wgrad(lib, M, N, K)
+                print(f"ok {i}: wgrad M={M} N={N} K={K}", flush=True)
+            elif sys.argv[4] == "attn":
+                d = rng.choice([32, 64])
+                n, L, A, rel = rng.randint(1, 6), 32 * rng.randint(1, 16), rng.randint(1, 12), rng.choice([False, True])
+                if i < first:
+                    continue
+                print(f"case {i}: attention n={n} L={L} A={A} d={d} rel={rel}", flush=True)
+                TK.test_attention_fwd_bwd(lib, n, L, A, d, rel)
+                print(f"ok {i}: attention n={n} L={L} A={A} d={d} rel={rel}", flush=True)
             else:
                 M, N, K = rng.randint(1, 40000), 4 * rng.randint(1, 800), 64 * rng.randint(1, 48)
                 form = rng.choice([0, 2, 4])
