@@ -14,9 +14,10 @@ With `topk`: random query / corpus sizes, dimensions and k through the retrieval
 tests/test_gpu_retrieval.py (cosine, dot and the reference's euclidean score against the fp64 ranking). With `loss`: the fused
 quadruplet-loss kernel at random B, D, p, swap (all three reductions, values and gradients against the oracle); with `gemm`:
 the NT GEMM epilogues at random M, N, K and tilings; with `wgrad`: the TN weight-gradient GEMM; with `attn`: the bf16
-attention forward + backward at random (sequences, L, heads, d, position bias) (tests/test_gpu_kernels.py).
+attention forward + backward at random (sequences, L, heads, d, position bias) (tests/test_gpu_kernels.py). With `fused`: the
+encoder check at MiniLM dims with at least 16,384 token rows (the LayerNorm-fused GEMMs and the 8-range wgrad run from there).
 
-    python tools/fuzz_shapes.py [cases] [seed] [first case to run] [fp8 | fp8train | x3 | topk | loss | gemm | wgrad | attn]"""
+    python tools/fuzz_shapes.py [cases] [seed] [first case to run] [fp8 | fp8train | x3 | topk | loss | gemm | wgrad | attn | fused]"""
 import os
 import random
 import re
@@ -94,11 +95,15 @@ def main():
             print(f"ok {i}: topk {mode} nq={nq} nc={nc} dim={dim} k={k}  ({time.time() - t0:.1f} s)", flush=True)
         return
     T.GRAD_LIMITS = {k: 1.5 * v for k, v in T.GRAD_LIMITS.items()}
-    for i in range(cases):
+    big = len(sys.argv) > 4 and sys.argv[4] == "fused"      # M >= 16,384 token rows at H = 384: the LayerNorm-fused GEMMs, the
+    for i in range(cases):                                  # 8-range wgrad and (L <= 128) the single-workgroup attention backward
         fam = rng.choice(["all-MiniLM-L6-v2", "all-mpnet-base-v2", "bert-base-uncased"])
         layers = rng.choice([1, 2])
         L = 32 * rng.randint(1, 16)
         B = rng.randint(1, 6 if L <= 256 else 2)
+        if big:
+            fam, L = "all-MiniLM-L6-v2", 32 * rng.randint(2, 6)
+            B = (16384 + 4 * L - 1) // (4 * L) + rng.randint(0, 6)
         drop = rng.choice([None, (0.1, 0.1, rng.randint(1, 1000)), (0.2, 0.05, rng.randint(1, 1000))])
         cfg = replace(PRESETS[fam], num_layers=layers, vocab_size=2048)
         if L + 2 > cfg.max_position:
