@@ -95,7 +95,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
     f32x4* p4 = (f32x4*)a.p; f32x4* g4 = (f32x4*)a.g; f32x4* m4 = (f32x4*)a.m; f32x4* v4 = (f32x4*)a.v;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (int64_t)gridDim.x * 256) {
         const float decay = a.chunk_decay[i >> 6] ? (1.0f - a.lr * a.wd) : 1.0f;   // 64 float4 per 256-element chunk
-        f32x4 p = p4[i], g = g4[i], m = m4[i], v = v4[i];
+        // the moments and the (zeroed) gradients are not touched again before the next step: streamed past the caches (step 4.575 ->
+        // 4.543 ms, three alternations); the parameters are read next by the bf16 refresh and stay plain (streamed: 4.600 -> 4.627)
+        f32x4 p = p4[i], g = ld_stream(g4 + i), m = ld_stream(m4 + i), v = ld_stream(v4 + i);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float gg = g[k] * coef;
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
             p[k] -= step * (m[k] / denom);
             g[k] = 0.f;                                                  // optimizer.zero_grad()
         }
-        p4[i] = p; m4[i] = m; v4[i] = v; g4[i] = g;
+        p4[i] = p; st_stream(m4 + i, m); st_stream(v4 + i, v); st_stream(g4 + i, g);
     }
 }
 
