@@ -267,6 +267,16 @@ def test_fp8_training_step_against_the_mx_oracle(name, B, L, layers, wkw, drop):
     segs, _ = build_layout(cfg)
     ga = enc.grads.cpu()
     assert torch.isfinite(ga).all()
+    # The loss is a sum of hinges: a hinge whose argument sits within the forward tolerance of zero is on in one implementation
+    # and off in the other, and its whole gradient comes or goes (loss equal to 7e-5, gradients 0.68 apart on a one-quadruplet
+    # batch: tools/fuzz_shapes.py fp8train, seed 102, case 14). Such a batch has no gradient to compare.
+    eo = emb_o.detach()
+    dist = lambda x, y: (x - y + 1e-6).norm(dim=-1)                                     # noqa: E731
+    args = torch.stack([1.0 + dist(eo[0], eo[1]) - dist(eo[0], eo[3]), 0.5 + dist(eo[0], eo[2]) - dist(eo[0], eo[3]),
+                        0.5 + dist(eo[0], eo[1]) - dist(eo[0], eo[2])])
+    if float(args.abs().min()) < 2e-3 * max(1.0, sc):       # (the forward tolerance on an embedding element is 4e-3 of that scale)
+        print(f"[fp8-train] {name} B={B} L={L} drop={drop}: a hinge within {float(args.abs().min()):.1e} of its kink -- gradients not compared")
+        return
     cls_max = {}
     gnorm = float(torch.sqrt(sum((P[s_.name].grad.double() ** 2).sum() for s_ in segs)))
     for s_ in segs:
