@@ -144,6 +144,18 @@ typedef struct {
 } QstTnGroup;
 int qst_gemm_tn_group(const QstTnGroup* grp, void* stream);
 
+/* The same GEMMs on the 8-wave, 8-phase K loop (csrc/gemm8p.h, csrc/gemm8.hip): one 512-thread workgroup per CU, 128 KB of
+ * LDS, K-tiles of 64 with three half-tiles of LDS-DMA in flight across the barriers. qst_gemm_nt / qst_gemm_tn_group take
+ * this path by themselves where it is faster (long reductions); these entry points force it (tests, tools).
+ * qst_gemm_nt8: tile 0 = 128 x 384 (8 waves of 64 x 96), 1 = 256 x 256 (8 waves of 128 x 64); needs K % 64 == 0,
+ * N % 8 == 0, lda / ldb / ldc % 8 == 0 (qst_gemm_nt8_supported tells). Epilogues and dropout as qst_gemm_nt.
+ * qst_gemm8_mode(mode): -1 = the library chooses per call (default); otherwise bit 0 = every supported NT GEMM, bit 1 =
+ * every weight-gradient launch on this path, 0 = none. Returns the previous mode; mode < -1 only reads it. Process-wide. */
+int qst_gemm_nt8_supported(const QstGemmArgs* a, int epi);
+int qst_gemm_nt8(const QstGemmArgs* a, int epi, int tile, void* stream);
+int qst_gemm_tn8_group(const QstTnGroup* grp, void* stream);
+int qst_gemm8_mode(int mode);
+
 /* Embedding gather + LayerNorm (BertEmbeddings / MPNetEmbeddings forward).
  * pos_ids: int32 [M] position row per token. type_emb may be NULL. Outputs: y f32, y bf16, xhat bf16, rstd f32. */
 int qst_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,

@@ -1113,6 +1113,10 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
 
 }  // namespace
 
+int qst_gemm8_mode_get();                               // gemm8.hip
+// shapes on which the 8-phase kernel is taken without being asked (measured: DESIGN.md, round 4)
+static bool nt8_auto(const QstGemmArgs* a, int epi) { (void)a; (void)epi; return false; }
+
 template <int EPI, int WAVES_M, int WAVES_N = 2, int TI = 2>
 static int launch_nt(const QstGemmArgs* a, hipStream_t st) {
     constexpr int NBM = 32 * TI * WAVES_M, NBN = 96 * WAVES_N;
@@ -1135,6 +1139,13 @@ extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
         if (a->drop.thr16 > 65535u || (int64_t)a->M * a->N >= ((int64_t)1 << 32)) return QST_ERR_UNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
+    // The 8-wave, 8-phase K loop (gemm8.hip): a->splits bit 5 forces its 128 x 384 tile, bit 6 its 256 x 256 tile, bit 7
+    // forbids it; otherwise qst_gemm8_mode / the shape decide (nt8_auto).
+    if ((a->splits & 0x60) && qst_gemm_nt8_supported(a, epi)) return qst_gemm_nt8(a, epi, (a->splits & 0x40) ? 1 : 0, stream);
+    if (!(a->splits & 0xFE7) && qst_gemm_nt8_supported(a, epi)) {
+        const int mode = qst_gemm8_mode_get();
+        if (mode >= 0 ? (mode & 1) != 0 : nt8_auto(a, epi)) return qst_gemm_nt8(a, epi, 0, stream);
+    }
     // Two 128-row workgroups per CU beat one 256-row workgroup on every shape of the step (their MFMA and
     // store phases interleave); a->splits (unused by nt otherwise) can force the tile height: 1 = 128, 2 = 256 rows.
     const bool small = (a->splits & 3) != 2;
@@ -1244,8 +1255,14 @@ extern "C" int qst_gemm_nt_ln(const QstGemmArgs* a, const QstLnEpi* ln, int mode
     return QST_OK;
 }
 
+static bool tn8_auto(const QstTnGroup* g) { (void)g; return false; }
+
 extern "C" int qst_gemm_tn_group(const QstTnGroup* grp_in, void* stream) {
     if (!grp_in || grp_in->nprob <= 0 || grp_in->nprob > QST_TN_MAX_PROB) return QST_ERR_BAD_ARG;
+    {
+        const int mode = qst_gemm8_mode_get();
+        if (mode >= 0 ? (mode & 2) != 0 : tn8_auto(grp_in)) return qst_gemm_tn8_group(grp_in, stream);
+    }
     QstTnGroup g = *grp_in;
     g.total_tiles = 0;
     for (int i = 0; i < g.nprob; ++i) {
