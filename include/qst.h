@@ -137,6 +137,10 @@ int qst_dropout_advance(uint32_t* state_dev, void* stream);
  *   grad_emb   : fp32 [nseq, H]
  *   grads      : fp32 arena; gradients are ACCUMULATED into it (zero it for a fresh step)
  *   workspace  : qst_encoder_bwd_workspace_bytes
+ *   saved      : the arena a TRAINING forward of this process filled (any handle of the same model and arena kind: the
+ *                dropout rates that forward ran under are remembered per arena, so the masks rebuilt here are its masks
+ *                whatever qst_encoder_set_dropout has been told since); an arena without such a forward, or the fp32
+ *                arena of QST_PREC_BF16X3 given to a bf16 / fp8 handle (or the reverse), is refused with QST_ERR_BAD_ARG.
  */
 int qst_encoder_backward(qst_encoder* enc, const int64_t* ids, const int64_t* mask, const int64_t* type_ids,
                          int nseq, int L, const float* params, const void* shadow_bf16,

@@ -14,7 +14,9 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
+#include <string>
 
 #include <hip/hip_runtime.h>
 
@@ -40,14 +42,17 @@ struct Rccl {
     AllReduceFn all_reduce = nullptr;
     CommDestroyFn comm_destroy = nullptr;
     GetErrorStringFn error_string = nullptr;
-    int last_error = 0;
 };
-Rccl g_rccl;
+Rccl g_rccl;                                  // written once under the mutex, read only after g_rccl_ready
+std::atomic<bool> g_rccl_ready{false};
 std::mutex g_rccl_mutex;                      // binding happens once, from whichever thread asks first
+std::string g_load_error;                     // why the binding failed (under the mutex)
+thread_local int t_last_error = 0;            // the calling thread's last RCCL status (as qst_set_hip_error keeps HIP's)
 
 bool rccl_load() {
+    if (g_rccl_ready.load(std::memory_order_acquire)) return true;
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
-    if (g_rccl.lib) return true;
+    if (g_rccl_ready.load(std::memory_order_relaxed)) return true;
     const char* names[] = {"librccl.so", "librccl.so.1"};
     void* h = nullptr;
     for (const char* n : names)
@@ -55,7 +60,7 @@ bool rccl_load() {
     if (!h)
         for (const char* n : names)
             if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-    if (!h) return false;
+    if (!h) { g_load_error = "RCCL could not be loaded (librccl.so / librccl.so.1)"; return false; }
     Rccl r;
     r.lib = h;
     r.get_unique_id = (GetUniqueIdFn)dlsym(h, "ncclGetUniqueId");
@@ -63,14 +68,21 @@ bool rccl_load() {
     r.all_reduce = (AllReduceFn)dlsym(h, "ncclAllReduce");
     r.comm_destroy = (CommDestroyFn)dlsym(h, "ncclCommDestroy");
     r.error_string = (GetErrorStringFn)dlsym(h, "ncclGetErrorString");
-    if (!r.get_unique_id || !r.comm_init_rank || !r.all_reduce || !r.comm_destroy) return false;
+    const char* missing = !r.get_unique_id ? "ncclGetUniqueId" : !r.comm_init_rank ? "ncclCommInitRank"
+                          : !r.all_reduce ? "ncclAllReduce" : !r.comm_destroy ? "ncclCommDestroy" : nullptr;
+    if (missing) {
+        g_load_error = std::string("librccl.so is loaded but does not export ") + missing;
+        dlclose(h);
+        return false;
+    }
     g_rccl = r;
+    g_rccl_ready.store(true, std::memory_order_release);
     return true;
 }
 
 int rccl_rc(int rc) {
     if (rc == 0) return QST_OK;
-    g_rccl.last_error = rc;
+    t_last_error = rc;
     return QST_ERR_COMM;
 }
 
@@ -117,14 +129,23 @@ extern "C" int qst_allreduce_bucket(qst_comm* comm, void* ptr, int64_t count, in
 extern "C" int qst_comm_rank(const qst_comm* comm) { return comm ? comm->rank : QST_ERR_BAD_ARG; }
 extern "C" int qst_comm_world(const qst_comm* comm) { return comm ? comm->world : QST_ERR_BAD_ARG; }
 
+// (A handle is invalid after qst_comm_destroy, as a freed pointer is: the library cannot tell a destroyed handle from a live
+// one without keeping a registry; callers drop the handle when they destroy it, as comm.NativeComm does.)
 extern "C" void qst_comm_destroy(qst_comm* comm) {
     if (!comm) return;
-    if (comm->comm && g_rccl.comm_destroy) (void)g_rccl.comm_destroy(comm->comm);
+    if (comm->comm && g_rccl_ready.load(std::memory_order_acquire)) (void)g_rccl.comm_destroy(comm->comm);
+    comm->comm = nullptr;
     delete comm;
 }
 
+// text for the calling thread's last QST_ERR_COMM
 extern "C" const char* qst_comm_last_error(void) {
-    if (!g_rccl.lib) return "RCCL could not be loaded (librccl.so / librccl.so.1)";
-    if (g_rccl.error_string && g_rccl.last_error) return g_rccl.error_string(g_rccl.last_error);
+    if (!g_rccl_ready.load(std::memory_order_acquire)) {
+        static thread_local std::string msg;
+        std::lock_guard<std::mutex> lock(g_rccl_mutex);
+        msg = g_load_error.empty() ? "RCCL has not been loaded yet" : g_load_error;
+        return msg.c_str();
+    }
+    if (g_rccl.error_string && t_last_error) return g_rccl.error_string(t_last_error);
     return "";
 }

@@ -5,6 +5,8 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <mutex>
+#include <unordered_map>
 
 #include "qst_common.h"
 #include "qst_kernels.h"
@@ -101,6 +103,36 @@ enum { W_QKV = 0, B_QKV, W_O, B_O, LN1_G, LN1_B, W_1, B_1, W_2, B_2, LN2_G, LN2_
 
 }  // namespace
 
+// What the training forward that FILLED an activation arena did with dropout, and which kind of arena it left: a backward
+// regenerates the masks of that forward -- with ITS thresholds, whatever qst_encoder_set_dropout has been told since (fit()
+// and bench.py switch dropout on live encoders; several forwards may be alive before their backwards run) and whichever
+// handle runs the backward. Process-wide, keyed by the arena's device address; a backward over an arena no training forward
+// of this process has filled, or over the other kind of arena, is refused (QST_ERR_BAD_ARG) instead of guessing the rates.
+// (Rounds 2-3 kept a 16-entry ring per handle and fell back on the handle's current rates when it had no entry: wrong
+// gradients without an error once the ring wrapped or a backward ran on another handle -- ADVICE r03.)
+namespace {
+enum { ARENA_BF16 = 0, ARENA_X3 = 1 };          // the bf16 activation arena (bf16 and fp8 forwards) / the fp32 one of bf16x3
+struct FwdRec { uint32_t hidden = 0, attn = 0; int kind = ARENA_BF16; uint64_t seq = 0; };
+std::mutex g_rec_mu;
+std::unordered_map<const void*, FwdRec> g_recs;
+uint64_t g_rec_seq = 0;
+void rec_put(const void* saved, uint32_t hidden, uint32_t attn, int kind) {
+    std::lock_guard<std::mutex> lk(g_rec_mu);
+    g_recs[saved] = FwdRec{hidden, attn, kind, ++g_rec_seq};
+    if (g_recs.size() > 4096) {                 // arenas that were freed long ago: drop the older half
+        const uint64_t cut = g_rec_seq - 2048;
+        for (auto it = g_recs.begin(); it != g_recs.end();) it = it->second.seq < cut ? g_recs.erase(it) : std::next(it);
+    }
+}
+bool rec_get(const void* saved, int kind, FwdRec* out) {
+    std::lock_guard<std::mutex> lk(g_rec_mu);
+    const auto it = g_recs.find(saved);
+    if (it == g_recs.end() || it->second.kind != kind) return false;
+    *out = it->second;
+    return true;
+}
+}  // namespace
+
 struct qst_encoder {
     qst_config cfg;
     Layout lay;
@@ -112,12 +144,6 @@ struct qst_encoder {
     // caller's device counter {seed lo, seed hi, step, 0} that every training forward advances
     uint32_t drop_hidden = 0, drop_attn = 0;
     uint32_t* drop_state = nullptr;
-    // What the last training forwards did with dropout, by activation arena: a backward regenerates the masks of the forward
-    // that FILLED `saved` -- with that forward's thresholds, whatever qst_encoder_set_dropout has been told since (fit() and
-    // bench.py switch dropout on live encoders; several forwards may be alive before their backwards run).
-    struct FwdRec { const void* saved = nullptr; uint32_t hidden = 0, attn = 0; };
-    FwdRec fwd_recs[16];
-    int fwd_next = 0;
     // Where the one-kernel feed-forward block (csrc/ffn.hip) is used (qst_encoder_set_ffn_chain): bit 0 = inference forward
     // (default: the [M, I] tensor never leaves the chip, 121 vs 144 us per layer at M = 32768), bit 1 = training forward,
     // bit 2 = backward. The training variants are correct and tested but measured SLOWER than the two-kernel path (178 vs
@@ -596,10 +622,7 @@ static int forward_mx_train(qst_encoder* e, const int64_t* ids, const int64_t* m
         return qst_gemm_nt_f8(&g, epi, st);
     };
     {
-        qst_encoder::FwdRec* rec = nullptr;
-        for (auto& r : e->fwd_recs) if (r.saved == saved) rec = &r;
-        if (!rec) { rec = &e->fwd_recs[e->fwd_next]; e->fwd_next = (e->fwd_next + 1) % 16; }
-        *rec = qst_encoder::FwdRec{saved, thr.hidden, thr.attn};
+        rec_put(saved, thr.hidden, thr.attn, ARENA_BF16);
     }
     int32_t* pos_ids = (int32_t*)(sv + p.pos_ids);
     QST_TRY(qst_forward_prologue(ids, nseq, L, c.arch, c.pad_token_id, pos_ids, dropping ? e->drop_state : nullptr,
@@ -712,10 +735,7 @@ static int forward_x3_train(qst_encoder* e, const int64_t* ids, const int64_t* m
     QST_TRY(qst_forward_prologue(ids, nseq, L, c.arch, c.pad_token_id, pos_ids, dropping ? e->drop_state : nullptr,
                                  dropping ? (uint32_t*)(sv + p.dropst) : nullptr, st));
     {
-        qst_encoder::FwdRec* rec = nullptr;
-        for (auto& r : e->fwd_recs) if (r.saved == saved) rec = &r;
-        if (!rec) { rec = &e->fwd_recs[e->fwd_next]; e->fwd_next = (e->fwd_next + 1) % 16; }
-        *rec = qst_encoder::FwdRec{saved, thr.hidden, thr.attn};
+        rec_put(saved, thr.hidden, thr.attn, ARENA_X3);
     }
     const bool hdrop = dropping && thr.hidden != 0;
     // out = (A . W^T + bias) * mask(site) + resid   (BertSelfOutput / BertOutput: LayerNorm(dropout(dense(x)) + input))
@@ -800,8 +820,9 @@ static int backward_x3(qst_encoder* e, const int64_t* ids, const int64_t* mask, 
     // dropout: the masks of the forward that filled `saved` (its thresholds from the handle's record, its (seed, step) from the
     // snapshot in the arena). ds = d(loss)/d(LayerNorm input) continues down the residual path as it is; the projection
     // that was dropped sees ds * mask (dsm, in a buffer that is free at that point).
-    DropThr thr = {e->drop_state ? e->drop_hidden : 0u, e->drop_state ? e->drop_attn : 0u};
-    for (const auto& r : e->fwd_recs) if (r.saved == saved) thr = DropThr{r.hidden, r.attn};
+    FwdRec fr;
+    if (!rec_get(saved, ARENA_X3, &fr)) return QST_ERR_BAD_ARG;      // not an arena a bf16x3 training forward has filled
+    const DropThr thr = {fr.hidden, fr.attn};
     const void* dst8 = sv + p.dropst;
     const bool hdrop = thr.hidden != 0, adrop = thr.attn != 0;
     auto masked = [&](const float* g, uint32_t site, float* tmp, const float** out) -> int {
@@ -881,10 +902,7 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     QST_TRY(qst_forward_prologue(ids, nseq, L, c.arch, c.pad_token_id, pos_ids, dropping ? e->drop_state : nullptr,
                                  dropping ? (uint32_t*)(sv + p.dropst) : nullptr, st));
     if (training) {                                   // remember what this forward did, for the backward over the same arena
-        qst_encoder::FwdRec* rec = nullptr;
-        for (auto& r : e->fwd_recs) if (r.saved == saved) rec = &r;
-        if (!rec) { rec = &e->fwd_recs[e->fwd_next]; e->fwd_next = (e->fwd_next + 1) % 16; }
-        *rec = qst_encoder::FwdRec{saved, thr.hidden, thr.attn};
+        rec_put(saved, thr.hidden, thr.attn, ARENA_BF16);
     }
     {
         const QstDrop de = drop_of(thr, dst8, false, QST_DROP_SITE_EMBED);
@@ -1019,9 +1037,10 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
     // runs inside the epilogue of the dgrad GEMM that produces its input; those write one partial row per 128-row tile
     const bool fuse_ln = qst_gemm_nt_ln_supported(H) != 0 && M >= kFuseLnMinRows;
     // dropout: the masks of the forward that filled `saved` are recomputed from its (seed, step) snapshot in the arena and
-    // ITS thresholds (recorded by that forward); an arena this handle has no record of falls back on the current settings
-    DropThr thr = {e->drop_state ? e->drop_hidden : 0u, e->drop_state ? e->drop_attn : 0u};
-    for (const auto& r : e->fwd_recs) if (r.saved == saved) thr = DropThr{r.hidden, r.attn};
+    // ITS thresholds (recorded by that forward, process-wide: any handle of the same model may run the backward)
+    FwdRec fr;
+    if (!rec_get(saved, ARENA_BF16, &fr)) return QST_ERR_BAD_ARG;    // not an arena a bf16 / fp8 training forward has filled
+    const DropThr thr = {fr.hidden, fr.attn};
     const bool dropping = thr.hidden != 0 || thr.attn != 0;
     const void* dst8 = sv + p.dropst;
     const bool fuse_ffn = fuse_ln && !dropping && (e->ffn_chain & 4) && qst_ffn_chain_supported(H, I) != 0;

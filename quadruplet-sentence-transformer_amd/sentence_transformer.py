@@ -162,8 +162,15 @@ class _EncodeFn(torch.autograd.Function):
             # data-parallel fit(): the LAST outstanding encoder pass of the step (the only one on the fused [4B, L]
             # path) runs in stages with each finished layer's gradients handed to the all-reduce; gradients of earlier
             # passes of the same step are already in the arena and travel with them
-            model._dp_works += staged_backward(model._enc, ids, mask, types, grad_emb, ctx.saved, None, dp["buckets"],
-                                               dp["group"], dp["overlap"], precision=ctx.prec)
+            if ctx.prec == "bf16x3":
+                # the parity path's backward is one call: the same buckets, in the staged backward's order, after it
+                model._enc.backward(ids, mask, types, grad_emb, ctx.saved, precision=ctx.prec)
+                model._dp_works += allreduce_ranges(model._enc.grads,
+                                                    staged_reduce_order(dp["buckets"], model._enc.total, dp["overlap"]),
+                                                    dp["group"], async_op=dp["overlap"])
+            else:
+                model._dp_works += staged_backward(model._enc, ids, mask, types, grad_emb, ctx.saved, None, dp["buckets"],
+                                                   dp["group"], dp["overlap"], precision=ctx.prec)
             model._dp_reduced = True
         else:
             model._enc.backward(ids, mask, types, grad_emb, ctx.saved, precision=ctx.prec)
@@ -238,8 +245,8 @@ class SentenceTransformer(nn.Module):
             self._synthetic_tokenizer = SyntheticTokenizer(cfg)
         # "bf16" (throughput) or "bf16x3" (fp32-class parity path) for no-grad forwards: encode() and evaluators
         self.inference_precision = "bf16"
-        # "bf16" or "bf16x3" for forwards that keep a graph (fit(precision=...)): the parity path trains with fp32-class
-        # gradients as the reference's fp32 run does (training/main.py:142) -- single process
+        # "bf16", "bf16x3" or "fp8" for forwards that keep a graph (fit(precision=...), reset when fit() returns or raises): the
+        # parity path "bf16x3" trains with fp32-class gradients as the reference's fp32 run does (training/main.py:142)
         self.training_precision = "bf16"
         self._live_graphs = 0          # training forwards whose backward has not run yet
         self._dp = None                # data-parallel state of a running fit(): {"group", "buckets", "overlap"}
@@ -439,6 +446,10 @@ class SentenceTransformer(nn.Module):
                 return lr * min(1.0, float(step) / float(max(1, warmup_steps)))
             return warmup_linear_lr(lr, step, warmup_steps, t_total)
 
+        if precision not in ("bf16", "bf16x3", "fp8"):
+            raise ValueError("fit(precision=...) is 'bf16', 'bf16x3' or 'fp8'")
+        if data_parallel not in (None, "off", "split_batch", "per_rank_batches"):
+            raise ValueError(f"data_parallel={data_parallel!r}: expected 'split_batch', 'per_rank_batches' or 'off'")
         enc = self._enc
         enc.ensure_train_state()
         enc.grads.zero_()
@@ -452,8 +463,6 @@ class SentenceTransformer(nn.Module):
         world, rank = 1, 0
         if data_parallel != "off" and dist.is_available() and dist.is_initialized():
             world, rank = dist.get_world_size(process_group), dist.get_rank(process_group)
-        if data_parallel not in (None, "off", "split_batch", "per_rank_batches"):
-            raise ValueError(f"data_parallel={data_parallel!r}: expected 'split_batch', 'per_rank_batches' or 'off'")
         dp_mode = (data_parallel or "split_batch") if world > 1 else "off"
         self._dp = None if world == 1 else {"group": process_group, "buckets": gradient_buckets(self.cfg),
                                             "overlap": bool(overlap_grad_reduce)}
@@ -467,76 +476,78 @@ class SentenceTransformer(nn.Module):
         if not is_main and evaluator is not None and output_path is not None:
             scratch_dir = tempfile.mkdtemp(prefix=f"qst_eval_rank{rank}_")
             eval_out = scratch_dir
-        if precision not in ("bf16", "bf16x3", "fp8"):
-            raise ValueError("fit(precision=...) is 'bf16', 'bf16x3' or 'fp8'")
-        if precision == "bf16x3" and world > 1:
-            raise ValueError("fit(precision='bf16x3') is the single-process parity path: run one process")
         self.training_precision = precision
-        enc.set_dropout(p_hidden, p_attn, int(dropout_seed) + rank)
-        global_step = 0
-        if resume_from_checkpoint is not None:
-            global_step = self._load_training_state(resume_from_checkpoint)
-            enc.set_dropout_step(self._resume_dropout_step)     # the mask stream continues where the checkpoint left it
-        self._fit_meta = {"scheduler": sched, "lr": lr, "warmup_steps": int(warmup_steps), "t_total": t_total}
-        iters = [iter(dl) for dl in dataloaders]
-        if global_step > 0:
-            # resumed run: consume the batches the interrupted run already trained on (exact for unshuffled loaders)
-            for i, dl in enumerate(dataloaders):
-                for _ in range(global_step % max(1, len(dl))):
-                    next(iters[i])
-        first_epoch, skip_steps = divmod(global_step, steps_per_epoch)
-        for epoch in range(first_epoch, epochs):
-            training_steps = skip_steps if epoch == first_epoch else 0
-            for lm in loss_models:
-                lm.train()
-            self._rebind_grads()
-            for _ in range(steps_per_epoch - training_steps):
-                for idx, lm in enumerate(loss_models):
-                    try:
-                        data = next(iters[idx])
-                    except StopIteration:
-                        iters[idx] = iter(dataloaders[idx])
-                        data = next(iters[idx])
-                    features, labels = data
-                    weight = 1.0
-                    if dp_mode == "split_batch":
-                        features, labels, n_total, n_mine = _shard_batch(features, labels, rank, world)
-                        weight = float(n_mine) * world / float(max(1, n_total))   # mean over the GLOBAL batch after the 1/world
-                    if _loss_reduction(lm) == "sum":
-                        weight = float(world)
-                    if labels.numel() > 0:
-                        labels = labels.to(self._target_device)
-                        features = [batch_to_device(f, self._target_device) for f in features]
-                        loss_value = lm(features, labels)
-                        (loss_value if weight == 1.0 else loss_value * weight).backward()
-                    if world > 1:
-                        if not self._dp_reduced:
-                            # empty shard (the last batch had fewer rows than ranks), or a loss model that bypassed
-                            # _EncodeFn: take part in the SAME sequence of all-reduces the other ranks issue from inside
-                            # staged_backward -- per-layer slices in its order, or one arena-wide reduce without overlap
-                            self._dp_works += allreduce_ranges(
-                                enc.grads, staged_reduce_order(self._dp["buckets"], enc.total, self._dp["overlap"]),
-                                process_group, async_op=self._dp["overlap"])
-                        for w in self._dp_works:
-                            w.wait()
-                        self._dp_works, self._dp_reduced, self._live_graphs = [], False, 0
-                    # clip_grad_norm_ + AdamW.step + zero_grad, one pass over the arena, norm stays on the device
-                    enc.adamw_step(lr_at(global_step), betas, eps, weight_decay, float(max_grad_norm), 1.0 / world)
-                training_steps += 1
-                global_step += 1
-                if evaluation_steps > 0 and training_steps % evaluation_steps == 0:
-                    self._eval_during_training(evaluator, eval_out, save_best_model and is_main, epoch, training_steps, callback)
-                    for lm in loss_models:
-                        lm.train()
-                if checkpoint_path is not None and checkpoint_save_steps is not None and checkpoint_save_steps > 0 \
-                        and global_step % checkpoint_save_steps == 0 and is_main:
-                    self._save_checkpoint(checkpoint_path, checkpoint_save_total_limit, global_step)
-            self._eval_during_training(evaluator, eval_out, save_best_model and is_main, epoch, -1, callback)
-        if scratch_dir is not None:
-            shutil.rmtree(scratch_dir, ignore_errors=True)
-        self._dp = None
-        enc.set_dropout(0.0, 0.0)
-        self.training_precision = "bf16"
+        try:
+            enc.set_dropout(p_hidden, p_attn, int(dropout_seed) + rank)
+            global_step = 0
+            if resume_from_checkpoint is not None:
+                global_step = self._load_training_state(resume_from_checkpoint)
+                enc.set_dropout_step(self._resume_dropout_step)     # the mask stream continues where the checkpoint left it
+            self._fit_meta = {"scheduler": sched, "lr": lr, "warmup_steps": int(warmup_steps), "t_total": t_total}
+            iters = [iter(dl) for dl in dataloaders]
+            if global_step > 0:
+                # resumed run: consume the batches the interrupted run already trained on (exact for unshuffled loaders)
+                for i, dl in enumerate(dataloaders):
+                    for _ in range(global_step % max(1, len(dl))):
+                        next(iters[i])
+            first_epoch, skip_steps = divmod(global_step, steps_per_epoch)
+            for epoch in range(first_epoch, epochs):
+                training_steps = skip_steps if epoch == first_epoch else 0
+                for lm in loss_models:
+                    lm.train()
+                self._rebind_grads()
+                for _ in range(steps_per_epoch - training_steps):
+                    for idx, lm in enumerate(loss_models):
+                        try:
+                            data = next(iters[idx])
+                        except StopIteration:
+                            iters[idx] = iter(dataloaders[idx])
+                            data = next(iters[idx])
+                        features, labels = data
+                        weight = 1.0
+                        if dp_mode == "split_batch":
+                            features, labels, n_total, n_mine = _shard_batch(features, labels, rank, world)
+                            weight = float(n_mine) * world / float(max(1, n_total))   # mean over the GLOBAL batch after the 1/world
+                        if _loss_reduction(lm) == "sum":
+                            weight = float(world)
+                        if labels.numel() > 0:
+                            labels = labels.to(self._target_device)
+                            features = [batch_to_device(f, self._target_device) for f in features]
+                            loss_value = lm(features, labels)
+                            (loss_value if weight == 1.0 else loss_value * weight).backward()
+                        if world > 1:
+                            if not self._dp_reduced:
+                                # empty shard (the last batch had fewer rows than ranks), or a loss model that bypassed
+                                # _EncodeFn: take part in the SAME sequence of all-reduces the other ranks issue from inside
+                                # staged_backward -- per-layer slices in its order, or one arena-wide reduce without overlap
+                                self._dp_works += allreduce_ranges(
+                                    enc.grads, staged_reduce_order(self._dp["buckets"], enc.total, self._dp["overlap"]),
+                                    process_group, async_op=self._dp["overlap"])
+                            for w in self._dp_works:
+                                w.wait()
+                            self._dp_works, self._dp_reduced, self._live_graphs = [], False, 0
+                        # clip_grad_norm_ + AdamW.step + zero_grad, one pass over the arena, norm stays on the device
+                        enc.adamw_step(lr_at(global_step), betas, eps, weight_decay, float(max_grad_norm), 1.0 / world)
+                    training_steps += 1
+                    global_step += 1
+                    if evaluation_steps > 0 and training_steps % evaluation_steps == 0:
+                        self._eval_during_training(evaluator, eval_out, save_best_model and is_main, epoch, training_steps, callback)
+                        for lm in loss_models:
+                            lm.train()
+                    if checkpoint_path is not None and checkpoint_save_steps is not None and checkpoint_save_steps > 0 \
+                            and global_step % checkpoint_save_steps == 0 and is_main:
+                        self._save_checkpoint(checkpoint_path, checkpoint_save_total_limit, global_step)
+                self._eval_during_training(evaluator, eval_out, save_best_model and is_main, epoch, -1, callback)
+        finally:
+            # whatever ended the loop (EarlyStoppingException derives from BaseException and must pass through untouched,
+            # training/main.py:149): the scratch directory goes, and the model leaves train()-time state behind -- a later
+            # forward must not silently run with this fit()'s dropout, precision or data-parallel group
+            if scratch_dir is not None:
+                shutil.rmtree(scratch_dir, ignore_errors=True)
+            self._dp = None
+            self._dp_works, self._dp_reduced, self._live_graphs = [], False, 0
+            enc.set_dropout(0.0, 0.0)
+            self.training_precision = "bf16"
         if evaluator is None and output_path is not None and is_main:
             self.save(output_path)
         if checkpoint_path is not None and is_main:

@@ -83,9 +83,9 @@ def staged_backward(enc: HipEncoder, ids, mask, types, grad_emb, saved, ws=None,
     optimiser step (the global-norm clip needs every reduced gradient, so replicas stay bit-identical).
 
     buckets=None (single process): one call, no exchange.
-    precision: "bf16", or "fp8" when `saved` was filled by forward(training=True, precision="fp8") -- the same bf16 stages,
-    run on THAT handle: it holds the record of what its forward did with dropout (a handle that never saw the arena, or saw
-    it in an earlier bf16 step with other rates, would rebuild the wrong masks)."""
+    precision: "bf16", or "fp8" when `saved` was filled by forward(training=True, precision="fp8") -- the same bf16 stages
+    on that handle. What a training forward did with dropout is recorded per activation arena, process-wide, so either
+    handle rebuilds the masks of the forward that filled `saved` (an arena no training forward has filled is refused)."""
     lib, st = enc.lib, _lib.current_stream_ptr()
     n, L = ids.shape
     if precision not in ("bf16", "fp8"):
@@ -140,16 +140,17 @@ class QuadrupletTrainer:
         """precision: "bf16" (the throughput path); "fp8" -- BASELINE configs[4]: the forward's Linears on the fp8 matrix
         cores (MXFP8 weights and activations), dgrad / wgrad in bf16 from the fp32 master weights (H and I multiples of 128;
         dropout as on the bf16 path); or "bf16x3" -- the parity path: fp32 activations, every product as three
-        split-bf16 MFMAs, gradients fp32-class (the reference trains in fp32, training/main.py:142). Single process,
-        several times slower.
+        split-bf16 MFMAs, gradients fp32-class (the reference trains in fp32, training/main.py:142). Several times slower;
+        data-parallel too (round 4): its backward is one call, so the buckets are all-reduced after it, in the staged
+        backward's order, without overlap.
         dropout: None / 0 = off; a float p = HF's hidden_dropout_prob = attention_probs_dropout_prob = p; a pair
         (p_hidden, p_attn). The reference's fit() trains with 0.1 (HF config defaults, train() mode). Ranks of a
         data-parallel job should pass different dropout_seed values (fit() adds the rank)."""
         self.cfg = cfg
         if precision not in ("bf16", "bf16x3", "fp8"):
             raise ValueError("training precision is 'bf16', 'bf16x3' or 'fp8'")
-        if precision == "bf16x3" and (world_size > 1 or force_dp or use_graph):
-            raise ValueError("precision='bf16x3' is the single-process parity path: no data parallelism or graph")
+        if precision == "bf16x3" and use_graph:
+            raise ValueError("precision='bf16x3' (the parity path) trains without a graph")
         if precision == "fp8" and use_graph:
             raise ValueError("precision='fp8' (fp8 forward GEMMs, bf16 backward) trains without a graph")
         self.precision = precision
@@ -244,6 +245,9 @@ class QuadrupletTrainer:
         if self.precision == "bf16x3":
             enc.backward(ids, mask, types, stacked(g), saved, precision="bf16x3")
             works = []
+            if self.world > 1 or self.force_dp:     # the same buckets in the same order as the staged backward, after the call
+                works = allreduce_ranges(enc.grads, staged_reduce_order(self.buckets, enc.total, self.overlap), self.group,
+                                         async_op=True)
         elif self.precision == "fp8" and not (self.world > 1 or self.force_dp):
             enc.backward(ids, mask, types, stacked(g), saved, precision="fp8")
             works = []

@@ -35,7 +35,7 @@ def _dp_case(name):
     return PRESETS[name], 4, 32
 
 
-def _worker(rank, world, port, overlap, out_dir, case="tiny-bert", dropout=None):
+def _worker(rank, world, port, overlap, out_dir, case="tiny-bert", dropout=None, precision="bf16"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -45,7 +45,7 @@ def _worker(rank, world, port, overlap, out_dir, case="tiny-bert", dropout=None)
     cfg, B, L = _dp_case(case)
     arena = synthetic_params(cfg, seed=14, std=0.05, bias_std=0.02, ln_jitter=0.05)
     tr = QuadrupletTrainer(cfg, arena=arena, device="cuda:0", lr=1e-3, world_size=world, overlap=overlap,
-                           dropout=dropout, dropout_seed=100 + rank)           # every rank its own mask stream
+                           dropout=dropout, dropout_seed=100 + rank, precision=precision)   # every rank its own mask stream
     for step in range(2):
         ids, mask, types = synthetic_quadruplets(cfg, world * B, L, seed=14, ragged=True, step=step)
         sl = slice(rank * B, (rank + 1) * B)                  # this rank's shard of the global batch
@@ -80,6 +80,30 @@ def test_two_rank_step_equals_single_rank_on_global_batch(tmp_path, overlap, cas
     bad = np.abs(p0 - ref) > 0.05 * moved
     assert bad.mean() < 1e-3, f"{bad.sum()} of {bad.size} parameters differ"
     assert np.abs(p0 - ref).max() <= 2.1e-3 and np.abs(p0 - ref).mean() < 2e-3 * moved
+
+
+def test_parity_precision_trains_data_parallel(tmp_path):
+    """precision="bf16x3" (the path that meets the north-star tolerance) under two ranks: replicas bit-identical, and equal to
+    the single-process bf16x3 step on the global batch up to fp32 summation order -- its gradients are fp32-class, so the
+    agreement is two orders tighter than the bf16 path's."""
+    from quadruplet_sentence_transformer_amd.synthetic import synthetic_params, synthetic_quadruplets
+    from quadruplet_sentence_transformer_amd.trainer import QuadrupletTrainer
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), True, str(tmp_path), "tiny-bert", None, "bf16x3"), nprocs=world, join=True)
+    p0, p1 = np.load(tmp_path / "params_0.npy"), np.load(tmp_path / "params_1.npy")
+    np.testing.assert_array_equal(p0, p1)
+    cfg, B, L = _dp_case("tiny-bert")
+    arena = synthetic_params(cfg, seed=14, std=0.05, bias_std=0.02, ln_jitter=0.05)
+    tr = QuadrupletTrainer(cfg, arena=arena, device="cuda:0", lr=1e-3, world_size=1, precision="bf16x3")
+    for step in range(2):
+        ids, mask, types = synthetic_quadruplets(cfg, world * B, L, seed=14, ragged=True, step=step)
+        tr.step(*[torch.from_numpy(x).cuda() for x in (ids, mask, types)])
+    ref = tr.enc.params.cpu().numpy()
+    moved = np.abs(ref - arena).max()
+    assert moved > 1e-4
+    bad = np.abs(p0 - ref) > 0.02 * moved            # (zero-gradient parameters get an Adam update whose sign is rounding noise)
+    assert bad.mean() < 1e-3, f"{bad.sum()} of {bad.size} parameters differ"
+    assert np.abs(p0 - ref).mean() < 2e-4 * moved
 
 
 def test_replicas_stay_identical_with_per_rank_dropout(tmp_path):

@@ -305,9 +305,11 @@ FP8_TRAIN_GRAD_LIMITS = {"w": 7.9e-2, "emb": 6.5e-2, "vec": 8.2e-2, "b_qkv": 8.5
 
 
 def test_staged_backward_after_an_fp8_forward_rebuilds_that_forwards_masks():
-    """The data-parallel (staged) backward over an arena filled by forward(training=True, precision="fp8") must run on the
-    handle that ran that forward: the bf16 handle may hold a record of the SAME arena from an earlier bf16 step with other
-    dropout rates, and would rebuild those masks. One-call backward(precision="fp8") is the reference."""
+    """The data-parallel (staged) backward over an arena filled by forward(training=True, precision="fp8") rebuilds the masks
+    of THAT forward on whichever handle runs it: the record of what a training forward did with dropout is kept per arena,
+    process-wide (round 4; rounds 2-3 kept a ring per handle, and the bf16 handle, which had seen the SAME arena in an earlier
+    bf16 step at other rates, rebuilt those masks -- ADVICE r03). One-call backward(precision="fp8") is the reference. An arena
+    that no training forward has filled is refused instead of guessed at."""
     from dataclasses import replace
     from quadruplet_sentence_transformer_amd.config import PRESETS
     from quadruplet_sentence_transformer_amd.encoder import HipEncoder
@@ -331,8 +333,14 @@ def test_staged_backward_after_an_fp8_forward_rebuilds_that_forwards_masks():
     staged_backward(enc, ids, mask, types, g, saved, None, None, None, True, precision="fp8")
     assert float((enc.grads - ref).norm() / ref.norm()) < 1e-5
     enc.grads.zero_()
-    staged_backward(enc, ids, mask, types, g, saved, None, None, None, True)            # the bf16 handle: the stale record
-    assert float((enc.grads - ref).norm() / ref.norm()) > 1e-2
+    staged_backward(enc, ids, mask, types, g, saved, None, None, None, True)            # the bf16 handle: same arena, same record
+    assert float((enc.grads - ref).norm() / ref.norm()) < 1e-5
+    from quadruplet_sentence_transformer_amd._lib import QstError
+    fresh = torch.empty_like(arena)                                                       # never filled by a forward
+    with pytest.raises(QstError):
+        enc.backward(ids, mask, types, g, fresh)
+    with pytest.raises(QstError):
+        enc.backward(ids, mask, types, g, saved, precision="bf16x3")                      # the other kind of arena
 
 
 def test_fp8_training_trains():
