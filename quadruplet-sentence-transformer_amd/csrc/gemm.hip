@@ -1144,7 +1144,11 @@ extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
     if ((a->splits & 0x60) && qst_gemm_nt8_supported(a, epi)) return qst_gemm_nt8(a, epi, (a->splits & 0x40) ? 1 : 0, stream);
     if (!(a->splits & 0xFE7) && qst_gemm_nt8_supported(a, epi)) {
         const int mode = qst_gemm8_mode_get();
-        if (mode >= 0 ? (mode & 1) != 0 : nt8_auto(a, epi)) return qst_gemm_nt8(a, epi, 0, stream);
+        if (mode >= 0 && (mode & 4)) {                 // experiment: the shapes on which it won back to back, 256 x 256 tile
+            if ((epi == QST_EPI_BF16 || epi == QST_EPI_GELU || ((mode & 8) && epi == QST_EPI_GELU_BWD)) && a->N >= 2304 && a->K >= 768 &&
+                a->M >= 16384)
+                return qst_gemm_nt8(a, epi, 1, stream);
+        } else if (mode >= 0 ? (mode & 1) != 0 : nt8_auto(a, epi)) return qst_gemm_nt8(a, epi, 0, stream);
     }
     // Two 128-row workgroups per CU beat one 256-row workgroup on every shape of the step (their MFMA and
     // store phases interleave); a->splits (unused by nt otherwise) can force the tile height: 1 = 128, 2 = 256 rows.
