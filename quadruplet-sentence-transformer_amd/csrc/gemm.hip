@@ -1114,8 +1114,13 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
 }  // namespace
 
 int qst_gemm8_mode_get();                               // gemm8.hip
-// shapes on which the 8-phase kernel is taken without being asked (measured: DESIGN.md, round 4)
-static bool nt8_auto(const QstGemmArgs* a, int epi) { (void)a; (void)epi; return false; }
+// Shapes on which the 8-phase kernel (its 256 x 256 tile) is taken without being asked: the wide bf16-output forward GEMMs of
+// the H = 768 models (QKV, FFN-1 + GELU). Measured in the step, same process (tools/ab_gemm8.py): bert-base B = 128 L = 384
+// 152.3 -> 150.8 ms, forward-only 56.7 -> 55.4; mpnet-base B = 32 L = 256 27.49 -> 27.43 ms. Every other shape loses on it
+// in-step (all NT GEMMs: +4%; the fp32 + residual epilogues and K = 384 most), DESIGN.md finding 25.
+static bool nt8_auto(const QstGemmArgs* a, int epi) {
+    return (epi == QST_EPI_BF16 || epi == QST_EPI_GELU) && a->N >= 2304 && a->K >= 768 && a->M >= 16384;
+}
 
 template <int EPI, int WAVES_M, int WAVES_N = 2, int TI = 2>
 static int launch_nt(const QstGemmArgs* a, hipStream_t st) {
@@ -1144,11 +1149,7 @@ extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
     if ((a->splits & 0x60) && qst_gemm_nt8_supported(a, epi)) return qst_gemm_nt8(a, epi, (a->splits & 0x40) ? 1 : 0, stream);
     if (!(a->splits & 0xFE7) && qst_gemm_nt8_supported(a, epi)) {
         const int mode = qst_gemm8_mode_get();
-        if (mode >= 0 && (mode & 4)) {                 // experiment: the shapes on which it won back to back, 256 x 256 tile
-            if ((epi == QST_EPI_BF16 || epi == QST_EPI_GELU || ((mode & 8) && epi == QST_EPI_GELU_BWD)) && a->N >= 2304 && a->K >= 768 &&
-                a->M >= 16384)
-                return qst_gemm_nt8(a, epi, 1, stream);
-        } else if (mode >= 0 ? (mode & 1) != 0 : nt8_auto(a, epi)) return qst_gemm_nt8(a, epi, 0, stream);
+        if (mode >= 0 ? (mode & 1) != 0 : nt8_auto(a, epi)) return qst_gemm_nt8(a, epi, mode >= 0 ? 0 : 1, stream);
     }
     // Two 128-row workgroups per CU beat one 256-row workgroup on every shape of the step (their MFMA and
     // store phases interleave); a->splits (unused by nt otherwise) can force the tile height: 1 = 128, 2 = 256 rows.
