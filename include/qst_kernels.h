@@ -245,7 +245,10 @@ typedef struct {
     int32_t nseq, L, A, d;
     void* ctx; float* lse;                       /* forward: outputs; backward: inputs */
     const void* dctx; void* dqkv; float* drel; float* delta_scratch;       /* backward only */
-    int32_t force_split;   /* backward: != 0 takes the dQ + dK/dV kernel pair even where the single-workgroup kernel applies */
+    int32_t force_split;   /* backward: 0 = the library chooses; 1 = the dQ + dK/dV kernel pair even where a one-workgroup-per-
+                              (sequence, head) kernel applies; 2 = that kernel for d = 64 (one evaluation of the scores, dQ in
+                              registers across 256-key passes) where its LDS fits, also with dropout / position bias, where the
+                              pair is faster */
     QstDrop drop;
 } QstAttnDesc;
 int qst_attention_fwd_ex(const QstAttnDesc* a, void* stream);

@@ -900,6 +900,252 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
     QST_STAMP_ONCE(14);
 }
 
+
+// tr_frag on the ROW-READ image of 128-byte rows (rr_off<64>): correct for any swizzle that keeps 16-byte chunks whole;
+// the four rows a half-wave reads collide pairwise in the banks (2-way), the price of one image instead of two
+__device__ __forceinline__ bf16x8 tr_frag_rr64(const char* img, int row0, int ddb, int lane) {
+    const int li = lane & 15, q = li >> 2, p = li & 3, gsel = (lane >> 4) & 1, h = lane >> 5;
+    const int chunk = ddb * 4 + gsel * 2 + (p >> 1), rem = 8 * (p & 1);
+    const int ra = row0 + 4 * h + q, rb = ra + 8;
+    const bf16x4 a = lds_tr(img + rr_off<64>(ra, chunk) + rem);
+    const bf16x4 b = lds_tr(img + rr_off<64>(rb, chunk) + rem);
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[e] = a[e]; f[4 + e] = b[e]; }
+    return f;
+}
+
+// ------------------------------------------------------------------ backward, d = 64, L <= 512: one workgroup per (sequence, head)
+// The two-kernel path above evaluates S, P, dP and dS twice (7 contractions, two passes over q / k / v / dO, two exp per
+// score). Here a 512-thread workgroup (8 waves) owns one (sequence, head): keys are walked in passes of 256 (wave w owns
+// the 32 keys 256 p + 32 w .. and accumulates dK^T, dV^T for them, orientation as in the dK/dV kernel: S = Q.K^T, rows =
+// queries in registers, column = key on the lane), queries in chunks of 128. Per (pass, chunk): every wave with keys
+// evaluates its four 32 x 32 score tiles once, adds into dK / dV and drops dS (bf16, unscaled) into a [key][query] LDS
+// image; after one barrier wave w = 2 qt + b multiplies K^T (transposing reads of the pass's K image) with that image
+// for query tile qt, d-half b: dQ^T tile += K^T.dS^T over the pass's keys. The dQ tiles of ALL chunks stay in registers
+// across the passes (NC x 16 registers per wave), so every output is written once, in bf16, with no atomics.
+// delta_i = dO_i.O_i is computed while the first pass stages dO. One image per operand serves row reads and
+// transposing reads (the row-read swizzle makes the transposing reads 2-way conflicted; two more images would not fit).
+template <int NC, bool REL, bool DROP>
+__global__ __launch_bounds__(512, 1) void attn_bwd_one64_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int D = 64, KS = 4, DB = 2, CPR = 8;
+    char* qimg = smem;                        // [128 q][128 B]
+    char* dimg = smem + 16384;                // dO chunk
+    char* kimg = smem + 32768;                // [256 keys][128 B] of this pass
+    char* dsimg = smem + 65536;               // dS [256 keys][128 queries] bf16, ds_off
+    float* lse_s = (float*)(smem + 131072);   // [L]
+    float* del_s = lse_s + a.L;               // [L]
+    float* relv = del_s + a.L;                // [2L]   (REL)
+    float* drel_s = relv + 2 * a.L;           // [8][2L] (REL)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, fr = lane & 31;
+    const int head = blockIdx.x % a.A, seq = blockIdx.x / a.A;
+    const int ld = a.ld, L = a.L;
+    const bf16* base = a.qkv + qkv_base(a, seq, head, D);
+    const bf16* dbase_p = a.dctx + (size_t)seq * L * a.H + head * D;
+    const bf16* obase_p = a.ctx + (size_t)seq * L * a.H + head * D;
+    const int nchunk = (L + 127) / 128, npass = (L + 255) / 256;
+
+    for (int t = tid; t < L; t += 512) lse_s[t] = a.lse_in[((size_t)seq * a.A + head) * L + t];
+    if (REL)
+        for (int t = tid; t < 2 * L; t += 512) {
+            relv[t] = a.rel[(size_t)head * 2 * L + t];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) drel_s[w * 2 * L + t] = 0.f;
+        }
+    const DropCtx dc = DROP ? drop_ctx8(a.drop) : DropCtx{0u, 0u, 1.f};
+    const uint32_t dhead = (uint32_t)(seq * a.A + head) * L;            // mask row of query i: (dhead + i) * L
+    const uint32_t dsh = 8u * (uint32_t)(lane & 3);
+    const int qt_mine = wave >> 1, b_mine = wave & 1;                    // this wave's dQ^T tile of every chunk
+
+    f32x16 dq[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[c][r] = 0.f;
+
+    for (int p = 0; p < npass; ++p) {
+        const int nkeys = min(256, L - 256 * p);
+        const int j0 = 256 * p + 32 * wave;
+        const bool active = j0 < L;
+        const int kj = j0 + fr;
+        __syncthreads();                                     // the previous pass's readers of kimg are done
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                        // K rows of this pass: 256 x 8 chunks of 16 bytes
+            const int idx = tid + 512 * k, row = idx / CPR, c = idx % CPR;
+            const u32x4 z = {0, 0, 0, 0};
+            const u32x4 v = row < nkeys ? *(const u32x4*)(base + (size_t)(256 * p + row) * ld + a.woff + c * 8) : z;
+            *(u32x4*)(kimg + rr_off<D>(row, c)) = v;
+        }
+        bf16x8 vf[KS];
+        float madd = 0.f;
+        if (active) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) vf[s] = *(const bf16x8*)(base + (size_t)kj * ld + 2 * a.woff + 16 * s + 8 * h);
+            madd = a.mask[(size_t)seq * L + kj] ? 0.f : kMaskMin;
+        }
+        f32x16 dk[DB], dv[DB];
+#pragma unroll
+        for (int b = 0; b < DB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[b][r] = 0.f; dv[b][r] = 0.f; }
+
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (c >= nchunk) break;
+            const int rows = min(128, L - c * 128);
+            __syncthreads();                                 // the previous chunk's readers of qimg / dimg / dsimg are done
+            {
+                u32x4 vq[2], vd[2], vo[2];
+                const u32x4 z = {0, 0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int idx = tid + 512 * k, row = idx / CPR, cc = idx % CPR;
+                    const bool ok = row < rows;
+                    vq[k] = ok ? *(const u32x4*)(base + (size_t)(c * 128 + row) * ld + cc * 8) : z;
+                    vd[k] = ok ? *(const u32x4*)(dbase_p + (size_t)(c * 128 + row) * a.H + cc * 8) : z;
+                    if (p == 0) vo[k] = ok ? *(const u32x4*)(obase_p + (size_t)(c * 128 + row) * a.H + cc * 8) : z;
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int idx = tid + 512 * k, row = idx / CPR, cc = idx % CPR;
+                    *(u32x4*)(qimg + rr_off<D>(row, cc)) = vq[k];
+                    *(u32x4*)(dimg + rr_off<D>(row, cc)) = vd[k];
+                    if (p == 0) {                            // delta_i = sum_dd dO[i][dd] O[i][dd]: 8 adjacent lanes per row
+                        float part = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            part += bf16lo(vd[k][e]) * bf16lo(vo[k][e]) + bf16hi(vd[k][e]) * bf16hi(vo[k][e]);
+                        part += dpp_mov<0xB1>(part);         // quad_perm [1,0,3,2]
+                        part += dpp_mov<0x4E>(part);         // quad_perm [2,3,0,1]
+                        part += dpp_mov<0x141>(part);        // row_half_mirror: the other quad of the 8 lanes
+                        if (cc == 0 && row < rows) del_s[c * 128 + row] = part;
+                    }
+                }
+            }
+            __syncthreads();
+            if (active) {
+#pragma unroll 1
+                for (int it = 0; it < rows / 32; ++it) {
+                    f32x16 s, dp;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        // (this wave's K fragments are re-read from the pass image per tile: 16 registers fewer to keep alive
+                        // through the elementwise part, where the kernel is at the register limit)
+                        const bf16x8 kf = *(const bf16x8*)(kimg + rr_off<D>(32 * wave + fr, 2 * ks + h));
+                        const bf16x8 qf = *(const bf16x8*)(qimg + rr_off<D>(it * 32 + fr, 2 * ks + h));
+                        const bf16x8 df = *(const bf16x8*)(dimg + rr_off<D>(it * 32 + fr, 2 * ks + h));
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf, s, 0, 0, 0);          // rows i, col j
+                        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], dp, 0, 0, 0);
+                    }
+                    const int i0 = c * 128 + it * 32;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int il = i0 + 8 * g + 4 * h;              // accumulator registers 4g..4g+3 = query rows il..il+3
+                        const f32x4 l4 = *(const f32x4*)(lse_s + il), d4 = *(const f32x4*)(del_s + il);
+                        uint32_t wq[4] = {0u, 0u, 0u, 0u};
+                        if (DROP && dc.thr) {
+                            const uint32_t mine = drop_word4(dc, (dhead + (uint32_t)(il + (lane & 3))) * L + (uint32_t)(kj & ~3));
+                            wq[0] = quad_bcast<0>(mine); wq[1] = quad_bcast<1>(mine); wq[2] = quad_bcast<2>(mine); wq[3] = quad_bcast<3>(mine);
+                        }
+                        uint32_t sw[2];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = 4 * g + e;
+                            float v = s[r] * a.scale;
+                            if (REL) v += relv[kj - (il + e) + L];
+                            v += madd;
+                            const float pr = __expf(v - l4[e]);
+                            float mk = 1.f;
+                            if (DROP && dc.thr) mk = (((wq[e] >> dsh) & 0xFFu) >= dc.thr) ? dc.scale : 0.f;
+                            const float dsr = pr * (dp[r] * mk - d4[e]);               // dS (unscaled) = d(score)
+                            dp[r] = pr * mk;                      // dP is spent: its register takes the (dropped) probability dV needs
+                            s[r] = dsr;
+                        }
+                        sw[0] = pack_bf16x2(s[4 * g], s[4 * g + 1]);
+                        sw[1] = pack_bf16x2(s[4 * g + 2], s[4 * g + 3]);
+                        u32x2 pkd; pkd[0] = sw[0]; pkd[1] = sw[1];
+                        *(u32x2*)(dsimg + ds_off(32 * wave + fr, (it * 32 + 8 * g + 4 * h) * 2)) = pkd;
+                    }
+                    if (REL && a.drel) {
+                        float lo = 0.f, hi = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) diag_add(s[r], r, lane, lo, hi);
+                        diag_store(drel_s + wave * 2 * L, L, j0, i0, lane, lo, hi);
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const bf16x8 pf = acc_frag(dp, ks), sf = acc_frag(s, ks);
+#pragma unroll
+                        for (int b = 0; b < DB; ++b) {
+                            const bf16x8 dt = tr_frag_rr64(dimg, it * 32 + 16 * ks, b, lane);
+                            const bf16x8 qt = tr_frag_rr64(qimg, it * 32 + 16 * ks, b, lane);
+                            dv[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt, pf, dv[b], 0, 0, 0);
+                            dk[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, sf, dk[b], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            __syncthreads();                                 // every wave's dS tiles of this chunk are in the image
+            if (qt_mine * 32 < rows) {
+                // dQ^T[dd half b][query tile qt] += sum over this pass's keys K^T . dS^T
+                const int li = lane & 15, q = li >> 2, pp = li & 3, gsel = (lane >> 4) & 1;
+                const int byte = qt_mine * 64 + gsel * 32 + 8 * pp;
+                for (int ks = 0; ks < nkeys / 16; ++ks) {
+                    const bf16x4 lo = lds_tr(dsimg + ds_off(16 * ks + 4 * h + q, byte));
+                    const bf16x4 hi = lds_tr(dsimg + ds_off(16 * ks + 8 + 4 * h + q, byte));
+                    bf16x8 df;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { df[e] = lo[e]; df[4 + e] = hi[e]; }
+                    const bf16x8 kt = tr_frag_rr64(kimg, 16 * ks, b_mine, lane);
+                    dq[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, df, dq[c], 0, 0, 0);
+                }
+            }
+        }
+        if (active) {
+            bf16* krow = a.dqkv + qkv_base(a, seq, head, D) + (size_t)kj * ld + a.woff;
+            bf16* vrow = krow + a.woff;
+#pragma unroll
+            for (int b = 0; b < DB; ++b)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 pk;
+                    pk[0] = pack_bf16x2(dk[b][4 * g] * a.scale, dk[b][4 * g + 1] * a.scale);
+                    pk[1] = pack_bf16x2(dk[b][4 * g + 2] * a.scale, dk[b][4 * g + 3] * a.scale);
+                    *(u32x2*)(krow + b * 32 + 8 * g + 4 * h) = pk;
+                    pk[0] = pack_bf16x2(dv[b][4 * g], dv[b][4 * g + 1]);
+                    pk[1] = pack_bf16x2(dv[b][4 * g + 2], dv[b][4 * g + 3]);
+                    *(u32x2*)(vrow + b * 32 + 8 * g + 4 * h) = pk;
+                }
+        }
+    }
+    // dQ: this wave's tile of every chunk (rows = d inside half b, column = query on the lane)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int qi = c * 128 + qt_mine * 32 + fr;
+        if (c >= nchunk || qi >= L) continue;
+        bf16* orow = a.dqkv + qkv_base(a, seq, head, D) + (size_t)qi * ld + b_mine * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32x2 pk;
+            pk[0] = pack_bf16x2(dq[c][4 * g] * a.scale, dq[c][4 * g + 1] * a.scale);
+            pk[1] = pack_bf16x2(dq[c][4 * g + 2] * a.scale, dq[c][4 * g + 3] * a.scale);
+            *(u32x2*)(orow + 8 * g + 4 * h) = pk;
+        }
+    }
+    if (REL && a.drel) {
+        __syncthreads();
+        for (int t = tid; t < 2 * L; t += 512) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += drel_s[w * 2 * L + t];
+            if (v != 0.f) atomicAdd(a.drel + (size_t)head * 2 * L + t, v);
+        }
+    }
+}
+
 template <typename K>
 int set_lds(K kern, size_t bytes) {
     QST_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -971,6 +1217,28 @@ extern "C" int qst_attention_bwd_ex(const QstAttnDesc* q, void* stream) {
         if (rel) { if (drop) QST_RUN((attn_bwd_fused_kernel<32, true, true>), gf, lds_f); else QST_RUN((attn_bwd_fused_kernel<32, true, false>), gf, lds_f); }
         else     { if (drop) QST_RUN((attn_bwd_fused_kernel<32, false, true>), gf, lds_f); else QST_RUN((attn_bwd_fused_kernel<32, false, false>), gf, lds_f); }
         return QST_OK;
+    }
+    // d = 64: one 512-thread workgroup per (sequence, head), a single evaluation of the scores, dQ kept in registers across the
+    // key passes (attn_bwd_one64_kernel); needs 128 KB of images + the per-query constants (+ 18 L floats with the position
+    // bias): every L <= 512 without the bias, L <= 384 with it. Measured against the two-kernel path (tools/one_attn_bwd.py,
+    // round 4): mpnet shape 128 x 256 x 12 heads without bias / dropout 182 vs 199 us, with both 298 vs 275; bert-base
+    // configs[4] shape 512 x 384 without dropout 1520 vs 1452, with 1950 vs 1686 -- at 8 waves x 256 registers the accumulators
+    // (dQ 16 per chunk + dK, dV 64) leave too little for the mask / bias arithmetic and those variants spill (100-500 bytes
+    // per lane). Taken by itself only where it wins (no dropout, no bias, L <= 256); force_split = 2 forces it (tests, tools).
+    const bool one64_auto = !q->force_split && !drop && !rel && L <= 256;
+    if (d == 64 && (q->force_split == 2 || one64_auto)) {
+        const size_t lds_o = (size_t)131072 + (size_t)2 * L * 4 + (rel ? (size_t)18 * L * 4 : 0);
+        if (lds_o <= 163840) {
+            const int go = nseq * A;
+#define QST_ONE(NC_) do { \
+            if (rel) { if (drop) QST_RUN512((attn_bwd_one64_kernel<NC_, true, true>), go, lds_o); else QST_RUN512((attn_bwd_one64_kernel<NC_, true, false>), go, lds_o); } \
+            else     { if (drop) QST_RUN512((attn_bwd_one64_kernel<NC_, false, true>), go, lds_o); else QST_RUN512((attn_bwd_one64_kernel<NC_, false, false>), go, lds_o); } } while (0)
+#define QST_RUN512(K_, G_, LDS_) do { if ((rc = set_lds(K_, LDS_))) return rc; K_<<<G_, 512, LDS_, st>>>(a); QST_LAUNCH_CHECK(); } while (0)
+            if (L <= 256) QST_ONE(2); else if (L <= 384) QST_ONE(3); else QST_ONE(4);
+#undef QST_RUN512
+#undef QST_ONE
+            return QST_OK;
+        }
     }
     if (d == 32) {
         if (drop) QST_RUN((attn_bwd_dq_kernel<32, true>), grid, lds_q); else QST_RUN((attn_bwd_dq_kernel<32, false>), grid, lds_q);

@@ -421,7 +421,9 @@ def attn_ref(qkv, mask, rel, n, L, A, d):
 
 @pytest.mark.parametrize("n,L,A,d,use_rel", [(2, 32, 2, 32, False), (3, 128, 12, 32, False), (2, 160, 2, 64, True),
                                               (2, 256, 3, 64, False), (1, 384, 2, 64, True), (2, 64, 2, 32, True),
-                                              (5, 96, 3, 32, False), (2, 160, 2, 32, True)])
+                                              (5, 96, 3, 32, False), (2, 160, 2, 32, True), (2, 512, 2, 64, False),
+                                              (3, 288, 2, 64, True), (1, 512, 1, 64, True), (2, 32, 1, 64, False),
+                                              (2, 384, 3, 64, False)])
 def test_attention_fwd_bwd(lib, n, L, A, d, use_rel):
     H = A * d
     g = torch.Generator().manual_seed(n * L + A + d)
@@ -461,19 +463,26 @@ def test_attention_fwd_bwd(lib, n, L, A, d, use_rel):
     if use_rel:
         rel_l2 = ((drel.cpu() - relr.grad).norm() / relr.grad.norm()).item()
         assert rel_l2 < 1e-2, f"drel relative L2 error {rel_l2}"
-    if L <= 128 and d == 32:
-        # this shape ran the single-workgroup backward; the two-kernel path must agree with it
+    if (L <= 128 and d == 32) or d == 64:
+        # this shape ran a one-workgroup-per-(sequence, head) backward (d = 32, L <= 128: attn_bwd_fused_kernel; d = 64:
+        # attn_bwd_one64_kernel, except with the position bias at L > 384, where its LDS does not fit); the two-kernel path
+        # must agree with it
         dq2 = torch.empty_like(dq)
         drel2 = torch.zeros(A, 2 * L, device="cuda") if use_rel else None
         q = _lib.QstAttnDesc()
         q.qkv, q.mask, q.rel_pos, q.nseq, q.L, q.A, q.d = qd.data_ptr(), md.data_ptr(), _lib.ptr(reld), n, L, A, d
         q.ctx, q.lse, q.dctx, q.dqkv, q.drel = ctx.data_ptr(), lse.data_ptr(), dcd.data_ptr(), dq2.data_ptr(), _lib.ptr(drel2)
-        q.delta_scratch, q.force_split = delta.data_ptr(), 1
+        # force_split: 1 = the two-kernel path, 2 = the d = 64 one-workgroup kernel (taken by itself only without dropout and
+        # bias at L <= 256: everything else runs the two-kernel path unless forced)
+        q.delta_scratch, q.force_split = delta.data_ptr(), (2 if d == 64 else 1)
         _lib.check(lib.qst_attention_bwd_ex(q, stream()))
         torch.cuda.synchronize()
         torch.testing.assert_close(dq.float(), dq2.float(), rtol=2e-2, atol=2e-2 * max(1.0, gref.abs().max().item()))
         if use_rel:
             torch.testing.assert_close(drel, drel2, rtol=1e-3, atol=1e-3 * max(1.0, drel2.abs().max().item()))
+        if d == 64:       # and the forced kernel against the fp32 reference itself
+            rel_l2 = ((dq2.float().cpu() - gref).norm() / gref.norm()).item()
+            assert rel_l2 < 1e-2, f"one-workgroup d = 64 backward: dqkv relative L2 error {rel_l2}"
 
 
 @pytest.mark.parametrize("nseq,L,H,vocab,ntypes,irregular_pos", [
