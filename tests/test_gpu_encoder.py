@@ -204,9 +204,27 @@ def test_mpnet_base_full_dims_config3_shape():
 
 
 def test_bert_base_dims_l384():
-    # BASELINE.json configs[4] architecture (bf16 operands here; fp8 weights are not built), 3 key chunks of 128
+    # BASELINE.json configs[4] architecture, all 12 layers, forward (bf16 operands here; tests/test_gpu_fp8mx.py runs the same
+    # dims on the fp8 matrix cores): 3 key chunks of 128. Gradients at this sequence length: the two-layer case below (the CPU
+    # oracle's autograd over 12 layers x 1,536 tokens is minutes).
     run_case("bert-base-uncased", 1, 384, True, dict(std=0.02), check_grads=False, emb_atol_vs_bf16_oracle=1e-3,
              scale_by_emb=True)
+
+
+@pytest.mark.parametrize("drop", [None, (0.1, 0.1, 9)], ids=["eval", "train_mode_dropout"])
+def test_bert_base_two_layers_l384_with_gradients(drop):
+    """configs[4]'s sequence length WITH gradients (VERDICT r03 'missing' 5): bert-base layer dims (H = 768, d = 64, I = 3072),
+    two layers, L = 384 ragged -- three 128-key chunks in the attention forward, the two-kernel d = 64 backward over three
+    query / key blocks, the K >= 768 GEMM tiles and the H = 768 LayerNorm row kernels -- every gradient tensor against the
+    same-rounding oracle, with and without the reference's train()-mode dropout."""
+    from dataclasses import replace
+    PRESETS["bert-2l"] = replace(PRESETS["bert-base-uncased"], num_layers=2, vocab_size=4096)
+    try:
+        # (bert-base-uncased has no Normalize module: embeddings of norm ~sqrt(H), tolerances on that scale as in the 12-layer case)
+        run_case("bert-2l", 1, 384, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), emb_atol_vs_bf16_oracle=1.5e-3, dropout=drop,
+                 scale_by_emb=True)
+    finally:
+        del PRESETS["bert-2l"]
 
 
 @pytest.mark.parametrize("name,B,L,ragged,wkw,drop", [

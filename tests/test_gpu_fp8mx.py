@@ -208,7 +208,10 @@ def test_layernorm_mx_output_equals_quantising_its_bf16_output(lib, M, H):
     # same four places as the bf16 path; the oracle gets them from oracle/dropout_ref.py
     ("bert-base-uncased", 2, 128, 2, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), (0.1, 0.1)),
     ("all-mpnet-base-v2", 1, 64, 2, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), (0.1, 0.2)),
-    ("all-MiniLM-L6-v2", 2, 128, 2, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), (0.1, 0.1))])
+    ("all-MiniLM-L6-v2", 2, 128, 2, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), (0.1, 0.1)),
+    # configs[4]'s own sequence length, gradients included (VERDICT r03 'missing' 5)
+    ("bert-base-uncased", 1, 384, 2, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), None),
+    ("bert-base-uncased", 1, 384, 2, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), (0.1, 0.1))])
 def test_fp8_training_step_against_the_mx_oracle(name, B, L, layers, wkw, drop):
     """BASELINE configs[4] as a FINE-TUNING configuration (the reference path trains, training/main.py:128-148):
     forward(training=True, precision="fp8") -- every Linear on the fp8 matrix cores -- followed by backward(precision="fp8"),
