@@ -58,9 +58,14 @@ def main():
                 M, N, K = rng.randint(1, 40000), 64 * rng.randint(1, 48), 64 * rng.randint(1, 48)
                 if i < first:
                     continue
-                print(f"case {i}: wgrad M={M} N={N} K={K}", flush=True)
-                TK.test_gemm_tn_wgrad(lib, M, N, K)
-                print(f"ok {i}: wgrad M={M} N={N} K={K}", flush=True)
+                mode = rng.choice([0, 2])                  # tiled kernel / the 8-phase kernel of csrc/gemm8.hip (round 4)
+                print(f"case {i}: wgrad M={M} N={N} K={K} gemm8_mode={mode}", flush=True)
+                lib.qst_gemm8_mode(mode)
+                try:
+                    TK.test_gemm_tn_wgrad(lib, mode, M, N, K)
+                finally:
+                    lib.qst_gemm8_mode(-1)
+                print(f"ok {i}: wgrad M={M} N={N} K={K} gemm8_mode={mode}", flush=True)
             elif sys.argv[4] == "attn":
                 d = rng.choice([32, 64])
                 n, L, A, rel = rng.randint(1, 6), 32 * rng.randint(1, 16), rng.randint(1, 12), rng.choice([False, True])
@@ -71,7 +76,7 @@ def main():
                 print(f"ok {i}: attention n={n} L={L} A={A} d={d} rel={rel}", flush=True)
             else:
                 M, N, K = rng.randint(1, 40000), 4 * rng.randint(1, 800), 64 * rng.randint(1, 48)
-                form = rng.choice([0, 2, 4])
+                form = rng.choice([0, 2, 4, 0x20, 0x40])   # 0x20 / 0x40: the 8-phase kernel's two tiles (N % 8 != 0: the tiled kernel)
                 if i < first:
                     continue
                 t0 = time.time()
