@@ -1,11 +1,11 @@
 """Old and 8-phase grouped wgrad kernels at one layer's shapes, a few launches each (for rocprofv3 --pmc / --kernel-trace).
-   QST_H (384), QST_M (32768), QST_DIAG (bits 16.. of QstTnGroup.splits for the 8-phase kernel: 1 = no flush)"""
+   QST_H (384), QST_M (32768). (Round 4 ran it on a diagnostic build whose flush could be compiled out: QST_DIAG; that switch is gone.)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import quadruplet_sentence_transformer_amd
 from quadruplet_sentence_transformer_amd import _lib
 
-H = int(os.environ.get("QST_H", "384")); M = int(os.environ.get("QST_M", "32768")); diag = int(os.environ.get("QST_DIAG", "0"))
+H = int(os.environ.get("QST_H", "384")); M = int(os.environ.get("QST_M", "32768")); diag = 0
 I = 4 * H
 lib = _lib.load(); st = _lib.current_stream_ptr()
 bf = torch.bfloat16
