@@ -245,10 +245,9 @@ typedef struct {
     int32_t nseq, L, A, d;
     void* ctx; float* lse;                       /* forward: outputs; backward: inputs */
     const void* dctx; void* dqkv; float* drel; float* delta_scratch;       /* backward only */
-    int32_t force_split;   /* backward: 0 = the library chooses; 1 = the dQ + dK/dV kernel pair even where a one-workgroup-per-
-                              (sequence, head) kernel applies; 2 = that kernel for d = 64 (one evaluation of the scores, dQ in
-                              registers across 256-key passes) where its LDS fits, also with dropout / position bias, where the
-                              pair is faster */
+    int32_t force_split;   /* backward: 0 = the library chooses (a one-workgroup-per-(sequence, head) kernel where there is one: d = 32 at
+                              L <= 128; d = 64 wherever its LDS fits, i.e. L <= 512, or <= 384 with the position bias); 1 = the
+                              dQ + dK/dV kernel pair; 2 = the d = 64 one-workgroup kernel (same as 0 today; tests name it) */
     QstDrop drop;
 } QstAttnDesc;
 int qst_attention_fwd_ex(const QstAttnDesc* a, void* stream);

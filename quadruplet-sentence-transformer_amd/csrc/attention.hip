@@ -990,9 +990,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_one64_kernel(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dk[b][r] = 0.f; dv[b][r] = 0.f; }
 
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            if (c >= nchunk) break;
+#pragma unroll 1
+        for (int c = 0; c < nchunk; ++c) {
             const int rows = min(128, L - c * 128);
             __syncthreads();                                 // the previous chunk's readers of qimg / dimg / dsimg are done
             {
@@ -1093,15 +1092,23 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_one64_kernel(AttnArgs a) {
                 // dQ^T[dd half b][query tile qt] += sum over this pass's keys K^T . dS^T
                 const int li = lane & 15, q = li >> 2, pp = li & 3, gsel = (lane >> 4) & 1;
                 const int byte = qt_mine * 64 + gsel * 32 + 8 * pp;
-                for (int ks = 0; ks < nkeys / 16; ++ks) {
-                    const bf16x4 lo = lds_tr(dsimg + ds_off(16 * ks + 4 * h + q, byte));
-                    const bf16x4 hi = lds_tr(dsimg + ds_off(16 * ks + 8 + 4 * h + q, byte));
-                    bf16x8 df;
+                // (the chunk loop is a real loop -- one copy of the score-tile code -- so the accumulator of chunk c is picked by a
+                // uniform switch around the k loop: dq[] stays in registers only while every index is a constant)
+                auto accumulate = [&](f32x16& acc) {
+                    for (int ks = 0; ks < nkeys / 16; ++ks) {
+                        const bf16x4 lo = lds_tr(dsimg + ds_off(16 * ks + 4 * h + q, byte));
+                        const bf16x4 hi = lds_tr(dsimg + ds_off(16 * ks + 8 + 4 * h + q, byte));
+                        bf16x8 df;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { df[e] = lo[e]; df[4 + e] = hi[e]; }
-                    const bf16x8 kt = tr_frag_rr64(kimg, 16 * ks, b_mine, lane);
-                    dq[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, df, dq[c], 0, 0, 0);
-                }
+                        for (int e = 0; e < 4; ++e) { df[e] = lo[e]; df[4 + e] = hi[e]; }
+                        const bf16x8 kt = tr_frag_rr64(kimg, 16 * ks, b_mine, lane);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, df, acc, 0, 0, 0);
+                    }
+                };
+                if (c == 0) accumulate(dq[0]);
+                if (NC > 1 && c == 1) accumulate(dq[1]);
+                if (NC > 2 && c == 2) accumulate(dq[2]);
+                if (NC > 3 && c == 3) accumulate(dq[3]);
             }
         }
         if (active) {
@@ -1221,11 +1228,12 @@ extern "C" int qst_attention_bwd_ex(const QstAttnDesc* q, void* stream) {
     // d = 64: one 512-thread workgroup per (sequence, head), a single evaluation of the scores, dQ kept in registers across the
     // key passes (attn_bwd_one64_kernel); needs 128 KB of images + the per-query constants (+ 18 L floats with the position
     // bias): every L <= 512 without the bias, L <= 384 with it. Measured against the two-kernel path (tools/one_attn_bwd.py,
-    // round 4): mpnet shape 128 x 256 x 12 heads without bias / dropout 182 vs 199 us, with both 298 vs 275; bert-base
-    // configs[4] shape 512 x 384 without dropout 1520 vs 1452, with 1950 vs 1686 -- at 8 waves x 256 registers the accumulators
-    // (dQ 16 per chunk + dK, dV 64) leave too little for the mask / bias arithmetic and those variants spill (100-500 bytes
-    // per lane). Taken by itself only where it wins (no dropout, no bias, L <= 256); force_split = 2 forces it (tests, tools).
-    const bool one64_auto = !q->force_split && !drop && !rel && L <= 256;
+    // round 4, us): mpnet shape 128 x 256 x 12 heads with bias + dropout 259 vs 273, dropout only 205 vs 225, neither 186 vs
+    // 204; bert-base configs[4] shape 512 x 384 with dropout 1,560 vs 1,665, without 1,366 vs 1,441. (The first version, with
+    // the chunk loop unrolled so that dq[c] had a constant index, spilled 100-500 bytes per lane in the masked variants and lost
+    // to the pair by 8-16%; as a real loop with the accumulator picked by a uniform switch it is 0-44 bytes at L <= 256, 32 at
+    // L = 384 with dropout.) force_split: 1 = the pair, 2 = this kernel.
+    const bool one64_auto = !q->force_split;
     if (d == 64 && (q->force_split == 2 || one64_auto)) {
         const size_t lds_o = (size_t)131072 + (size_t)2 * L * 4 + (rel ? (size_t)18 * L * 4 : 0);
         if (lds_o <= 163840) {

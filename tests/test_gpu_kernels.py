@@ -472,17 +472,15 @@ def test_attention_fwd_bwd(lib, n, L, A, d, use_rel):
         q = _lib.QstAttnDesc()
         q.qkv, q.mask, q.rel_pos, q.nseq, q.L, q.A, q.d = qd.data_ptr(), md.data_ptr(), _lib.ptr(reld), n, L, A, d
         q.ctx, q.lse, q.dctx, q.dqkv, q.drel = ctx.data_ptr(), lse.data_ptr(), dcd.data_ptr(), dq2.data_ptr(), _lib.ptr(drel2)
-        # force_split: 1 = the two-kernel path, 2 = the d = 64 one-workgroup kernel (taken by itself only without dropout and
-        # bias at L <= 256: everything else runs the two-kernel path unless forced)
-        q.delta_scratch, q.force_split = delta.data_ptr(), (2 if d == 64 else 1)
+        # force_split = 1: the two-kernel path (the first call above ran the one-workgroup kernel where there is one)
+        q.delta_scratch, q.force_split = delta.data_ptr(), 1
         _lib.check(lib.qst_attention_bwd_ex(q, stream()))
         torch.cuda.synchronize()
         torch.testing.assert_close(dq.float(), dq2.float(), rtol=2e-2, atol=2e-2 * max(1.0, gref.abs().max().item()))
         if use_rel:
             torch.testing.assert_close(drel, drel2, rtol=1e-3, atol=1e-3 * max(1.0, drel2.abs().max().item()))
-        if d == 64:       # and the forced kernel against the fp32 reference itself
-            rel_l2 = ((dq2.float().cpu() - gref).norm() / gref.norm()).item()
-            assert rel_l2 < 1e-2, f"one-workgroup d = 64 backward: dqkv relative L2 error {rel_l2}"
+        rel_l2 = ((dq2.float().cpu() - gref).norm() / gref.norm()).item()
+        assert rel_l2 < 1e-2, f"two-kernel backward: dqkv relative L2 error {rel_l2}"
 
 
 @pytest.mark.parametrize("nseq,L,H,vocab,ntypes,irregular_pos", [
