@@ -11,6 +11,7 @@
 //  dK/dV    : S = Q.K^T    -> rows = queries (registers), column = key (lane); dV^T = dO^T.P, dK^T = Q^T.dS.
 // One workgroup = 4 waves = 128 queries (fwd, dQ) or 128 keys (dK/dV) of one (sequence, head); the other
 // side is streamed through LDS in chunks of 128 rows.
+#include <stdlib.h>
 #include "qst_common.h"
 #include "qst_kernels.h"
 
@@ -1233,7 +1234,9 @@ extern "C" int qst_attention_bwd_ex(const QstAttnDesc* q, void* stream) {
     // the chunk loop unrolled so that dq[c] had a constant index, spilled 100-500 bytes per lane in the masked variants and lost
     // to the pair by 8-16%; as a real loop with the accumulator picked by a uniform switch it is 0-44 bytes at L <= 256, 32 at
     // L = 384 with dropout.) force_split: 1 = the pair, 2 = this kernel.
-    const bool one64_auto = !q->force_split;
+    // (QST_ATTN_BWD_PAIR=1 in the environment: the kernel pair everywhere -- for A/B runs of the whole step, read once)
+    static const bool env_pair = [] { const char* e = getenv("QST_ATTN_BWD_PAIR"); return e && e[0] == '1'; }();
+    const bool one64_auto = !q->force_split && !env_pair;
     if (d == 64 && (q->force_split == 2 || one64_auto)) {
         const size_t lds_o = (size_t)131072 + (size_t)2 * L * 4 + (rel ? (size_t)18 * L * 4 : 0);
         if (lds_o <= 163840) {
