@@ -154,6 +154,9 @@ int qst_gemm_tn_group(const QstTnGroup* grp, void* stream);
 int qst_gemm_nt8_supported(const QstGemmArgs* a, int epi);
 int qst_gemm_nt8(const QstGemmArgs* a, int epi, int tile, void* stream);
 int qst_gemm_tn8_group(const QstTnGroup* grp, void* stream);
+/* qst_gemm_nt_f8's operands (MXFP8 x MXFP8, block scales in qst_quant_mx's layout) on the 8-phase loop with
+ * v_mfma_scale_f32_16x16x128_f8f6f4: epi QST_EPI_BF16, QST_EPI_F32_RESID (+ dropout), QST_EPI_GELU; tile as qst_gemm_nt8. */
+int qst_gemm_nt8_f8(const QstGemmArgs* a, int epi, int tile, void* stream);
 int qst_gemm8_mode(int mode);
 
 /* Embedding gather + LayerNorm (BertEmbeddings / MPNetEmbeddings forward).

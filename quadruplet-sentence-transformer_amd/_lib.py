@@ -117,6 +117,7 @@ SIGNATURES = {
     "qst_gemm_nt8_supported": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int]),
     "qst_gemm_nt8": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int, C.c_int, vp]),
     "qst_gemm_tn8_group": (C.c_int, [C.POINTER(QstTnGroup), vp]),
+    "qst_gemm_nt8_f8": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int, C.c_int, vp]),
     "qst_gemm8_mode": (C.c_int, [C.c_int]),
     "qst_embed_ln_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "qst_embed_ln_fwd_drop": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp,

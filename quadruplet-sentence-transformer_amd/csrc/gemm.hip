@@ -1191,6 +1191,16 @@ static int launch_nt_f8(const QstGemmArgs* a, hipStream_t st) {
     return QST_OK;
 }
 
+// Shapes on which the MXFP8 GEMM takes the 8-phase kernel by itself. Back to back at M = 196,608 (tools/f8_8phase_bench.py, us,
+// tiled -> 8-phase 256 x 256): QKV 440 -> 409, FFN-2 + residual (K = 3072) 647 -> 582, FFN-1 + GELU 877 -> 824, out-proj +
+// residual (K = 768, N = 768: epilogue-bound) 248 -> 335.
+static bool f8_auto(const QstGemmArgs* a, int epi) {
+    if (a->M < 16384) return false;
+    if (epi == QST_EPI_BF16) return a->N >= 2304 && a->K >= 768;
+    if (epi == QST_EPI_F32_RESID) return a->K >= 2304;
+    return false;
+}
+
 extern "C" int qst_gemm_nt_f8(const QstGemmArgs* a, int epi, void* stream) {
     if (!a || !a->A || !a->B || !a->C || !a->aux || !a->bscale || a->M <= 0 || a->N <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
     if (a->K % 128 != 0 || a->lda % 16 != 0 || a->ldb % 16 != 0 || a->N % 8 != 0) return QST_ERR_UNSUPPORTED;
@@ -1201,6 +1211,12 @@ extern "C" int qst_gemm_nt_f8(const QstGemmArgs* a, int epi, void* stream) {
     }
     if ((int64_t)128 * a->lda >= 0x7FFFFF00LL || (int64_t)192 * a->ldb >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    // the 8-phase form (gemm8.hip: 16x16x128 MFMA, 256 x 256 tile): bit-identical; a->splits bit 6 forces it, bit 7 forbids it,
+    // otherwise qst_gemm8_mode bit 0 / the shape decide (f8_auto)
+    if (!(a->splits & 0x80) && (epi == QST_EPI_BF16 || epi == QST_EPI_F32_RESID || epi == QST_EPI_GELU) && a->N % 8 == 0 && a->ldc % 8 == 0) {
+        const int mode = qst_gemm8_mode_get();
+        if ((a->splits & 0x40) || (mode >= 0 ? (mode & 1) != 0 : f8_auto(a, epi))) return qst_gemm_nt8_f8(a, epi, 1, stream);
+    }
     switch (epi) {
         case QST_EPI_BF16: return a->ldc % 4 ? QST_ERR_UNSUPPORTED : launch_nt_f8<QST_EPI_BF16>(a, st);
         case QST_EPI_F32_RESID: return a->ldc % 4 ? QST_ERR_UNSUPPORTED : launch_nt_f8<QST_EPI_F32_RESID>(a, st);

@@ -35,21 +35,10 @@ __device__ __forceinline__ void pair8(const f32x4_t& x, const f32x4_t& y, float 
     }
 }
 
-template <int EPI, int TM, int TN>
-__global__ __launch_bounds__(512, 1) void gemm_nt8_kernel(QstGemmArgs g) {
-    using OPS = g8p::NtOps<TM, TN>;
-    constexpr int BM = OPS::BM, BN = OPS::BN, NP = TN / 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
-    const int wg = g8p::xcd_remap(blockIdx.x, ntm * ntn);
-    // (column-major tile order inside an XCD's share -- one weight panel per L2, the activation rows streamed past it -- was
-    // measured on the H = 768 shapes: within 1% of this order on every one)
-    const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
-    OPS o;
-    o.init((const bf16*)g.A + (size_t)m0 * g.lda, g.lda, min(BM, g.M - m0), (const bf16*)g.B + (size_t)n0 * g.ldb, g.ldb,
-           min(BN, g.N - n0), g.K, smem);
-    g8p::kloop8(o, o.nk);
-
+// Epilogue of an 8-phase NT tile (bf16 or MXFP8 operands: the accumulator layout is the same), registers only.
+template <int EPI, class OPS>
+__device__ __forceinline__ void nt8_epilogue(const QstGemmArgs& g, OPS& o, int m0, int n0) {
+    constexpr int BM = OPS::BM, BN = OPS::BN, TM = BM / 32, TN = BN / 64, NP = TN / 2;
     const int lane = threadIdx.x & 63, gq = lane >> 4;
     const int mw = m0 + o.wr * (BM / 2) + (lane & 15);                 // + 16 i
     const int nw = n0 + o.wc * (BN / 4) + pair_col(gq);                // + 32 jp
@@ -169,6 +158,41 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_kernel(QstGemmArgs g) {
             }
         }
     }
+}
+
+
+template <int EPI, int TM, int TN>
+__global__ __launch_bounds__(512, 1) void gemm_nt8_kernel(QstGemmArgs g) {
+    using OPS = g8p::NtOps<TM, TN>;
+    constexpr int BM = OPS::BM, BN = OPS::BN;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
+    const int wg = g8p::xcd_remap(blockIdx.x, ntm * ntn);
+    // (column-major tile order inside an XCD's share -- one weight panel per L2, the activation rows streamed past it -- was
+    // measured on the H = 768 shapes: within 1% of this order on every one)
+    const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
+    OPS o;
+    o.init((const bf16*)g.A + (size_t)m0 * g.lda, g.lda, min(BM, g.M - m0), (const bf16*)g.B + (size_t)n0 * g.ldb, g.ldb,
+           min(BN, g.N - n0), g.K, smem);
+    g8p::kloop8(o, o.nk);
+    nt8_epilogue<EPI>(g, o, m0, n0);
+}
+
+// The same tile on the fp8 matrix cores: A, B = e4m3 [rows, K] (lda / ldb in bytes), aux / bscale = their E8M0 block scales
+// (qst_quant_mx's stage-major layout), K % 128 == 0 -- the operands of qst_gemm_nt_f8 (gemm.hip).
+template <int EPI, int TM, int TN>
+__global__ __launch_bounds__(512, 1) void gemm_nt8_f8_kernel(QstGemmArgs g) {
+    using OPS = g8p::NtOpsF8<TM, TN>;
+    constexpr int BM = OPS::BM, BN = OPS::BN;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
+    const int wg = g8p::xcd_remap(blockIdx.x, ntm * ntn);
+    const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
+    OPS o;
+    o.init((const uint8_t*)g.A + (size_t)m0 * g.lda, g.lda, min(BM, g.M - m0), (const uint8_t*)g.aux, g.M, m0,
+           (const uint8_t*)g.B + (size_t)n0 * g.ldb, g.ldb, min(BN, g.N - n0), (const uint8_t*)g.bscale, g.N, n0, g.K, smem);
+    g8p::kloop8(o, o.nk);
+    nt8_epilogue<EPI>(g, o, m0, n0);
 }
 
 // ---------------------------------------------------------------- grouped weight gradients
@@ -347,6 +371,41 @@ extern "C" int qst_gemm_nt8(const QstGemmArgs* a, int epi, int tile, void* strea
         default: return QST_ERR_BAD_ARG;
     }
 #undef QST_NT8_CASE
+}
+
+template <int EPI, int TM, int TN>
+static int launch_nt8_f8(const QstGemmArgs* a, hipStream_t st) {
+    using OPS = g8p::NtOpsF8<TM, TN>;
+    static QstLdsAttr attr;
+    if (int rc = qst_ensure_lds(attr, (const void*)gemm_nt8_f8_kernel<EPI, TM, TN>, OPS::LDS_TOTAL)) return rc;
+    const int ntm = (a->M + OPS::BM - 1) / OPS::BM, ntn = (a->N + OPS::BN - 1) / OPS::BN;
+    gemm_nt8_f8_kernel<EPI, TM, TN><<<dim3(ntm * ntn), dim3(512), OPS::LDS_TOTAL, st>>>(*a);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+// MXFP8 x MXFP8 on the 8-phase loop: operands as qst_gemm_nt_f8; epi QST_EPI_BF16, QST_EPI_F32_RESID (+ dropout of the
+// projection output), QST_EPI_GELU (gelu'(u) and h as bf16). tile: 0 = 128 x 384, 1 = 256 x 256.
+extern "C" int qst_gemm_nt8_f8(const QstGemmArgs* a, int epi, int tile, void* stream) {
+    if (!a || !a->A || !a->B || !a->C || !a->aux || !a->bscale || a->M <= 0 || a->N <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
+    if (a->K % 128 != 0 || a->lda % 16 != 0 || a->ldb % 16 != 0 || a->N % 8 != 0 || a->ldc % 8 != 0) return QST_ERR_UNSUPPORTED;
+    if (epi == QST_EPI_F32_RESID && a->resid && a->ldr % 4 != 0) return QST_ERR_UNSUPPORTED;
+    if ((int64_t)256 * a->lda >= 0x7FFFFF00LL || (int64_t)384 * a->ldb >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
+    if ((int64_t)(a->K / 128) * (a->M > a->N ? a->M : a->N) * 4 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
+    if (epi == QST_EPI_GELU && !a->C2) return QST_ERR_BAD_ARG;
+    if (a->drop.thr16 && a->drop.state) {
+        if (a->drop_where != 1 || epi != QST_EPI_F32_RESID) return QST_ERR_BAD_ARG;
+        if (a->drop.thr16 > 65535u || (int64_t)a->M * a->N >= ((int64_t)1 << 32)) return QST_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+#define QST_NT8F_CASE(E) case E: return tile == 1 ? launch_nt8_f8<E, 8, 4>(a, st) : launch_nt8_f8<E, 4, 6>(a, st);
+    switch (epi) {
+        QST_NT8F_CASE(QST_EPI_BF16)
+        QST_NT8F_CASE(QST_EPI_F32_RESID)
+        QST_NT8F_CASE(QST_EPI_GELU)
+        default: return QST_ERR_UNSUPPORTED;
+    }
+#undef QST_NT8F_CASE
 }
 
 template <int TM, int TN>

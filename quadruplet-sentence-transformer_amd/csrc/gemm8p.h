@@ -79,18 +79,20 @@ __device__ __forceinline__ void bar() {
 template <class OPS>
 __device__ __forceinline__ void kloop8(OPS& o, int nk) {
     constexpr int NA = OPS::NA, NB = OPS::NB, LGK = OPS::LGK;
-    // vector-memory operations issued after A1(t+1) when phase 4t+4 waits. OPS::touch(kt) / NTOUCH: a hook for NTOUCH extra
-    // vector-memory instructions per K-tile and wave behind the B0 stage (round 4 tried an L2 touch-ahead of the operand
-    // rows two and four K-tiles early there: 167 -> 185 / 191 us on the MiniLM weight gradients, removed)
+    // vector-memory operations issued after A1(t+1) when phase 4t+4 waits. OPS::touch(kt) / NTOUCH: NTOUCH extra
+    // vector-memory instructions per K-tile and wave that travel with the B0 stage of K-tile kt (the fp8 form stages the
+    // K-tile's E8M0 block scales there; round 4 also tried an L2 touch-ahead of the operand rows two and four K-tiles early:
+    // 167 -> 185 / 191 us on the MiniLM weight gradients, removed)
     constexpr int NW = 2 * NB + NA + OPS::NTOUCH;
     static_assert(LGK <= 15 && NW <= 63, "counter fields");
-    o.stage_b(0, 0); o.stage_a(0, 0); o.stage_b(0, 1); o.stage_a(0, 1);
-    o.stage_b(1, 0); o.stage_a(1, 0); o.stage_b(1, 1);
-    wait_vm<2 * NB + NA>();                             // K-tile 0 has landed (this wave's part)
+    o.stage_b(0, 0); o.touch(0); o.stage_a(0, 0); o.stage_b(0, 1); o.stage_a(0, 1);
+    o.stage_b(1, 0); o.touch(1); o.stage_a(1, 0); o.stage_b(1, 1);
+    wait_vm<NW>();                                      // K-tile 0 has landed (this wave's part)
     bar();
     if (o.wr == 1) bar();                               // waves 4-7 run one barrier behind
 #pragma unroll 1
     for (int t = 0; t < nk; t += 2) {
+        o.begin_iter(t);
         // ---- K-tile t (buffer 0)
         o.template rd_b<0, 0>();
         __builtin_amdgcn_sched_barrier(0);
@@ -210,6 +212,7 @@ struct NtOps {
         for (int t = 0; t < NB; ++t) dma16(r, d + lb[t], vb[t], so);
     }
     __device__ __forceinline__ void touch(int) {}
+    __device__ __forceinline__ void begin_iter(int) {}
     template <int BUF, int QM, int PART> __device__ __forceinline__ void rd_a() {
         if (PART == 1) return;
 #pragma unroll
@@ -235,6 +238,142 @@ struct NtOps {
                 for (int j = 0; j < TN / 2; ++j)
                     acc[QM * (TM / 2) + i][QN * (TN / 2) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         fb[QN][j][s], fa[i][s], acc[QM * (TM / 2) + i][QN * (TN / 2) + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    }
+};
+
+// ---------------------------------------------------------------- NT operands, MXFP8 x MXFP8 (v_mfma_scale_f32_16x16x128_f8f6f4)
+// The same tile geometry, LDS images, swizzle and DMA map as NtOps with a K-tile of 128 e4m3 elements = the same 128-byte rows;
+// one block-scaled MFMA per 16 x 16 tile and K-tile (32 cycles: twice the bf16 rate). Operand layout of the instruction
+// (tools/probe/mfma_f8_16x16_probe.hip): lane (r = l & 15, g = l >> 4) holds bytes k = 16 g .. 16 g + 15 of row r in registers
+// 0-3 and k = 64 + 16 g .. in registers 4-7 -- 16-byte chunks g and 4 + g of the row's 128 bytes -- and supplies the E8M0 scale
+// of MX block g (k = 32 g .. 32 g + 31) of row r in byte `opsel` of its scale register. Scales (uint8 E8M0, stage-major as
+// qst_quant_mx writes them: the four of a row and K-tile are one dword at (kt * rows + r) * 4) travel with the B0 stage of
+// their K-tile: every wave issues ONE 4-byte-per-lane LDS-DMA (waves 0-3: 64 A rows each, waves 4-7: 64 B rows; the tile has
+// at most 256 + 256 or 128 + 384 rows = 8 x 64) into a 4-slot ring of 2 KB, so all waves carry the same vmcnt.
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+template <int TM, int TN>
+struct NtOpsF8 {
+    static constexpr int BM = 32 * TM, BN = 64 * TN;
+    static constexpr int NA = BM / 128, NB = BN / 128, LGK = TM, NTOUCH = 1;
+    static constexpr int SCALE_OFF = LDS_BYTES;            // [4 slots][BM + BN rows] dwords behind the two K-tile buffers
+    static constexpr int LDS_TOTAL = LDS_BYTES + 4 * (BM + BN) * 4;
+    static_assert((BM + BN) * 128 == BUF_BYTES && (BM + BN) == 512, "tile geometry");
+    char* smem;
+    __amdgpu_buffer_rsrc_t ra, rb, rz, rs;     // rs: this wave's 64 scale rows (A or B)
+    uint32_t va[NA], vb[NB], la[NA], lb[NB], ha, hb, ao0, ao1, bo0, bo1;
+    uint32_t vs, ss;                           // scale DMA: per-lane byte offset, bytes per K-tile of the scale matrix
+    uint32_t sao, sbo;                         // per-lane LDS offsets of this lane's A / B scale dwords (slot 0, tile 0)
+    uint32_t gsh;                              // 8 * (lane >> 4): this lane's block inside the scale dword
+    int nk, wr, wc;
+    f32x4_t acc[TM][TN];
+    i32x8_t fa[TM / 2], fb[2][TN / 2];
+    int sa_[TM / 2], sb_[2][TN / 2];
+
+    // A: e4m3 [rows_a, K] (lda bytes) at the tile's first row, As: its scale matrix (all M rows: row index m0 + r); B likewise
+    __device__ __forceinline__ void init(const uint8_t* A, int lda, int rows_a, const uint8_t* As, int M, int m0,
+                                         const uint8_t* B, int ldb, int rows_b, const uint8_t* Bs, int N, int n0, int K, char* smem_) {
+        const int tid = threadIdx.x, lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        smem = smem_; wr = wave >> 2; wc = wave & 3; nk = K >> 7;
+        ra = rsrc(A, (uint32_t)rows_a * (uint32_t)lda);
+        rb = rsrc(B, (uint32_t)rows_b * (uint32_t)ldb);
+        rz = rsrc(A, 0u);
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+            const int jb = wave * NA + t;
+            const int row0 = (jb / (BM / 32)) * (BM / 2) + (jb % (BM / 32)) * 8, row = row0 + (lane >> 3);
+            va[t] = (uint32_t)row * lda + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+            la[t] = (uint32_t)row0 * 128u;
+        }
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            const int jb = wave * NB + t;
+            const int row0 = (jb / (BN / 64)) * (BN / 4) + (jb % (BN / 64)) * 8, row = row0 + (lane >> 3);
+            vb[t] = (uint32_t)row * ldb + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+            lb[t] = (uint32_t)(BM + row0) * 128u;
+        }
+        ha = (uint32_t)(BM / 4) * lda; hb = (uint32_t)(BN / 8) * ldb;
+        // fragment chunks g and 4 + g: positions differ in bit 2 of the chunk index whatever the row's swizzle
+        const uint32_t lo0 = (uint32_t)((lane & 15) * 128 + (((lane >> 4) ^ ((lane & 15) >> 1)) << 4));
+        ao0 = lo0 + wr * (BM / 2) * 128; ao1 = ao0 ^ 64u;
+        bo0 = lo0 + (BM + wc * (BN / 4)) * 128; bo1 = bo0 ^ 64u;
+        // scale rows of the tile in LDS order: A rows 0 .. BM-1, then B rows; wave w stages rows 64 w .. 64 w + 63 of that order
+        {
+            const int srow = wave * 64 + lane;                        // 0 .. 511
+            const bool isA = wave * 64 < BM;                          // wave-uniform (BM is a multiple of 64): scalar descriptor
+            const int r = isA ? srow : srow - BM;
+            const int rows = isA ? rows_a : rows_b, total = isA ? M : N, first = isA ? m0 : n0;
+            // one descriptor per wave is only possible when a wave's 64 rows are all A or all B: BM is a multiple of 64
+            const uint8_t* base = (isA ? As : Bs) + (size_t)first * 4;
+            rs = rsrc(base, (uint32_t)(((size_t)nk * total - first) * 4));
+            vs = r < rows ? (uint32_t)r * 4u : kOOB;
+            ss = (uint32_t)total * 4u;
+        }
+        sao = (uint32_t)(SCALE_OFF + (wr * (BM / 2) + (lane & 15)) * 4);
+        sbo = (uint32_t)(SCALE_OFF + (BM + wc * (BN / 4) + (lane & 15)) * 4);
+        gsh = 8u * (uint32_t)(lane >> 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    __device__ __forceinline__ void stage_a(int kt, int h) {
+        const __amdgpu_buffer_rsrc_t r = kt < nk ? ra : rz;
+        const uint32_t so = (uint32_t)kt * 128u + (h ? ha : 0u);
+        char* d = smem + (kt & 1) * BUF_BYTES + h * (BM / 4) * 128;
+#pragma unroll
+        for (int t = 0; t < NA; ++t) dma16(r, d + la[t], va[t], so);
+    }
+    __device__ __forceinline__ void stage_b(int kt, int h) {
+        const __amdgpu_buffer_rsrc_t r = kt < nk ? rb : rz;
+        const uint32_t so = (uint32_t)kt * 128u + (h ? hb : 0u);
+        char* d = smem + (kt & 1) * BUF_BYTES + h * (BN / 8) * 128;
+#pragma unroll
+        for (int t = 0; t < NB; ++t) dma16(r, d + lb[t], vb[t], so);
+    }
+    __device__ __forceinline__ void touch(int kt) {          // the K-tile's block scales: 64 rows x 4 bytes per wave
+        const __amdgpu_buffer_rsrc_t r = kt < nk ? rs : rz;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t*)(smem + SCALE_OFF + (kt & 3) * (BM + BN) * 4 + (threadIdx.x >> 6) * 256),
+                                                 4, (int)vs, (int)((uint32_t)kt * ss), 0, 0);
+    }
+    static __device__ __forceinline__ i32x8_t frag(const char* p0, const char* p1) {
+        const u32x4_t lo = *(const u32x4_t*)p0, hi = *(const u32x4_t*)p1;
+        i32x8_t f;
+        f[0] = (int)lo[0]; f[1] = (int)lo[1]; f[2] = (int)lo[2]; f[3] = (int)lo[3];
+        f[4] = (int)hi[0]; f[5] = (int)hi[1]; f[6] = (int)hi[2]; f[7] = (int)hi[3];
+        return f;
+    }
+    // BUF doubles as the K-tile's parity; its scale slot is (kt & 3) = BUF or BUF + 2: the skeleton's loop variable t is even in
+    // the first half of an iteration and both t and t + 1 alternate slots 0/1 and 2/3 from one iteration to the next
+    int slot2;                                              // 0 or 2: added to BUF for the scale slot of the current iteration
+    __device__ __forceinline__ void begin_iter(int t) { slot2 = t & 2; }
+    template <int BUF, int QM, int PART> __device__ __forceinline__ void rd_a() {
+        if (PART == 1) return;
+        const char* sc = smem + (BUF + slot2) * (BM + BN) * 4;
+#pragma unroll
+        for (int i = 0; i < TM / 2; ++i) {
+            fa[i] = frag(smem + BUF * BUF_BYTES + (QM * (BM / 4) + i * 16) * 128 + ao0, smem + BUF * BUF_BYTES + (QM * (BM / 4) + i * 16) * 128 + ao1);
+            sa_[i] = (int)(*(const uint32_t*)(sc + (QM * (BM / 4) + i * 16) * 4 + sao) >> gsh);
+        }
+    }
+    template <int BUF, int QN> __device__ __forceinline__ void rd_b() {
+        const char* sc = smem + (BUF + slot2) * (BM + BN) * 4;
+#pragma unroll
+        for (int j = 0; j < TN / 2; ++j) {
+            fb[QN][j] = frag(smem + BUF * BUF_BYTES + (QN * (BN / 8) + j * 16) * 128 + bo0, smem + BUF * BUF_BYTES + (QN * (BN / 8) + j * 16) * 128 + bo1);
+            sb_[QN][j] = (int)(*(const uint32_t*)(sc + (QN * (BN / 8) + j * 16) * 4 + sbo) >> gsh);
+        }
+    }
+    template <int QM, int QN> __device__ __forceinline__ void mm() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < TM / 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN / 2; ++j)
+                acc[QM * (TM / 2) + i][QN * (TN / 2) + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                    fb[QN][j], fa[i], acc[QM * (TM / 2) + i][QN * (TN / 2) + j], 0, 0, 0, sb_[QN][j], 0, sa_[i]);
         __builtin_amdgcn_s_setprio(0);
     }
 };
@@ -340,6 +479,7 @@ struct TnOps {
         for (int t = 0; t < NB; ++t) dma16(r, d + lb[t], h ? vb[1][t] : vb[0][t], so);
     }
     __device__ __forceinline__ void touch(int) {}
+    __device__ __forceinline__ void begin_iter(int) {}
     static __device__ __forceinline__ bf16x8_t tr_frag(const char* p) {
         typedef __attribute__((address_space(3))) bf16x4_t lds_v4;
         const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(p));

@@ -70,7 +70,7 @@ def gemm_args(**kw):
     return a
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 192, 128), (300, 384, 768), (1000, 2304, 768), (520, 768, 3072)])
+@pytest.mark.parametrize("M,N,K", [(128, 192, 128), (300, 384, 768), (1000, 2304, 768), (520, 768, 3072), (17000, 2304, 896)])
 def test_gemm_f8_matches_fp32_on_dequantised_operands(lib, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g) * 4)
@@ -110,6 +110,26 @@ def test_gemm_f8_matches_fp32_on_dequantised_operands(lib, M, N, K):
         step = torch.ldexp(torch.ones(()), (sr.to(torch.int32) - 127 + 8 - 3))[..., None].expand(M, N // 32, 32).reshape(M, N)
         assert ((got - dr).abs() <= 1.01 * step).all()
         assert (Hq.cpu() != qr).float().mean().item() < 2e-2
+    # the 8-phase form (csrc/gemm8.hip: v_mfma_scale_f32_16x16x128_f8f6f4, scales staged by LDS-DMA) in both tiles against the
+    # tiled kernel: fp32 + residual, bf16 and the two-output GELU epilogue (ragged M / N edge tiles included)
+    for tile in (0, 1):
+        C8 = torch.empty(M, N, device="cuda")
+        _lib.check(lib.qst_gemm_nt8_f8(gemm_args(A=Aq, B=Bq, aux=As, bscale=Bs, C=C8, bias=bias.cuda(), resid=resid.cuda(), M=M, N=N, K=K,
+                                                 lda=K, ldb=K, ldc=N, ldr=N), 1, tile, st()))
+        np.testing.assert_allclose(C8.cpu().double().numpy(), (ref + bias.double() + resid.double()).numpy(), rtol=0, atol=2e-5 * acc_scale + 1e-5)
+        torch.testing.assert_close(C8, C, rtol=0, atol=2e-5 * acc_scale + 1e-5)
+        Cb8 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        _lib.check(lib.qst_gemm_nt8_f8(gemm_args(A=Aq, B=Bq, aux=As, bscale=Bs, C=Cb8, bias=bias.cuda(), M=M, N=N, K=K, lda=K, ldb=K, ldc=N),
+                                       0, tile, st()))
+        np.testing.assert_allclose(Cb8.float().cpu().double().numpy(), (ref + bias.double()).numpy(), rtol=8e-3, atol=8e-3 * scale)
+        G1, H1 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        G8, H8 = torch.empty_like(G1), torch.empty_like(H1)
+        _lib.check(lib.qst_gemm_nt_f8(gemm_args(A=Aq, B=Bq, aux=As, bscale=Bs, C=G1, C2=H1, bias=bias.cuda(), M=M, N=N, K=K, lda=K, ldb=K,
+                                                ldc=N, splits=0x80), 2, st()))
+        _lib.check(lib.qst_gemm_nt8_f8(gemm_args(A=Aq, B=Bq, aux=As, bscale=Bs, C=G8, C2=H8, bias=bias.cuda(), M=M, N=N, K=K, lda=K, ldb=K,
+                                                 ldc=N), 2, tile, st()))
+        torch.testing.assert_close(H8.float(), H1.float(), rtol=8e-3, atol=8e-3 * scale)
+        torch.testing.assert_close(G8.float(), G1.float(), rtol=8e-3, atol=2e-2)
     # refused shapes
     assert lib.qst_gemm_nt_f8(gemm_args(A=Aq, B=Bq, aux=As, bscale=Bs, C=C, M=M, N=N, K=K - 32, lda=K, ldb=K, ldc=N), 1, st()) == -2
     assert lib.qst_gemm_nt_f8(gemm_args(A=Aq, B=Bq, aux=As, C=C, M=M, N=N, K=K, lda=K, ldb=K, ldc=N), 1, st()) == -1

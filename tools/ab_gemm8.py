@@ -1,7 +1,7 @@
 """Same-process A/B of qst_gemm8_mode on the whole training step.
 
     python tools/ab_gemm8.py [model] [batch] [seq_len] [rounds] [modes, comma separated: 0 = tiled kernels, 1 = NT on the
-                              8-phase path, 2 = weight gradients on it, 3 = both, -1 = the library's own choice]
+                              8-phase path, 2 = weight gradients on it, 3 = both, -1 = the library's own choice] [iters] [bf16 | fp8]
 """
 import os
 import sys
@@ -35,16 +35,18 @@ def main():
     rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 3
     modes = [int(x) for x in (sys.argv[5] if len(sys.argv) > 5 else "0,1,2,3").split(",")]
     iters = int(sys.argv[6]) if len(sys.argv) > 6 else 10
+    precision = sys.argv[7] if len(sys.argv) > 7 else "bf16"          # "fp8": the fp8-forward training step
     lib = _lib.load()
     cfg = PRESETS[model]
-    tr = QuadrupletTrainer(cfg, arena=synthetic_params(cfg, seed=14), device="cuda:0", lr=2e-5, weight_decay=0.01, max_grad_norm=1.0)
+    tr = QuadrupletTrainer(cfg, arena=synthetic_params(cfg, seed=14), device="cuda:0", lr=2e-5, weight_decay=0.01, max_grad_norm=1.0,
+                           precision=precision)
     batch = [torch.from_numpy(x).cuda() for x in synthetic_quadruplets(cfg, B, L, seed=14)]
     res = {m: [[], []] for m in modes}
     for _ in range(rounds):
         for m in modes:
             lib.qst_gemm8_mode(m)
             res[m][0].append(timed(lambda: tr.step(*batch), iters))
-            res[m][1].append(timed(lambda: tr.forward_loss(*batch), iters))
+            res[m][1].append(timed(lambda: tr.forward_loss(*batch, precision=precision), iters))
     lib.qst_gemm8_mode(-1)
     for m in modes:
         st, fw = res[m]
