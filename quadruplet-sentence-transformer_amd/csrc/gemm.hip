@@ -1114,12 +1114,20 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
 }  // namespace
 
 int qst_gemm8_mode_get();                               // gemm8.hip
-// Shapes on which the 8-phase kernel (its 256 x 256 tile) is taken without being asked: the wide bf16-output forward GEMMs of
-// the H = 768 models (QKV, FFN-1 + GELU). Measured in the step, same process (tools/ab_gemm8.py): bert-base B = 128 L = 384
-// 152.3 -> 150.8 ms, forward-only 56.7 -> 55.4; mpnet-base B = 32 L = 256 27.49 -> 27.43 ms. Every other shape loses on it
-// in-step (all NT GEMMs: +4%; the fp32 + residual epilogues and K = 384 most), DESIGN.md finding 25.
+// Shapes on which the 8-phase kernel (its 256 x 256 tile) is taken without being asked. It needs several tiles per CU (one
+// workgroup per CU, nothing overlaps its epilogue: at 384 tiles -- N = 768, M = 32768 -- it loses to the tiled kernel on every
+// epilogue) and a long reduction or a cheap epilogue. Back to back at M = 196,608 (tools/g8_bench.py 768 196608, us, tiled ->
+// 8-phase): QKV 735 -> 691, FFN-1 + GELU 1,348 -> 1,276, out-proj dgrad (bf16, N = K = 768) 273 -> 232, FFN-2 + residual
+// (K = 3072) 1,042 -> 904 / 987 -> 856, QKV dgrad + residual (K = 2304) 761 -> 691; GELU' dgrad 1,157 -> 1,202 and out-proj +
+// residual (K = 768) 357 -> 406 stay tiled. In the step, same process (tools/ab_gemm8.py): bert-base B = 128 L = 384 bf16
+// 156.2 -> 153.6 ms with the first two alone (round 4, finding 26), with the K >= 2304 residual GEMMs as well: see DESIGN.md.
 static bool nt8_auto(const QstGemmArgs* a, int epi) {
-    return (epi == QST_EPI_BF16 || epi == QST_EPI_GELU) && a->N >= 2304 && a->K >= 768 && a->M >= 16384;
+    const int64_t tiles = (int64_t)((a->M + 255) / 256) * ((a->N + 255) / 256);
+    if (tiles < 1024 || a->K < 768) return false;
+    if (epi == QST_EPI_BF16) return true;
+    if (epi == QST_EPI_GELU) return a->N >= 2304;
+    if (epi == QST_EPI_F32_RESID || epi == QST_EPI_F32_RESID_BF16) return a->K >= 2304;
+    return false;
 }
 
 template <int EPI, int WAVES_M, int WAVES_N = 2, int TI = 2>
