@@ -1126,6 +1126,7 @@ static bool nt8_auto(const QstGemmArgs* a, int epi) {
     if (tiles < 1024 || a->K < 768) return false;
     if (epi == QST_EPI_BF16) return true;
     if (epi == QST_EPI_GELU) return a->N >= 2304;
+    if (epi == QST_EPI_GELU_BWD) return a->N >= 2304 && tiles >= 4096;     // (1,183 -> 1,149 us at M = 196,608; 198 -> 202 at 32,768)
     if (epi == QST_EPI_F32_RESID || epi == QST_EPI_F32_RESID_BF16) return a->K >= 2304;
     return false;
 }

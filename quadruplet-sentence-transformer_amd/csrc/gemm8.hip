@@ -56,10 +56,12 @@ __device__ __forceinline__ void nt8_epilogue(const QstGemmArgs& g, OPS& o, int m
     if (kF32 && g.drop_where == 1) dc = drop_ctx(g.drop);
 
     if constexpr (kF32) {
-        // the residual rows of row-tile i + 2 are requested before the stores of row-tile i are issued: vmcnt retires in
-        // order, so the wait for row-tile i + 1's rows also waits for every older store -- with two tiles of distance those are
-        // the stores of row-tile i - 1, issued a whole tile earlier
-        f32x4 rv[3][NP][2];
+        // The residual rows of HALF the wave's row-tiles are requested in one burst before that half's first store (TM NP
+        // 16-byte loads per lane: 64 registers at TM = 8): vmcnt retires in order, so a load issued behind stores waits for
+        // them, and a burst per row-tile (two loads, then two stores, eight times over) exposed most of a memory round trip per
+        // row-tile -- one workgroup per CU has nothing else to run meanwhile.
+        constexpr int HT = TM / 2;
+        f32x4 rv[HT][NP][2];
         auto load_resid = [&](int i, f32x4 (&dst)[NP][2]) {
             const int m = mw + 16 * i;
 #pragma unroll
@@ -71,11 +73,12 @@ __device__ __forceinline__ void nt8_epilogue(const QstGemmArgs& g, OPS& o, int m
                 dst[jp][1] = ok ? ld_stream((const f32x4*)(p + 4)) : z4;
             }
         };
-        load_resid(0, rv[0]);
-        if (TM > 1) load_resid(1, rv[1]);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            if (i + 2 < TM) load_resid(i + 2, rv[(i + 2) % 3]);
+            if (i % HT == 0) {
+#pragma unroll
+                for (int k = 0; k < HT; ++k) load_resid(i + k, rv[k]);
+            }
             const int m = mw + 16 * i;
 #pragma unroll
             for (int jp = 0; jp < NP; ++jp) {
@@ -96,7 +99,7 @@ __device__ __forceinline__ void nt8_epilogue(const QstGemmArgs& g, OPS& o, int m
                 }
                 f32x4 lo, hi;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { lo[e] = v[e] + rv[i % 3][jp][0][e]; hi[e] = v[4 + e] + rv[i % 3][jp][1][e]; }
+                for (int e = 0; e < 4; ++e) { lo[e] = v[e] + rv[i % HT][jp][0][e]; hi[e] = v[4 + e] + rv[i % HT][jp][1][e]; }
                 float* c = (float*)g.C + (size_t)m * g.ldc + n;
                 st_stream((f32x4*)c, lo);
                 st_stream((f32x4*)(c + 4), hi);
@@ -109,7 +112,7 @@ __device__ __forceinline__ void nt8_epilogue(const QstGemmArgs& g, OPS& o, int m
             }
         }
     } else {
-        u32x4 av[3][NP];
+        u32x4 av[TM][NP];                                  // every saved gelu'(u) row of the wave's block, requested up front
         const u32x4 zu = {0u, 0u, 0u, 0u};
         auto load_aux = [&](int i, u32x4 (&dst)[NP]) {
             const int m = mw + 16 * i;
@@ -119,10 +122,12 @@ __device__ __forceinline__ void nt8_epilogue(const QstGemmArgs& g, OPS& o, int m
                 dst[jp] = (m < g.M && n < g.N) ? ld_stream((const u32x4*)((const bf16*)g.aux + (size_t)m * g.ldc + n)) : zu;
             }
         };
-        if (EPI == QST_EPI_GELU_BWD) { load_aux(0, av[0]); if (TM > 1) load_aux(1, av[1]); }
+        if (EPI == QST_EPI_GELU_BWD) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) load_aux(i, av[i]);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            if (EPI == QST_EPI_GELU_BWD && i + 2 < TM) load_aux(i + 2, av[(i + 2) % 3]);
             const int m = mw + 16 * i;
 #pragma unroll
             for (int jp = 0; jp < NP; ++jp) {
@@ -154,7 +159,7 @@ __device__ __forceinline__ void nt8_epilogue(const QstGemmArgs& g, OPS& o, int m
                 } else {                                                    // QST_EPI_GELU_BWD: acc * gelu'(u)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        pk[e] = pack_bf16x2(v[2 * e] * bf16lo(av[i % 3][jp][e]), v[2 * e + 1] * bf16hi(av[i % 3][jp][e]));
+                        pk[e] = pack_bf16x2(v[2 * e] * bf16lo(av[i][jp][e]), v[2 * e + 1] * bf16hi(av[i][jp][e]));
                     st_stream((u32x4*)((bf16*)g.C + off), pk);
                 }
             }
