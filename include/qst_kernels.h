@@ -296,6 +296,14 @@ int qst_attention_bwd_f32(const float* qkv, const float* ctx, const float* dctx,
                           int nseq, int L, int A, int d, float* dqkv, float* drel_bias, void* stream);
 int qst_attention_bwd_f32_drop(const float* qkv, const float* ctx, const float* dctx, const int64_t* mask, const float* rel_bias,
                                int nseq, int L, int A, int d, float* dqkv, float* drel_bias, const QstDrop* drop, void* stream);
+/* The same gradients on the matrix cores (csrc/x3.hip): every contraction as three split-bf16 MFMAs per product, softmax,
+ * dropout mask and dS in fp32; agrees with qst_attention_bwd_f32 to fp32 rounding (tests/test_gpu_encoder.py). `scratch`:
+ * qst_attention_bwd_x3_scratch_bytes(nseq, L, A) bytes (row maxima, 1 / row sums and dO . O of every query). L % 32 == 0,
+ * L <= 512, d in {32, 64}. This is what the QST_PREC_BF16X3 backward of qst_encoder_backward runs. */
+size_t qst_attention_bwd_x3_scratch_bytes(int nseq, int L, int A);
+int qst_attention_bwd_x3(const float* qkv, const float* ctx, const float* dctx, const int64_t* mask, const float* rel_bias,
+                         int nseq, int L, int A, int d, float* dqkv, float* drel_bias, void* scratch, const QstDrop* drop,
+                         void* stream);
 /* out[i] = in[i] * mask multiplier(i) (+ resid[i], nullable), i < n (n % 4 == 0; in may be out): the hidden-state dropout of
  * the parity-precision training path (element index = flat index, the 16-bit generator of QstDrop). */
 int qst_dropout_apply_f32(const QstDrop* d, const float* in, const float* resid, int64_t n, float* out, void* stream);

@@ -156,6 +156,8 @@ SIGNATURES = {
     "qst_ln_bwd_f32": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp]),
     "qst_attention_bwd_f32": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "qst_attention_bwd_f32_drop": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "qst_attention_bwd_x3_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "qst_attention_bwd_x3": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "qst_dropout_apply_f32": (C.c_int, [vp, vp, vp, C.c_int64, vp, vp]),
     "qst_comm_unique_id": (C.c_int, [vp]),
     "qst_comm_init": (C.c_int, [C.c_int, C.c_int, vp, C.POINTER(vp)]),

@@ -335,7 +335,7 @@ X3TrainPlan plan_x3_train(const qst_config& c, int nseq, int L) {
 }
 // its backward's scratch: gradient activations, the transposed copies the x3 GEMM contracts over (dY^T, X^T: [cols, M]) and
 // one transposed weight
-struct X3BwdPlan { size_t dx, dy, ds, dbig, dctx, dqkv, tA, tB, wT, drel, total; };
+struct X3BwdPlan { size_t dx, dy, ds, dbig, dctx, dqkv, tA, tB, wT, drel, astats, total; };
 X3BwdPlan plan_x3_bwd(const qst_config& c, int nseq, int L) {
     X3BwdPlan p;
     const size_t M = (size_t)nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads;
@@ -347,6 +347,7 @@ X3BwdPlan plan_x3_bwd(const qst_config& c, int nseq, int L) {
     p.tA = take(wide * M * 4); p.tB = take((I > H ? I : H) * M * 4);
     p.wT = take((H * I > 3 * H * H ? H * I : 3 * H * H) * 4);
     p.drel = (c.arch == QST_ARCH_MPNET) ? take(A * (size_t)L * L * 4) : 0;
+    p.astats = take(qst_attention_bwd_x3_scratch_bytes(nseq, L, (int)A));
     p.total = off;
     return p;
 }
@@ -807,7 +808,7 @@ static int backward_x3(qst_encoder* e, const int64_t* ids, const int64_t* mask, 
     auto wgrad = [&](const float* dY, int out, const float* X, int in, int wseg, int bseg) -> int {
         QST_TRY(qst_transpose_f32(dY, M, out, out, tA, M, st));
         QST_TRY(qst_transpose_f32(X, M, in, in, tB, M, st));
-        QST_TRY(nt3(tA, M, tB, M, G(wseg), in, nullptr, G(wseg), in, out, in, M, 1, st));
+        QST_TRY(nt3(tA, M, tB, M, G(wseg), in, nullptr, nullptr, in, out, in, M, 3, st));    // += over shares of the token rows
         return qst_colsum_f32(dY, M, out, out, G(bseg), st);
     };
     const float* rel = nullptr;
@@ -851,7 +852,7 @@ static int backward_x3(qst_encoder* e, const int64_t* ids, const int64_t* mask, 
         QST_TRY(wgrad(dsm, H, F(a.ctx), H, b + W_O, b + B_O));
         {
             const QstDrop dp = drop_of(thr, dst8, true, QST_DROP_SITE_PROBS(l));
-            QST_TRY(qst_attention_bwd_f32_drop(F(a.qkv), F(a.ctx), dctx, mask, rel, nseq, L, A, d, dqkv, drel, adrop ? &dp : nullptr, st));
+            QST_TRY(qst_attention_bwd_x3(F(a.qkv), F(a.ctx), dctx, mask, rel, nseq, L, A, d, dqkv, drel, ws + w.astats, adrop ? &dp : nullptr, st));
         }
         QST_TRY(dgrad(dqkv, 3 * H, b + W_QKV, H, dx, ds));                           // dx_in = dqkv . Wqkv + ds1
         QST_TRY(wgrad(dqkv, 3 * H, xin, H, b + W_QKV, b + B_QKV));

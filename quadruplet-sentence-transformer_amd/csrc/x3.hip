@@ -7,6 +7,7 @@
 //
 //   gemm_nt_x3 : C[M,N] (fp32) = A[M,K] (fp32) . B[N,K]^T (fp32) + bias [+ resid] [GELU]
 //   attn_fwd_x3: softmax(Q K^T / sqrt(d) + rel + mask) V on fp32 qkv -> fp32 ctx
+#include <algorithm>
 #include "qst_common.h"
 #include "qst_kernels.h"
 
@@ -35,7 +36,7 @@ __device__ __forceinline__ uint32_t x_off(int row, int chunk) {
     return (uint32_t)(row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4));
 }
 
-template <int EPI>   // 0: +bias ; 1: +bias +resid ; 2: gelu(+bias)
+template <int EPI>   // 0: +bias ; 1: +bias +resid ; 2: gelu(+bias) ; 3: C += A . B^T over this workgroup's share of K (fp32 atomics)
 __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(QstGemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // A hi | A lo | B hi | B lo (8 KB each); epilogue 34 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -78,10 +79,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(QstGemmArgs g) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int nk = g.K / XBK;
+    // EPI 3 (weight gradients: K = the token rows): gridDim.y workgroups share the reduction, g.splits K-tiles each
+    const int kt0 = EPI == 3 ? (int)blockIdx.y * g.splits : 0;
+    const int nk = EPI == 3 ? min(g.K / XBK, kt0 + g.splits) : g.K / XBK;
     const int fr = lane & 31, fh = lane >> 5;
-    gload(0);
-    for (int kt = 0; kt < nk; ++kt) {
+    if (kt0 >= nk) return;
+    gload(kt0);
+    for (int kt = kt0; kt < nk; ++kt) {
         __syncthreads();                 // previous tile's fragment reads are done
         lstore();
         __syncthreads();
@@ -127,6 +131,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(QstGemmArgs g) {
                 const int m = m0 + wm * 64 + i * 32 + row;
                 if (m >= g.M) continue;
                 f32x4 v = *(const f32x4*)(stg + row * 68 + c4 * 4);
+                if (EPI == 3) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd((float*)g.C + (size_t)m * g.ldc + n + e, v[e]);
+                    continue;
+                }
                 v += bias;
                 if (EPI == 1 && g.resid) v += *(const f32x4*)(g.resid + (size_t)m * g.ldr + n);
                 if (EPI == 2) {
@@ -297,6 +306,275 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(AttnX3Args a) {
         }
 }
 
+// ---------------------------------------------------------------- attention backward on the x3 products
+// Two kernels, both shaped like the forward (a wave owns 32 rows of one (sequence, head); the other side streams through LDS
+// in chunks of 128 rows as hi / lo bf16 images), every contraction three MFMAs per product, everything elementwise in fp32:
+//   dq kernel : wave = 32 queries. Pass 1 over the keys: row maximum m_i and l_i = sum_j exp(s_ij - m_i) (kept apart, as the
+//               fp32 kernel of x3_bwd.hip does: a row with every key masked has m_i = -3.4e38); delta_i = dO_i . O_i from the
+//               rows the lane loads anyway; all three go to `stats` for the second kernel. Pass 2: S^T = K Q^T and
+//               dP^T = V dO^T (rows = keys in registers, column = the lane's query), dS = P (dP mask - delta),
+//               dQ^T += K^T dS^T with the dS^T registers as the B operand (the forward's P V step).
+//   dkv kernel: wave = 32 keys. S = Q K^T and dP = dO V^T (rows = queries in registers, column = the lane's key), then
+//               dK^T += Q^T dS, dV^T += dO^T (P mask); the position-bias gradient leaves as one atomic per score.
+// Scores are evaluated twice (once per kernel): the parity path trades those MFMAs for having no dS round trip.
+struct AttnBwdX3Args {
+    const float* qkv; const float* ctx; const float* dctx; const int64_t* mask; const float* rel;
+    float* dqkv; float* drel; float* stats;       // stats: [3][nseq * A * L] = m, 1 / l, delta
+    int nseq, L, A, H; float scale;
+    QstDrop drop;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_x3_dq_kernel(AttnBwdX3Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = D / 16, DB = D / 32, IMG = 128 * D * 2;
+    char* khi = smem; char* klo = smem + IMG; char* kthi = smem + 2 * IMG; char* ktlo = smem + 3 * IMG;
+    char* vhi = smem + 4 * IMG; char* vlo = smem + 5 * IMG;
+    float* madd = (float*)(smem + 6 * IMG);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, fr = lane & 31;
+    const int nqb = (a.L + 127) / 128;
+    const int qb = blockIdx.x % nqb, head = (blockIdx.x / nqb) % a.A, seq = blockIdx.x / (nqb * a.A);
+    const int ld = 3 * a.H;
+    const float* base = a.qkv + (size_t)seq * a.L * ld + head * D;
+    const int i0 = qb * 128 + wave * 32;
+    const bool active = i0 < a.L;
+    const int qi = i0 + fr;
+    for (int t = tid; t < a.L; t += 256) madd[t] = a.mask[(size_t)seq * a.L + t] ? 0.f : kMaskMin;
+    bf16x8 qh[KS], ql[KS], doh[KS], dol[KS];
+    float delta = 0.f;
+    if (active) {
+        const float* drow = a.dctx + ((size_t)seq * a.L + qi) * a.H + head * D;
+        const float* orow = a.ctx + ((size_t)seq * a.L + qi) * a.H + head * D;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            load_frag_x3(base + (size_t)qi * ld + 16 * s + 8 * h, qh[s], ql[s]);
+            load_frag_x3(drow + 16 * s + 8 * h, doh[s], dol[s]);
+            const f32x4 d0 = *(const f32x4*)(drow + 16 * s + 8 * h), d1 = *(const f32x4*)(drow + 16 * s + 8 * h + 4);
+            const f32x4 o0 = *(const f32x4*)(orow + 16 * s + 8 * h), o1 = *(const f32x4*)(orow + 16 * s + 8 * h + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) delta += d0[e] * o0[e] + d1[e] * o1[e];
+        }
+        delta += swap32(delta);
+    }
+    const int nchunk = (a.L + 127) / 128;
+    auto scores = [&](int c, int jt, f32x16& s) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const uint32_t off = rr_off<D>(jt * 32 + fr, 2 * ks + h);
+            s = mfma3(*(const bf16x8*)(khi + off), *(const bf16x8*)(klo + off), qh[ks], ql[ks], s);
+        }
+        const int j0 = c * 128 + jt * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float v = s[r] * a.scale;
+            if (a.rel) v += a.rel[((size_t)head * a.L + qi) * a.L + j];
+            s[r] = v + madd[j];
+        }
+    };
+    // ---- pass 1: m_i, l_i
+    float m = -INFINITY, l = 0.f;
+    for (int c = 0; c < nchunk; ++c) {
+        const int rows = min(128, a.L - c * 128);
+        __syncthreads();
+        stage_x3<D, false>(khi, klo, base + (size_t)c * 128 * ld + a.H, ld, rows, tid);
+        __syncthreads();
+        if (!active) continue;
+        for (int jt = 0; jt < rows / 32; ++jt) {
+            f32x16 s;
+            scores(c, jt, s);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+            mx = fmaxf(mx, swap32(mx));
+            const float mn = fmaxf(m, mx);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ps += expf(s[r] - mn);
+            ps += swap32(ps);
+            l = l * expf(m - mn) + ps;
+            m = mn;
+        }
+    }
+    const float inv_l = 1.0f / l;
+    if (active && h == 0) {
+        const size_t n = (size_t)a.nseq * a.A * a.L, row = ((size_t)seq * a.A + head) * a.L + qi;
+        a.stats[row] = m; a.stats[n + row] = inv_l; a.stats[2 * n + row] = delta;
+    }
+    // ---- pass 2: dQ
+    f32x16 dq[DB];
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[b][r] = 0.f;
+    const DropCtx dc = drop_ctx8(a.drop);
+    const uint32_t drow_idx = ((uint32_t)(seq * a.A + head) * a.L + qi) * a.L;
+    for (int c = 0; c < nchunk; ++c) {
+        const int rows = min(128, a.L - c * 128);
+        __syncthreads();
+        stage_x3<D, false>(khi, klo, base + (size_t)c * 128 * ld + a.H, ld, rows, tid);
+        stage_x3<D, true>(kthi, ktlo, base + (size_t)c * 128 * ld + a.H, ld, rows, tid);
+        stage_x3<D, false>(vhi, vlo, base + (size_t)c * 128 * ld + 2 * a.H, ld, rows, tid);
+        __syncthreads();
+        if (!active) continue;
+        for (int jt = 0; jt < rows / 32; ++jt) {
+            f32x16 s, dp;
+            scores(c, jt, s);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const uint32_t off = rr_off<D>(jt * 32 + fr, 2 * ks + h);
+                dp = mfma3(*(const bf16x8*)(vhi + off), *(const bf16x8*)(vlo + off), doh[ks], dol[ks], dp);
+            }
+            const int j0 = c * 128 + jt * 32;
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+                float mk[4] = {1.f, 1.f, 1.f, 1.f};
+                if (dc.thr) {                     // registers 4g .. 4g+3 are four consecutive keys: the bytes of one random word
+                    const uint32_t w = drop_word4(dc, drow_idx + j0 + 8 * (r >> 2) + 4 * h);
+                    mk[0] = drop_keep_byte<0>(dc, w) ? dc.scale : 0.f;
+                    mk[1] = drop_keep_byte<1>(dc, w) ? dc.scale : 0.f;
+                    mk[2] = drop_keep_byte<2>(dc, w) ? dc.scale : 0.f;
+                    mk[3] = drop_keep_byte<3>(dc, w) ? dc.scale : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float p = expf(s[r + e] - m) * inv_l;
+                    s[r + e] = p * (dp[r + e] * mk[e] - delta);                   // dS
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 sh, sl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { sh[e] = f2bf(s[8 * ks + e]); sl[e] = f2bf(s[8 * ks + e] - bf2f(sh[e])); }
+#pragma unroll
+                for (int b = 0; b < DB; ++b)
+                    dq[b] = mfma3(tr_frag<D>(kthi, jt * 32 + 16 * ks, b, lane), tr_frag<D>(ktlo, jt * 32 + 16 * ks, b, lane), sh, sl, dq[b]);
+            }
+        }
+    }
+    if (!active) return;
+    float* out = a.dqkv + ((size_t)seq * a.L + qi) * ld + head * D;
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = dq[b][4 * g + e] * a.scale;
+            *(f32x4*)(out + b * 32 + 8 * g + 4 * h) = v;
+        }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_x3_dkv_kernel(AttnBwdX3Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = D / 16, DB = D / 32, IMG = 128 * D * 2;
+    char* qhi = smem; char* qlo = smem + IMG; char* qthi = smem + 2 * IMG; char* qtlo = smem + 3 * IMG;
+    char* dhi = smem + 4 * IMG; char* dlo = smem + 5 * IMG; char* dthi = smem + 6 * IMG; char* dtlo = smem + 7 * IMG;
+    float* sm = (float*)(smem + 8 * IMG);                  // [3][L]: m, 1 / l, delta of this (sequence, head)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, fr = lane & 31;
+    const int L = a.L, nkb = (L + 127) / 128;
+    const int kb = blockIdx.x % nkb, head = (blockIdx.x / nkb) % a.A, seq = blockIdx.x / (nkb * a.A);
+    const int ld = 3 * a.H;
+    const float* base = a.qkv + (size_t)seq * L * ld + head * D;
+    const float* dbase = a.dctx + (size_t)seq * L * a.H + head * D;
+    const int j0 = kb * 128 + wave * 32;
+    const bool active = j0 < L;
+    const int kj = j0 + fr;
+    {
+        const size_t n = (size_t)a.nseq * a.A * L, row0 = ((size_t)seq * a.A + head) * L;
+        for (int t = tid; t < 3 * L; t += 256) { const int w = t / L, i = t - w * L; sm[t] = a.stats[w * n + row0 + i]; }
+    }
+    bf16x8 kh[KS], kl[KS], vh[KS], vl[KS];
+    float maddj = 0.f;
+    if (active) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            load_frag_x3(base + (size_t)kj * ld + a.H + 16 * s + 8 * h, kh[s], kl[s]);
+            load_frag_x3(base + (size_t)kj * ld + 2 * a.H + 16 * s + 8 * h, vh[s], vl[s]);
+        }
+        maddj = a.mask[(size_t)seq * L + kj] ? 0.f : kMaskMin;
+    }
+    f32x16 dk[DB], dv[DB];
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[b][r] = 0.f; dv[b][r] = 0.f; }
+    const DropCtx dc = drop_ctx8(a.drop);
+    const int nchunk = (L + 127) / 128;
+    for (int c = 0; c < nchunk; ++c) {
+        const int rows = min(128, L - c * 128);
+        __syncthreads();
+        stage_x3<D, false>(qhi, qlo, base + (size_t)c * 128 * ld, ld, rows, tid);
+        stage_x3<D, true>(qthi, qtlo, base + (size_t)c * 128 * ld, ld, rows, tid);
+        stage_x3<D, false>(dhi, dlo, dbase + (size_t)c * 128 * a.H, a.H, rows, tid);
+        stage_x3<D, true>(dthi, dtlo, dbase + (size_t)c * 128 * a.H, a.H, rows, tid);
+        __syncthreads();
+        if (!active) continue;
+        for (int it = 0; it < rows / 32; ++it) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const uint32_t off = rr_off<D>(it * 32 + fr, 2 * ks + h);
+                s = mfma3(*(const bf16x8*)(qhi + off), *(const bf16x8*)(qlo + off), kh[ks], kl[ks], s);
+                dp = mfma3(*(const bf16x8*)(dhi + off), *(const bf16x8*)(dlo + off), vh[ks], vl[ks], dp);
+            }
+            const int ibase = c * 128 + it * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = ibase + (r & 3) + 8 * (r >> 2) + 4 * h;           // the query of register r
+                float v = s[r] * a.scale;
+                if (a.rel) v += a.rel[((size_t)head * L + i) * L + kj];
+                v += maddj;
+                const float p = expf(v - sm[i]) * sm[L + i];
+                float mk = 1.f;
+                if (dc.thr) {
+                    const uint32_t idx = ((uint32_t)(seq * a.A + head) * L + (uint32_t)i) * L + (uint32_t)kj;
+                    mk = (((drop_word4(dc, idx) >> (8u * (idx & 3u))) & 0xFFu) >= dc.thr) ? dc.scale : 0.f;
+                }
+                const float ds = p * (dp[r] * mk - sm[2 * L + i]);
+                if (a.drel) atomicAdd(a.drel + ((size_t)head * L + i) * L + kj, ds);
+                s[r] = ds;
+                dp[r] = p * mk;                                                 // what dV contracts with
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 sh, sl, ph, pl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sh[e] = f2bf(s[8 * ks + e]); sl[e] = f2bf(s[8 * ks + e] - bf2f(sh[e]));
+                    ph[e] = f2bf(dp[8 * ks + e]); pl[e] = f2bf(dp[8 * ks + e] - bf2f(ph[e]));
+                }
+#pragma unroll
+                for (int b = 0; b < DB; ++b) {
+                    dk[b] = mfma3(tr_frag<D>(qthi, it * 32 + 16 * ks, b, lane), tr_frag<D>(qtlo, it * 32 + 16 * ks, b, lane), sh, sl, dk[b]);
+                    dv[b] = mfma3(tr_frag<D>(dthi, it * 32 + 16 * ks, b, lane), tr_frag<D>(dtlo, it * 32 + 16 * ks, b, lane), ph, pl, dv[b]);
+                }
+            }
+        }
+    }
+    if (!active) return;
+    float* ok = a.dqkv + ((size_t)seq * L + kj) * ld + a.H + head * D;
+    float* ov = ok + a.H;
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v, w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = dk[b][4 * g + e] * a.scale; w[e] = dv[b][4 * g + e]; }
+            *(f32x4*)(ok + b * 32 + 8 * g + 4 * h) = v;
+            *(f32x4*)(ov + b * 32 + 8 * g + 4 * h) = w;
+        }
+}
+
 }  // namespace
 
 extern "C" int qst_gemm_nt_x3(const QstGemmArgs* a, int epi, void* stream) {
@@ -305,6 +583,18 @@ extern "C" int qst_gemm_nt_x3(const QstGemmArgs* a, int epi, void* stream) {
     const int grid = ((a->M + 127) / 128) * ((a->N + 127) / 128);
     const size_t lds = 4 * 32 * 68 * sizeof(float);    // 34816 >= 32 KB of operand images
     hipStream_t st = (hipStream_t)stream;
+    if (epi == 3) {
+        // a few output tiles and a long reduction (dW = dY^T X): share K among enough workgroups to fill the chip, each
+        // at least 8 K-tiles deep; partial tiles meet in C through fp32 atomics
+        const int nkt = a->K / XBK;
+        const int want = std::max(1, std::min((2048 + grid - 1) / grid, nkt / 8));
+        const int per = (nkt + want - 1) / want;
+        QstGemmArgs g = *a;
+        g.splits = per;
+        gemm_nt_x3_kernel<3><<<dim3(grid, (nkt + per - 1) / per), 256, lds, st>>>(g);
+        QST_LAUNCH_CHECK();
+        return QST_OK;
+    }
     switch (epi) {
         case 0: gemm_nt_x3_kernel<0><<<grid, 256, lds, st>>>(*a); break;
         case 1: gemm_nt_x3_kernel<1><<<grid, 256, lds, st>>>(*a); break;
@@ -338,6 +628,39 @@ extern "C" int qst_attention_fwd_x3_drop(const float* qkv, const int64_t* mask, 
         static QstLdsAttr attr;
         if (int rc = qst_ensure_lds(attr, (const void*)attn_fwd_x3_kernel<64>, 70000)) return rc;
         attn_fwd_x3_kernel<64><<<grid, 256, lds, st>>>(a);
+    }
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+extern "C" size_t qst_attention_bwd_x3_scratch_bytes(int nseq, int L, int A) { return (size_t)3 * nseq * A * L * sizeof(float); }
+extern "C" int qst_attention_bwd_x3(const float* qkv, const float* ctx, const float* dctx, const int64_t* mask, const float* rel_bias,
+                                    int nseq, int L, int A, int d, float* dqkv, float* drel_bias, void* scratch,
+                                    const QstDrop* drop, void* stream) {
+    if (!qkv || !ctx || !dctx || !mask || !dqkv || !scratch || nseq <= 0 || L <= 0 || A <= 0) return QST_ERR_BAD_ARG;
+    if (drel_bias && !rel_bias) return QST_ERR_BAD_ARG;
+    if ((d != 32 && d != 64) || (L % 32) != 0 || L > 512) return QST_ERR_UNSUPPORTED;
+    const bool dropping = drop && drop->thr16 && drop->state;
+    if (dropping && (drop->thr16 > 65535u || (int64_t)nseq * A * L * L >= ((int64_t)1 << 32))) return QST_ERR_UNSUPPORTED;
+    AttnBwdX3Args a{};
+    if (dropping) a.drop = *drop;
+    a.qkv = qkv; a.ctx = ctx; a.dctx = dctx; a.mask = mask; a.rel = rel_bias; a.dqkv = dqkv; a.drel = drel_bias;
+    a.stats = (float*)scratch;
+    a.nseq = nseq; a.L = L; a.A = A; a.H = A * d; a.scale = 1.0f / sqrtf((float)d);
+    const int grid = nseq * A * ((L + 127) / 128);
+    const size_t lds_q = (size_t)6 * 128 * d * 2 + (size_t)L * 4, lds_k = (size_t)8 * 128 * d * 2 + (size_t)3 * L * 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (d == 32) {
+        static QstLdsAttr attr;
+        if (int rc = qst_ensure_lds(attr, (const void*)attn_bwd_x3_dkv_kernel<32>, 8 * 128 * 32 * 2 + 3 * 512 * 4)) return rc;
+        attn_bwd_x3_dq_kernel<32><<<grid, 256, lds_q, st>>>(a);
+        attn_bwd_x3_dkv_kernel<32><<<grid, 256, lds_k, st>>>(a);
+    } else {
+        static QstLdsAttr attr_q, attr_k;
+        if (int rc = qst_ensure_lds(attr_q, (const void*)attn_bwd_x3_dq_kernel<64>, 6 * 128 * 64 * 2 + 512 * 4)) return rc;
+        if (int rc = qst_ensure_lds(attr_k, (const void*)attn_bwd_x3_dkv_kernel<64>, 8 * 128 * 64 * 2 + 3 * 512 * 4)) return rc;
+        attn_bwd_x3_dq_kernel<64><<<grid, 256, lds_q, st>>>(a);
+        attn_bwd_x3_dkv_kernel<64><<<grid, 256, lds_k, st>>>(a);
     }
     QST_LAUNCH_CHECK();
     return QST_OK;

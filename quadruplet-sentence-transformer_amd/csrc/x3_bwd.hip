@@ -48,17 +48,25 @@ __global__ __launch_bounds__(256) void gelu_bwd_f32_kernel(const float* dh, cons
     if (i < n) du[i] = dh[i] * gelu_exact_grad(u[i]);
 }
 
-// one workgroup per 64 columns; its four waves take every fourth row; fixed summation order
+// bias gradients: a workgroup sums CS_ROWS rows of every column (thread t: columns 4t .. 4t+3 of each 1024-column panel, rows
+// in order, whole 16-byte loads) and adds its partial sums to out[] -- M / CS_ROWS workgroups instead of N / 64
+constexpr int CS_ROWS = 64;
 __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* x, int M, int N, int ld, float* out) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (c < N)
-        for (int m = wave; m < M; m += 4) s += x[(size_t)m * ld + c];
-    red[wave][lane] = s;
-    __syncthreads();
-    if (wave == 0 && c < N) out[c] += (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    const int r0 = blockIdx.x * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+    for (int c = threadIdx.x * 4; c < N; c += 1024) {
+        if (c + 3 < N && (ld & 3) == 0 && ((uintptr_t)x & 15) == 0) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            for (int m = r0; m < r1; ++m) s += *(const f32x4*)(x + (size_t)m * ld + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(out + c + e, s[e]);
+        } else {
+            for (int e = 0; e < 4 && c + e < N; ++e) {
+                float s = 0.f;
+                for (int m = r0; m < r1; ++m) s += x[(size_t)m * ld + c + e];
+                atomicAdd(out + c + e, s);
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void embed_sum_f32_kernel(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
@@ -307,7 +315,7 @@ extern "C" int qst_gelu_bwd_f32(const float* dh, const float* u, int64_t n, floa
 }
 extern "C" int qst_colsum_f32(const float* x, int M, int N, int ld, float* out, void* stream) {
     if (!x || !out || M <= 0 || N <= 0 || ld < N) return QST_ERR_BAD_ARG;
-    colsum_f32_kernel<<<(N + 63) / 64, 256, 0, (hipStream_t)stream>>>(x, M, N, ld, out);
+    colsum_f32_kernel<<<(M + CS_ROWS - 1) / CS_ROWS, 256, 0, (hipStream_t)stream>>>(x, M, N, ld, out);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }

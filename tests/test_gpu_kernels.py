@@ -4,6 +4,7 @@ Tolerances: kernels that round operands to bf16 are compared with a reference fe
 bf16-rounded operands (fp32 accumulate), so only accumulation order differs: rtol 2e-3 on
 bf16 outputs (one bf16 ulp = 2^-8 relative), 1e-4 on fp32 outputs.
 """
+import ctypes as C
 import math
 
 import numpy as np
@@ -481,6 +482,87 @@ def test_attention_fwd_bwd(lib, n, L, A, d, use_rel):
             torch.testing.assert_close(drel, drel2, rtol=1e-3, atol=1e-3 * max(1.0, drel2.abs().max().item()))
         rel_l2 = ((dq2.float().cpu() - gref).norm() / gref.norm()).item()
         assert rel_l2 < 1e-2, f"two-kernel backward: dqkv relative L2 error {rel_l2}"
+
+
+@pytest.mark.parametrize("n,L,A,d,use_rel,drop", [(2, 32, 2, 32, False, False), (3, 128, 12, 32, False, True), (2, 160, 2, 64, True, False),
+                                                   (2, 288, 2, 64, True, True), (1, 512, 2, 64, False, False), (2, 96, 3, 32, True, True),
+                                                   (3, 384, 2, 64, False, True)])
+def test_attention_bwd_x3_matches_the_fp32_kernel_and_autograd(lib, n, L, A, d, use_rel, drop):
+    """The parity-precision attention backward (csrc/x3.hip: split-bf16 x3 MFMAs, fp32 softmax / dS) against the scalar fp32
+    kernel it replaced in the bf16x3 backward (csrc/x3_bwd.hip, same dropout masks) and, without dropout, fp64 autograd of
+    HF's attention (modeling_bert.py:111-136 / modeling_mpnet.py:149-158). One sequence is all padding but its first token."""
+    H = A * d
+    g = torch.Generator().manual_seed(7 * n * L + A + d)
+    qkv = torch.randn(n * L, 3 * H, generator=g)
+    lens = torch.randint(max(1, L // 8), L + 1, (n,), generator=g)
+    lens[0] = L
+    lens[-1] = 1 if n > 1 else L
+    mask = (torch.arange(L)[None, :] < lens[:, None]).long()
+    rel = (0.5 * torch.randn(A, L, L, generator=g)) if use_rel else None
+    dctx = torch.randn(n * L, H, generator=g)
+    qd, md, reld, dcd = dev(qkv), dev(mask), (dev(rel) if use_rel else None), dev(dctx)
+    state = torch.tensor([14, 0, 3, 0], dtype=torch.int32, device="cuda")
+    dd = _lib.QstDrop()
+    if drop:
+        dd.state, dd.site, dd.thr16 = state.data_ptr(), 5, 6554
+    dp = C.byref(dd) if drop else None
+    ctx = torch.empty(n * L, H, device="cuda")
+    _lib.check(lib.qst_attention_fwd_x3_drop(qd.data_ptr(), md.data_ptr(), _lib.ptr(reld), n, L, A, d, ctx.data_ptr(), dp, stream()))
+    out = {}
+    for which in ("f32", "x3"):
+        dq = torch.full((n * L, 3 * H), float("nan"), device="cuda")
+        drel = torch.zeros(A, L, L, device="cuda") if use_rel else None
+        if which == "f32":
+            _lib.check(lib.qst_attention_bwd_f32_drop(qd.data_ptr(), ctx.data_ptr(), dcd.data_ptr(), md.data_ptr(), _lib.ptr(reld),
+                                                      n, L, A, d, dq.data_ptr(), _lib.ptr(drel), dp, stream()))
+        else:
+            scratch = torch.empty(lib.qst_attention_bwd_x3_scratch_bytes(n, L, A) // 4, device="cuda")
+            _lib.check(lib.qst_attention_bwd_x3(qd.data_ptr(), ctx.data_ptr(), dcd.data_ptr(), md.data_ptr(), _lib.ptr(reld),
+                                                n, L, A, d, dq.data_ptr(), _lib.ptr(drel), scratch.data_ptr(), dp, stream()))
+        torch.cuda.synchronize()
+        out[which] = (dq.cpu(), drel.cpu() if use_rel else None)
+    scale = out["f32"][0].abs().max().item()
+    torch.testing.assert_close(out["x3"][0], out["f32"][0], rtol=1e-4, atol=2e-5 * max(1.0, scale))
+    if use_rel:
+        # (a query that sees one key has P = 1 and dS = dP - delta = 0 by cancellation: what is left is the rounding of the two
+        # routes to dO . V -- 2^-17 per split-bf16 product against 2^-24 -- hence the absolute term)
+        torch.testing.assert_close(out["x3"][1], out["f32"][1], rtol=1e-4, atol=1e-4 * max(1.0, out["f32"][1].abs().max().item()))
+    if not drop:
+        qr = qkv.double().requires_grad_(True)
+        relr = rel.double().requires_grad_(True) if use_rel else None
+        q, k, v = [t.view(n, L, A, d).transpose(1, 2) for t in qr.view(n, L, 3 * H).split(H, dim=-1)]
+        sc = q @ k.transpose(-1, -2) / math.sqrt(d)
+        if use_rel:
+            sc = sc + relr[None]
+        sc = sc + (1.0 - mask[:, None, None, :].double()) * torch.finfo(torch.float32).min
+        ref = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(n * L, H)
+        (ref * dctx.double()).sum().backward()
+        torch.testing.assert_close(out["x3"][0].double(), qr.grad, rtol=1e-4, atol=2e-5 * max(1.0, scale))
+        if use_rel:
+            torch.testing.assert_close(out["x3"][1].double(), relr.grad, rtol=1e-4, atol=1e-4 * max(1.0, relr.grad.abs().max().item()))
+    assert lib.qst_attention_bwd_x3(qd.data_ptr(), ctx.data_ptr(), dcd.data_ptr(), md.data_ptr(), None, n, L, A, d,
+                                    out["x3"][0].data_ptr(), None, None, None, stream()) == -1           # no scratch
+    assert lib.qst_attention_bwd_x3(qd.data_ptr(), ctx.data_ptr(), dcd.data_ptr(), md.data_ptr(), None, n, L, A, 48,
+                                    out["x3"][0].data_ptr(), None, ctx.data_ptr(), None, stream()) == -2          # head size
+
+
+@pytest.mark.parametrize("M,N,K", [(384, 384, 4096), (1152, 384, 32 * 70), (128, 1536, 8192), (100, 60, 64)])
+def test_gemm_nt_x3_shared_reduction_and_column_sums(lib, M, N, K):
+    """qst_gemm_nt_x3 form 3 (C += A B^T with the reduction shared among workgroups: the weight gradients of the bf16x3
+    backward) and qst_colsum_f32 (its bias gradients) against fp64."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    Cd = dev(C0)
+    Ad, Bd = dev(A), dev(B)
+    _lib.check(lib.qst_gemm_nt_x3(gemm_args(A=Ad, B=Bd, C=Cd, M=M, N=N, K=K, lda=K, ldb=K, ldc=N), 3, stream()))
+    want = C0.double() + A.double() @ B.double().t()
+    torch.testing.assert_close(Cd.cpu().double(), want, rtol=1e-5, atol=2e-5 * math.sqrt(K))
+    x = torch.randn(K, N, generator=g)
+    o0 = torch.randn(N, generator=g)
+    od = dev(o0)
+    _lib.check(lib.qst_colsum_f32(dev(x).data_ptr(), K, N, N, od.data_ptr(), stream()))
+    torch.testing.assert_close(od.cpu().double(), o0.double() + x.double().sum(0), rtol=1e-5, atol=1e-5 * math.sqrt(K))
 
 
 @pytest.mark.parametrize("nseq,L,H,vocab,ntypes,irregular_pos", [
