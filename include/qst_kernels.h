@@ -268,8 +268,14 @@ int qst_rel_pos_fwd(const float* table, const int32_t* lut, int A, int L, float*
 int qst_rel_pos_bwd(const float* drel_pos, const int32_t* lut, int buckets, int A, int L, float* dtable, void* stream);
 
 /* Parity-precision (QST_PREC_BF16X3) forward kernels: fp32 operands split into hi+lo bf16 on the fly, three MFMAs
- * per product, fp32 out. epi: 0 = +bias, 1 = +bias +resid, 2 = gelu(+bias). K % 32 == 0. */
+ * per product, fp32 out. epi: 0 = +bias, 1 = +bias +resid, 2 = gelu(+bias), 3 = C += A . B^T with the reduction shared among
+ * workgroups (fp32 atomics; no bias). K % 32 == 0. */
 int qst_gemm_nt_x3(const QstGemmArgs* a, int epi, void* stream);
+/* Weight gradient at parity precision, the argument roles of qst_gemm_tn: C[N, K] (f32) += A[M, N]^T . B[M, K] with fp32
+ * row-major operands (A = dY, B = the layer input; M = token rows, M % 32 == 0), colsum[n] += sum_m A[m, n] when colsum is
+ * set. The reduction over M is shared among workgroups (about a->splits of them when splits > 0, 256 otherwise); partial
+ * tiles meet in C through fp32 atomics. */
+int qst_gemm_tn_x3(const QstGemmArgs* a, void* stream);
 int qst_attention_fwd_x3(const float* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A, int d,
                          float* ctx, void* stream);
 /* ... with dropout of the probabilities (drop nullable; QST_DROP_SITE_PROBS, the 8-bit form): parity-precision TRAINING */

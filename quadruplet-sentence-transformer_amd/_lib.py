@@ -175,6 +175,7 @@ SIGNATURES = {
     "qst_shadow_matrix": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
     "qst_shadow_all": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     "qst_gemm_nt_x3": (C.c_int, [C.POINTER(QstGemmArgs), C.c_int, vp]),
+    "qst_gemm_tn_x3": (C.c_int, [C.POINTER(QstGemmArgs), vp]),
     "qst_attention_fwd_x3": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "qst_attention_fwd_x3_drop": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
 }

@@ -333,18 +333,16 @@ X3TrainPlan plan_x3_train(const qst_config& c, int nseq, int L) {
     p.total = off;
     return p;
 }
-// its backward's scratch: gradient activations, the transposed copies the x3 GEMM contracts over (dY^T, X^T: [cols, M]) and
-// one transposed weight
-struct X3BwdPlan { size_t dx, dy, ds, dbig, dctx, dqkv, tA, tB, wT, drel, astats, total; };
+// its backward's scratch: gradient activations, one transposed weight (the dgrad's B operand) and the attention backward's
+// per-query statistics
+struct X3BwdPlan { size_t dx, dy, ds, dbig, dctx, dqkv, wT, drel, astats, total; };
 X3BwdPlan plan_x3_bwd(const qst_config& c, int nseq, int L) {
     X3BwdPlan p;
     const size_t M = (size_t)nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads;
-    const size_t wide = I > 3 * H ? I : 3 * H;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     p.dx = take(M * H * 4); p.dy = take(M * H * 4); p.ds = take(M * H * 4); p.dbig = take(M * I * 4);
     p.dctx = take(M * H * 4); p.dqkv = take(M * 3 * H * 4);
-    p.tA = take(wide * M * 4); p.tB = take((I > H ? I : H) * M * 4);
     p.wT = take((H * I > 3 * H * H ? H * I : 3 * H * H) * 4);
     p.drel = (c.arch == QST_ARCH_MPNET) ? take(A * (size_t)L * L * 4) : 0;
     p.astats = take(qst_attention_bwd_x3_scratch_bytes(nseq, L, (int)A));
@@ -780,8 +778,8 @@ static int forward_x3_train(qst_encoder* e, const int64_t* ids, const int64_t* m
     return QST_OK;
 }
 
-// ... and its backward: fp32-class gradients ACCUMULATED into `grads`. Every contraction is a gemm_nt_x3 call: a dgrad
-// against the transposed weight, a wgrad as (dY^T) . (X^T)^T with the token rows as the reduction dimension.
+// ... and its backward: fp32-class gradients ACCUMULATED into `grads`. Every contraction runs on split-bf16 x3 products: a
+// dgrad is gemm_nt_x3 against the transposed weight, a wgrad (+ bias gradient) one gemm_tn_x3 launch over the token rows.
 static int backward_x3(qst_encoder* e, const int64_t* ids, const int64_t* mask, const int64_t* type_ids, int nseq, int L,
                        const float* params, const float* grad_emb, float* grads, void* saved, size_t saved_bytes,
                        void* workspace, size_t workspace_bytes, hipStream_t st) {
@@ -798,18 +796,18 @@ static int backward_x3(qst_encoder* e, const int64_t* ids, const int64_t* mask, 
     auto F = [&](size_t o) { return (float*)(sv + o); };
     auto Wk = [&](size_t o) { return (float*)(ws + o); };
     float* dx = Wk(w.dx); float* dy = Wk(w.dy); float* ds = Wk(w.ds); float* dbig = Wk(w.dbig);
-    float* dctx = Wk(w.dctx); float* dqkv = Wk(w.dqkv); float* tA = Wk(w.tA); float* tB = Wk(w.tB); float* wT = Wk(w.wT);
+    float* dctx = Wk(w.dctx); float* dqkv = Wk(w.dqkv); float* wT = Wk(w.wT);
     // dX[M, in] = dY[M, out] . W[out, in] (+ resid)
     auto dgrad = [&](const float* dY, int out, int wseg, int in, float* dX, const float* resid) -> int {
         QST_TRY(qst_transpose_f32(P(wseg), out, in, in, wT, out, st));
         return nt3(dY, out, wT, out, dX, in, nullptr, resid, in, M, in, out, resid ? 1 : 0, st);
     };
-    // dW[out, in] += dY^T . X ; db[out] += column sums of dY
+    // dW[out, in] += dY^T . X ; db[out] += column sums of dY: one launch, straight from the row-major activations
     auto wgrad = [&](const float* dY, int out, const float* X, int in, int wseg, int bseg) -> int {
-        QST_TRY(qst_transpose_f32(dY, M, out, out, tA, M, st));
-        QST_TRY(qst_transpose_f32(X, M, in, in, tB, M, st));
-        QST_TRY(nt3(tA, M, tB, M, G(wseg), in, nullptr, nullptr, in, out, in, M, 3, st));    // += over shares of the token rows
-        return qst_colsum_f32(dY, M, out, out, G(bseg), st);
+        QstGemmArgs g{};
+        g.A = dY; g.B = X; g.C = G(wseg); g.colsum = G(bseg);
+        g.M = M; g.N = out; g.K = in; g.lda = out; g.ldb = in; g.ldc = in;
+        return qst_gemm_tn_x3(&g, st);
     };
     const float* rel = nullptr;
     float* drel = nullptr;

@@ -29,6 +29,30 @@ __device__ __forceinline__ f32x16 mfma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 
     return c;
 }
 
+// LDS image geometry shared by the attention kernels and the TN GEMM: rr = rows read as rows (one 16-byte chunk = 8
+// k-values of a row), tr = rows read through ds_read_b64_tr_b16 (a fragment whose k runs DOWN the image rows)
+template <int D> __device__ __forceinline__ uint32_t rr_off(int row, int chunk) {
+    if (D == 32) return (uint32_t)(row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4));
+    return (uint32_t)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+}
+template <int D> __device__ __forceinline__ uint32_t tr_off(int row, int byte) {
+    if (D == 32) return (uint32_t)(row * 64 + byte);
+    return (uint32_t)(row * 128 + (byte ^ (((row >> 1) & 1) << 6)));
+}
+__device__ __forceinline__ bf16x4 lds_tr(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
+}
+template <int D> __device__ __forceinline__ bf16x8 tr_frag(const char* img, int row0, int ddb, int lane) {
+    const int li = lane & 15, q = li >> 2, p = li & 3, gsel = (lane >> 4) & 1, h = lane >> 5;
+    const int byte = ddb * 64 + gsel * 32 + 8 * p;
+    const bf16x4 a = lds_tr(img + tr_off<D>(row0 + 4 * h + q, byte));
+    const bf16x4 b = lds_tr(img + tr_off<D>(row0 + 8 + 4 * h + q, byte));
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[e] = a[e]; f[4 + e] = b[e]; }
+    return f;
+}
+
 // ---------------------------------------------------------------- GEMM
 constexpr int XBK = 32;
 // per-operand image [128 rows][32 bf16] (64-byte rows), chunk c of row r at position c ^ ((r>>2)&3)
@@ -36,7 +60,11 @@ __device__ __forceinline__ uint32_t x_off(int row, int chunk) {
     return (uint32_t)(row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4));
 }
 
-template <int EPI>   // 0: +bias ; 1: +bias +resid ; 2: gelu(+bias) ; 3: C += A . B^T over this workgroup's share of K (fp32 atomics)
+// EPI 0: +bias ; 1: +bias +resid ; 2: gelu(+bias) ; 3: C += A . B^T over this workgroup's share of K (fp32 atomics).
+// TN (EPI 3 only): the operands are given with the reduction index as their ROW index -- A [K, M], B [K, N] row-major, i.e.
+// dW[out, in] += dY[tokens, out]^T . X[tokens, in] straight from the activations -- staged as [32 k][64 column] sub-images
+// and read with transposing LDS reads; column sums of A (the bias gradient) ride along in the tiles of the first column panel.
+template <int EPI, bool TN = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(QstGemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // A hi | A lo | B hi | B lo (8 KB each); epilogue 34 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -45,24 +73,42 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(QstGemmArgs g) {
     const int m0 = (blockIdx.x / ntn) * 128, n0 = (blockIdx.x % ntn) * 128;
     const float* A = (const float*)g.A;
     const float* B = (const float*)g.B;
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc(A + (size_t)m0 * g.lda, (uint32_t)min(128, g.M - m0) * g.lda * 4u);
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc(B + (size_t)n0 * g.ldb, (uint32_t)min(128, g.N - n0) * g.ldb * 4u);
-    // staging: a tile is 128 rows x 32 floats = 1024 float4; thread t takes rows t/8 + 32 i, float4 column t%8
-    const int srow = tid >> 3, sc4 = tid & 7;
+    // EPI 3 (weight gradients: K = the token rows): gridDim.y workgroups share the reduction, g.splits K-tiles each
+    const int kt0 = EPI == 3 ? (int)blockIdx.y * g.splits : 0;
+    const int nk = EPI == 3 ? min(g.K / XBK, kt0 + g.splits) : g.K / XBK;
+    if (kt0 >= nk) return;
+    const __amdgpu_buffer_rsrc_t ra = TN
+        ? make_rsrc(A + (size_t)kt0 * XBK * g.lda, (uint32_t)min((size_t)(g.K - kt0 * XBK) * g.lda * 4u, (size_t)0x7FFFFF00u))
+        : make_rsrc(A + (size_t)m0 * g.lda, (uint32_t)min(128, g.M - m0) * g.lda * 4u);
+    const __amdgpu_buffer_rsrc_t rb = TN
+        ? make_rsrc(B + (size_t)kt0 * XBK * g.ldb, (uint32_t)min((size_t)(g.K - kt0 * XBK) * g.ldb * 4u, (size_t)0x7FFFFF00u))
+        : make_rsrc(B + (size_t)n0 * g.ldb, (uint32_t)min(128, g.N - n0) * g.ldb * 4u);
+    // staging, NT: a tile is 128 rows x 32 floats = 1024 float4; thread t takes rows t/8 + 32 i, float4 column t%8
+    //          TN: a tile is 32 k-rows x 128 floats; thread t takes k-rows t/32 + 8 i, float4 column t%32
+    const int srow = TN ? tid >> 5 : tid >> 3, sc4 = TN ? tid & 31 : tid & 7;
+    const bool do_bias = TN && g.colsum && n0 == 0;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     u32x4 sa[4], sb[4];
     auto gload = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = srow + 32 * i;
-            sa[i] = buf_load16(ra, (uint32_t)r * g.lda * 4u + (uint32_t)(kt * XBK + sc4 * 4) * 4u);
-            sb[i] = buf_load16(rb, (uint32_t)r * g.ldb * 4u + (uint32_t)(kt * XBK + sc4 * 4) * 4u);
+            if (TN) {
+                const uint32_t r = (uint32_t)((kt - kt0) * XBK + srow + 8 * i);
+                // columns past the matrix must not alias the next row: those lanes ask for an out-of-range offset (zeros)
+                sa[i] = buf_load16(ra, m0 + sc4 * 4 < g.M ? r * g.lda * 4u + (uint32_t)(m0 + sc4 * 4) * 4u : 0x80000000u);
+                sb[i] = buf_load16(rb, n0 + sc4 * 4 < g.N ? r * g.ldb * 4u + (uint32_t)(n0 + sc4 * 4) * 4u : 0x80000000u);
+            } else {
+                const int r = srow + 32 * i;
+                sa[i] = buf_load16(ra, (uint32_t)r * g.lda * 4u + (uint32_t)(kt * XBK + sc4 * 4) * 4u);
+                sb[i] = buf_load16(rb, (uint32_t)r * g.ldb * 4u + (uint32_t)(kt * XBK + sc4 * 4) * 4u);
+            }
         }
     };
     auto lstore = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = srow + 32 * i;
-            const uint32_t o = x_off(r, sc4 >> 1) + (sc4 & 1) * 8;
+            const int r = TN ? srow + 8 * i : srow + 32 * i;
+            const uint32_t o = TN ? (uint32_t)(sc4 >> 4) * 4096u + tr_off<64>(r, (sc4 & 15) * 8) : x_off(r, sc4 >> 1) + (sc4 & 1) * 8;
             u32x2 hi, lo;
             split4(__builtin_bit_cast(f32x4, sa[i]), hi, lo);
             *(u32x2*)(smem + o) = hi;
@@ -70,6 +116,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(QstGemmArgs g) {
             split4(__builtin_bit_cast(f32x4, sb[i]), hi, lo);
             *(u32x2*)(smem + 16384 + o) = hi;
             *(u32x2*)(smem + 24576 + o) = lo;
+            if (do_bias) bsum += __builtin_bit_cast(f32x4, sa[i]);
         }
     };
     f32x16 acc[2][2];
@@ -79,11 +126,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(QstGemmArgs g) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // EPI 3 (weight gradients: K = the token rows): gridDim.y workgroups share the reduction, g.splits K-tiles each
-    const int kt0 = EPI == 3 ? (int)blockIdx.y * g.splits : 0;
-    const int nk = EPI == 3 ? min(g.K / XBK, kt0 + g.splits) : g.K / XBK;
     const int fr = lane & 31, fh = lane >> 5;
-    if (kt0 >= nk) return;
     gload(kt0);
     for (int kt = kt0; kt < nk; ++kt) {
         __syncthreads();                 // previous tile's fragment reads are done
@@ -95,6 +138,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(QstGemmArgs g) {
             bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
+                if (TN) {
+                    ah[i] = tr_frag<64>(smem + wm * 4096, ks * 16, i, lane);
+                    al[i] = tr_frag<64>(smem + 8192 + wm * 4096, ks * 16, i, lane);
+                    bh[i] = tr_frag<64>(smem + 16384 + wn * 4096, ks * 16, i, lane);
+                    bl[i] = tr_frag<64>(smem + 24576 + wn * 4096, ks * 16, i, lane);
+                    continue;
+                }
                 const uint32_t oa = x_off(wm * 64 + i * 32 + fr, ks * 2 + fh), ob = x_off(wn * 64 + i * 32 + fr, ks * 2 + fh);
                 ah[i] = *(const bf16x8*)(smem + oa);
                 al[i] = *(const bf16x8*)(smem + 8192 + oa);
@@ -108,6 +158,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(QstGemmArgs g) {
         }
     }
     __syncthreads();
+    if (do_bias) {                                 // 8 k-row phases x 128 columns of partial sums -> one atomic per column
+        float* red = (float*)smem;
+        *(f32x4*)(red + srow * 128 + sc4 * 4) = bsum;
+        __syncthreads();
+        if (tid < 128 && m0 + tid < g.M) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[k * 128 + tid];
+            atomicAdd(g.colsum + m0 + tid, t);
+        }
+        __syncthreads();
+    }
     float* stg = (float*)smem + wave * (32 * 68);
     const int c4 = lane & 15, rsub = lane >> 4;
     const int n = n0 + wn * 64 + c4 * 4;
@@ -150,27 +212,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(QstGemmArgs g) {
 
 // ---------------------------------------------------------------- attention
 constexpr float kMaskMin = -3.4028234663852886e38f;
-template <int D> __device__ __forceinline__ uint32_t rr_off(int row, int chunk) {
-    if (D == 32) return (uint32_t)(row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4));
-    return (uint32_t)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-}
-template <int D> __device__ __forceinline__ uint32_t tr_off(int row, int byte) {
-    if (D == 32) return (uint32_t)(row * 64 + byte);
-    return (uint32_t)(row * 128 + (byte ^ (((row >> 1) & 1) << 6)));
-}
-__device__ __forceinline__ bf16x4 lds_tr(const char* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
-}
-template <int D> __device__ __forceinline__ bf16x8 tr_frag(const char* img, int row0, int ddb, int lane) {
-    const int li = lane & 15, q = li >> 2, p = li & 3, gsel = (lane >> 4) & 1, h = lane >> 5;
-    const int byte = ddb * 64 + gsel * 32 + 8 * p;
-    const bf16x4 a = lds_tr(img + tr_off<D>(row0 + 4 * h + q, byte));
-    const bf16x4 b = lds_tr(img + tr_off<D>(row0 + 8 + 4 * h + q, byte));
-    bf16x8 f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { f[e] = a[e]; f[4 + e] = b[e]; }
-    return f;
-}
 // stage rows x D fp32 (row stride ld floats) into hi and lo bf16 LDS images
 template <int D, bool TR>
 __device__ __forceinline__ void stage_x3(char* hi_img, char* lo_img, const float* g, int ld, int rows, int tid) {
@@ -587,7 +628,7 @@ extern "C" int qst_gemm_nt_x3(const QstGemmArgs* a, int epi, void* stream) {
         // a few output tiles and a long reduction (dW = dY^T X): share K among enough workgroups to fill the chip, each
         // at least 8 K-tiles deep; partial tiles meet in C through fp32 atomics
         const int nkt = a->K / XBK;
-        const int want = std::max(1, std::min((2048 + grid - 1) / grid, nkt / 8));
+        const int want = std::max(1, std::min((512 + grid - 1) / grid, std::max(1, nkt / 8)));
         const int per = (nkt + want - 1) / want;
         QstGemmArgs g = *a;
         g.splits = per;
@@ -601,6 +642,25 @@ extern "C" int qst_gemm_nt_x3(const QstGemmArgs* a, int epi, void* stream) {
         case 2: gemm_nt_x3_kernel<2><<<grid, 256, lds, st>>>(*a); break;
         default: return QST_ERR_BAD_ARG;
     }
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+// C[N, K] += A[M, N]^T . B[M, K], colsum[n] += sum_m A[m, n]  (the argument roles of qst_gemm_tn; fp32 operands, x3 products)
+extern "C" int qst_gemm_tn_x3(const QstGemmArgs* a, void* stream) {
+    if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
+    if (a->M % XBK != 0 || a->lda % 4 != 0 || a->ldb % 4 != 0 || a->N % 4 != 0 || a->K % 4 != 0 || a->ldc % 4 != 0) return QST_ERR_UNSUPPORTED;
+    if (((uintptr_t)a->A | (uintptr_t)a->B) & 15) return QST_ERR_UNSUPPORTED;
+    QstGemmArgs g = *a;
+    g.M = a->N; g.N = a->K; g.K = a->M;            // the kernel's names: C[M, N] over a reduction of K rows
+    const int grid = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+    const int nkt = g.K / XBK;
+    const int target = a->splits > 0 ? a->splits : 256;       // tools/x3_wgrad_sweep.py: 256 - 512 workgroups are the fastest on every layer shape
+    const int want = std::max(1, std::min((target + grid - 1) / grid, std::max(1, nkt / 8)));
+    const int per = (nkt + want - 1) / want;
+    g.splits = per;
+    const size_t lds = 4 * 32 * 68 * sizeof(float);
+    gemm_nt_x3_kernel<3, true><<<dim3(grid, (nkt + per - 1) / per), 256, lds, (hipStream_t)stream>>>(g);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }

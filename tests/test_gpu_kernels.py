@@ -558,6 +558,15 @@ def test_gemm_nt_x3_shared_reduction_and_column_sums(lib, M, N, K):
     _lib.check(lib.qst_gemm_nt_x3(gemm_args(A=Ad, B=Bd, C=Cd, M=M, N=N, K=K, lda=K, ldb=K, ldc=N), 3, stream()))
     want = C0.double() + A.double() @ B.double().t()
     torch.testing.assert_close(Cd.cpu().double(), want, rtol=1e-5, atol=2e-5 * math.sqrt(K))
+    # the same product from operands stored with the reduction index as the row index (what the backward calls), + column sums
+    At, Bt = dev(A.t().contiguous()), dev(B.t().contiguous())
+    Cd2, cs0 = dev(C0), torch.randn(M, generator=g)
+    csd = dev(cs0)
+    for splits in (0, 64):
+        Cd2.copy_(C0); csd.copy_(cs0)
+        _lib.check(lib.qst_gemm_tn_x3(gemm_args(A=At, B=Bt, C=Cd2, colsum=csd, M=K, N=M, K=N, lda=M, ldb=N, ldc=N, splits=splits), stream()))
+        torch.testing.assert_close(Cd2.cpu().double(), want, rtol=1e-5, atol=2e-5 * math.sqrt(K))
+        torch.testing.assert_close(csd.cpu().double(), cs0.double() + A.double().sum(1), rtol=1e-5, atol=1e-5 * math.sqrt(K))
     x = torch.randn(K, N, generator=g)
     o0 = torch.randn(N, generator=g)
     od = dev(o0)
