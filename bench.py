@@ -461,8 +461,8 @@ def time_x3_training(trainer, cfg, batches, steps, B):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
         return {"value": round(B / (ms * 1e-3), 1), "unit": "quadruplets/s", "ms_per_step": round(ms, 4),
-                "what": "the full training step at parity precision (bf16x3: fp32 activations, three split-bf16 MFMAs per product, "
-                        "fp32 attention backward); dropout off"}
+                "what": "the full training step at parity precision (bf16x3: fp32 activations, three split-bf16 MFMAs per product in "
+                        "every GEMM and in attention forward and backward, fp32 softmax / LayerNorm / GELU); dropout off"}
     except Exception as ex:                               # a side figure must not take the bench line down
         return {"error": f"{type(ex).__name__}: {ex}"}
 

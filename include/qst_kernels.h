@@ -269,7 +269,8 @@ int qst_rel_pos_bwd(const float* drel_pos, const int32_t* lut, int buckets, int 
 
 /* Parity-precision (QST_PREC_BF16X3) forward kernels: fp32 operands split into hi+lo bf16 on the fly, three MFMAs
  * per product, fp32 out. epi: 0 = +bias, 1 = +bias +resid, 2 = gelu(+bias), 3 = C += A . B^T with the reduction shared among
- * workgroups (fp32 atomics; no bias). K % 32 == 0. */
+ * workgroups (fp32 atomics; no bias), 4 = C = +bias and C2 = gelu(C) (both fp32, ldc), 5 = C = (A . B^T) * gelu'(aux) with aux
+ * fp32 in the layout of C. K % 32 == 0. */
 int qst_gemm_nt_x3(const QstGemmArgs* a, int epi, void* stream);
 /* Weight gradient at parity precision, the argument roles of qst_gemm_tn: C[N, K] (f32) += A[M, N]^T . B[M, K] with fp32
  * row-major operands (A = dY, B = the layer input; M = token rows, M % 32 == 0), colsum[n] += sum_m A[m, n] when colsum is

@@ -767,8 +767,12 @@ static int forward_x3_train(qst_encoder* e, const int64_t* ids, const int64_t* m
         }
         QST_TRY(proj(F(a.ctx), H, b + W_O, b + B_O, x, F(a.s1), QST_DROP_SITE_ATTN_OUT(l)));
         QST_TRY(qst_ln_fwd(F(a.s1), P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, F(a.y1), nullptr, nullptr, nullptr, st));
-        QST_TRY(nt3(F(a.y1), H, P(b + W_1), H, F(a.u), I, P(b + B_1), nullptr, 0, M, I, H, 0, st));
-        QST_TRY(qst_gelu_f32(F(a.u), (int64_t)M * I, F(a.h), st));
+        {                                                      // u = y1 W1^T + b1 and h = gelu(u) from one launch
+            QstGemmArgs g{};
+            g.A = F(a.y1); g.B = P(b + W_1); g.C = F(a.u); g.C2 = F(a.h); g.bias = P(b + B_1);
+            g.M = M; g.N = I; g.K = H; g.lda = H; g.ldb = H; g.ldc = I;
+            QST_TRY(qst_gemm_nt_x3(&g, 4, st));
+        }
         QST_TRY(proj(F(a.h), I, b + W_2, b + B_2, F(a.y1), F(a.s2), QST_DROP_SITE_FFN_OUT(l)));
         QST_TRY(qst_ln_fwd(F(a.s2), P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, M, H, F(a.x), nullptr, nullptr, nullptr, st));
         x = F(a.x);
@@ -839,9 +843,14 @@ static int backward_x3(qst_encoder* e, const int64_t* ids, const int64_t* mask, 
         QST_TRY(qst_ln_bwd_f32(dx, F(a.s2), P(b + LN2_G), c.layer_norm_eps, M, H, ds, G(b + LN2_G), G(b + LN2_B), st));
         const float* dsm = ds;
         QST_TRY(masked(ds, QST_DROP_SITE_FFN_OUT(l), dctx, &dsm));                   // (dctx is free until the attention part)
-        QST_TRY(dgrad(dsm, H, b + W_2, I, dbig, nullptr));                           // dh
+        {                                                                            // du = (dsm . W2) * gelu'(u)
+            QST_TRY(qst_transpose_f32(P(b + W_2), H, I, I, wT, H, st));
+            QstGemmArgs g{};
+            g.A = dsm; g.B = wT; g.C = dbig; g.aux = F(a.u);
+            g.M = M; g.N = I; g.K = H; g.lda = H; g.ldb = H; g.ldc = I;
+            QST_TRY(qst_gemm_nt_x3(&g, 5, st));
+        }
         QST_TRY(wgrad(dsm, H, F(a.h), I, b + W_2, b + B_2));
-        QST_TRY(qst_gelu_bwd_f32(dbig, F(a.u), (int64_t)M * I, dbig, st));          // du
         QST_TRY(dgrad(dbig, I, b + W_1, H, dy, ds));                                 // dy1 = du . W1 + ds2
         QST_TRY(wgrad(dbig, I, F(a.y1), H, b + W_1, b + B_1));
         QST_TRY(qst_ln_bwd_f32(dy, F(a.s1), P(b + LN1_G), c.layer_norm_eps, M, H, ds, G(b + LN1_G), G(b + LN1_B), st));

@@ -60,21 +60,32 @@ __device__ __forceinline__ uint32_t x_off(int row, int chunk) {
     return (uint32_t)(row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4));
 }
 
-// EPI 0: +bias ; 1: +bias +resid ; 2: gelu(+bias) ; 3: C += A . B^T over this workgroup's share of K (fp32 atomics).
+// EPI 0: +bias ; 1: +bias +resid ; 2: gelu(+bias) ; 3: C += A . B^T over this workgroup's share of K (fp32 atomics) ;
+// 4: C = +bias and C2 = gelu(C) ; 5: C = (A . B^T) * gelu'(aux).
 // TN (EPI 3 only): the operands are given with the reduction index as their ROW index -- A [K, M], B [K, N] row-major, i.e.
 // dW[out, in] += dY[tokens, out]^T . X[tokens, in] straight from the activations -- staged as [32 k][64 column] sub-images
 // and read with transposing LDS reads; column sums of A (the bias gradient) ride along in the tiles of the first column panel.
-template <int EPI, bool TN = false>
+// BK = K-tile depth. 32 is what runs: 64-deep tiles (two 64 KB ring slots, one workgroup per CU) measured slower -- weight
+// gradients of a MiniLM layer 320 vs 228 us, the bf16x3 training step 18.5 vs 14.7 ms.
+template <int EPI, bool TN = false, int BK = 32>
 __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(QstGemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // A hi | A lo | B hi | B lo (8 KB each); epilogue 34 KB
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // A hi | A lo | B hi | B lo (IMG bytes each); epilogue 34 KB
+    constexpr int XBK = BK, IMG = 128 * BK * 2, C4 = BK / 4, NP = TN ? BK / 8 : 128 * C4 / 256, SUB = BK * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int ntn = (g.N + 127) / 128;
-    const int m0 = (blockIdx.x / ntn) * 128, n0 = (blockIdx.x % ntn) * 128;
+    // Workgroup -> work, XCD-aware (consecutive workgroup ids go round the eight XCDs, each with its own L2): the workgroups
+    // that read the same rows sit on ONE XCD. NT: the ntn tiles of a 128-row A panel (panel = xcd + 8 * ...). Shared reduction
+    // (EPI 3): all tiles of one share of K, whose operand rows every tile of the share reads. Padding workgroups return.
+    const int ntn = (g.N + 127) / 128, ntm = (g.M + 127) / 128;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int group = xcd + 8 * (EPI == 3 ? jx / (ntm * ntn) : jx / ntn);       // A panel (NT) or share of K (EPI 3)
+    const int tile = EPI == 3 ? jx % (ntm * ntn) : group * ntn + jx % ntn;
+    if (EPI != 3 && group >= ntm) return;
+    const int m0 = (tile / ntn) * 128, n0 = (tile % ntn) * 128;
     const float* A = (const float*)g.A;
     const float* B = (const float*)g.B;
     // EPI 3 (weight gradients: K = the token rows): gridDim.y workgroups share the reduction, g.splits K-tiles each
-    const int kt0 = EPI == 3 ? (int)blockIdx.y * g.splits : 0;
+    const int kt0 = EPI == 3 ? group * g.splits : 0;
     const int nk = EPI == 3 ? min(g.K / XBK, kt0 + g.splits) : g.K / XBK;
     if (kt0 >= nk) return;
     const __amdgpu_buffer_rsrc_t ra = TN
@@ -83,39 +94,40 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(QstGemmArgs g) {
     const __amdgpu_buffer_rsrc_t rb = TN
         ? make_rsrc(B + (size_t)kt0 * XBK * g.ldb, (uint32_t)min((size_t)(g.K - kt0 * XBK) * g.ldb * 4u, (size_t)0x7FFFFF00u))
         : make_rsrc(B + (size_t)n0 * g.ldb, (uint32_t)min(128, g.N - n0) * g.ldb * 4u);
-    // staging, NT: a tile is 128 rows x 32 floats = 1024 float4; thread t takes rows t/8 + 32 i, float4 column t%8
-    //          TN: a tile is 32 k-rows x 128 floats; thread t takes k-rows t/32 + 8 i, float4 column t%32
-    const int srow = TN ? tid >> 5 : tid >> 3, sc4 = TN ? tid & 31 : tid & 7;
+    // staging, NT: a tile is 128 rows x BK floats; thread t takes rows t / C4 + (256 / C4) i, float4 column t % C4
+    //          TN: a tile is BK k-rows x 128 floats; thread t takes k-rows t/32 + 8 i, float4 column t%32
+    const int srow = TN ? tid >> 5 : tid / C4, sc4 = TN ? tid & 31 : tid % C4;
     const bool do_bias = TN && g.colsum && n0 == 0;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-    u32x4 sa[4], sb[4];
+    u32x4 sa[NP], sb[NP];
     auto gload = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NP; ++i) {
             if (TN) {
                 const uint32_t r = (uint32_t)((kt - kt0) * XBK + srow + 8 * i);
                 // columns past the matrix must not alias the next row: those lanes ask for an out-of-range offset (zeros)
                 sa[i] = buf_load16(ra, m0 + sc4 * 4 < g.M ? r * g.lda * 4u + (uint32_t)(m0 + sc4 * 4) * 4u : 0x80000000u);
                 sb[i] = buf_load16(rb, n0 + sc4 * 4 < g.N ? r * g.ldb * 4u + (uint32_t)(n0 + sc4 * 4) * 4u : 0x80000000u);
             } else {
-                const int r = srow + 32 * i;
+                const int r = srow + (256 / C4) * i;
                 sa[i] = buf_load16(ra, (uint32_t)r * g.lda * 4u + (uint32_t)(kt * XBK + sc4 * 4) * 4u);
                 sb[i] = buf_load16(rb, (uint32_t)r * g.ldb * 4u + (uint32_t)(kt * XBK + sc4 * 4) * 4u);
             }
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](char* smem) {                                    // (the ring slot being filled)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = TN ? srow + 8 * i : srow + 32 * i;
-            const uint32_t o = TN ? (uint32_t)(sc4 >> 4) * 4096u + tr_off<64>(r, (sc4 & 15) * 8) : x_off(r, sc4 >> 1) + (sc4 & 1) * 8;
+        for (int i = 0; i < NP; ++i) {
+            const int r = TN ? srow + 8 * i : srow + (256 / C4) * i;
+            const uint32_t o = TN ? (uint32_t)(sc4 >> 4) * SUB + tr_off<64>(r, (sc4 & 15) * 8)
+                                  : (BK == 32 ? x_off(r, sc4 >> 1) : rr_off<64>(r, sc4 >> 1)) + (sc4 & 1) * 8;
             u32x2 hi, lo;
             split4(__builtin_bit_cast(f32x4, sa[i]), hi, lo);
             *(u32x2*)(smem + o) = hi;
-            *(u32x2*)(smem + 8192 + o) = lo;
+            *(u32x2*)(smem + IMG + o) = lo;
             split4(__builtin_bit_cast(f32x4, sb[i]), hi, lo);
-            *(u32x2*)(smem + 16384 + o) = hi;
-            *(u32x2*)(smem + 24576 + o) = lo;
+            *(u32x2*)(smem + 2 * IMG + o) = hi;
+            *(u32x2*)(smem + 3 * IMG + o) = lo;
             if (do_bias) bsum += __builtin_bit_cast(f32x4, sa[i]);
         }
     };
@@ -127,37 +139,43 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(QstGemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int fr = lane & 31, fh = lane >> 5;
+    // Two ring slots of operand images: K-tile kt + 1 is split and written into the other slot after this wave has issued the
+    // MFMAs of K-tile kt, so one wave's conversion work runs under the others' MFMAs and a K-tile costs ONE barrier.
+    char* const ring = smem;
     gload(kt0);
+    lstore(ring);
+    __syncthreads();
     for (int kt = kt0; kt < nk; ++kt) {
-        __syncthreads();                 // previous tile's fragment reads are done
-        lstore();
-        __syncthreads();
+        char* const smem = ring + ((kt - kt0) & 1) * (4 * IMG);
         if (kt + 1 < nk) gload(kt + 1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 if (TN) {
-                    ah[i] = tr_frag<64>(smem + wm * 4096, ks * 16, i, lane);
-                    al[i] = tr_frag<64>(smem + 8192 + wm * 4096, ks * 16, i, lane);
-                    bh[i] = tr_frag<64>(smem + 16384 + wn * 4096, ks * 16, i, lane);
-                    bl[i] = tr_frag<64>(smem + 24576 + wn * 4096, ks * 16, i, lane);
+                    ah[i] = tr_frag<64>(smem + wm * SUB, ks * 16, i, lane);
+                    al[i] = tr_frag<64>(smem + IMG + wm * SUB, ks * 16, i, lane);
+                    bh[i] = tr_frag<64>(smem + 2 * IMG + wn * SUB, ks * 16, i, lane);
+                    bl[i] = tr_frag<64>(smem + 3 * IMG + wn * SUB, ks * 16, i, lane);
                     continue;
                 }
-                const uint32_t oa = x_off(wm * 64 + i * 32 + fr, ks * 2 + fh), ob = x_off(wn * 64 + i * 32 + fr, ks * 2 + fh);
+                const int ra_ = wm * 64 + i * 32 + fr, rb_ = wn * 64 + i * 32 + fr;
+                const uint32_t oa = BK == 32 ? x_off(ra_, ks * 2 + fh) : rr_off<64>(ra_, ks * 2 + fh);
+                const uint32_t ob = BK == 32 ? x_off(rb_, ks * 2 + fh) : rr_off<64>(rb_, ks * 2 + fh);
                 ah[i] = *(const bf16x8*)(smem + oa);
-                al[i] = *(const bf16x8*)(smem + 8192 + oa);
-                bh[i] = *(const bf16x8*)(smem + 16384 + ob);
-                bl[i] = *(const bf16x8*)(smem + 24576 + ob);
+                al[i] = *(const bf16x8*)(smem + IMG + oa);
+                bh[i] = *(const bf16x8*)(smem + 2 * IMG + ob);
+                bl[i] = *(const bf16x8*)(smem + 3 * IMG + ob);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma3(bh[j], bl[j], ah[i], al[i], acc[i][j]);   // D rows = n, col = m
         }
+        if (kt + 1 < nk) lstore(ring + ((kt + 1 - kt0) & 1) * (4 * IMG));
+        __syncthreads();                 // slot (kt + 1) & 1 is complete; every wave has left slot kt & 1
     }
-    __syncthreads();
     if (do_bias) {                                 // 8 k-row phases x 128 columns of partial sums -> one atomic per column
         float* red = (float*)smem;
         *(f32x4*)(red + srow * 128 + sc4 * 4) = bsum;
@@ -203,6 +221,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(QstGemmArgs g) {
                 if (EPI == 2) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));   // exact erf here
+                }
+                if (EPI == 4) {                         // training FFN-1: u = A W^T + b to C, h = gelu(u) to C2
+                    f32x4 hh;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hh[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
+                    *(f32x4*)((float*)g.C2 + (size_t)m * g.ldc + n) = hh;
+                }
+                if (EPI == 5) {                         // FFN-2 dgrad: du = (dY W) * gelu'(u), u = aux (fp32, the layout of C)
+                    const f32x4 u = *(const f32x4*)((const float*)g.aux + (size_t)m * g.ldc + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] *= 0.5f * (1.0f + erff(u[e] * 0.70710678118654752f)) + u[e] * 0.3989422804014327f * expf(-0.5f * u[e] * u[e]);
                 }
                 *(f32x4*)((float*)g.C + (size_t)m * g.ldc + n) = v;
             }
@@ -618,21 +648,29 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_dkv_kernel(AttnBwdX3Args a) {
 
 }  // namespace
 
+// K-tiles per share of a shared reduction: about `target` workgroups in all, a multiple of eight shares (one XCD each), every
+// share at least 8 K-tiles deep where the reduction is long enough
+static int x3_share(int nkt, int tiles, int target) {
+    int shares = std::max(1, std::min((target + tiles - 1) / tiles, std::max(1, nkt / 8)));
+    shares = std::max(8, (shares + 4) / 8 * 8);
+    return std::max(1, (nkt + shares - 1) / shares);
+}
+
 extern "C" int qst_gemm_nt_x3(const QstGemmArgs* a, int epi, void* stream) {
     if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
     if (a->K % XBK != 0 || a->lda % 4 != 0 || a->ldb % 4 != 0 || a->N % 4 != 0 || a->ldc % 4 != 0) return QST_ERR_UNSUPPORTED;
-    const int grid = ((a->M + 127) / 128) * ((a->N + 127) / 128);
-    const size_t lds = 4 * 32 * 68 * sizeof(float);    // 34816 >= 32 KB of operand images
+    const int tiles = ((a->M + 127) / 128) * ((a->N + 127) / 128);
+    const int grid = (((a->M + 127) / 128 + 7) / 8 * 8) * ((a->N + 127) / 128);      // A panels padded to the eight XCDs
     hipStream_t st = (hipStream_t)stream;
+    const size_t lds = 65536;                           // two ring slots of four 8 KB operand images (the epilogue's 34816 bytes fit)
     if (epi == 3) {
         // a few output tiles and a long reduction (dW = dY^T X): share K among enough workgroups to fill the chip, each
         // at least 8 K-tiles deep; partial tiles meet in C through fp32 atomics
         const int nkt = a->K / XBK;
-        const int want = std::max(1, std::min((512 + grid - 1) / grid, std::max(1, nkt / 8)));
-        const int per = (nkt + want - 1) / want;
+        const int per = x3_share(nkt, tiles, 256);
         QstGemmArgs g = *a;
         g.splits = per;
-        gemm_nt_x3_kernel<3><<<dim3(grid, (nkt + per - 1) / per), 256, lds, st>>>(g);
+        gemm_nt_x3_kernel<3><<<((nkt + per - 1) / per + 7) / 8 * 8 * tiles, 256, lds, st>>>(g);
         QST_LAUNCH_CHECK();
         return QST_OK;
     }
@@ -640,6 +678,8 @@ extern "C" int qst_gemm_nt_x3(const QstGemmArgs* a, int epi, void* stream) {
         case 0: gemm_nt_x3_kernel<0><<<grid, 256, lds, st>>>(*a); break;
         case 1: gemm_nt_x3_kernel<1><<<grid, 256, lds, st>>>(*a); break;
         case 2: gemm_nt_x3_kernel<2><<<grid, 256, lds, st>>>(*a); break;
+        case 4: if (!a->C2) return QST_ERR_BAD_ARG; gemm_nt_x3_kernel<4><<<grid, 256, lds, st>>>(*a); break;
+        case 5: if (!a->aux) return QST_ERR_BAD_ARG; gemm_nt_x3_kernel<5><<<grid, 256, lds, st>>>(*a); break;
         default: return QST_ERR_BAD_ARG;
     }
     QST_LAUNCH_CHECK();
@@ -653,14 +693,11 @@ extern "C" int qst_gemm_tn_x3(const QstGemmArgs* a, void* stream) {
     if (((uintptr_t)a->A | (uintptr_t)a->B) & 15) return QST_ERR_UNSUPPORTED;
     QstGemmArgs g = *a;
     g.M = a->N; g.N = a->K; g.K = a->M;            // the kernel's names: C[M, N] over a reduction of K rows
-    const int grid = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+    const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
     const int nkt = g.K / XBK;
-    const int target = a->splits > 0 ? a->splits : 256;       // tools/x3_wgrad_sweep.py: 256 - 512 workgroups are the fastest on every layer shape
-    const int want = std::max(1, std::min((target + grid - 1) / grid, std::max(1, nkt / 8)));
-    const int per = (nkt + want - 1) / want;
+    const int per = x3_share(nkt, tiles, a->splits > 0 ? a->splits : 256);   // tools/x3_wgrad_sweep.py: 128 - 512 workgroups are the fastest
     g.splits = per;
-    const size_t lds = 4 * 32 * 68 * sizeof(float);
-    gemm_nt_x3_kernel<3, true><<<dim3(grid, (nkt + per - 1) / per), 256, lds, (hipStream_t)stream>>>(g);
+    gemm_nt_x3_kernel<3, true><<<((nkt + per - 1) / per + 7) / 8 * 8 * tiles, 256, 65536, (hipStream_t)stream>>>(g);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
