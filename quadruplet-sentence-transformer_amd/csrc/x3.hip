@@ -99,23 +99,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(QstGemmArgs g) {
     const int srow = TN ? tid >> 5 : tid / C4, sc4 = TN ? tid & 31 : tid % C4;
     const bool do_bias = TN && g.colsum && n0 == 0;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-    u32x4 sa[NP], sb[NP];
-    auto gload = [&](int kt) {
+    u32x4 sa0[NP], sb0[NP], sa1[NP], sb1[NP];          // two K-tiles of operand rows in flight (global -> registers)
+    auto gload = [&](int kt, u32x4 (&sa)[NP], u32x4 (&sb)[NP]) {
+        const bool live = kt < nk;                          // (uniform) past the end: out-of-range offsets, zeros come back
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             if (TN) {
                 const uint32_t r = (uint32_t)((kt - kt0) * XBK + srow + 8 * i);
                 // columns past the matrix must not alias the next row: those lanes ask for an out-of-range offset (zeros)
-                sa[i] = buf_load16(ra, m0 + sc4 * 4 < g.M ? r * g.lda * 4u + (uint32_t)(m0 + sc4 * 4) * 4u : 0x80000000u);
-                sb[i] = buf_load16(rb, n0 + sc4 * 4 < g.N ? r * g.ldb * 4u + (uint32_t)(n0 + sc4 * 4) * 4u : 0x80000000u);
+                sa[i] = buf_load16(ra, live && m0 + sc4 * 4 < g.M ? r * g.lda * 4u + (uint32_t)(m0 + sc4 * 4) * 4u : 0x80000000u);
+                sb[i] = buf_load16(rb, live && n0 + sc4 * 4 < g.N ? r * g.ldb * 4u + (uint32_t)(n0 + sc4 * 4) * 4u : 0x80000000u);
             } else {
                 const int r = srow + (256 / C4) * i;
-                sa[i] = buf_load16(ra, (uint32_t)r * g.lda * 4u + (uint32_t)(kt * XBK + sc4 * 4) * 4u);
-                sb[i] = buf_load16(rb, (uint32_t)r * g.ldb * 4u + (uint32_t)(kt * XBK + sc4 * 4) * 4u);
+                sa[i] = buf_load16(ra, live ? (uint32_t)r * g.lda * 4u + (uint32_t)(kt * XBK + sc4 * 4) * 4u : 0x80000000u);
+                sb[i] = buf_load16(rb, live ? (uint32_t)r * g.ldb * 4u + (uint32_t)(kt * XBK + sc4 * 4) * 4u : 0x80000000u);
             }
         }
     };
-    auto lstore = [&](char* smem) {                                    // (the ring slot being filled)
+    auto lstore = [&](char* smem, u32x4 (&sa)[NP], u32x4 (&sb)[NP]) {   // (smem: the ring slot being filled)
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int r = TN ? srow + 8 * i : srow + (256 / C4) * i;
@@ -140,14 +141,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(QstGemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int fr = lane & 31, fh = lane >> 5;
     // Two ring slots of operand images: K-tile kt + 1 is split and written into the other slot after this wave has issued the
-    // MFMAs of K-tile kt, so one wave's conversion work runs under the others' MFMAs and a K-tile costs ONE barrier.
+    // MFMAs of K-tile kt, so one wave's conversion work runs under the others' MFMAs and a K-tile costs ONE barrier. The rows
+    // of K-tile kt + 2 are requested before the MFMAs of kt: one K-tile of MFMAs (~1,500 cycles) does not cover a load's
+    // round trip, two register sets do.
     char* const ring = smem;
-    gload(kt0);
-    lstore(ring);
-    __syncthreads();
-    for (int kt = kt0; kt < nk; ++kt) {
-        char* const smem = ring + ((kt - kt0) & 1) * (4 * IMG);
-        if (kt + 1 < nk) gload(kt + 1);
+    auto compute = [&](const char* smem) {
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8 ah[2], al[2], bh[2], bl[2];
@@ -173,8 +171,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(QstGemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma3(bh[j], bl[j], ah[i], al[i], acc[i][j]);   // D rows = n, col = m
         }
-        if (kt + 1 < nk) lstore(ring + ((kt + 1 - kt0) & 1) * (4 * IMG));
-        __syncthreads();                 // slot (kt + 1) & 1 is complete; every wave has left slot kt & 1
+    };
+    // Branch-free: K-tiles past the end are requested at an out-of-range offset (zeros: they add nothing), so the loop always
+    // runs whole pairs. With the loads under `if (kt + 2 < nk)` hipcc's waitcnt pass drained the queue before every request.
+    gload(kt0, sa0, sb0);
+    gload(kt0 + 1, sa1, sb1);
+    lstore(ring, sa0, sb0);
+    __syncthreads();
+    for (int kt = kt0; kt < nk; kt += 2) {
+        gload(kt + 2, sa0, sb0);         // slot 0 holds kt, set 1 holds kt + 1 (in flight), set 0 is free
+        __builtin_amdgcn_sched_barrier(0);       // (the scheduler otherwise sinks the requests below the MFMAs and the stores)
+        compute(ring);
+        lstore(ring + 4 * IMG, sa1, sb1);
+        __syncthreads();                 // slot 1 is complete; every wave has left slot 0
+        gload(kt + 3, sa1, sb1);         // slot 1 holds kt + 1, set 0 holds kt + 2 (in flight), set 1 is free
+        __builtin_amdgcn_sched_barrier(0);
+        compute(ring + 4 * IMG);
+        lstore(ring, sa0, sb0);
+        __syncthreads();
     }
     if (do_bias) {                                 // 8 k-row phases x 128 columns of partial sums -> one atomic per column
         float* red = (float*)smem;
