@@ -438,17 +438,6 @@ __device__ __forceinline__ i32x8 f8_frag(const char* img, int row, int ks, int h
     return f;
 }
 
-// MX scale exponent of a block with largest magnitude amax: the smallest e with amax * 2^-e <= 448 (e4m3's largest
-// value), from the float's own exponent and mantissa -- integer arithmetic, so the oracle reproduces it bit for bit.
-// (The OCP recipe floor(log2 amax) - 8 lets elements in (448, 512) saturate; this one never saturates.) amax = 0 -> -127.
-__device__ __forceinline__ int mx_exponent(float amax) {
-    const uint32_t u = __builtin_bit_cast(uint32_t, amax);
-    if ((u & 0x7F800000u) == 0u) return -127;                       // zero (or a float denormal: quantises to zero)
-    int e = (int)((u >> 23) & 0xFF) - 127 - 8 + ((u & 0x7FFFFFu) > 0x600000u ? 1 : 0);
-    return e < -127 ? -127 : (e > 126 ? 126 : e);
-}
-__device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (uint32_t)(e + 127) << 23); }   // -126 <= e <= 127
-
 constexpr int QST_EPI_GELU_MX_TRAIN_ = 6;    // = QST_EPI_GELU_MX_TRAIN: C / C2 as QST_EPI_GELU (gelu'(u), h as bf16) AND h as MXFP8 in C3 / C4
 constexpr int QST_EPI_GELU_MX_ = 5;          // = QST_EPI_GELU_MX: C = e4m3 of gelu(acc + bias) [M, ldc bytes], C2 = E8M0 [M, ldc / 32]
 
@@ -1207,6 +1196,8 @@ static bool f8_auto(const QstGemmArgs* a, int epi) {
     if (a->M < 16384) return false;
     if (epi == QST_EPI_BF16) return a->N >= 2304 && a->K >= 768;
     if (epi == QST_EPI_F32_RESID) return a->K >= 2304;
+    // (QST_EPI_GELU_MX_TRAIN, FFN-1 of the fp8 training forward, has an 8-phase form too -- a->splits bit 6 -- and stays tiled:
+    //  three outputs, 5 bytes per element: 1,104 vs 1,030 us back to back at M = 196,608, 1,355 vs 1,256 us inside the step)
     return false;
 }
 
@@ -1222,7 +1213,8 @@ extern "C" int qst_gemm_nt_f8(const QstGemmArgs* a, int epi, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     // the 8-phase form (gemm8.hip: 16x16x128 MFMA, 256 x 256 tile): bit-identical; a->splits bit 6 forces it, bit 7 forbids it,
     // otherwise qst_gemm8_mode bit 0 / the shape decide (f8_auto)
-    if (!(a->splits & 0x80) && (epi == QST_EPI_BF16 || epi == QST_EPI_F32_RESID || epi == QST_EPI_GELU) && a->N % 8 == 0 && a->ldc % 8 == 0) {
+    const bool mxt_ok = epi == QST_EPI_GELU_MX_TRAIN && a->C2 && a->C3 && a->C4 && a->ldc == a->N && a->N % 32 == 0;
+    if (!(a->splits & 0x80) && (epi == QST_EPI_BF16 || epi == QST_EPI_F32_RESID || epi == QST_EPI_GELU || mxt_ok) && a->N % 8 == 0 && a->ldc % 8 == 0) {
         const int mode = qst_gemm8_mode_get();
         if ((a->splits & 0x40) || (mode >= 0 ? (mode & 1) != 0 : f8_auto(a, epi))) return qst_gemm_nt8_f8(a, epi, 1, stream);
     }

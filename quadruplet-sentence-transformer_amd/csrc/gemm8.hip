@@ -143,7 +143,7 @@ __device__ __forceinline__ void nt8_epilogue(const QstGemmArgs& g, OPS& o, int m
 #pragma unroll
                     for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
                     st_stream((u32x4*)((bf16*)g.C + off), pk);
-                } else if (EPI == QST_EPI_GELU) {
+                } else if (EPI == QST_EPI_GELU || EPI == QST_EPI_GELU_MX_TRAIN) {
                     u32x4 pg;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -156,6 +156,32 @@ __device__ __forceinline__ void nt8_epilogue(const QstGemmArgs& g, OPS& o, int m
                     }
                     st_stream((u32x4*)((bf16*)g.C + off), pg);             // gelu'(u), saved for backward
                     st_stream((u32x4*)((bf16*)g.C2 + off), pk);            // h = gelu(u)
+                    if (EPI == QST_EPI_GELU_MX_TRAIN) {
+                        // ... and the bf16-rounded h as MXFP8 (C3 = e4m3 [M, N], C4 = E8M0, stage-major): the four lanes of a
+                        // row (one per 16-lane row of the wave) hold the 32 columns of one MX block, so its amax is two
+                        // row-swaps away. (All four take this branch together: same m, same 32-column block, N % 32 == 0.)
+                        float hv[8], amax = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { hv[2 * e] = bf16lo(pk[e]); hv[2 * e + 1] = bf16hi(pk[e]); }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(hv[e]));
+                        amax = fmaxf(amax, swap32(amax));
+                        {
+                            float a2 = amax, b2 = amax;
+                            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a2), "+v"(b2));
+                            amax = fmaxf(a2, b2);
+                        }
+                        const int ex = mx_exponent(amax);
+                        const float inv = pow2f(-ex);
+                        uint32_t p0 = 0, p1 = 0;
+                        p0 = __builtin_amdgcn_cvt_pk_fp8_f32(hv[0] * inv, hv[1] * inv, p0, false);
+                        p0 = __builtin_amdgcn_cvt_pk_fp8_f32(hv[2] * inv, hv[3] * inv, p0, true);
+                        p1 = __builtin_amdgcn_cvt_pk_fp8_f32(hv[4] * inv, hv[5] * inv, p1, false);
+                        p1 = __builtin_amdgcn_cvt_pk_fp8_f32(hv[6] * inv, hv[7] * inv, p1, true);
+                        u32x2 q2; q2[0] = p0; q2[1] = p1;
+                        st_stream((u32x2*)((uint8_t*)g.C3 + off), q2);
+                        if (gq == 0) ((uint8_t*)g.C4)[((size_t)(n >> 7) * g.M + m) * 4 + ((n >> 5) & 3)] = (uint8_t)(ex + 127);
+                    }
                 } else {                                                    // QST_EPI_GELU_BWD: acc * gelu'(u)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -400,6 +426,8 @@ extern "C" int qst_gemm_nt8_f8(const QstGemmArgs* a, int epi, int tile, void* st
     if ((int64_t)256 * a->lda >= 0x7FFFFF00LL || (int64_t)384 * a->ldb >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
     if ((int64_t)(a->K / 128) * (a->M > a->N ? a->M : a->N) * 4 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
     if (epi == QST_EPI_GELU && !a->C2) return QST_ERR_BAD_ARG;
+    if (epi == QST_EPI_GELU_MX_TRAIN && (!a->C2 || !a->C3 || !a->C4)) return QST_ERR_BAD_ARG;
+    if (epi == QST_EPI_GELU_MX_TRAIN && (a->ldc != a->N || a->N % 32 != 0)) return QST_ERR_UNSUPPORTED;
     if (a->drop.thr16 && a->drop.state) {
         if (a->drop_where != 1 || epi != QST_EPI_F32_RESID) return QST_ERR_BAD_ARG;
         if (a->drop.thr16 > 65535u || (int64_t)a->M * a->N >= ((int64_t)1 << 32)) return QST_ERR_UNSUPPORTED;
@@ -410,6 +438,7 @@ extern "C" int qst_gemm_nt8_f8(const QstGemmArgs* a, int epi, int tile, void* st
         QST_NT8F_CASE(QST_EPI_BF16)
         QST_NT8F_CASE(QST_EPI_F32_RESID)
         QST_NT8F_CASE(QST_EPI_GELU)
+        QST_NT8F_CASE(QST_EPI_GELU_MX_TRAIN)
         default: return QST_ERR_UNSUPPORTED;
     }
 #undef QST_NT8F_CASE

@@ -46,6 +46,17 @@ static inline int qst_ensure_lds(QstLdsAttr& st, const void* fn, int bytes) {
 }
 #endif
 
+// MX scale exponent of a block with largest magnitude amax: the smallest e with amax * 2^-e <= 448 (e4m3's largest
+// value), from the float's own exponent and mantissa -- integer arithmetic, so the oracle reproduces it bit for bit.
+// (The OCP recipe floor(log2 amax) - 8 lets elements in (448, 512) saturate; this one never saturates.) amax = 0 -> -127.
+__device__ __forceinline__ int mx_exponent(float amax) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, amax);
+    if ((u & 0x7F800000u) == 0u) return -127;                       // zero (or a float denormal: quantises to zero)
+    int e = (int)((u >> 23) & 0xFF) - 127 - 8 + ((u & 0x7FFFFFu) > 0x600000u ? 1 : 0);
+    return e < -127 ? -127 : (e > 126 ? 126 : e);
+}
+__device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (uint32_t)(e + 127) << 23); }   // -126 <= e <= 127
+
 // Wave64 all-reduce on the VALU cross-lane path (DPP + readlane) instead of __shfl_xor, which lowers to
 // ds_bpermute: six dependent LDS round trips per reduction made the row kernels latency-bound.
 // Butterfly inside each row of 16 lanes (quad_perm xor1, xor2, row_half_mirror, row_mirror: sums are symmetric,

@@ -130,6 +130,25 @@ def test_gemm_f8_matches_fp32_on_dequantised_operands(lib, M, N, K):
                                                  ldc=N), 2, tile, st()))
         torch.testing.assert_close(H8.float(), H1.float(), rtol=8e-3, atol=8e-3 * scale)
         torch.testing.assert_close(G8.float(), G1.float(), rtol=8e-3, atol=2e-2)
+        if N % 128 == 0:
+            # the training FFN-1 epilogue (gelu'(u), h as bf16 AND the bf16-rounded h as MXFP8): tiled against 8-phase, bit for bit
+            # wherever the bf16 h agrees (the MX copy is a function of it)
+            outs = []
+            for fn, extra in ((lib.qst_gemm_nt_f8, (6, st())), (lib.qst_gemm_nt8_f8, (6, tile, st()))):
+                Gm, Hm = torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+                Qm = torch.zeros(M, N, dtype=torch.uint8, device="cuda")
+                Sm = torch.zeros(N // 128 * M * 4, dtype=torch.uint8, device="cuda")
+                _lib.check(fn(gemm_args(A=Aq, B=Bq, aux=As, bscale=Bs, C=Gm, C2=Hm, C3=Qm, C4=Sm, bias=bias.cuda(), M=M, N=N, K=K, lda=K,
+                                        ldb=K, ldc=N, splits=0x80), *extra))
+                outs.append((Gm, Hm, Qm, Sm))
+            (G6, H6, Q6, S6), (G7, H7, Q7, S7) = outs
+            torch.testing.assert_close(H7.float(), H8.float(), rtol=0, atol=0)          # the same h as the two-output epilogue
+            torch.testing.assert_close(G7.float(), G8.float(), rtol=0, atol=0)
+            qr, sr, _ = R.mx_quant(H7.float().cpu())                                 # the oracle's MX copy of THIS bf16 h
+            assert (row_major(S7.cpu(), M, N) == sr).all() and (Q7.cpu() == qr).all()
+            same = (H6 == H7).view(M, N // 32, 32).all(-1)                          # blocks whose bf16 h agrees between the kernels
+            assert same.float().mean().item() > 0.98
+            assert torch.equal(Q6.view(M, N // 32, 32)[same], Q7.view(M, N // 32, 32)[same])
     # refused shapes
     assert lib.qst_gemm_nt_f8(gemm_args(A=Aq, B=Bq, aux=As, bscale=Bs, C=C, M=M, N=N, K=K - 32, lda=K, ldb=K, ldc=N), 1, st()) == -2
     assert lib.qst_gemm_nt_f8(gemm_args(A=Aq, B=Bq, aux=As, C=C, M=M, N=N, K=K, lda=K, ldb=K, ldc=N), 1, st()) == -1

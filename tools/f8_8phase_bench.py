@@ -35,7 +35,7 @@ def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 196608
     dev, bf = "cuda", torch.bfloat16
     g = torch.Generator(device=dev).manual_seed(3)
-    for name, N, K, epi in [("QKV", 2304, 768, 0), ("out", 768, 768, 1), ("FFN1", 3072, 768, 2), ("FFN2", 768, 3072, 1),
+    for name, N, K, epi in [("QKV", 2304, 768, 0), ("out", 768, 768, 1), ("FFN1", 3072, 768, 2), ("FFN1mx", 3072, 768, 6), ("FFN2", 768, 3072, 1),
                             ("ragged", 1000, 896, 0)]:
         Mx = M if name != "ragged" else 3000
         A = torch.randn(Mx, K, device=dev, generator=g)
@@ -54,6 +54,12 @@ def main():
             f = _lib.QstGemmArgs()
             f.A, f.B, f.aux, f.bscale, f.bias = Aq.data_ptr(), Wq.data_ptr(), As.data_ptr(), Ws.data_ptr(), bias.data_ptr()
             f.C, f.C2 = C.data_ptr(), C2.data_ptr()
+            if epi == 6:                         # the training FFN-1: + the bf16-rounded h as MXFP8
+                C3 = torch.zeros(Mx, N, device=dev, dtype=torch.uint8)
+                C4 = torch.zeros(N // 128 * Mx * 4, device=dev, dtype=torch.uint8)
+                f.C3, f.C4 = C3.data_ptr(), C4.data_ptr()
+                f._keep = (C3, C4)
+                f.splits = 0x80 if which == 0 else 0
             f.resid = resid.data_ptr() if resid is not None else None
             f.M, f.N, f.K, f.lda, f.ldb, f.ldc, f.ldr = Mx, N, K, K, K, N, N
             outs.append((C, C2))
