@@ -91,7 +91,10 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // Round 3, on the LayerNorm-fused kernel with operands flushed from the caches as they are inside the step
 // (tools/mall_probe.py): K = 1536 cold 111 vs 97 us, warm 62 vs 58 -- the cold penalty is not a per-stage latency. Nor is it
 // the access pattern: a tile-blocked A, every stage one contiguous 16 KB read, measured 94 vs 98 us cold.)
-template <int WAVES_M, int WAVES_N, typename HOOK = NoHook, bool A_ONCE = false>
+// A_SLOTS = 3 (the LayerNorm-fused kernel: one workgroup per CU, 128 x 384 tile): the activation stages get a ring of their own,
+// three slots deep, so TWO stages of A rows -- the lines that come from HBM; the weight stages hit in L2 -- are in flight under
+// every stage of MFMAs instead of one: ring = 3 x 16 KB of A + 2 x 48 KB of B = 144 KB.
+template <int WAVES_M, int WAVES_N, typename HOOK = NoHook, bool A_ONCE = false, int A_SLOTS = 2>
 __device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, int m0, int n0, f32x16 (&acc)[2][3],
                                             HOOK after_first_issue = HOOK()) {
     constexpr int NBM = 64 * WAVES_M, NBN = 96 * WAVES_N, NW = WAVES_M * WAVES_N;
@@ -122,14 +125,22 @@ __device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, in
         const int row = (wave * B_PER_WAVE + t) * 8 + (lane >> 3);
         vb[t] = (uint32_t)row * g.ldb * 2u + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
     }
-    auto issue = [&](int kt) {
-        char* st = smem + (kt & 1) * NT_STAGE;
+    constexpr bool DEEP = A_SLOTS == 3;
+    auto slot_a = [&](int kt) { return smem + (DEEP ? (kt % 3) * NT_A_BYTES : (kt & 1) * NT_STAGE); };
+    auto slot_b = [&](int kt) { return smem + (DEEP ? 3 * NT_A_BYTES + (kt & 1) * NT_B_BYTES : (kt & 1) * NT_STAGE + NT_A_BYTES); };
+    auto issue_a = [&](int kt) {
+        char* st = slot_a(kt);
         const uint32_t ko = (uint32_t)kt * (NBK * 2);
 #pragma unroll
         for (int t = 0; t < A_PER_WAVE; ++t) dma16<A_ONCE>(ra, st + (wave * A_PER_WAVE + t) * 1024, va[t], ko);
-#pragma unroll
-        for (int t = 0; t < B_PER_WAVE; ++t) dma16(rb, st + NT_A_BYTES + (wave * B_PER_WAVE + t) * 1024, vb[t], ko);
     };
+    auto issue_b = [&](int kt) {
+        char* st = slot_b(kt);
+        const uint32_t ko = (uint32_t)kt * (NBK * 2);
+#pragma unroll
+        for (int t = 0; t < B_PER_WAVE; ++t) dma16(rb, st + (wave * B_PER_WAVE + t) * 1024, vb[t], ko);
+    };
+    auto issue = [&](int kt) { issue_a(kt); issue_b(kt); };
 
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -143,11 +154,17 @@ __device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, in
     issue(0);
     after_first_issue();
     for (int kt = 0; kt < nk; ++kt) {
-        wait_vmcnt<0>();                              // stage kt has landed for this wave's DMAs
-        __builtin_amdgcn_s_barrier();                 // ... for everyone's; and everyone is done reading slot (kt-1)&1
-        if (kt + 1 < nk) issue(kt + 1);
-        const char* pa = smem + (kt & 1) * NT_STAGE;
-        const char* pb = pa + NT_A_BYTES;
+        // stage kt has landed for this wave's DMAs. DEEP: the queue holds, oldest first, A(kt), B(kt), A(kt + 1) -- the last
+        // one may stay in flight (A_PER_WAVE instructions; stage 0 drains everything, the hook's loads included)
+        if (DEEP && kt > 0 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(A_PER_WAVE) : "memory");
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                 // ... for everyone's; and everyone is done reading the slots of stage kt - 1
+        if (DEEP) {
+            if (kt + 1 < nk) { issue_b(kt + 1); if (kt == 0) issue_a(1); }
+            if (kt + 2 < nk) issue_a(kt + 2);
+        } else if (kt + 1 < nk) issue(kt + 1);
+        const char* pa = slot_a(kt);
+        const char* pb = slot_b(kt);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 fa[2], fb[3];
@@ -669,7 +686,10 @@ __global__ __launch_bounds__(256) void quant_mx_kernel(const SRC* src, int64_t n
 // four waves of a row panel stage their sub-tiles into one [32][384] fp32 slab, then each takes 8 complete rows
 // (6 columns per lane, as the row kernels in rowops.hip do).
 constexpr int LN_N = 384, LN_LD = 388;               // slab row stride 1552 B: ds_write_b128 conflict-free
-constexpr int LN_RING = 2 * (128 + LN_N) * NBK * 2;  // the K-loop ring (128 KB); the epilogue slabs reuse 99 KB of it
+#ifndef QST_LN_ASLOTS
+#define QST_LN_ASLOTS 3
+#endif
+constexpr int LN_RING = (QST_LN_ASLOTS * 128 + 2 * LN_N) * NBK * 2;  // the K-loop ring (3 A slots + 2 B slots = 144 KB); the epilogue slabs reuse 99 KB of it
 constexpr int LN_LDS = LN_RING + 3 * LN_N * 4;       // + bias / gamma / beta, loaded before the K loop
 
 template <int MODE, int DROPW = 0>        // DROPW: QstGemmArgs.drop_where as a compile-time constant (0 = no dropout)
@@ -730,7 +750,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
         for (int q = 0; q < 3; ++q)
             if (tid + 512 * q < 3 * LN_N) vec_s[tid + 512 * q] = v3[q];
     };
-    nt_mainloop<2, 4, decltype(early_loads), true>(g, smem, m0, 0, acc, early_loads);      // the tile spans whole rows: A is read once
+    nt_mainloop<2, 4, decltype(early_loads), true, QST_LN_ASLOTS>(g, smem, m0, 0, acc, early_loads);   // the tile spans whole rows: A is read once
     LN_STAMP(2);
 
     f32x2 ag[3], ab[3];
