@@ -19,6 +19,14 @@
  * of a training step whose backward is the bf16 one: qst_encoder_backward* on this handle with the bf16 shadows) runs every Linear on the fp8 matrix
  * cores: weights AND activations as OCP MXFP8 (e4m3 elements, one E8M0 scale per 32 input features;
  * v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulation), attention in bf16, residual stream / LayerNorm in fp32.
+ * QST_PREC_F16 (round 5) is QST_PREC_BF16 with IEEE half in bf16's place: the same kernels compiled on the other 16-bit
+ * operand type (v_mfma_f32_32x32x16_f16: same issue rate, same bytes), 11 significand bits instead of 8 -- embeddings
+ * within the north-star tolerance (rtol 1e-3 / atol 1e-4) of the fp32 reference for the six-layer models, where bf16's
+ * are not -- and a 5-bit exponent: forward kernels saturate at +-65,504, and a training step runs under a loss scale
+ * (qst_amp_scaler_init / qst_clip_adamw_step_amp), which is what the reference's own reduced precision does:
+ * torch.cuda.amp.autocast + GradScaler, /root/reference/training/main.py:142 (`use_amp`), models/evaluators.py:92-94.
+ * The shadow of a QST_PREC_F16 handle holds IEEE half (qst_refresh_shadow on that handle), its activation arena f16
+ * tensors of the bf16 arena's sizes; its backward is refused on another precision's arena and vice versa.
  */
 #ifndef QST_H
 #define QST_H
@@ -41,7 +49,7 @@ typedef enum {
 } qst_status;
 
 enum { QST_ARCH_BERT = 0, QST_ARCH_MPNET = 1 };
-enum { QST_PREC_BF16 = 0, QST_PREC_BF16X3 = 1, QST_PREC_FP8 = 3 };   /* 2 was an fp8-weights-only mode (removed) */
+enum { QST_PREC_BF16 = 0, QST_PREC_BF16X3 = 1, QST_PREC_FP8 = 3, QST_PREC_F16 = 4 };   /* 2 was an fp8-weights-only mode (removed) */
 enum { QST_REDUCE_NONE = 0, QST_REDUCE_SUM = 1, QST_REDUCE_MEAN = 2 };
 
 /* Encoder architecture. Mirrors HF BertConfig / MPNetConfig fields that the
@@ -211,6 +219,30 @@ int qst_clip_adamw_step_sched(const qst_encoder* enc, float* params, float* grad
                               float base_lr, float beta1, float beta2, float eps, float weight_decay,
                               float max_grad_norm, float grad_scale, int64_t warmup_steps, int64_t total_steps,
                               int64_t* step_dev, float* norm_out, float* scratch, void* stream);
+
+/* Mixed-precision optimiser step: what SentenceTransformer.fit(use_amp=True) wraps around AdamW -- scaler.scale(loss)
+ * .backward(); scaler.unscale_(optimizer); clip_grad_norm_; scaler.step(optimizer); scaler.update(); and the scheduler
+ * step skipped whenever the scale changed (sentence-transformers 2.2.2 fit(); reference call site
+ * /root/reference/training/main.py:128-148 with use_amp = True) -- with torch.cuda.amp.GradScaler's defaults as ST builds it
+ * (init_scale 65536, growth_factor 2, backoff_factor 0.5, growth_interval 2000), all on the device:
+ *   scaler_dev : fp32 [4] {scale, growth tracker, 1.0 if the LAST step was skipped, number of skipped steps so far};
+ *                qst_amp_scaler_init writes {init_scale, 0, 0, 0}. scaler_dev[0] is what the backward multiplies the loss
+ *                gradient by: pass scaler_dev as qst_quadruplet_loss's grad_out (reduction sum / mean).
+ *   step_dev   : int64 [2] {optimiser steps taken, scheduler steps taken}. Bias correction uses the first, the learning rate
+ *                (WarmupLinear as qst_clip_adamw_step_sched) the second.
+ * The call unscales by 1 / scale (times grad_scale, the 1 / world_size of a data-parallel step), takes the global norm of
+ * the unscaled gradients (norm_out), and: if the norm is not finite (an inf / nan anywhere in `grads`: an f16 gradient
+ * overflowed) the parameters, the moments and the optimiser step count stay as they are, the gradients are zeroed, scale *=
+ * backoff and the tracker restarts; otherwise clip + AdamW + zero_grad as qst_clip_adamw_step, tracker += 1, and at
+ * growth_interval scale *= growth. The scheduler count advances only when the scale did not change (ST's rule).
+ * growth_interval <= 0: a STATIC scale (no growth; an overflow still skips the step, without backoff).
+ * scratch: fp32 [1024 + 8]. Every rank of a data-parallel job sees the same reduced gradients, so the same decisions. */
+int qst_amp_scaler_init(float* scaler_dev, float init_scale, void* stream);
+int qst_clip_adamw_step_amp(const qst_encoder* enc, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                            float base_lr, float beta1, float beta2, float eps, float weight_decay,
+                            float max_grad_norm, float grad_scale, int64_t warmup_steps, int64_t total_steps,
+                            int64_t* step_dev, float* scaler_dev, float growth_factor, float backoff_factor,
+                            int32_t growth_interval, float* norm_out, float* scratch, void* stream);
 
 /* Retrieval scoring for the encode()-driven evaluators: what sentence-transformers'
  * InformationRetrievalEvaluator does per corpus chunk -- util.cos_sim / util.dot_score of the query embeddings

@@ -70,6 +70,8 @@ typedef struct {
     int32_t drop_where;
     void* C3;             // QST_EPI_GELU_MX_TRAIN only (see the enum)
     void* C4;
+    int32_t sat16;        // f16 twins only (qst_gemm_nt_f16 / qst_gemm_nt8_f16): != 0 = 16-bit outputs saturate at +-65,504
+                          // instead of overflowing to inf (forward launches); 0 = IEEE overflow (backward launches)
 } QstGemmArgs;
 
 /* C[M,N] = A[M,K] . B[N,K]^T with epilogue `epi`. K % 64 == 0, lda/ldb % 8 == 0. */
@@ -326,6 +328,48 @@ int qst_topk_rows(const float* scores, int64_t ld, const int64_t* index_map, int
 int qst_shadow_all(const float* params, void* shadow, const int64_t* table_dev, int nseg, int nblocks, void* stream);
 /* bf16 shadow: dst[i] = bf16(src[i]) and dstT = transpose for a [rows, cols] matrix. */
 int qst_shadow_matrix(const float* src, int rows, int cols, void* dst_bf16, void* dstT_bf16, void* stream);
+
+/* ---- f16-operand twins (QST_PREC_F16, round 5) ----
+ * Every entry point above whose matrix-core operands or 16-bit outputs are bf16 exists a second time with IEEE half in
+ * their place: same arguments, same layouts, `void*` 16-bit tensors holding f16 instead of bf16 (the sources are compiled
+ * twice on one operand type, csrc/qst_common.h: op16). v_mfma_f32_32x32x16_f16 / 16x16x32_f16 issue at the bf16 rate on
+ * the same bytes; f16 carries 11 significand bits against bf16's 8, at the price of a 5-bit exponent: forward kernels
+ * saturate at +-65,504 (QstGemmArgs.sat16 for qst_gemm_nt_f16 / qst_gemm_nt8_f16; the LayerNorm, GELU, fused-LayerNorm mode 0,
+ * feed-forward-chain mode 0 and attention-forward kernels always), backward kernels keep IEEE inf so that an overflowed
+ * gradient shows up in the global norm (qst_clip_adamw_step_amp). The reference's counterpart is torch.cuda.amp.autocast
+ * (fp16) + GradScaler: /root/reference/training/main.py:142, models/evaluators.py:92-94. */
+int qst_gemm_nt_f16(const QstGemmArgs* a, int epi, void* stream);
+int qst_gemm_nt_ln_f16(const QstGemmArgs* a, const QstLnEpi* ln, int mode, void* stream);
+int qst_ffn_chain_f16(const QstFfnArgs* a, const QstLnEpi* ln, int mode, void* stream);
+int qst_gemm_tn_f16(const QstGemmArgs* a, void* stream);
+int qst_gemm_tn_group_f16(const QstTnGroup* grp, void* stream);
+int qst_gemm_nt8_supported_f16(const QstGemmArgs* a, int epi);
+int qst_gemm_nt8_f16(const QstGemmArgs* a, int epi, int tile, void* stream);
+int qst_gemm_tn8_group_f16(const QstTnGroup* grp, void* stream);
+int qst_embed_ln_fwd_f16(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
+                         const float* word_emb, const float* pos_emb, const float* type_emb,
+                         const float* gamma, const float* beta, float eps, int M, int H,
+                         float* y, void* y_f16, void* xhat_f16, float* rstd, void* stream);
+int qst_embed_ln_fwd_drop_f16(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
+                              const float* word_emb, const float* pos_emb, const float* type_emb,
+                              const float* gamma, const float* beta, float eps, int M, int H,
+                              float* y, void* y_f16, void* xhat_f16, float* rstd, const QstDrop* drop, void* stream);
+int qst_ln_fwd_f16(const float* s, const float* gamma, const float* beta, float eps, int M, int H,
+                   float* y, void* y_f16, void* xhat_f16, float* rstd, void* stream);
+int qst_ln_bwd_f16(const float* dy, const void* xhat_f16, const float* rstd, const float* gamma, int M, int H,
+                   float* ds, void* ds_f16, float* dgamma, float* dbeta, float* scratch, void* stream);
+int qst_ln_bwd_drop_f16(const float* dy, const void* xhat_f16, const float* rstd, const float* gamma, int M, int H,
+                        float* ds, void* ds_f16, float* dgamma, float* dbeta, float* scratch,
+                        const QstDrop* drop_in, const QstDrop* drop_out, void* stream);
+int qst_attention_fwd_f16(const void* qkv, const int64_t* mask, const float* rel_pos, int nseq, int L, int A, int d,
+                          void* ctx, float* lse, void* stream);
+int qst_attention_bwd_f16(const void* qkv, const void* ctx, const void* dctx, const float* lse, const int64_t* mask,
+                          const float* rel_bias, int nseq, int L, int A, int d, void* dqkv, float* drel,
+                          float* delta_scratch, void* stream);
+int qst_attention_fwd_ex_f16(const QstAttnDesc* a, void* stream);
+int qst_attention_bwd_ex_f16(const QstAttnDesc* a, void* stream);
+int qst_shadow_all_f16(const float* params, void* shadow, const int64_t* table_dev, int nseg, int nblocks, void* stream);
+int qst_shadow_matrix_f16(const float* src, int rows, int cols, void* dst_f16, void* dstT_f16, void* stream);
 
 /* sizeof() of the argument structs above as this library was compiled, for bindings to check their mirror of the layout:
  * which = 0 QstGemmArgs, 1 QstLnEpi, 2 QstFfnArgs, 3 QstTnGroup, 4 QstLnReduceBatch, 5 QstDrop, 6 QstAttnDesc. */

@@ -21,8 +21,8 @@ transformers import), so autograd gives the backward oracle as well:
 Pinned by tests/golden/*.npz, which oracle/make_golden.py generates from the real
 reference loss module and HF BertModel/MPNetModel (tests/test_oracle_golden.py).
 
-`bf16_operands=True` rounds every GEMM operand (activations, weights, Q/K/V, P)
-to bf16 and keeps fp32 results -- the arithmetic the HIP kernels do -- so
+`bf16_operands=True` (or "bf16"; "f16" = IEEE half, the operand type of QST_PREC_F16 -- operand_dtype below) rounds every
+GEMM operand (activations, weights, Q/K/V, P) to that 16-bit type and keeps fp32 results -- the arithmetic the HIP kernels do -- so
 kernel bugs can be told apart from bf16 rounding. In that mode the contractions are
 accumulated in fp64 and rounded to fp32 once: products of bf16 values are exact in
 fp64 and the sum no longer depends on the BLAS library's reduction order or thread
@@ -47,8 +47,23 @@ def _r(x: torch.Tensor, on: bool) -> torch.Tensor:
     return x + (x.detach().to(torch.bfloat16).to(torch.float32) - x.detach())
 
 
-def _b16(x: torch.Tensor) -> torch.Tensor:
-    return x.detach().to(torch.bfloat16).to(torch.float64)
+_OPERAND_DTYPES = {True: torch.bfloat16, "bf16": torch.bfloat16, "f16": torch.float16, "fp16": torch.float16}
+
+
+def operand_dtype(bf16_operands):
+    """The 16-bit matrix-core operand type a `bf16_operands` argument names: False / None = none (plain fp32), True / "bf16" =
+    bfloat16 (QST_PREC_BF16), "f16" = IEEE half (QST_PREC_F16: 11 significand bits, the reference's `use_amp` precision class,
+    /root/reference/training/main.py:142). torch's float32 -> float16 cast rounds to nearest even and overflows to inf; the
+    kernels' forward epilogues saturate at 65,504 instead -- no golden case comes near either."""
+    if bf16_operands is None or bf16_operands is False:
+        return None
+    if isinstance(bf16_operands, torch.dtype):
+        return bf16_operands
+    return _OPERAND_DTYPES[bf16_operands]
+
+
+def _b16(x: torch.Tensor, dt: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    return x.detach().to(dt).to(torch.float64)
 
 
 class _MmBf16(torch.autograd.Function):
@@ -58,19 +73,20 @@ class _MmBf16(torch.autograd.Function):
     csrc/attention.hip rounds dO, P and dS once each)."""
 
     @staticmethod
-    def forward(ctx, a, b):
-        a16, b16 = _b16(a), _b16(b)
+    def forward(ctx, a, b, dt=torch.bfloat16):
+        a16, b16 = _b16(a, dt), _b16(b, dt)
         ctx.save_for_backward(a16, b16)
         ctx.shapes = (a.shape, b.shape)
+        ctx.dt = dt
         return torch.matmul(a16, b16).float()
 
     @staticmethod
     def backward(ctx, g):
         a16, b16 = ctx.saved_tensors
-        g16 = _b16(g)
+        g16 = _b16(g, ctx.dt)
         ga = torch.matmul(g16, b16.transpose(-1, -2)).sum_to_size(ctx.shapes[0]).float()
         gb = torch.matmul(a16.transpose(-1, -2), g16).sum_to_size(ctx.shapes[1]).float()
-        return ga, gb
+        return ga, gb, None
 
 
 class _LinearBf16(torch.autograd.Function):
@@ -79,32 +95,35 @@ class _LinearBf16(torch.autograd.Function):
     kernel sums the fragments it already holds, csrc/gemm.hip gemm_tn_group_kernel)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
-        x16, w16 = _b16(x), _b16(w)
+    def forward(ctx, x, w, b, dt=torch.bfloat16):
+        x16, w16 = _b16(x, dt), _b16(w, dt)
         ctx.save_for_backward(x16, w16)
         ctx.has_bias = b is not None
+        ctx.dt = dt
         y = torch.matmul(x16, w16.t()).float()
         return y if b is None else y + b
 
     @staticmethod
     def backward(ctx, g):
         x16, w16 = ctx.saved_tensors
-        g16 = _b16(g)
+        g16 = _b16(g, ctx.dt)
         g2, x2 = g16.reshape(-1, g16.shape[-1]), x16.reshape(-1, x16.shape[-1])
-        return torch.matmul(g16, w16).float(), torch.matmul(g2.t(), x2).float(), (g2.sum(0).float() if ctx.has_bias else None)
+        return torch.matmul(g16, w16).float(), torch.matmul(g2.t(), x2).float(), (g2.sum(0).float() if ctx.has_bias else None), None
 
 
 def _mm(a, b, bf16):
     """a @ b; with bf16 operands: _MmBf16 (forward and backward on bf16-rounded operands)."""
-    if not bf16:
+    dt = operand_dtype(bf16)
+    if dt is None:
         return torch.matmul(a, b)
-    return _MmBf16.apply(a, b)
+    return _MmBf16.apply(a, b, dt)
 
 
 def _linear(x, w, b, bf16):
-    if not bf16:
+    dt = operand_dtype(bf16)
+    if dt is None:
         return F.linear(x, w, b)
-    return _LinearBf16.apply(x, w, b)
+    return _LinearBf16.apply(x, w, b, dt)
 
 
 def mpnet_position_ids(ids: torch.Tensor, pad: int = 1) -> torch.Tensor:

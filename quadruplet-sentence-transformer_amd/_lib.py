@@ -46,7 +46,7 @@ class QstGemmArgs(C.Structure):
     _fields_ = [("A", vp), ("B", vp), ("C", vp), ("C2", vp), ("aux", vp), ("bias", vp), ("resid", vp),
                 ("colsum", vp), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32),
                 ("ldb", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32), ("splits", C.c_int32), ("bscale", vp),
-                ("drop", QstDrop), ("drop_where", C.c_int32), ("C3", vp), ("C4", vp)]
+                ("drop", QstDrop), ("drop_where", C.c_int32), ("C3", vp), ("C4", vp), ("sat16", C.c_int32)]
 
 
 class QstLnEpi(C.Structure):
@@ -180,6 +180,18 @@ SIGNATURES = {
     "qst_attention_fwd_x3_drop": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
 }
 
+# f16-operand twins (include/qst_kernels.h, "f16-operand twins"): same signatures, IEEE half where the original has bf16
+F16_TWINS = ["qst_gemm_nt", "qst_gemm_nt_ln", "qst_ffn_chain", "qst_gemm_tn", "qst_gemm_tn_group", "qst_gemm_nt8_supported",
+             "qst_gemm_nt8", "qst_gemm_tn8_group", "qst_embed_ln_fwd", "qst_embed_ln_fwd_drop", "qst_ln_fwd", "qst_ln_bwd",
+             "qst_ln_bwd_drop", "qst_attention_fwd", "qst_attention_bwd", "qst_attention_fwd_ex", "qst_attention_bwd_ex",
+             "qst_shadow_all", "qst_shadow_matrix"]
+for _n in F16_TWINS:
+    SIGNATURES[_n + "_f16"] = SIGNATURES[_n]
+SIGNATURES["qst_amp_scaler_init"] = (C.c_int, [vp, C.c_float, vp])
+SIGNATURES["qst_clip_adamw_step_amp"] = (C.c_int, [vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                                  C.c_float, C.c_float, C.c_int64, C.c_int64, vp, vp, C.c_float, C.c_float,
+                                                  C.c_int32, vp, vp, vp])
+
 _lib: Optional[C.CDLL] = None
 
 
@@ -212,6 +224,11 @@ def make_config(cfg, precision: int = 0) -> QstConfig:
     return QstConfig(cfg.arch, cfg.vocab_size, cfg.hidden_size, cfg.num_layers, cfg.num_heads,
                      cfg.intermediate_size, cfg.max_position, cfg.type_vocab_size, cfg.layer_norm_eps,
                      int(cfg.normalize), cfg.rel_buckets, cfg.rel_max_distance, cfg.pad_token_id, precision)
+
+
+def kfn(lib, name: str, op: str = "bf16"):
+    """The kernel-level entry point `name` for 16-bit operand type `op` ("bf16" or "f16": the _f16 twin)."""
+    return getattr(lib, name + ("_f16" if op == "f16" else ""))
 
 
 def ptr(t) -> Optional[int]:

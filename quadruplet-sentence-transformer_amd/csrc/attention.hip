@@ -33,25 +33,25 @@ template <int D> __device__ __forceinline__ uint32_t tr_off(int row, int byte) {
     if (D == 32) return (uint32_t)(row * 64 + byte);
     return (uint32_t)(row * 128 + (byte ^ (((row >> 1) & 1) << 6)));
 }
-__device__ __forceinline__ bf16x4 lds_tr(const char* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
+__device__ __forceinline__ op16x4 lds_tr(const char* p) {
+    return lds_tr16_op(p);
 }
 // A-operand fragment (32 rows = dd block `ddb`, k = 16 rows of the image starting at `row0`), k order matching an
 // accumulator-sourced B operand: element e of lane-half h <-> image row row0 + 8*(e>>2) + 4h + (e&3)
-template <int D> __device__ __forceinline__ bf16x8 tr_frag(const char* img, int row0, int ddb, int lane) {
+template <int D> __device__ __forceinline__ op16x8 tr_frag(const char* img, int row0, int ddb, int lane) {
     const int li = lane & 15, q = li >> 2, p = li & 3, gsel = (lane >> 4) & 1, h = lane >> 5;
     const int byte = ddb * 64 + gsel * 32 + 8 * p;
-    const bf16x4 a = lds_tr(img + tr_off<D>(row0 + 4 * h + q, byte));
-    const bf16x4 b = lds_tr(img + tr_off<D>(row0 + 8 + 4 * h + q, byte));
-    bf16x8 f;
+    const op16x4 a = lds_tr(img + tr_off<D>(row0 + 4 * h + q, byte));
+    const op16x4 b = lds_tr(img + tr_off<D>(row0 + 8 + 4 * h + q, byte));
+    op16x8 f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { f[e] = a[e]; f[4 + e] = b[e]; }
     return f;
 }
-__device__ __forceinline__ bf16x8 acc_frag(const f32x16& acc, int s) {
-    bf16x8 f;
+__device__ __forceinline__ op16x8 acc_frag(const f32x16& acc, int s) {
+    op16x8 f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = (bf16)acc[8 * s + e];
+    for (int e = 0; e < 8; ++e) f[e] = (op16)acc[8 * s + e];
     return f;
 }
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -89,7 +89,7 @@ struct Stager {
     static constexpr int CPR = D / 8;                 // 16-byte chunks per row
     static constexpr int PER = 128 * CPR / 256;       // chunks per thread per tensor (2 for d=32, 4 for d=64)
     u32x4 v[3][PER];
-    __device__ __forceinline__ void load(int t, const bf16* g, int ld, int rows, int tid) {
+    __device__ __forceinline__ void load(int t, const op16* g, int ld, int rows, int tid) {
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int idx = tid + 256 * k, row = idx / CPR, c = idx % CPR;
@@ -112,8 +112,8 @@ struct Stager {
 // table cost one uncoalesced 4-byte gather per score element (lanes 1 KB apart) and one global float atomic per
 // element for the gradient -- forward 227 vs 70 us and backward 677 vs 251 us at L = 256, d = 64.
 struct AttnArgs {
-    const bf16* qkv; const bf16* ctx; const bf16* dctx; const float* lse_in; const int64_t* mask;
-    const float* rel; bf16* out; bf16* dqkv; float* lse_out; float* drel; float* delta;
+    const op16* qkv; const op16* ctx; const op16* dctx; const float* lse_in; const int64_t* mask;
+    const float* rel; op16* out; op16* dqkv; float* lse_out; float* drel; float* delta;
     int nseq, L, A, H; float scale;
     // q / k / v (and their gradients) of one (sequence, head) are [L] rows of `ld` = 3H elements of the token-major
     // [M, 3H] tensor (q | k | v, heads concatenated) starting at qkv_base(); the k and v parts follow at + woff = H and
@@ -130,6 +130,7 @@ __device__ __forceinline__ size_t qkv_base(const AttnArgs& a, int seq, int head,
 // ------------------------------------------------------------------ forward
 template <int D, bool DROP = false>
 __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs a) {
+    op_saturate(true);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = D / 16, DB = D / 32, IMG = 128 * D * 2;
     char* kimg = smem;                  // row-read image of the K chunk
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs
         bid = 2 * ((bid >> 4) * 8 + (bid & 7)) + ((bid >> 3) & 1);
     const int qb = bid % nqb, head = (bid / nqb) % a.A, seq = bid / (nqb * a.A);
     const int ld = a.ld;
-    const bf16* base = a.qkv + qkv_base(a, seq, head, D);
+    const op16* base = a.qkv + qkv_base(a, seq, head, D);
     const int i0 = qb * 128 + wave * 32;
     const bool active = i0 < a.L;
     const int qi = i0 + fr;
@@ -159,10 +160,10 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs
     if (a.rel)
         for (int t = tid; t < 2 * a.L; t += 256) relv[t] = kLog2e * a.rel[(size_t)head * 2 * a.L + t];
 
-    bf16x8 qf[KS];
+    op16x8 qf[KS];
     if (active) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) qf[s] = *(const bf16x8*)(base + (size_t)qi * ld + 16 * s + 8 * h);
+        for (int s = 0; s < KS; ++s) qf[s] = *(const op16x8*)(base + (size_t)qi * ld + 16 * s + 8 * h);
     }
     f32x16 o[DB];
 #pragma unroll
@@ -192,8 +193,8 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(kimg + rr_off<D>(jt * 32 + fr, 2 * ks + h));
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+                const op16x8 kf = *(const op16x8*)(kimg + rr_off<D>(jt * 32 + fr, 2 * ks + h));
+                s = mfma32_op(kf, qf[ks], s);
             }
             const int j0 = c * 128 + jt * 32;
             float mx = -INFINITY;
@@ -232,11 +233,11 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs
                 for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 pf = acc_frag(s, ks);
+                const op16x8 pf = acc_frag(s, ks);
 #pragma unroll
                 for (int b = 0; b < DB; ++b) {
-                    const bf16x8 vf = tr_frag<D>(vimg, jt * 32 + 16 * ks, b, lane);
-                    o[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[b], 0, 0, 0);
+                    const op16x8 vf = tr_frag<D>(vimg, jt * 32 + 16 * ks, b, lane);
+                    o[b] = mfma32_op(vf, pf, o[b]);
                 }
             }
         }
@@ -251,12 +252,12 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_fwd_kernel(AttnArgs
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             u32x2 pk;
-            pk[0] = pack_bf16x2(o[b][4 * g] * inv, o[b][4 * g + 1] * inv);
-            pk[1] = pack_bf16x2(o[b][4 * g + 2] * inv, o[b][4 * g + 3] * inv);
+            pk[0] = pack_op2(o[b][4 * g] * inv, o[b][4 * g + 1] * inv);
+            pk[1] = pack_op2(o[b][4 * g + 2] * inv, o[b][4 * g + 3] * inv);
             *(u32x2*)(stg + rr_off<D>(fr, (b * 64 + 16 * g) >> 4) + 8 * h) = pk;
         }
     constexpr int CPR = D / 8;
-    bf16* obase = a.out + ((size_t)seq * a.L + i0) * a.H + head * D;
+    op16* obase = a.out + ((size_t)seq * a.L + i0) * a.H + head * D;
 #pragma unroll
     for (int kk = 0; kk < 32 * CPR / 64; ++kk) {
         const int idx = lane + 64 * kk, row = idx / CPR, c = idx % CPR;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dq_kernel(AttnA
     const int nqb = (a.L + 127) / 128;
     const int qb = blockIdx.x % nqb, head = (blockIdx.x / nqb) % a.A, seq = blockIdx.x / (nqb * a.A);
     const int ld = a.ld;
-    const bf16* base = a.qkv + qkv_base(a, seq, head, D);
+    const op16* base = a.qkv + qkv_base(a, seq, head, D);
     const int i0 = qb * 128 + wave * 32;
     const bool active = i0 < a.L;
     const int qi = i0 + fr;
@@ -289,16 +290,16 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dq_kernel(AttnA
     if (a.rel)
         for (int t = tid; t < 2 * a.L; t += 256) relv[t] = a.rel[(size_t)head * 2 * a.L + t];
 
-    bf16x8 qf[KS], dof[KS];
+    op16x8 qf[KS], dof[KS];
     float lse = 0.f, delta = 0.f;
     if (active) {
-        const bf16* orow = a.ctx + ((size_t)seq * a.L + qi) * a.H + head * D;
-        const bf16* drow = a.dctx + ((size_t)seq * a.L + qi) * a.H + head * D;
+        const op16* orow = a.ctx + ((size_t)seq * a.L + qi) * a.H + head * D;
+        const op16* drow = a.dctx + ((size_t)seq * a.L + qi) * a.H + head * D;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            qf[s] = *(const bf16x8*)(base + (size_t)qi * ld + 16 * s + 8 * h);
-            dof[s] = *(const bf16x8*)(drow + 16 * s + 8 * h);
-            const bf16x8 of = *(const bf16x8*)(orow + 16 * s + 8 * h);
+            qf[s] = *(const op16x8*)(base + (size_t)qi * ld + 16 * s + 8 * h);
+            dof[s] = *(const op16x8*)(drow + 16 * s + 8 * h);
+            const op16x8 of = *(const op16x8*)(orow + 16 * s + 8 * h);
 #pragma unroll
             for (int e = 0; e < 8; ++e) delta += (float)dof[s][e] * (float)of[e];
         }
@@ -334,10 +335,10 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dq_kernel(AttnA
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(kimg + rr_off<D>(jt * 32 + fr, 2 * ks + h));
-                const bf16x8 vf = *(const bf16x8*)(vimg + rr_off<D>(jt * 32 + fr, 2 * ks + h));
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);
+                const op16x8 kf = *(const op16x8*)(kimg + rr_off<D>(jt * 32 + fr, 2 * ks + h));
+                const op16x8 vf = *(const op16x8*)(vimg + rr_off<D>(jt * 32 + fr, 2 * ks + h));
+                s = mfma32_op(kf, qf[ks], s);
+                dp = mfma32_op(vf, dof[ks], dp);
             }
             const int j0 = c * 128 + jt * 32;
             if (DROP && dc.thr) {
@@ -362,24 +363,24 @@ __global__ __launch_bounds__(256, D == 32 ? 4 : 2) void attn_bwd_dq_kernel(AttnA
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 df = acc_frag(s, ks);
+                const op16x8 df = acc_frag(s, ks);
 #pragma unroll
                 for (int b = 0; b < DB; ++b) {
-                    const bf16x8 kt = tr_frag<D>(ktr, jt * 32 + 16 * ks, b, lane);
-                    dq[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, df, dq[b], 0, 0, 0);
+                    const op16x8 kt = tr_frag<D>(ktr, jt * 32 + 16 * ks, b, lane);
+                    dq[b] = mfma32_op(kt, df, dq[b]);
                 }
             }
         }
     }
     if (!active) return;
-    bf16* orow = a.dqkv + qkv_base(a, seq, head, D) + (size_t)qi * ld;
+    op16* orow = a.dqkv + qkv_base(a, seq, head, D) + (size_t)qi * ld;
 #pragma unroll
     for (int b = 0; b < DB; ++b)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             u32x2 pk;
-            pk[0] = pack_bf16x2(dq[b][4 * g], dq[b][4 * g + 1]);
-            pk[1] = pack_bf16x2(dq[b][4 * g + 2], dq[b][4 * g + 3]);
+            pk[0] = pack_op2(dq[b][4 * g], dq[b][4 * g + 1]);
+            pk[1] = pack_op2(dq[b][4 * g + 2], dq[b][4 * g + 3]);
             *(u32x2*)(orow + b * 32 + 8 * g + 4 * h) = pk;
         }
 }
@@ -401,8 +402,8 @@ __global__ __launch_bounds__(256, (D == 32 && !DROP) ? 4 : 2) void attn_bwd_dkv_
     const int nkb = (a.L + 127) / 128;
     const int kb = blockIdx.x % nkb, head = (blockIdx.x / nkb) % a.A, seq = blockIdx.x / (nkb * a.A);
     const int ld = a.ld;
-    const bf16* base = a.qkv + qkv_base(a, seq, head, D);
-    const bf16* dbase = a.dctx + (size_t)seq * a.L * a.H + head * D;
+    const op16* base = a.qkv + qkv_base(a, seq, head, D);
+    const op16* dbase = a.dctx + (size_t)seq * a.L * a.H + head * D;
     const int j0 = kb * 128 + wave * 32;
     const bool active = j0 < a.L;
     const int kj = j0 + fr;
@@ -412,13 +413,13 @@ __global__ __launch_bounds__(256, (D == 32 && !DROP) ? 4 : 2) void attn_bwd_dkv_
             relv[t] = a.rel[(size_t)head * 2 * a.L + t];
             drel_s[t] = drel_s[2 * a.L + t] = drel_s[4 * a.L + t] = drel_s[6 * a.L + t] = 0.f;
         }
-    bf16x8 kf[KS], vf[KS];
+    op16x8 kf[KS], vf[KS];
     float madd = 0.f;
     if (active) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            kf[s] = *(const bf16x8*)(base + (size_t)kj * ld + a.woff + 16 * s + 8 * h);
-            vf[s] = *(const bf16x8*)(base + (size_t)kj * ld + 2 * a.woff + 16 * s + 8 * h);
+            kf[s] = *(const op16x8*)(base + (size_t)kj * ld + a.woff + 16 * s + 8 * h);
+            vf[s] = *(const op16x8*)(base + (size_t)kj * ld + 2 * a.woff + 16 * s + 8 * h);
         }
         madd = a.mask[(size_t)seq * a.L + kj] ? 0.f : kMaskMin;
     }
@@ -457,10 +458,10 @@ __global__ __launch_bounds__(256, (D == 32 && !DROP) ? 4 : 2) void attn_bwd_dkv_
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 qf = *(const bf16x8*)(qimg + rr_off<D>(it * 32 + fr, 2 * ks + h));
-                const bf16x8 df = *(const bf16x8*)(dimg + rr_off<D>(it * 32 + fr, 2 * ks + h));
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], s, 0, 0, 0);      // rows i, col j
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], dp, 0, 0, 0);
+                const op16x8 qf = *(const op16x8*)(qimg + rr_off<D>(it * 32 + fr, 2 * ks + h));
+                const op16x8 df = *(const op16x8*)(dimg + rr_off<D>(it * 32 + fr, 2 * ks + h));
+                s = mfma32_op(qf, kf[ks], s);      // rows i, col j
+                dp = mfma32_op(df, vf[ks], dp);
             }
             const int i0 = c * 128 + it * 32;
             f32x16 p;
@@ -501,30 +502,30 @@ __global__ __launch_bounds__(256, (D == 32 && !DROP) ? 4 : 2) void attn_bwd_dkv_
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 pf = acc_frag(p, ks), sf = acc_frag(s, ks);
+                const op16x8 pf = acc_frag(p, ks), sf = acc_frag(s, ks);
 #pragma unroll
                 for (int b = 0; b < DB; ++b) {
-                    const bf16x8 dt = tr_frag<D>(dtr, it * 32 + 16 * ks, b, lane);
-                    const bf16x8 qt = tr_frag<D>(qtr, it * 32 + 16 * ks, b, lane);
-                    dv[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt, pf, dv[b], 0, 0, 0);
-                    dk[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, sf, dk[b], 0, 0, 0);
+                    const op16x8 dt = tr_frag<D>(dtr, it * 32 + 16 * ks, b, lane);
+                    const op16x8 qt = tr_frag<D>(qtr, it * 32 + 16 * ks, b, lane);
+                    dv[b] = mfma32_op(dt, pf, dv[b]);
+                    dk[b] = mfma32_op(qt, sf, dk[b]);
                 }
             }
         }
     }
     if (active) {
-        bf16* krow = a.dqkv + qkv_base(a, seq, head, D) + (size_t)kj * ld + a.woff;
-        bf16* vrow = krow + a.woff;
+        op16* krow = a.dqkv + qkv_base(a, seq, head, D) + (size_t)kj * ld + a.woff;
+        op16* vrow = krow + a.woff;
 #pragma unroll
         for (int b = 0; b < DB; ++b)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 u32x2 pk;
-                pk[0] = pack_bf16x2(dk[b][4 * g], dk[b][4 * g + 1]);
-                pk[1] = pack_bf16x2(dk[b][4 * g + 2], dk[b][4 * g + 3]);
+                pk[0] = pack_op2(dk[b][4 * g], dk[b][4 * g + 1]);
+                pk[1] = pack_op2(dk[b][4 * g + 2], dk[b][4 * g + 3]);
                 *(u32x2*)(krow + b * 32 + 8 * g + 4 * h) = pk;
-                pk[0] = pack_bf16x2(dv[b][4 * g], dv[b][4 * g + 1]);
-                pk[1] = pack_bf16x2(dv[b][4 * g + 2], dv[b][4 * g + 3]);
+                pk[0] = pack_op2(dv[b][4 * g], dv[b][4 * g + 1]);
+                pk[1] = pack_op2(dv[b][4 * g + 2], dv[b][4 * g + 3]);
                 *(u32x2*)(vrow + b * 32 + 8 * g + 4 * h) = pk;
             }
     }
@@ -553,13 +554,13 @@ __device__ __forceinline__ uint32_t ds_off(int row, int byte) { return (uint32_t
 // rows a half-wave reads (row0 + 4h + q, q = 0..3) share r >> 2, so each is still read whole, 256 contiguous bytes per
 // half-wave: no bank conflict, and the separate transposed copies of Q and dO (two more 16-byte LDS stores per thread and
 // tensor) are not needed.
-__device__ __forceinline__ bf16x8 tr_frag_rr32(const char* img, int row0, int lane) {
+__device__ __forceinline__ op16x8 tr_frag_rr32(const char* img, int row0, int lane) {
     const int li = lane & 15, q = li >> 2, p = li & 3, gsel = (lane >> 4) & 1, h = lane >> 5;
     const int ra = row0 + 4 * h + q, rb = ra + 8;
     const int chunk = 2 * gsel + (p >> 1), rem = 8 * (p & 1);
-    const bf16x4 a = lds_tr(img + ra * 64 + ((chunk ^ ((ra >> 2) & 3)) << 4) + rem);
-    const bf16x4 b = lds_tr(img + rb * 64 + ((chunk ^ ((rb >> 2) & 3)) << 4) + rem);
-    bf16x8 f;
+    const op16x4 a = lds_tr(img + ra * 64 + ((chunk ^ ((ra >> 2) & 3)) << 4) + rem);
+    const op16x4 b = lds_tr(img + rb * 64 + ((chunk ^ ((rb >> 2) & 3)) << 4) + rem);
+    op16x8 f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { f[e] = a[e]; f[4 + e] = b[e]; }
     return f;
@@ -567,10 +568,10 @@ __device__ __forceinline__ bf16x8 tr_frag_rr32(const char* img, int row0, int la
 
 // A-operand fragment that carries one fp32 value per row into a 32 x 32 accumulator tile: row (lane & 31) holds
 // x = hi + lo (two bf16) at k = 0, 1; every other k is zero. Multiplied by a B fragment of ones at k = 0, 1.
-__device__ __forceinline__ bf16x8 row_frag(float x, int h) {
-    const float hi = bf16lo(pack_bf16x2(x, 0.f));
-    u32x4 u = {h == 0 ? pack_bf16x2(x, x - hi) : 0u, 0u, 0u, 0u};
-    return __builtin_bit_cast(bf16x8, u);
+__device__ __forceinline__ op16x8 row_frag(float x, int h) {
+    const float hi = op_lo(pack_op2(x, 0.f));
+    u32x4 u = {h == 0 ? pack_op2(x, x - hi) : 0u, 0u, 0u, 0u};
+    return __builtin_bit_cast(op16x8, u);
 }
 
 template <int D, bool REL, bool DROP = false>
@@ -595,8 +596,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
     const int nitems = a.nseq * a.A;
     const float sc2 = a.scale * kLog2e, inv_scale = 1.0f / a.scale;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    u32x4 ones_u = {h == 0 ? 0x3F803F80u : 0u, 0u, 0u, 0u};          // B fragment: 1.0 at k = 0, 1 (held by the lanes of half 0)
-    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
+    u32x4 ones_u = {h == 0 ? pack_op2(1.f, 1.f) : 0u, 0u, 0u, 0u};  // B fragment: 1.0 at k = 0, 1 (held by the lanes of half 0)
+    const op16x8 ones = __builtin_bit_cast(op16x8, ones_u);
 
     // Persistent over (sequence, head) items: the global loads of item n+1 are in flight (in registers) while item n
     // is computed -- a workgroup per item spent most of its life waiting for its own loads at two workgroups per CU.
@@ -689,7 +690,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
         // -lse / scale enters the score accumulator (see the tile loop): q.k - lse / scale. A sequence of padding only has
         // lse ~ -2e38 (every key carries the finite mask constant of the forward): clamped, so that the value stays finite
         // through the bf16 hi/lo split; with every key masked the probabilities are exp2(-inf) = 0 whatever it is.
-        if (tid < rows) lse_s[tid] = fminf(-nlse * inv_scale, 1.0e30f);
+        // (f16 operands: the clamp sits inside half's range; real rows have |lse / scale| of a few hundred)
+        if (tid < rows) lse_s[tid] = fminf(-nlse * inv_scale, QST_OP_F16 ? 6.0e4f : 1.0e30f);
         if (REL)
             for (int t = tid; t < 2 * a.L; t += 256) {
                 relv[t] = kLog2e * a.rel[(size_t)head * 2 * a.L + t];
@@ -701,7 +703,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
             float part = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                part += bf16lo(pd[k][e]) * bf16lo(po[k][e]) + bf16hi(pd[k][e]) * bf16hi(po[k][e]);
+                part += op_lo(pd[k][e]) * op_lo(po[k][e]) + op_hi(pd[k][e]) * op_hi(po[k][e]);
 #pragma unroll
             for (int o = 1; o < CPR; o <<= 1) part += __shfl_xor(part, o);
             const int idx = tid + 256 * k, row = idx / CPR, c = idx % CPR;
@@ -727,11 +729,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
             // this wave's K / V operand fragments (lane = key row). Image rows of a wave's own keys are touched by no
             // other wave before the next barrier, so the V rows parked in the dS image are read before this wave's
             // first dS tile overwrites them (program order).
-            bf16x8 kf[KS], vf[KS];
+            op16x8 kf[KS], vf[KS];
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                kf[s] = *(const bf16x8*)(ktr + tr_off<D>(active ? kj : 0, (16 * s + 8 * h) * 2));
-                vf[s] = *(const bf16x8*)(dsimg + ds_off(active ? kj : 0, (16 * s + 8 * h) * 2));
+                kf[s] = *(const op16x8*)(ktr + tr_off<D>(active ? kj : 0, (16 * s + 8 * h) * 2));
+                vf[s] = *(const op16x8*)(dsimg + ds_off(active ? kj : 0, (16 * s + 8 * h) * 2));
             }
             // Unrolled over the (at most four) query tiles, prefetch quarter `it` issued by EVERY wave at one place in the
             // code: `it` is a constant in each copy and each prefetch register has a single definition, so the loads go
@@ -752,16 +754,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
                 // tile has. Reading them as per-row scalars cost 8 ds_read_b128 per tile (half-wave broadcasts, 45% of the
                 // kernel's LDS traffic, and the LDS pipe shared by the CU's 8 waves is what bounds this kernel) plus 8 packed
                 // adds; this way it is 2 ds_read_b32 and 2 of the idle matrix core's cycles.
-                const bf16x8 la = row_frag(lse_s[it * 32 + fr], h), da = row_frag(del_s[it * 32 + fr], h);
-                f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la, ones, zero16, 0, 0, 0);
-                f32x16 nd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, ones, zero16, 0, 0, 0);
+                const op16x8 la = row_frag(lse_s[it * 32 + fr], h), da = row_frag(del_s[it * 32 + fr], h);
+                f32x16 s = mfma32_op(la, ones, zero16);
+                f32x16 nd = mfma32_op(da, ones, zero16);
                 f32x16 dp = DROP ? zero16 : nd;                     // dropout: mask * dP~ - delta needs -delta on its own
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const bf16x8 qf = *(const bf16x8*)(qimg + rr_off<D>(it * 32 + fr, 2 * ks + h));
-                    const bf16x8 df = *(const bf16x8*)(dimg + rr_off<D>(it * 32 + fr, 2 * ks + h));
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], s, 0, 0, 0);      // rows i, col j
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], dp, 0, 0, 0);
+                    const op16x8 qf = *(const op16x8*)(qimg + rr_off<D>(it * 32 + fr, 2 * ks + h));
+                    const op16x8 df = *(const op16x8*)(dimg + rr_off<D>(it * 32 + fr, 2 * ks + h));
+                    s = mfma32_op(qf, kf[ks], s);      // rows i, col j
+                    dp = mfma32_op(df, vf[ks], dp);
                 }
                 if (it == 1) QST_STAMP(10);
                 // Elementwise part, trimmed because it and the LDS pipe (not the MFMAs) bound this kernel: s already holds
@@ -799,13 +801,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
                             mk[1] = (((wq[e + 1] >> dsh) & 0xFFu) >= dc.thr) ? dc.scale : 0.f;
                             ndv[0] = nd[r]; ndv[1] = nd[r + 1];
                             dpv = dpv * mk + ndv;
-                            pw[g][e >> 1] = pack_bf16x2(pr[0] * mk[0], pr[1] * mk[1]);
+                            pw[g][e >> 1] = pack_op2(pr[0] * mk[0], pr[1] * mk[1]);
                         } else {
-                            pw[g][e >> 1] = pack_bf16x2(pr[0], pr[1]);
+                            pw[g][e >> 1] = pack_op2(pr[0], pr[1]);
                         }
                         const f32x2 dsr = pr * dpv;                               // dS (unscaled) = d(score)
                         if (REL && a.drel) { diag_add(dsr[0], r, lane, dlo, dhi); diag_add(dsr[1], r + 1, lane, dlo, dhi); }
-                        sw[g][e >> 1] = pack_bf16x2(dsr[0], dsr[1]);
+                        sw[g][e >> 1] = pack_op2(dsr[0], dsr[1]);
                     }
                     u32x2 pkd;
                     pkd[0] = sw[g][0]; pkd[1] = sw[g][1];
@@ -818,13 +820,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
                     u32x4 pu, su;
                     pu[0] = pw[2 * ks][0]; pu[1] = pw[2 * ks][1]; pu[2] = pw[2 * ks + 1][0]; pu[3] = pw[2 * ks + 1][1];
                     su[0] = sw[2 * ks][0]; su[1] = sw[2 * ks][1]; su[2] = sw[2 * ks + 1][0]; su[3] = sw[2 * ks + 1][1];
-                    const bf16x8 pf = __builtin_bit_cast(bf16x8, pu), sf = __builtin_bit_cast(bf16x8, su);
+                    const op16x8 pf = __builtin_bit_cast(op16x8, pu), sf = __builtin_bit_cast(op16x8, su);
 #pragma unroll
                     for (int b = 0; b < DB; ++b) {
-                        const bf16x8 dt = tr_frag_rr32(dimg, it * 32 + 16 * ks, lane);
-                        const bf16x8 qt = tr_frag_rr32(qimg, it * 32 + 16 * ks, lane);
-                        dv[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt, pf, dv[b], 0, 0, 0);
-                        dk[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, sf, dk[b], 0, 0, 0);
+                        const op16x8 dt = tr_frag_rr32(dimg, it * 32 + 16 * ks, lane);
+                        const op16x8 qt = tr_frag_rr32(qimg, it * 32 + 16 * ks, lane);
+                        dv[b] = mfma32_op(dt, pf, dv[b]);
+                        dk[b] = mfma32_op(qt, sf, dk[b]);
                     }
                 }
                 if (it == 1) QST_STAMP(12);
@@ -852,15 +854,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
             const int li = lane & 15, q = li >> 2, pp = li & 3, gsel = (lane >> 4) & 1;
             const int byte = wave * 64 + gsel * 32 + 8 * pp;
             for (int ks = 0; ks < rows / 16; ++ks) {
-                const bf16x4 lo = lds_tr(dsimg + ds_off(16 * ks + 4 * h + q, byte));
-                const bf16x4 hi = lds_tr(dsimg + ds_off(16 * ks + 8 + 4 * h + q, byte));
-                bf16x8 df;
+                const op16x4 lo = lds_tr(dsimg + ds_off(16 * ks + 4 * h + q, byte));
+                const op16x4 hi = lds_tr(dsimg + ds_off(16 * ks + 8 + 4 * h + q, byte));
+                op16x8 df;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { df[e] = lo[e]; df[4 + e] = hi[e]; }
 #pragma unroll
                 for (int b = 0; b < DB; ++b) {
-                    const bf16x8 kt = tr_frag<D>(ktr, 16 * ks, b, lane);
-                    dq[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, df, dq[b], 0, 0, 0);
+                    const op16x8 kt = tr_frag<D>(ktr, 16 * ks, b, lane);
+                    dq[b] = mfma32_op(kt, df, dq[b]);
                 }
             }
             QST_STAMP(5);
@@ -874,14 +876,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
                 for (int g = 0; g < 4; ++g) {
                     u32x2 o2;
                     const uint32_t off = rr_off<D>(fr, (b * 64 + 16 * g) >> 4) + 8 * h;
-                    o2[0] = pack_bf16x2(dq[b][4 * g] * a.scale, dq[b][4 * g + 1] * a.scale);
-                    o2[1] = pack_bf16x2(dq[b][4 * g + 2] * a.scale, dq[b][4 * g + 3] * a.scale);
+                    o2[0] = pack_op2(dq[b][4 * g] * a.scale, dq[b][4 * g + 1] * a.scale);
+                    o2[1] = pack_op2(dq[b][4 * g + 2] * a.scale, dq[b][4 * g + 3] * a.scale);
                     *(u32x2*)(stg + off) = o2;
-                    o2[0] = pack_bf16x2(dk[b][4 * g], dk[b][4 * g + 1]);
-                    o2[1] = pack_bf16x2(dk[b][4 * g + 2], dk[b][4 * g + 3]);
+                    o2[0] = pack_op2(dk[b][4 * g], dk[b][4 * g + 1]);
+                    o2[1] = pack_op2(dk[b][4 * g + 2], dk[b][4 * g + 3]);
                     *(u32x2*)(stg + 32 * D * 2 + off) = o2;
-                    o2[0] = pack_bf16x2(dv[b][4 * g], dv[b][4 * g + 1]);
-                    o2[1] = pack_bf16x2(dv[b][4 * g + 2], dv[b][4 * g + 3]);
+                    o2[0] = pack_op2(dv[b][4 * g], dv[b][4 * g + 1]);
+                    o2[1] = pack_op2(dv[b][4 * g + 2], dv[b][4 * g + 3]);
                     *(u32x2*)(stg + 2 * 32 * D * 2 + off) = o2;
                 }
             // wave-private staging: no workgroup barrier, the LDS queue is in order within a wave
@@ -904,13 +906,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
 
 // tr_frag on the ROW-READ image of 128-byte rows (rr_off<64>): correct for any swizzle that keeps 16-byte chunks whole;
 // the four rows a half-wave reads collide pairwise in the banks (2-way), the price of one image instead of two
-__device__ __forceinline__ bf16x8 tr_frag_rr64(const char* img, int row0, int ddb, int lane) {
+__device__ __forceinline__ op16x8 tr_frag_rr64(const char* img, int row0, int ddb, int lane) {
     const int li = lane & 15, q = li >> 2, p = li & 3, gsel = (lane >> 4) & 1, h = lane >> 5;
     const int chunk = ddb * 4 + gsel * 2 + (p >> 1), rem = 8 * (p & 1);
     const int ra = row0 + 4 * h + q, rb = ra + 8;
-    const bf16x4 a = lds_tr(img + rr_off<64>(ra, chunk) + rem);
-    const bf16x4 b = lds_tr(img + rr_off<64>(rb, chunk) + rem);
-    bf16x8 f;
+    const op16x4 a = lds_tr(img + rr_off<64>(ra, chunk) + rem);
+    const op16x4 b = lds_tr(img + rr_off<64>(rb, chunk) + rem);
+    op16x8 f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { f[e] = a[e]; f[4 + e] = b[e]; }
     return f;
@@ -942,9 +944,9 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_one64_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, fr = lane & 31;
     const int head = blockIdx.x % a.A, seq = blockIdx.x / a.A;
     const int ld = a.ld, L = a.L;
-    const bf16* base = a.qkv + qkv_base(a, seq, head, D);
-    const bf16* dbase_p = a.dctx + (size_t)seq * L * a.H + head * D;
-    const bf16* obase_p = a.ctx + (size_t)seq * L * a.H + head * D;
+    const op16* base = a.qkv + qkv_base(a, seq, head, D);
+    const op16* dbase_p = a.dctx + (size_t)seq * L * a.H + head * D;
+    const op16* obase_p = a.ctx + (size_t)seq * L * a.H + head * D;
     const int nchunk = (L + 127) / 128, npass = (L + 255) / 256;
 
     for (int t = tid; t < L; t += 512) lse_s[t] = a.lse_in[((size_t)seq * a.A + head) * L + t];
@@ -978,11 +980,11 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_one64_kernel(AttnArgs a) {
             const u32x4 v = row < nkeys ? *(const u32x4*)(base + (size_t)(256 * p + row) * ld + a.woff + c * 8) : z;
             *(u32x4*)(kimg + rr_off<D>(row, c)) = v;
         }
-        bf16x8 vf[KS];
+        op16x8 vf[KS];
         float madd = 0.f;
         if (active) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) vf[s] = *(const bf16x8*)(base + (size_t)kj * ld + 2 * a.woff + 16 * s + 8 * h);
+            for (int s = 0; s < KS; ++s) vf[s] = *(const op16x8*)(base + (size_t)kj * ld + 2 * a.woff + 16 * s + 8 * h);
             madd = a.mask[(size_t)seq * L + kj] ? 0.f : kMaskMin;
         }
         f32x16 dk[DB], dv[DB];
@@ -1015,7 +1017,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_one64_kernel(AttnArgs a) {
                         float part = 0.f;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            part += bf16lo(vd[k][e]) * bf16lo(vo[k][e]) + bf16hi(vd[k][e]) * bf16hi(vo[k][e]);
+                            part += op_lo(vd[k][e]) * op_lo(vo[k][e]) + op_hi(vd[k][e]) * op_hi(vo[k][e]);
                         part += dpp_mov<0xB1>(part);         // quad_perm [1,0,3,2]
                         part += dpp_mov<0x4E>(part);         // quad_perm [2,3,0,1]
                         part += dpp_mov<0x141>(part);        // row_half_mirror: the other quad of the 8 lanes
@@ -1034,11 +1036,11 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_one64_kernel(AttnArgs a) {
                     for (int ks = 0; ks < KS; ++ks) {
                         // (this wave's K fragments are re-read from the pass image per tile: 16 registers fewer to keep alive
                         // through the elementwise part, where the kernel is at the register limit)
-                        const bf16x8 kf = *(const bf16x8*)(kimg + rr_off<D>(32 * wave + fr, 2 * ks + h));
-                        const bf16x8 qf = *(const bf16x8*)(qimg + rr_off<D>(it * 32 + fr, 2 * ks + h));
-                        const bf16x8 df = *(const bf16x8*)(dimg + rr_off<D>(it * 32 + fr, 2 * ks + h));
-                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf, s, 0, 0, 0);          // rows i, col j
-                        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], dp, 0, 0, 0);
+                        const op16x8 kf = *(const op16x8*)(kimg + rr_off<D>(32 * wave + fr, 2 * ks + h));
+                        const op16x8 qf = *(const op16x8*)(qimg + rr_off<D>(it * 32 + fr, 2 * ks + h));
+                        const op16x8 df = *(const op16x8*)(dimg + rr_off<D>(it * 32 + fr, 2 * ks + h));
+                        s = mfma32_op(qf, kf, s);          // rows i, col j
+                        dp = mfma32_op(df, vf[ks], dp);
                     }
                     const int i0 = c * 128 + it * 32;
 #pragma unroll
@@ -1064,8 +1066,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_one64_kernel(AttnArgs a) {
                             dp[r] = pr * mk;                      // dP is spent: its register takes the (dropped) probability dV needs
                             s[r] = dsr;
                         }
-                        sw[0] = pack_bf16x2(s[4 * g], s[4 * g + 1]);
-                        sw[1] = pack_bf16x2(s[4 * g + 2], s[4 * g + 3]);
+                        sw[0] = pack_op2(s[4 * g], s[4 * g + 1]);
+                        sw[1] = pack_op2(s[4 * g + 2], s[4 * g + 3]);
                         u32x2 pkd; pkd[0] = sw[0]; pkd[1] = sw[1];
                         *(u32x2*)(dsimg + ds_off(32 * wave + fr, (it * 32 + 8 * g + 4 * h) * 2)) = pkd;
                     }
@@ -1077,13 +1079,13 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_one64_kernel(AttnArgs a) {
                     }
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        const bf16x8 pf = acc_frag(dp, ks), sf = acc_frag(s, ks);
+                        const op16x8 pf = acc_frag(dp, ks), sf = acc_frag(s, ks);
 #pragma unroll
                         for (int b = 0; b < DB; ++b) {
-                            const bf16x8 dt = tr_frag_rr64(dimg, it * 32 + 16 * ks, b, lane);
-                            const bf16x8 qt = tr_frag_rr64(qimg, it * 32 + 16 * ks, b, lane);
-                            dv[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt, pf, dv[b], 0, 0, 0);
-                            dk[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, sf, dk[b], 0, 0, 0);
+                            const op16x8 dt = tr_frag_rr64(dimg, it * 32 + 16 * ks, b, lane);
+                            const op16x8 qt = tr_frag_rr64(qimg, it * 32 + 16 * ks, b, lane);
+                            dv[b] = mfma32_op(dt, pf, dv[b]);
+                            dk[b] = mfma32_op(qt, sf, dk[b]);
                         }
                     }
                 }
@@ -1097,13 +1099,13 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_one64_kernel(AttnArgs a) {
                 // uniform switch around the k loop: dq[] stays in registers only while every index is a constant)
                 auto accumulate = [&](f32x16& acc) {
                     for (int ks = 0; ks < nkeys / 16; ++ks) {
-                        const bf16x4 lo = lds_tr(dsimg + ds_off(16 * ks + 4 * h + q, byte));
-                        const bf16x4 hi = lds_tr(dsimg + ds_off(16 * ks + 8 + 4 * h + q, byte));
-                        bf16x8 df;
+                        const op16x4 lo = lds_tr(dsimg + ds_off(16 * ks + 4 * h + q, byte));
+                        const op16x4 hi = lds_tr(dsimg + ds_off(16 * ks + 8 + 4 * h + q, byte));
+                        op16x8 df;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { df[e] = lo[e]; df[4 + e] = hi[e]; }
-                        const bf16x8 kt = tr_frag_rr64(kimg, 16 * ks, b_mine, lane);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, df, acc, 0, 0, 0);
+                        const op16x8 kt = tr_frag_rr64(kimg, 16 * ks, b_mine, lane);
+                        acc = mfma32_op(kt, df, acc);
                     }
                 };
                 if (c == 0) accumulate(dq[0]);
@@ -1113,18 +1115,18 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_one64_kernel(AttnArgs a) {
             }
         }
         if (active) {
-            bf16* krow = a.dqkv + qkv_base(a, seq, head, D) + (size_t)kj * ld + a.woff;
-            bf16* vrow = krow + a.woff;
+            op16* krow = a.dqkv + qkv_base(a, seq, head, D) + (size_t)kj * ld + a.woff;
+            op16* vrow = krow + a.woff;
 #pragma unroll
             for (int b = 0; b < DB; ++b)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     u32x2 pk;
-                    pk[0] = pack_bf16x2(dk[b][4 * g] * a.scale, dk[b][4 * g + 1] * a.scale);
-                    pk[1] = pack_bf16x2(dk[b][4 * g + 2] * a.scale, dk[b][4 * g + 3] * a.scale);
+                    pk[0] = pack_op2(dk[b][4 * g] * a.scale, dk[b][4 * g + 1] * a.scale);
+                    pk[1] = pack_op2(dk[b][4 * g + 2] * a.scale, dk[b][4 * g + 3] * a.scale);
                     *(u32x2*)(krow + b * 32 + 8 * g + 4 * h) = pk;
-                    pk[0] = pack_bf16x2(dv[b][4 * g], dv[b][4 * g + 1]);
-                    pk[1] = pack_bf16x2(dv[b][4 * g + 2], dv[b][4 * g + 3]);
+                    pk[0] = pack_op2(dv[b][4 * g], dv[b][4 * g + 1]);
+                    pk[1] = pack_op2(dv[b][4 * g + 2], dv[b][4 * g + 3]);
                     *(u32x2*)(vrow + b * 32 + 8 * g + 4 * h) = pk;
                 }
         }
@@ -1134,12 +1136,12 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_one64_kernel(AttnArgs a) {
     for (int c = 0; c < NC; ++c) {
         const int qi = c * 128 + qt_mine * 32 + fr;
         if (c >= nchunk || qi >= L) continue;
-        bf16* orow = a.dqkv + qkv_base(a, seq, head, D) + (size_t)qi * ld + b_mine * 32;
+        op16* orow = a.dqkv + qkv_base(a, seq, head, D) + (size_t)qi * ld + b_mine * 32;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             u32x2 pk;
-            pk[0] = pack_bf16x2(dq[c][4 * g] * a.scale, dq[c][4 * g + 1] * a.scale);
-            pk[1] = pack_bf16x2(dq[c][4 * g + 2] * a.scale, dq[c][4 * g + 3] * a.scale);
+            pk[0] = pack_op2(dq[c][4 * g] * a.scale, dq[c][4 * g + 1] * a.scale);
+            pk[1] = pack_op2(dq[c][4 * g + 2] * a.scale, dq[c][4 * g + 3] * a.scale);
             *(u32x2*)(orow + 8 * g + 4 * h) = pk;
         }
     }
@@ -1171,7 +1173,7 @@ static int check_attn(int nseq, int L, int A, int d) {
 static int fill_args(const QstAttnDesc* q, AttnArgs& a) {
     if (!q || !q->qkv || !q->mask || !q->ctx) return QST_ERR_BAD_ARG;
     if (int rc = check_attn(q->nseq, q->L, q->A, q->d)) return rc;
-    a.qkv = (const bf16*)q->qkv; a.mask = q->mask; a.rel = q->rel_pos;
+    a.qkv = (const op16*)q->qkv; a.mask = q->mask; a.rel = q->rel_pos;
     a.nseq = q->nseq; a.L = q->L; a.A = q->A; a.H = q->A * q->d; a.scale = 1.0f / sqrtf((float)q->d);
     a.ld = 3 * a.H; a.woff = a.H;
     a.drop = q->drop;
@@ -1181,10 +1183,10 @@ static int fill_args(const QstAttnDesc* q, AttnArgs& a) {
     return QST_OK;
 }
 
-extern "C" int qst_attention_fwd_ex(const QstAttnDesc* q, void* stream) {
+extern "C" int QST_K(qst_attention_fwd_ex)(const QstAttnDesc* q, void* stream) {
     AttnArgs a{};
     if (int rc = fill_args(q, a)) return rc;
-    a.out = (bf16*)q->ctx; a.lse_out = q->lse;
+    a.out = (op16*)q->ctx; a.lse_out = q->lse;
     const int nseq = a.nseq, L = a.L, A = a.A, d = q->d;
     const bool rel = a.rel != nullptr, drop = a.drop.thr16 != 0u;
     int rc;
@@ -1201,13 +1203,13 @@ extern "C" int qst_attention_fwd_ex(const QstAttnDesc* q, void* stream) {
     return QST_OK;
 }
 
-extern "C" int qst_attention_bwd_ex(const QstAttnDesc* q, void* stream) {
+extern "C" int QST_K(qst_attention_bwd_ex)(const QstAttnDesc* q, void* stream) {
     AttnArgs a{};
     if (int rc = fill_args(q, a)) return rc;
     if (!q->dctx || !q->lse || !q->dqkv || !q->delta_scratch) return QST_ERR_BAD_ARG;
     if (q->drel && !q->rel_pos) return QST_ERR_BAD_ARG;
-    a.ctx = (const bf16*)q->ctx; a.dctx = (const bf16*)q->dctx; a.lse_in = q->lse;
-    a.dqkv = (bf16*)q->dqkv; a.drel = q->drel; a.delta = q->delta_scratch;
+    a.ctx = (const op16*)q->ctx; a.dctx = (const op16*)q->dctx; a.lse_in = q->lse;
+    a.dqkv = (op16*)q->dqkv; a.drel = q->drel; a.delta = q->delta_scratch;
     const int nseq = a.nseq, L = a.L, A = a.A, d = q->d;
     const bool rel = a.rel != nullptr, drop = a.drop.thr16 != 0u;
     int rc;
@@ -1264,21 +1266,22 @@ extern "C" int qst_attention_bwd_ex(const QstAttnDesc* q, void* stream) {
     return QST_OK;
 }
 
-extern "C" int qst_attention_fwd(const void* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A,
+extern "C" int QST_K(qst_attention_fwd)(const void* qkv, const int64_t* mask, const float* rel_bias, int nseq, int L, int A,
                                  int d, void* ctx, float* lse, void* stream) {
     QstAttnDesc q{};
     q.qkv = qkv; q.mask = mask; q.rel_pos = rel_bias; q.nseq = nseq; q.L = L; q.A = A; q.d = d; q.ctx = ctx; q.lse = lse;
-    return qst_attention_fwd_ex(&q, stream);
+    return QST_K(qst_attention_fwd_ex)(&q, stream);
 }
-extern "C" int qst_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse,
+extern "C" int QST_K(qst_attention_bwd)(const void* qkv, const void* ctx, const void* dctx, const float* lse,
                                  const int64_t* mask, const float* rel_bias, int nseq, int L, int A, int d,
                                  void* dqkv, float* drel, float* delta_scratch, void* stream) {
     QstAttnDesc q{};
     q.qkv = qkv; q.mask = mask; q.rel_pos = rel_bias; q.nseq = nseq; q.L = L; q.A = A; q.d = d; q.ctx = (void*)ctx;
     q.lse = (float*)lse; q.dctx = dctx; q.dqkv = dqkv; q.drel = drel; q.delta_scratch = delta_scratch;
-    return qst_attention_bwd_ex(&q, stream);
+    return QST_K(qst_attention_bwd_ex)(&q, stream);
 }
 
+#if !QST_OP_F16
 // Diagnostic (not declared in the public headers): resident workgroups per CU the runtime reports for the d=32 kernels.
 extern "C" int qst_debug_attn_occupancy(int which, int lds_bytes) {
     int n = -1;
@@ -1287,3 +1290,4 @@ extern "C" int qst_debug_attn_occupancy(int which, int lds_bytes) {
     if (which == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dkv_kernel<32, false>, 256, lds_bytes);
     return n;
 }
+#endif

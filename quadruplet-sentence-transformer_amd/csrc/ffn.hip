@@ -61,19 +61,20 @@ constexpr int F_HB = 2 * F_SLOT;           // chunk images at 96 KB (3 x 16 KB)
 constexpr int F_VEC = F_HB + 3 * F_IMG;    // fp32 vectors at 144 KB: bias1 [I], then bias2 / gamma / beta [384]
 constexpr int LN_LD = 388;                 // epilogue slab row stride in floats (1552 B: ds_write_b128 conflict-free)
 
-template <int NB> struct Frag { bf16x8 a; bf16x8 b[NB]; };     // one k-step's MFMA operands of a wave (b[] statically indexed)
+template <int NB> struct Frag { op16x8 a; op16x8 b[NB]; };     // one k-step's MFMA operands of a wave (b[] statically indexed)
 
 struct FfnArgs {
-    const bf16* A; const bf16* B1; const bf16* B2;
+    const op16* A; const op16* B1; const op16* B2;
     const float* bias1; const float* bias2; const float* resid;
-    const bf16* aux; bf16* save_gp; bf16* save_h;
-    float* C; bf16* C2;
+    const op16* aux; op16* save_gp; op16* save_h;
+    float* C; op16* C2;
     int M, I;
     int diag;        // timing experiments (QstFfnArgs.diag): 1 = drop the A loads, 2 = drop the weight loads, 4 = L2 touch-ahead
 };
 
 template <int MODE, bool SAVE>
 __global__ __launch_bounds__(512, 1) void ffn_chain_kernel(FfnArgs g, QstLnEpi e) {
+    op_saturate(MODE == 0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -211,13 +212,13 @@ __global__ __launch_bounds__(512, 1) void ffn_chain_kernel(FfnArgs g, QstLnEpi e
             // the compiler from folding the groups back together.
             Frag<3> f0, f1;                                      // two named fragment sets (no runtime-indexed arrays)
             const int arow = wm * 32 + fr, brow = wn * 96 + fr;
-#define load1(ks, f) do { (f).a = *(const bf16x8*)(pa + img_off(arow, (ks) * 2 + fh));                                   \
-                          (f).b[0] = *(const bf16x8*)(pb + img_off(brow, (ks) * 2 + fh));                                \
-                          (f).b[1] = *(const bf16x8*)(pb + img_off(brow + 32, (ks) * 2 + fh));                           \
-                          (f).b[2] = *(const bf16x8*)(pb + img_off(brow + 64, (ks) * 2 + fh)); } while (0)
-#define mma1(f) do { acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((f).b[0], (f).a, acc1[0], 0, 0, 0);               \
-                     acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((f).b[1], (f).a, acc1[1], 0, 0, 0);               \
-                     acc1[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((f).b[2], (f).a, acc1[2], 0, 0, 0); } while (0)   /* D rows = n, col = m */
+#define load1(ks, f) do { (f).a = *(const op16x8*)(pa + img_off(arow, (ks) * 2 + fh));                                   \
+                          (f).b[0] = *(const op16x8*)(pb + img_off(brow, (ks) * 2 + fh));                                \
+                          (f).b[1] = *(const op16x8*)(pb + img_off(brow + 32, (ks) * 2 + fh));                           \
+                          (f).b[2] = *(const op16x8*)(pb + img_off(brow + 64, (ks) * 2 + fh)); } while (0)
+#define mma1(f) do { acc1[0] = mfma32_op((f).b[0], (f).a, acc1[0]);               \
+                     acc1[1] = mfma32_op((f).b[1], (f).a, acc1[1]);               \
+                     acc1[2] = mfma32_op((f).b[2], (f).a, acc1[2]); } while (0)   /* D rows = n, col = m */
 #define FENCE __builtin_amdgcn_sched_barrier(0)
             load1(0, f0); FENCE;
             load1(1, f1); FENCE; mma1(f0); FENCE; issue_pieces(s + 1, 0, 2); FENCE;
@@ -256,8 +257,8 @@ __global__ __launch_bounds__(512, 1) void ffn_chain_kernel(FfnArgs g, QstLnEpi e
                             x2[1] = acc1[j][4 * g4 + 2 * h2 + 1] + b4[2 * h2 + 1];
                             gelu_parts2(x2, cdf, pdf);
                             const qst_f32x2 gg = x2 * pdf + cdf, hh = x2 * cdf;
-                            pg[h2] = pack_bf16x2(gg[0], gg[1]);
-                            out[h2] = pack_bf16x2(hh[0], hh[1]);
+                            pg[h2] = pack_op2(gg[0], gg[1]);
+                            out[h2] = pack_op2(hh[0], hh[1]);
                         }
                         if (SAVE)
                             __builtin_amdgcn_raw_buffer_store_b64(pg, rgp, (int)(((uint32_t)ml * I + c * FIC + nl) * 2u), 0, 0);
@@ -265,8 +266,8 @@ __global__ __launch_bounds__(512, 1) void ffn_chain_kernel(FfnArgs g, QstLnEpi e
                         const u32x2 ax = *(const u32x2*)p;       // gelu'(u) of the same four elements
 #pragma unroll
                         for (int h2 = 0; h2 < 2; ++h2)
-                            out[h2] = pack_bf16x2(acc1[j][4 * g4 + 2 * h2] * bf16lo(ax[h2]),
-                                                  acc1[j][4 * g4 + 2 * h2 + 1] * bf16hi(ax[h2]));
+                            out[h2] = pack_op2(acc1[j][4 * g4 + 2 * h2] * op_lo(ax[h2]),
+                                                  acc1[j][4 * g4 + 2 * h2 + 1] * op_hi(ax[h2]));
                     }
                     *(u32x2*)p = out;
                 }
@@ -283,11 +284,11 @@ __global__ __launch_bounds__(512, 1) void ffn_chain_kernel(FfnArgs g, QstLnEpi e
             const char* ph = hbuf + kt * F_IMG;
             Frag<6> f0, f1;
             const int arow = wm * 32 + fr, brow = wn * 192 + fr;
-#define load2(ks, f) do { (f).a = *(const bf16x8*)(ph + img_off(arow, (ks) * 2 + fh));                                   \
+#define load2(ks, f) do { (f).a = *(const op16x8*)(ph + img_off(arow, (ks) * 2 + fh));                                   \
                           _Pragma("unroll") for (int j = 0; j < 6; ++j)                                                  \
-                              (f).b[j] = *(const bf16x8*)(pb + img_off(brow + j * 32, (ks) * 2 + fh)); } while (0)
+                              (f).b[j] = *(const op16x8*)(pb + img_off(brow + j * 32, (ks) * 2 + fh)); } while (0)
 #define mma2(f) do { _Pragma("unroll") for (int j = 0; j < 6; ++j)                                                       \
-                         acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((f).b[j], (f).a, acc2[j], 0, 0, 0); } while (0)
+                         acc2[j] = mfma32_op((f).b[j], (f).a, acc2[j]); } while (0)
             load2(0, f0); FENCE;
             load2(1, f1); FENCE; mma2(f0); FENCE; issue_pieces(s + 1, 0, 2); FENCE;
             load2(2, f0); FENCE; mma2(f1); FENCE; issue_pieces(s + 1, 2, 4); FENCE;
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(512, 1) void ffn_chain_kernel(FfnArgs g, QstLnEpi e
                 rv[k][t][0] = rv[k][t][1] = 0.f;
                 xv[k][t] = 0u;
                 if (ok && g.resid) rv[k][t] = *(const f32x2*)(g.resid + (size_t)m * FH + col);
-                if (MODE == 1 && ok) xv[k][t] = *(const uint32_t*)((const bf16*)e.xhat + (size_t)m * FH + col);
+                if (MODE == 1 && ok) xv[k][t] = *(const uint32_t*)((const op16*)e.xhat + (size_t)m * FH + col);
             }
             rs[k] = (MODE == 1 && ok) ? e.rstd[m] : 0.f;
         }
@@ -387,8 +388,8 @@ __global__ __launch_bounds__(512, 1) void ffn_chain_kernel(FfnArgs g, QstLnEpi e
                         o[0] = h0 * ga[0] + be[0];
                         o[1] = h1 * ga[1] + be[1];
                         *(f32x2*)(g.C + (size_t)m * FH + col) = o;
-                        if (g.C2) *(uint32_t*)(g.C2 + (size_t)m * FH + col) = pack_bf16x2(o[0], o[1]);
-                        if (e.xhat) *(uint32_t*)((bf16*)e.xhat + (size_t)m * FH + col) = pack_bf16x2(h0, h1);
+                        if (g.C2) *(uint32_t*)(g.C2 + (size_t)m * FH + col) = pack_op2(o[0], o[1]);
+                        if (e.xhat) *(uint32_t*)((op16*)e.xhat + (size_t)m * FH + col) = pack_op2(h0, h1);
                     }
                 }
             } else {
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(512, 1) void ffn_chain_kernel(FfnArgs g, QstLnEpi e
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     const f32x2 ga = *(const f32x2*)(vec_s + FH + 2 * (lane + 64 * t));
-                    x[t][0] = bf16lo(xv[k][t]); x[t][1] = bf16hi(xv[k][t]);
+                    x[t][0] = op_lo(xv[k][t]); x[t][1] = op_hi(xv[k][t]);
                     v[t][0] += rv[k][t][0];
                     v[t][1] += rv[k][t][1];
                     ag[t][0] += v[t][0] * x[t][0]; ag[t][1] += v[t][1] * x[t][1];
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(512, 1) void ffn_chain_kernel(FfnArgs g, QstLnEpi e
                         o[0] = rs[k] * (v[t][0] - m1 - x[t][0] * m2);
                         o[1] = rs[k] * (v[t][1] - m1 - x[t][1] * m2);
                         *(f32x2*)(g.C + (size_t)m * FH + col) = o;
-                        if (g.C2) *(uint32_t*)(g.C2 + (size_t)m * FH + col) = pack_bf16x2(o[0], o[1]);
+                        if (g.C2) *(uint32_t*)(g.C2 + (size_t)m * FH + col) = pack_op2(o[0], o[1]);
                     }
                 }
             }
@@ -442,9 +443,11 @@ __global__ __launch_bounds__(512, 1) void ffn_chain_kernel(FfnArgs g, QstLnEpi e
 
 }  // namespace
 
+#if !QST_OP_F16
 extern "C" int qst_ffn_chain_supported(int H, int I) { return (H == FH && I > 0 && I % FIC == 0 && I <= 4096) ? 1 : 0; }
+#endif
 
-extern "C" int qst_ffn_chain(const QstFfnArgs* a, const QstLnEpi* ln, int mode, void* stream) {
+extern "C" int QST_K(qst_ffn_chain)(const QstFfnArgs* a, const QstLnEpi* ln, int mode, void* stream) {
     if (!a || !ln || !a->A || !a->B1 || !a->B2 || !a->C || !ln->gamma || a->M <= 0) return QST_ERR_BAD_ARG;
     if (mode != 0 && mode != 1) return QST_ERR_BAD_ARG;
     if (!qst_ffn_chain_supported(a->H, a->I)) return QST_ERR_UNSUPPORTED;
@@ -452,10 +455,10 @@ extern "C" int qst_ffn_chain(const QstFfnArgs* a, const QstLnEpi* ln, int mode, 
     if (mode == 1 && (!ln->xhat || !ln->rstd || !a->aux || !a->save_h)) return QST_ERR_BAD_ARG;
     if ((int64_t)128 * a->I * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
     FfnArgs g{};
-    g.A = (const bf16*)a->A; g.B1 = (const bf16*)a->B1; g.B2 = (const bf16*)a->B2;
+    g.A = (const op16*)a->A; g.B1 = (const op16*)a->B1; g.B2 = (const op16*)a->B2;
     g.bias1 = a->bias1; g.bias2 = a->bias2; g.resid = a->resid;
-    g.aux = (const bf16*)a->aux; g.save_gp = (bf16*)a->save_gp; g.save_h = (bf16*)a->save_h;
-    g.C = a->C; g.C2 = (bf16*)a->C2; g.M = a->M; g.I = a->I; g.diag = (a->diag & 3) | ((a->diag & 4) ? 0 : 4);
+    g.aux = (const op16*)a->aux; g.save_gp = (op16*)a->save_gp; g.save_h = (op16*)a->save_h;
+    g.C = a->C; g.C2 = (op16*)a->C2; g.M = a->M; g.I = a->I; g.diag = (a->diag & 3) | ((a->diag & 4) ? 0 : 4);
     const int lds = F_VEC + (a->I + 3 * FH) * 4 + 8 * 256;
     if (lds > 160 * 1024) return QST_ERR_UNSUPPORTED;
     const int ntm = (a->M + FBM - 1) / FBM;

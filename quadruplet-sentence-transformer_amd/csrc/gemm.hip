@@ -107,8 +107,8 @@ __device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, in
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
     const int rows_a = min(NBM, g.M - m0), rows_b = min(NBN, g.N - n0);
-    const bf16* Ab = (const bf16*)g.A + (size_t)m0 * g.lda;
-    const bf16* Bb = (const bf16*)g.B + (size_t)n0 * g.ldb;
+    const op16* Ab = (const op16*)g.A + (size_t)m0 * g.lda;
+    const op16* Bb = (const op16*)g.B + (size_t)n0 * g.ldb;
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(Ab, (uint32_t)rows_a * g.lda * 2u);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(Bb, (uint32_t)rows_b * g.ldb * 2u);
 
@@ -167,16 +167,16 @@ __device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, in
         const char* pb = slot_b(kt);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 fa[2], fb[3];
+            op16x8 fa[2], fb[3];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *(const bf16x8*)(pa + nt_off(wm * 64 + i * 32 + fr, ks * 2 + fh));
+            for (int i = 0; i < 2; ++i) fa[i] = *(const op16x8*)(pa + nt_off(wm * 64 + i * 32 + fr, ks * 2 + fh));
 #pragma unroll
-            for (int j = 0; j < 3; ++j) fb[j] = *(const bf16x8*)(pb + nt_off(wn * 96 + j * 32 + fr, ks * 2 + fh));
+            for (int j = 0; j < 3; ++j) fb[j] = *(const op16x8*)(pb + nt_off(wn * 96 + j * 32 + fr, ks * 2 + fh));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // D rows = n, col = m
+                    acc[i][j] = mfma32_op(fb[j], fa[i], acc[i][j]);   // D rows = n, col = m
         }
     }
     __builtin_amdgcn_s_barrier();                     // all waves done with the ring before the epilogue reuses it
@@ -201,8 +201,8 @@ __device__ __forceinline__ void nt_mainloop_tall(const QstGemmArgs& g, char* sme
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int rows_a = min(NBM, g.M - m0), rows_b = min(NBN, g.N - n0);
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc((const bf16*)g.A + (size_t)m0 * g.lda, (uint32_t)rows_a * g.lda * 2u);
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc((const bf16*)g.B + (size_t)n0 * g.ldb, (uint32_t)rows_b * g.ldb * 2u);
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc((const op16*)g.A + (size_t)m0 * g.lda, (uint32_t)rows_a * g.lda * 2u);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc((const op16*)g.B + (size_t)n0 * g.ldb, (uint32_t)rows_b * g.ldb * 2u);
     uint32_t va[A_PER_WAVE], vb[B_PER_WAVE];
 #pragma unroll
     for (int t = 0; t < A_PER_WAVE; ++t) {
@@ -239,16 +239,16 @@ __device__ __forceinline__ void nt_mainloop_tall(const QstGemmArgs& g, char* sme
         const char* pb = pa + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[4], fb[3];
+            op16x8 fa[4], fb[3];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = *(const bf16x8*)(pa + nt_off32(wm * 128 + i * 32 + fr, ks * 2 + fh));
+            for (int i = 0; i < 4; ++i) fa[i] = *(const op16x8*)(pa + nt_off32(wm * 128 + i * 32 + fr, ks * 2 + fh));
 #pragma unroll
-            for (int j = 0; j < 3; ++j) fb[j] = *(const bf16x8*)(pb + nt_off32(wn * 96 + j * 32 + fr, ks * 2 + fh));
+            for (int j = 0; j < 3; ++j) fb[j] = *(const op16x8*)(pb + nt_off32(wn * 96 + j * 32 + fr, ks * 2 + fh));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma32_op(fb[j], fa[i], acc[i][j]);
         }
     }
     __builtin_amdgcn_s_barrier();
@@ -313,8 +313,8 @@ __device__ __forceinline__ void nt_epilogue(const QstGemmArgs& g, f32x16 (&acc)[
                 const size_t o = (size_t)m * g.ldc + n;
                 st_stream((f32x4*)((float*)g.C + o), v);
                 if (EPI == QST_EPI_F32_RESID_BF16) {
-                    u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
-                    st_stream((u32x2*)((bf16*)g.C2 + o), pk);
+                    u32x2 pk; pk[0] = pack_op2(v[0], v[1]); pk[1] = pack_op2(v[2], v[3]);
+                    st_stream((u32x2*)((op16*)g.C2 + o), pk);
                 }
             }
         } else {
@@ -329,7 +329,7 @@ __device__ __forceinline__ void nt_epilogue(const QstGemmArgs& g, f32x16 (&acc)[
                 const int n = n_base + c8 * 8;
                 const u32x4 z = {0u, 0u, 0u, 0u};
                 if (EPI == QST_EPI_GELU_BWD)
-                    av[t] = (m < g.M && n < g.N) ? ld_stream((const u32x4*)((const bf16*)g.aux + (size_t)m * g.ldc + n)) : z;
+                    av[t] = (m < g.M && n < g.N) ? ld_stream((const u32x4*)((const op16*)g.aux + (size_t)m * g.ldc + n)) : z;
             }
 #pragma unroll
             for (int j = 0; j < 3; ++j)
@@ -365,7 +365,7 @@ __device__ __forceinline__ void nt_epilogue(const QstGemmArgs& g, f32x16 (&acc)[
                 u32x4 pk;
                 if (EPI == QST_EPI_BF16) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                    for (int e = 0; e < 4; ++e) pk[e] = pack_op2(v[2 * e], v[2 * e + 1]);
                 } else if (EPI == QST_EPI_GELU) {
                     // h = gelu(u) feeds FFN2; gelu'(u) (not u) is what backward needs: both share one exp and one
                     // rcp, so the dgrad epilogue is a single multiply instead of a second erf evaluation
@@ -376,17 +376,17 @@ __device__ __forceinline__ void nt_epilogue(const QstGemmArgs& g, f32x16 (&acc)[
                         x2[0] = v[2 * e]; x2[1] = v[2 * e + 1];
                         gelu_parts2(x2, cdf, pdf);
                         const qst_f32x2 gg = x2 * pdf + cdf, hh = x2 * cdf;
-                        pg[e] = pack_bf16x2(gg[0], gg[1]);
-                        pk[e] = pack_bf16x2(hh[0], hh[1]);
+                        pg[e] = pack_op2(gg[0], gg[1]);
+                        pk[e] = pack_op2(hh[0], hh[1]);
                     }
-                    if (full) st_stream((u32x4*)((bf16*)g.C + o), pg);                     // gelu'(u), saved for backward
-                    else { u32x2 h2; h2[0] = pg[0]; h2[1] = pg[1]; st_stream((u32x2*)((bf16*)g.C + o), h2); }
+                    if (full) st_stream((u32x4*)((op16*)g.C + o), pg);                     // gelu'(u), saved for backward
+                    else { u32x2 h2; h2[0] = pg[0]; h2[1] = pg[1]; st_stream((u32x2*)((op16*)g.C + o), h2); }
                 } else {   // QST_EPI_GELU_BWD: acc * gelu'(u)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        pk[e] = pack_bf16x2(v[2 * e] * bf16lo(av[t][e]), v[2 * e + 1] * bf16hi(av[t][e]));
+                        pk[e] = pack_op2(v[2 * e] * op_lo(av[t][e]), v[2 * e + 1] * op_hi(av[t][e]));
                 }
-                bf16* dst = (EPI == QST_EPI_GELU) ? (bf16*)g.C2 : (bf16*)g.C;
+                op16* dst = (EPI == QST_EPI_GELU) ? (op16*)g.C2 : (op16*)g.C;
                 if (full) st_stream((u32x4*)(dst + o), pk);
                 else { u32x2 h2; h2[0] = pk[0]; h2[1] = pk[1]; st_stream((u32x2*)(dst + o), h2); }
             }
@@ -396,6 +396,7 @@ __device__ __forceinline__ void nt_epilogue(const QstGemmArgs& g, f32x16 (&acc)[
 
 template <int EPI, int WAVES_M, int WAVES_N = 2, int TI = 2>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 2 ? 2 : 1) void gemm_nt_kernel(QstGemmArgs g) {
+    op_saturate(g.sat16 != 0);                        // f16 build, forward launches: 16-bit outputs clamp at +-65,504
     constexpr int NBM = 32 * TI * WAVES_M, NBN = 96 * WAVES_N, NW = WAVES_M * WAVES_N;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 2 ? 2 : 1) void 
 #undef NT_STAMP
 }
 
+#if !QST_OP_F16      // (the fp8 kernels exist once, in the bf16 build of this file)
 // ---------------------------------------------------------------- NT on the fp8 matrix cores (MXFP8, inference)
 // C = A . B^T with BOTH operands in OCP MXFP8: e4m3 elements + one E8M0 scale (a power of two) per 32 consecutive K
 // elements of a row, multiplied by v_mfma_scale_f32_32x32x64_f8f6f4 -- 64 K per instruction at twice the FLOP rate of the
@@ -597,13 +599,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f8_kernel(QstGemmArgs g) {
                     u32x4 pg, ph;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        pg[e] = pack_bf16x2(gp[2 * e], gp[2 * e + 1]);
-                        ph[e] = pack_bf16x2(hv[2 * e], hv[2 * e + 1]);
-                        hv[2 * e] = bf16lo(ph[e]); hv[2 * e + 1] = bf16hi(ph[e]);          // quantise the bf16-rounded h
+                        pg[e] = pack_op2(gp[2 * e], gp[2 * e + 1]);
+                        ph[e] = pack_op2(hv[2 * e], hv[2 * e + 1]);
+                        hv[2 * e] = op_lo(ph[e]); hv[2 * e + 1] = op_hi(ph[e]);          // quantise the bf16-rounded h
                     }
                     if (m < g.M && n < g.N) {
-                        st_stream((u32x4*)((bf16*)g.C + (size_t)m * g.ldc + n), pg);
-                        st_stream((u32x4*)((bf16*)g.C2 + (size_t)m * g.ldc + n), ph);
+                        st_stream((u32x4*)((op16*)g.C + (size_t)m * g.ldc + n), pg);
+                        st_stream((u32x4*)((op16*)g.C2 + (size_t)m * g.ldc + n), ph);
                     }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(hv[e]));
@@ -646,9 +648,9 @@ __global__ __launch_bounds__(256) void quant_mx_kernel(const SRC* src, int64_t n
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
         } else {
-            const u32x4 a = *(const u32x4*)((const bf16*)src + i * 8);
+            const u32x4 a = *(const u32x4*)((const op16*)src + i * 8);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] = bf16lo(a[e]); v[2 * e + 1] = bf16hi(a[e]); }
+            for (int e = 0; e < 4; ++e) { v[2 * e] = op_lo(a[e]); v[2 * e + 1] = op_hi(a[e]); }
         }
     } else {
 #pragma unroll
@@ -677,6 +679,8 @@ __global__ __launch_bounds__(256) void quant_mx_kernel(const SRC* src, int64_t n
     }
 }
 
+#endif  // !QST_OP_F16
+
 // ---------------------------------------------------------------- NT with a LayerNorm fused into the epilogue
 // For N = 384 (MiniLM's hidden size) one 128 x 384 tile spans whole rows, so the LayerNorm that always follows the
 // attention-output / FFN-2 projection (forward) and the LayerNorm backward that always follows the FFN-1 / QKV dgrad
@@ -694,6 +698,7 @@ constexpr int LN_LDS = LN_RING + 3 * LN_N * 4;       // + bias / gamma / beta, l
 
 template <int MODE, int DROPW = 0>        // DROPW: QstGemmArgs.drop_where as a compile-time constant (0 = no dropout)
 __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLnEpi e) {
+    op_saturate(MODE == 0);                           // f16 build: the forward epilogue saturates, the backward one keeps inf
     constexpr bool DROP = DROPW != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -725,7 +730,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
                 rv[i_][k][t][0] = rv[i_][k][t][1] = 0.f;                                                                 \
                 xv[i_][k][t] = 0u;                                                                                       \
                 if (ok && g.resid) rv[i_][k][t] = ld_stream((const f32x2*)(g.resid + (size_t)m * g.ldr + c)); \
-                if (MODE == 1 && ok) xv[i_][k][t] = ld_stream((const uint32_t*)((const bf16*)e.xhat + (size_t)m * LN_N + c)); \
+                if (MODE == 1 && ok) xv[i_][k][t] = ld_stream((const uint32_t*)((const op16*)e.xhat + (size_t)m * LN_N + c)); \
             }                                                                                                            \
             rs[i_][k] = (MODE == 1 && ok) ? e.rstd[m] : 0.f;                                                             \
         }                                                                                                                \
@@ -819,8 +824,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
                         o[0] = h0 * ga[0] + be[0];
                         o[1] = h1 * ga[1] + be[1];
                         if (!(g.splits & 4)) st_stream((f32x2*)((float*)g.C + (size_t)m * g.ldc + c), o);
-                        if (g.C2 && !(g.splits & 1)) st_stream((uint32_t*)((bf16*)g.C2 + (size_t)m * g.ldc + c), pack_bf16x2(o[0], o[1]));
-                        if (e.xhat && !(g.splits & 2)) st_stream((uint32_t*)((bf16*)e.xhat + (size_t)m * LN_N + c), pack_bf16x2(h0, h1));
+                        if (g.C2 && !(g.splits & 1)) st_stream((uint32_t*)((op16*)g.C2 + (size_t)m * g.ldc + c), pack_op2(o[0], o[1]));
+                        if (e.xhat && !(g.splits & 2)) st_stream((uint32_t*)((op16*)e.xhat + (size_t)m * LN_N + c), pack_op2(h0, h1));
                     }
                 }
             } else {
@@ -829,7 +834,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     const f32x2 ga = *(const f32x2*)(vec_s + LN_N + 2 * (lane + 64 * t));
-                    x[t][0] = bf16lo(xv[i][k][t]); x[t][1] = bf16hi(xv[i][k][t]);
+                    x[t][0] = op_lo(xv[i][k][t]); x[t][1] = op_hi(xv[i][k][t]);
                     v[t][0] += rv[i][k][t][0];                        // dy = dgrad + residual-path gradient
                     v[t][1] += rv[i][k][t][1];
                     if (DROP && dwhere == 3) {
@@ -858,7 +863,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
                                 drop_pair(dc, (uint32_t)m * LN_N + c, k0, k1);
                                 o[0] *= k0; o[1] *= k1;
                             }
-                            st_stream((uint32_t*)((bf16*)g.C2 + (size_t)m * g.ldc + c), pack_bf16x2(o[0], o[1]));
+                            st_stream((uint32_t*)((op16*)g.C2 + (size_t)m * g.ldc + c), pack_op2(o[0], o[1]));
                         }
                     }
                 }
@@ -908,8 +913,8 @@ __device__ __forceinline__ int tn_swz(int row) { return ((row >> 1) & 1) << 2; }
 __device__ __forceinline__ uint32_t tn_off(int row, int chunk) {
     return (uint32_t)(row * 384 + ((chunk ^ tn_swz(row)) << 4));
 }
-__device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
+__device__ __forceinline__ op16x4 lds_tr16(const char* p) {
+    return lds_tr16_op(p);
 }
 
 // Wave roles: waves 0-3 run the MFMAs (one per SIMD, the whole register file to themselves), waves 4-7 are loaders
@@ -975,7 +980,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
             const bool isA = wave < 6;
             const int half = wave & 1;
             const int ld = isA ? g.lda : g.ldb, c0 = isA ? n0 : k0, width = isA ? g.N : g.K;
-            const bf16* base = (const bf16*)(isA ? g.A : g.B) + (size_t)row0 * ld + c0;
+            const op16* base = (const op16*)(isA ? g.A : g.B) + (size_t)row0 * ld + c0;
             // range = rows [row0, mend); the last row's tail past the allocation reads as zero
             const uint32_t bytes = (uint32_t)min((size_t)(mend - row0) * ld * 2u - (size_t)c0 * 2u, (size_t)0x7FFFFF00u);
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, bytes);
@@ -1036,7 +1041,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
             // fragments of k-step ks + 1 are therefore read into a second register set while the MFMAs of ks issue (hipcc's own
             // schedule reads a k-step's 12 fragments, waits, multiplies: ~250 exposed cycles per 288 of MFMA, in-kernel stamps
             // of round 1: 990 cycles per 32-row stage for 576 of MFMA); the order is pinned with sched_group_barrier.
-            bf16x8 fa[2][3], fb[2][3];
+            op16x8 fa[2][3], fb[2][3];
 #define TN_LOAD(ks_, set_)                                                                                  \
     do {                                                                                                    \
         _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                     \
@@ -1044,8 +1049,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
                 const int row = (ks_) * 16 + 8 * fh + 4 * jj + q;                                           \
                 const int ca = wm * 12 + i * 4 + gsel * 2 + (p >> 1);                                       \
                 const int cb = wn * 12 + i * 4 + gsel * 2 + (p >> 1);                                       \
-                const bf16x4 ta = lds_tr16(pa + tn_off(row, ca) + 8 * (p & 1));                             \
-                const bf16x4 tb = lds_tr16(pb + tn_off(row, cb) + 8 * (p & 1));                             \
+                const op16x4 ta = lds_tr16(pa + tn_off(row, ca) + 8 * (p & 1));                             \
+                const op16x4 tb = lds_tr16(pb + tn_off(row, cb) + 8 * (p & 1));                             \
                 _Pragma("unroll") for (int e = 0; e < 4; ++e) { fa[set_][i][jj * 4 + e] = ta[e]; fb[set_][i][jj * 4 + e] = tb[e]; } \
             }                                                                                               \
         }                                                                                                   \
@@ -1054,7 +1059,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(QstTnGroup grp) {
     do {                                                                                                    \
         _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                       \
             _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                   \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set_][i], fb[set_][j], acc[i][j], 0, 0, 0); \
+                acc[i][j] = mfma32_op(fa[set_][i], fb[set_][j], acc[i][j]); \
         if (do_bias) {   /* lane (n' = lane&31, half h) holds dY[m = 8h .. 8h+7][n']: 8 of the 16 rows of this k-step */ \
             _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                   \
                 _Pragma("unroll") for (int e = 0; e < 8; ++e) bsum[i] += (float)fa[set_][i][e];             \
@@ -1153,7 +1158,7 @@ static int launch_nt(const QstGemmArgs* a, hipStream_t st) {
     return QST_OK;
 }
 
-extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
+extern "C" int QST_K(qst_gemm_nt)(const QstGemmArgs* a, int epi, void* stream) {
     if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
     if (a->K % NBK != 0 || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->N % 4 != 0 || a->ldc % 4 != 0) return QST_ERR_UNSUPPORTED;
     if ((int64_t)256 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)384 * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
@@ -1164,10 +1169,10 @@ extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     // The 8-wave, 8-phase K loop (gemm8.hip): a->splits bit 5 forces its 128 x 384 tile, bit 6 its 256 x 256 tile, bit 7
     // forbids it; otherwise qst_gemm8_mode / the shape decide (nt8_auto).
-    if ((a->splits & 0x60) && qst_gemm_nt8_supported(a, epi)) return qst_gemm_nt8(a, epi, (a->splits & 0x40) ? 1 : 0, stream);
-    if (!(a->splits & 0xFE7) && qst_gemm_nt8_supported(a, epi)) {
+    if ((a->splits & 0x60) && QST_K(qst_gemm_nt8_supported)(a, epi)) return QST_K(qst_gemm_nt8)(a, epi, (a->splits & 0x40) ? 1 : 0, stream);
+    if (!(a->splits & 0xFE7) && QST_K(qst_gemm_nt8_supported)(a, epi)) {
         const int mode = qst_gemm8_mode_get();
-        if (mode >= 0 ? (mode & 1) != 0 : nt8_auto(a, epi)) return qst_gemm_nt8(a, epi, mode >= 0 ? 0 : 1, stream);
+        if (mode >= 0 ? (mode & 1) != 0 : nt8_auto(a, epi)) return QST_K(qst_gemm_nt8)(a, epi, mode >= 0 ? 0 : 1, stream);
     }
     // Two 128-row workgroups per CU beat one 256-row workgroup on every shape of the step (their MFMA and
     // store phases interleave); a->splits (unused by nt otherwise) can force the tile height: 1 = 128, 2 = 256 rows.
@@ -1198,6 +1203,7 @@ extern "C" int qst_gemm_nt(const QstGemmArgs* a, int epi, void* stream) {
 #undef QST_NT_CASE
 }
 
+#if !QST_OP_F16
 template <int EPI>
 static int launch_nt_f8(const QstGemmArgs* a, hipStream_t st) {
     constexpr int lds = 2 * (128 + 192) * 128;                  // 80 KB ring; the epilogue staging (52.7 KB) fits inside
@@ -1257,15 +1263,16 @@ extern "C" int qst_quant_mx(const void* src, int src_is_bf16, int64_t rows, int 
     if (K % 32 != 0) return QST_ERR_UNSUPPORTED;
     const int64_t n8 = rows * K / 8;
     const unsigned grid = (unsigned)((n8 + 255) / 256);
-    if (src_is_bf16) quant_mx_kernel<bf16><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16*)src, n8, rows, K, (uint8_t*)q, (uint8_t*)scales);
+    if (src_is_bf16) quant_mx_kernel<op16><<<grid, 256, 0, (hipStream_t)stream>>>((const op16*)src, n8, rows, K, (uint8_t*)q, (uint8_t*)scales);
     else quant_mx_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)src, n8, rows, K, (uint8_t*)q, (uint8_t*)scales);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
 
 extern "C" int qst_gemm_nt_ln_supported(int N) { return N == LN_N ? 1 : 0; }
+#endif  // !QST_OP_F16
 
-extern "C" int qst_gemm_nt_ln(const QstGemmArgs* a, const QstLnEpi* ln, int mode, void* stream) {
+extern "C" int QST_K(qst_gemm_nt_ln)(const QstGemmArgs* a, const QstLnEpi* ln, int mode, void* stream) {
     if (!a || !ln || !a->A || !a->B || !a->C || !ln->gamma || a->M <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
     if (mode != 0 && mode != 1) return QST_ERR_BAD_ARG;
     if (mode == 0 && !ln->beta) return QST_ERR_BAD_ARG;
@@ -1299,11 +1306,11 @@ extern "C" int qst_gemm_nt_ln(const QstGemmArgs* a, const QstLnEpi* ln, int mode
 
 static bool tn8_auto(const QstTnGroup* g) { (void)g; return false; }
 
-extern "C" int qst_gemm_tn_group(const QstTnGroup* grp_in, void* stream) {
+extern "C" int QST_K(qst_gemm_tn_group)(const QstTnGroup* grp_in, void* stream) {
     if (!grp_in || grp_in->nprob <= 0 || grp_in->nprob > QST_TN_MAX_PROB) return QST_ERR_BAD_ARG;
     {
         const int mode = qst_gemm8_mode_get();
-        if (mode >= 0 ? (mode & 2) != 0 : tn8_auto(grp_in)) return qst_gemm_tn8_group(grp_in, stream);
+        if (mode >= 0 ? (mode & 2) != 0 : tn8_auto(grp_in)) return QST_K(qst_gemm_tn8_group)(grp_in, stream);
     }
     QstTnGroup g = *grp_in;
     g.total_tiles = 0;
@@ -1337,11 +1344,11 @@ extern "C" int qst_gemm_tn_group(const QstTnGroup* grp_in, void* stream) {
     return QST_OK;
 }
 
-extern "C" int qst_gemm_tn(const QstGemmArgs* a, void* stream) {
+extern "C" int QST_K(qst_gemm_tn)(const QstGemmArgs* a, void* stream) {
     if (!a) return QST_ERR_BAD_ARG;
     QstTnGroup g{};
     g.nprob = 1;
     g.splits = a->splits;
     g.prob[0] = *a;
-    return qst_gemm_tn_group(&g, stream);
+    return QST_K(qst_gemm_tn_group)(&g, stream);
 }

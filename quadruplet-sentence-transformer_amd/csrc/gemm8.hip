@@ -105,9 +105,9 @@ __device__ __forceinline__ void nt8_epilogue(const QstGemmArgs& g, OPS& o, int m
                 st_stream((f32x4*)(c + 4), hi);
                 if (EPI == QST_EPI_F32_RESID_BF16) {
                     u32x4 pk;
-                    pk[0] = pack_bf16x2(lo[0], lo[1]); pk[1] = pack_bf16x2(lo[2], lo[3]);
-                    pk[2] = pack_bf16x2(hi[0], hi[1]); pk[3] = pack_bf16x2(hi[2], hi[3]);
-                    st_stream((u32x4*)((bf16*)g.C2 + (size_t)m * g.ldc + n), pk);
+                    pk[0] = pack_op2(lo[0], lo[1]); pk[1] = pack_op2(lo[2], lo[3]);
+                    pk[2] = pack_op2(hi[0], hi[1]); pk[3] = pack_op2(hi[2], hi[3]);
+                    st_stream((u32x4*)((op16*)g.C2 + (size_t)m * g.ldc + n), pk);
                 }
             }
         }
@@ -119,7 +119,7 @@ __device__ __forceinline__ void nt8_epilogue(const QstGemmArgs& g, OPS& o, int m
 #pragma unroll
             for (int jp = 0; jp < NP; ++jp) {
                 const int n = nw + 32 * jp;
-                dst[jp] = (m < g.M && n < g.N) ? ld_stream((const u32x4*)((const bf16*)g.aux + (size_t)m * g.ldc + n)) : zu;
+                dst[jp] = (m < g.M && n < g.N) ? ld_stream((const u32x4*)((const op16*)g.aux + (size_t)m * g.ldc + n)) : zu;
             }
         };
         if (EPI == QST_EPI_GELU_BWD) {
@@ -141,8 +141,8 @@ __device__ __forceinline__ void nt8_epilogue(const QstGemmArgs& g, OPS& o, int m
                 u32x4 pk;
                 if (EPI == QST_EPI_BF16) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-                    st_stream((u32x4*)((bf16*)g.C + off), pk);
+                    for (int e = 0; e < 4; ++e) pk[e] = pack_op2(v[2 * e], v[2 * e + 1]);
+                    st_stream((u32x4*)((op16*)g.C + off), pk);
                 } else if (EPI == QST_EPI_GELU || EPI == QST_EPI_GELU_MX_TRAIN) {
                     u32x4 pg;
 #pragma unroll
@@ -151,18 +151,18 @@ __device__ __forceinline__ void nt8_epilogue(const QstGemmArgs& g, OPS& o, int m
                         x2[0] = v[2 * e]; x2[1] = v[2 * e + 1];
                         gelu_parts2(x2, cdf, pdf);
                         const qst_f32x2 gg = x2 * pdf + cdf, hh = x2 * cdf;
-                        pg[e] = pack_bf16x2(gg[0], gg[1]);
-                        pk[e] = pack_bf16x2(hh[0], hh[1]);
+                        pg[e] = pack_op2(gg[0], gg[1]);
+                        pk[e] = pack_op2(hh[0], hh[1]);
                     }
-                    st_stream((u32x4*)((bf16*)g.C + off), pg);             // gelu'(u), saved for backward
-                    st_stream((u32x4*)((bf16*)g.C2 + off), pk);            // h = gelu(u)
+                    st_stream((u32x4*)((op16*)g.C + off), pg);             // gelu'(u), saved for backward
+                    st_stream((u32x4*)((op16*)g.C2 + off), pk);            // h = gelu(u)
                     if (EPI == QST_EPI_GELU_MX_TRAIN) {
                         // ... and the bf16-rounded h as MXFP8 (C3 = e4m3 [M, N], C4 = E8M0, stage-major): the four lanes of a
                         // row (one per 16-lane row of the wave) hold the 32 columns of one MX block, so its amax is two
                         // row-swaps away. (All four take this branch together: same m, same 32-column block, N % 32 == 0.)
                         float hv[8], amax = 0.f;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { hv[2 * e] = bf16lo(pk[e]); hv[2 * e + 1] = bf16hi(pk[e]); }
+                        for (int e = 0; e < 4; ++e) { hv[2 * e] = op_lo(pk[e]); hv[2 * e + 1] = op_hi(pk[e]); }
 #pragma unroll
                         for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(hv[e]));
                         amax = fmaxf(amax, swap32(amax));
@@ -185,8 +185,8 @@ __device__ __forceinline__ void nt8_epilogue(const QstGemmArgs& g, OPS& o, int m
                 } else {                                                    // QST_EPI_GELU_BWD: acc * gelu'(u)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        pk[e] = pack_bf16x2(v[2 * e] * bf16lo(av[i][jp][e]), v[2 * e + 1] * bf16hi(av[i][jp][e]));
-                    st_stream((u32x4*)((bf16*)g.C + off), pk);
+                        pk[e] = pack_op2(v[2 * e] * op_lo(av[i][jp][e]), v[2 * e + 1] * op_hi(av[i][jp][e]));
+                    st_stream((u32x4*)((op16*)g.C + off), pk);
                 }
             }
         }
@@ -196,6 +196,7 @@ __device__ __forceinline__ void nt8_epilogue(const QstGemmArgs& g, OPS& o, int m
 
 template <int EPI, int TM, int TN>
 __global__ __launch_bounds__(512, 1) void gemm_nt8_kernel(QstGemmArgs g) {
+    op_saturate(g.sat16 != 0);
     using OPS = g8p::NtOps<TM, TN>;
     constexpr int BM = OPS::BM, BN = OPS::BN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_kernel(QstGemmArgs g) {
     // measured on the H = 768 shapes: within 1% of this order on every one)
     const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
     OPS o;
-    o.init((const bf16*)g.A + (size_t)m0 * g.lda, g.lda, min(BM, g.M - m0), (const bf16*)g.B + (size_t)n0 * g.ldb, g.ldb,
+    o.init((const op16*)g.A + (size_t)m0 * g.lda, g.lda, min(BM, g.M - m0), (const op16*)g.B + (size_t)n0 * g.ldb, g.ldb,
            min(BN, g.N - n0), g.K, smem);
     g8p::kloop8(o, o.nk);
     nt8_epilogue<EPI>(g, o, m0, n0);
@@ -237,18 +238,22 @@ struct BiasHook {
     bool on;
     float bsum[PER];
     template <int QM, class O> __device__ __forceinline__ void after_a(O& o) {
-        typedef __attribute__((ext_vector_type(2))) __bf16 v2bf;
+        typedef __attribute__((ext_vector_type(2))) op16 v2bf;
         if (!on || (o.wc >> 1) != QM) return;              // wave-uniform
-        v2bf one; one[0] = (__bf16)1.f; one[1] = (__bf16)1.f;
+        v2bf one; one[0] = (op16)1.f; one[1] = (op16)1.f;
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const g8p::bf16x8_t f = (o.wc & 1) ? o.fa[PER + e][s] : o.fa[e][s];
+                const g8p::op16x8 f = (o.wc & 1) ? o.fa[PER + e][s] : o.fa[e][s];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     v2bf pr; pr[0] = f[2 * r]; pr[1] = f[2 * r + 1];
+#if QST_OP_F16
+                    bsum[e] = __builtin_amdgcn_fdot2(pr, one, bsum[e], false);              // v_dot2_f32_f16
+#else
                     bsum[e] = __builtin_amdgcn_fdot2_f32_bf16(pr, one, bsum[e], false);
+#endif
                 }
             }
         }
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn8_group_kernel(QstTnGroup grp) 
         o.hook.on = (g.colsum != nullptr) && (k0 == 0);
 #pragma unroll
         for (int e = 0; e < BiasHook<TM>::PER; ++e) o.hook.bsum[e] = 0.f;
-        o.init((const bf16*)g.A + (size_t)row0 * g.lda, g.lda, g.N, n0, (const bf16*)g.B + (size_t)row0 * g.ldb, g.ldb, g.K, k0,
+        o.init((const op16*)g.A + (size_t)row0 * g.lda, g.lda, g.N, n0, (const op16*)g.B + (size_t)row0 * g.ldb, g.ldb, g.K, k0,
                row1 - row0, smem);
         g8p::kloop8(o, o.nk);
 
@@ -352,18 +357,24 @@ __global__ __launch_bounds__(512, 1) void gemm_tn8_group_kernel(QstTnGroup grp) 
     }
 }
 
+#if !QST_OP_F16
 std::atomic<int> g_mode{-1};       // qst_gemm8_mode
+#endif
 
 }  // namespace
 
 // -1 (default): the library chooses per call; otherwise bit 0 = NT GEMMs on this path where supported, bit 1 = weight
 // gradients on this path. Process-wide; for tools and A/B runs.
+#if !QST_OP_F16      // (one switch for both builds of this file; the f16 build reads it through qst_gemm8_mode_get)
 extern "C" int qst_gemm8_mode(int mode) {
     const int old = g_mode.load();
     if (mode >= -1) g_mode.store(mode);
     return old;
 }
 int qst_gemm8_mode_get() { return g_mode.load(); }
+#else
+int qst_gemm8_mode_get();
+#endif
 
 template <int EPI, int TM, int TN>
 static int launch_nt8(const QstGemmArgs* a, hipStream_t st) {
@@ -377,16 +388,16 @@ static int launch_nt8(const QstGemmArgs* a, hipStream_t st) {
 }
 
 // tile: 0 = 128 x 384 (8 waves of 64 x 96), 1 = 256 x 256 (8 waves of 128 x 64)
-extern "C" int qst_gemm_nt8_supported(const QstGemmArgs* a, int epi) {
+extern "C" int QST_K(qst_gemm_nt8_supported)(const QstGemmArgs* a, int epi) {
     if (!a || a->K % 64 != 0 || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->N % 8 != 0 || a->ldc % 8 != 0) return 0;
     if ((epi == QST_EPI_F32_RESID || epi == QST_EPI_F32_RESID_BF16) && a->resid && a->ldr % 4 != 0) return 0;
     if ((int64_t)256 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)384 * a->ldb * 2 >= 0x7FFFFF00LL) return 0;
     return epi >= QST_EPI_BF16 && epi <= QST_EPI_F32_RESID_BF16;
 }
 
-extern "C" int qst_gemm_nt8(const QstGemmArgs* a, int epi, int tile, void* stream) {
+extern "C" int QST_K(qst_gemm_nt8)(const QstGemmArgs* a, int epi, int tile, void* stream) {
     if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
-    if (!qst_gemm_nt8_supported(a, epi)) return QST_ERR_UNSUPPORTED;
+    if (!QST_K(qst_gemm_nt8_supported)(a, epi)) return QST_ERR_UNSUPPORTED;
     if ((epi == QST_EPI_GELU || epi == QST_EPI_F32_RESID_BF16) && !a->C2) return QST_ERR_BAD_ARG;
     if (epi == QST_EPI_GELU_BWD && !a->aux) return QST_ERR_BAD_ARG;
     if (a->drop.thr16 && a->drop.state) {
@@ -406,6 +417,7 @@ extern "C" int qst_gemm_nt8(const QstGemmArgs* a, int epi, int tile, void* strea
 #undef QST_NT8_CASE
 }
 
+#if !QST_OP_F16
 template <int EPI, int TM, int TN>
 static int launch_nt8_f8(const QstGemmArgs* a, hipStream_t st) {
     using OPS = g8p::NtOpsF8<TM, TN>;
@@ -444,6 +456,8 @@ extern "C" int qst_gemm_nt8_f8(const QstGemmArgs* a, int epi, int tile, void* st
 #undef QST_NT8F_CASE
 }
 
+#endif  // !QST_OP_F16
+
 template <int TM, int TN>
 static int launch_tn8(const QstTnGroup* grp_in, hipStream_t st) {
     constexpr int BMn = 32 * TM, BNk = 64 * TN;
@@ -471,7 +485,7 @@ static int launch_tn8(const QstTnGroup* grp_in, hipStream_t st) {
     return QST_OK;
 }
 
-extern "C" int qst_gemm_tn8_group(const QstTnGroup* grp_in, void* stream) {
+extern "C" int QST_K(qst_gemm_tn8_group)(const QstTnGroup* grp_in, void* stream) {
     if (!grp_in || grp_in->nprob <= 0 || grp_in->nprob > QST_TN_MAX_PROB) return QST_ERR_BAD_ARG;
     bool all256 = true;
     for (int i = 0; i < grp_in->nprob; ++i) {

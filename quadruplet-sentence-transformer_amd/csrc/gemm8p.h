@@ -35,9 +35,17 @@
 
 namespace g8p {
 
-typedef __bf16 bf16_t;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+// the 16-bit operand type of the translation unit (qst_common.h has the same switch; this header stands alone for the probes)
+#ifndef QST_OP_F16
+#define QST_OP_F16 0
+#endif
+#if QST_OP_F16
+typedef _Float16 op16;
+#else
+typedef __bf16 op16;
+#endif
+typedef __attribute__((ext_vector_type(8))) op16 op16x8;
+typedef __attribute__((ext_vector_type(4))) op16 op16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((address_space(3))) void lds_void_t;
 
@@ -51,9 +59,16 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 v2;
-    v2 v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+    typedef __attribute__((ext_vector_type(2))) op16 v2;
+    v2 v; v[0] = (op16)lo; v[1] = (op16)hi;
     return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ f32x4_t mfma16(op16x8 a, op16x8 b, f32x4_t c) {        // v_mfma_f32_16x16x32_{bf16,f16}
+#if QST_OP_F16
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
@@ -163,9 +178,9 @@ struct NtOps {
     uint32_t ao0, ao1, bo0, bo1;      // per-lane fragment read offsets (k-step 0 / 1)
     int nk, wr, wc;
     f32x4_t acc[TM][TN];
-    bf16x8_t fa[TM / 2][2], fb[2][TN / 2][2];
+    op16x8 fa[TM / 2][2], fb[2][TN / 2][2];
 
-    __device__ __forceinline__ void init(const bf16_t* A, int lda, int rows_a, const bf16_t* B, int ldb, int rows_b, int K,
+    __device__ __forceinline__ void init(const op16* A, int lda, int rows_a, const op16* B, int ldb, int rows_b, int K,
                                          char* smem_) {
         const int tid = threadIdx.x, lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -217,15 +232,15 @@ struct NtOps {
         if (PART == 1) return;
 #pragma unroll
         for (int i = 0; i < TM / 2; ++i) {
-            fa[i][0] = *(const bf16x8_t*)(smem + BUF * BUF_BYTES + (QM * (BM / 4) + i * 16) * 128 + ao0);
-            fa[i][1] = *(const bf16x8_t*)(smem + BUF * BUF_BYTES + (QM * (BM / 4) + i * 16) * 128 + ao1);
+            fa[i][0] = *(const op16x8*)(smem + BUF * BUF_BYTES + (QM * (BM / 4) + i * 16) * 128 + ao0);
+            fa[i][1] = *(const op16x8*)(smem + BUF * BUF_BYTES + (QM * (BM / 4) + i * 16) * 128 + ao1);
         }
     }
     template <int BUF, int QN> __device__ __forceinline__ void rd_b() {
 #pragma unroll
         for (int j = 0; j < TN / 2; ++j) {
-            fb[QN][j][0] = *(const bf16x8_t*)(smem + BUF * BUF_BYTES + (QN * (BN / 8) + j * 16) * 128 + bo0);
-            fb[QN][j][1] = *(const bf16x8_t*)(smem + BUF * BUF_BYTES + (QN * (BN / 8) + j * 16) * 128 + bo1);
+            fb[QN][j][0] = *(const op16x8*)(smem + BUF * BUF_BYTES + (QN * (BN / 8) + j * 16) * 128 + bo0);
+            fb[QN][j][1] = *(const op16x8*)(smem + BUF * BUF_BYTES + (QN * (BN / 8) + j * 16) * 128 + bo1);
         }
     }
     template <int QM, int QN> __device__ __forceinline__ void mm() {
@@ -236,8 +251,7 @@ struct NtOps {
             for (int i = 0; i < TM / 2; ++i)
 #pragma unroll
                 for (int j = 0; j < TN / 2; ++j)
-                    acc[QM * (TM / 2) + i][QN * (TN / 2) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        fb[QN][j][s], fa[i][s], acc[QM * (TM / 2) + i][QN * (TN / 2) + j], 0, 0, 0);
+                    acc[QM * (TM / 2) + i][QN * (TN / 2) + j] = mfma16(fb[QN][j][s], fa[i][s], acc[QM * (TM / 2) + i][QN * (TN / 2) + j]);
         __builtin_amdgcn_s_setprio(0);
     }
 };
@@ -408,10 +422,10 @@ struct TnOps {
     int nk, wr, wc;
     HOOK hook;
     f32x4_t acc[TM][TN];
-    bf16x8_t fa[TM / 2][2], fb[2][TN / 2][2];
+    op16x8 fa[TM / 2][2], fb[2][TN / 2][2];
 
     // A, B: first reduction row of this piece; rows: reduction rows in the piece; n0 / k0: first column of the tile
-    __device__ __forceinline__ void init(const bf16_t* A, int lda, int N, int n0, const bf16_t* B, int ldb, int K, int k0,
+    __device__ __forceinline__ void init(const op16* A, int lda, int N, int n0, const op16* B, int ldb, int K, int k0,
                                          int rows, char* smem_) {
         const int tid = threadIdx.x, lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -480,11 +494,12 @@ struct TnOps {
     }
     __device__ __forceinline__ void touch(int) {}
     __device__ __forceinline__ void begin_iter(int) {}
-    static __device__ __forceinline__ bf16x8_t tr_frag(const char* p) {
-        typedef __attribute__((address_space(3))) bf16x4_t lds_v4;
-        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(p));
-        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(p + 512));
-        bf16x8_t v;
+    static __device__ __forceinline__ op16x8 tr_frag(const char* p) {
+        typedef __attribute__((ext_vector_type(4))) __bf16 raw4;           // (ds_read_b64_tr_b16 moves 16-bit lanes of either type)
+        typedef __attribute__((address_space(3))) raw4 lds_v4;
+        const op16x4 lo = __builtin_bit_cast(op16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(p)));
+        const op16x4 hi = __builtin_bit_cast(op16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(p + 512)));
+        op16x8 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
         return v;
@@ -511,15 +526,14 @@ struct TnOps {
             for (int i = 0; i < TM / 2; ++i)
 #pragma unroll
                 for (int j = 0; j < TN / 2; ++j)
-                    acc[QM * (TM / 2) + i][QN * (TN / 2) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        fa[i][s], fb[QN][j][s], acc[QM * (TM / 2) + i][QN * (TN / 2) + j], 0, 0, 0);
+                    acc[QM * (TM / 2) + i][QN * (TN / 2) + j] = mfma16(fa[i][s], fb[QN][j][s], acc[QM * (TM / 2) + i][QN * (TN / 2) + j]);
         __builtin_amdgcn_s_setprio(0);
         if ((QM == 0 && QN == 1) || (QM == 1 && QN == 0)) hook.template after_a<QM>(*this);   // last use of fa of row QM
     }
 };
 
 // C tile = A[m0 .., :] . B[n0 .., :]^T over K (K % 64 == 0), the guide's 256 x 256 form -- kept for tools/probe/gemm8p_probe.hip
-__device__ __forceinline__ void kloop_nt(const bf16_t* A, int lda, int rows_a, const bf16_t* B, int ldb, int rows_b, int K,
+__device__ __forceinline__ void kloop_nt(const op16* A, int lda, int rows_a, const op16* B, int ldb, int rows_b, int K,
                                          int m0, int n0, char* smem, f32x4_t (&acc)[8][4]) {
     NtOps<8, 4> o;
     o.init(A + (size_t)m0 * lda, lda, rows_a, B + (size_t)n0 * ldb, ldb, rows_b, K, smem);

@@ -111,7 +111,7 @@ enum { W_QKV = 0, B_QKV, W_O, B_O, LN1_G, LN1_B, W_1, B_1, W_2, B_2, LN2_G, LN2_
 // (Rounds 2-3 kept a 16-entry ring per handle and fell back on the handle's current rates when it had no entry: wrong
 // gradients without an error once the ring wrapped or a backward ran on another handle -- ADVICE r03.)
 namespace {
-enum { ARENA_BF16 = 0, ARENA_X3 = 1 };          // the bf16 activation arena (bf16 and fp8 forwards) / the fp32 one of bf16x3
+enum { ARENA_BF16 = 0, ARENA_X3 = 1, ARENA_F16 = 2 };   // the bf16 activation arena (bf16 and fp8 forwards) / the fp32 one of bf16x3 / the f16 one
 struct FwdRec { uint32_t hidden = 0, attn = 0; int kind = ARENA_BF16; uint64_t seq = 0; };
 std::mutex g_rec_mu;
 std::unordered_map<const void*, FwdRec> g_recs;
@@ -198,7 +198,8 @@ extern "C" int qst_encoder_create(const qst_config* cfg, qst_encoder** out) {
     if (cfg->hidden_size % cfg->num_heads != 0 || (d != 32 && d != 64)) return QST_ERR_UNSUPPORTED;
     if (cfg->hidden_size % 64 != 0 || cfg->intermediate_size % 64 != 0 || cfg->hidden_size > 1024) return QST_ERR_UNSUPPORTED;
     if (cfg->type_vocab_size > 2) return QST_ERR_UNSUPPORTED;
-    if (cfg->precision != QST_PREC_BF16 && cfg->precision != QST_PREC_BF16X3 && cfg->precision != QST_PREC_FP8)
+    if (cfg->precision != QST_PREC_BF16 && cfg->precision != QST_PREC_BF16X3 && cfg->precision != QST_PREC_FP8 &&
+        cfg->precision != QST_PREC_F16)
         return QST_ERR_UNSUPPORTED;
     if (cfg->precision == QST_PREC_FP8 && (cfg->hidden_size % 128 != 0 || cfg->intermediate_size % 128 != 0))
         return QST_ERR_UNSUPPORTED;                      // the fp8 K loop takes 128-deep stages
@@ -438,36 +439,54 @@ extern "C" int qst_encoder_set_dropout(qst_encoder* e, float p_hidden, float p_a
     return QST_OK;
 }
 
-int nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* C2, const void* aux, const float* bias,
-       const float* resid, int ldr, int M, int N, int K, int epi, hipStream_t st) {
+// The kernels whose operands / 16-bit outputs are bf16 (QST_PREC_BF16, and the backward of QST_PREC_FP8) or IEEE half
+// (QST_PREC_F16): the same sources compiled on either type (qst_common.h: op16), entry points qst_* and qst_*_f16. The bf16
+// forward / backward below are written once against this table.
+struct OpKernels {
+    decltype(&qst_gemm_nt) gemm_nt;
+    decltype(&qst_gemm_nt_ln) gemm_nt_ln;
+    decltype(&qst_ffn_chain) ffn_chain;
+    decltype(&qst_gemm_tn_group) gemm_tn_group;
+    decltype(&qst_embed_ln_fwd_drop) embed_ln_fwd_drop;
+    decltype(&qst_ln_fwd) ln_fwd;
+    decltype(&qst_ln_bwd_drop) ln_bwd_drop;
+    decltype(&qst_attention_fwd_ex) attention_fwd_ex;
+    decltype(&qst_attention_bwd_ex) attention_bwd_ex;
+    decltype(&qst_shadow_all) shadow_all;
+    int arena_kind;            // what a training forward through these kernels leaves behind (FwdRec.kind)
+};
+const OpKernels kOpBf16 = {qst_gemm_nt, qst_gemm_nt_ln, qst_ffn_chain, qst_gemm_tn_group, qst_embed_ln_fwd_drop, qst_ln_fwd,
+                           qst_ln_bwd_drop, qst_attention_fwd_ex, qst_attention_bwd_ex, qst_shadow_all, ARENA_BF16};
+const OpKernels kOpF16 = {qst_gemm_nt_f16, qst_gemm_nt_ln_f16, qst_ffn_chain_f16, qst_gemm_tn_group_f16,
+                          qst_embed_ln_fwd_drop_f16, qst_ln_fwd_f16, qst_ln_bwd_drop_f16, qst_attention_fwd_ex_f16,
+                          qst_attention_bwd_ex_f16, qst_shadow_all_f16, ARENA_F16};
+const OpKernels& op_kernels(const qst_config& c) { return c.precision == QST_PREC_F16 ? kOpF16 : kOpBf16; }
+
+// sat: forward launches of the f16 build saturate their 16-bit outputs (QstGemmArgs.sat16); the bf16 build ignores it
+int nt(const OpKernels& K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* C2, const void* aux,
+       const float* bias, const float* resid, int ldr, int M, int N, int K_, int epi, bool sat, hipStream_t st) {
     QstGemmArgs g{};
     g.A = A; g.B = B; g.C = C; g.C2 = C2; g.aux = aux; g.bias = bias; g.resid = resid;
-    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
+    g.M = M; g.N = N; g.K = K_; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
+    g.sat16 = sat ? 1 : 0;
     take_drop(g);
-    return qst_gemm_nt(&g, epi, st);
+    return K.gemm_nt(&g, epi, st);
 }
 // GEMM with the following LayerNorm (mode 0) / LayerNorm backward (mode 1) fused into its epilogue (N = H = 384)
-int nt_ln(const void* A, int lda, const void* B, int ldb, float* C, void* C2, const float* bias, const float* resid,
-          int M, int H, int K, int mode, const float* gamma, const float* beta, float eps, void* xhat, float* rstd,
-          float* partials, hipStream_t st) {
+int nt_ln(const OpKernels& K, const void* A, int lda, const void* B, int ldb, float* C, void* C2, const float* bias,
+          const float* resid, int M, int H, int K_, int mode, const float* gamma, const float* beta, float eps, void* xhat,
+          float* rstd, float* partials, hipStream_t st) {
     QstGemmArgs g{};
     g.A = A; g.B = B; g.C = C; g.C2 = C2; g.bias = bias; g.resid = resid;
-    g.M = M; g.N = H; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = H; g.ldr = H;
+    g.M = M; g.N = H; g.K = K_; g.lda = lda; g.ldb = ldb; g.ldc = H; g.ldr = H;
     take_drop(g);
     QstLnEpi e{};
     e.gamma = gamma; e.beta = beta; e.eps = eps; e.xhat = xhat; e.rstd = rstd; e.partials = partials;
-    return qst_gemm_nt_ln(&g, &e, mode, st);
-}
-int tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, float* colsum, int M, int N, int K,
-       hipStream_t st) {
-    QstGemmArgs g{};
-    g.A = A; g.B = B; g.C = C; g.colsum = colsum; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-    g.splits = 0;
-    return qst_gemm_tn(&g, st);
+    return K.gemm_nt_ln(&g, &e, mode, st);
 }
 
 // the feed-forward block as one kernel (csrc/ffn.hip): mode 0 forward, mode 1 backward
-int ffn_chain(const void* A, const void* B1, const void* B2, const float* bias1, const float* bias2, const float* resid,
+int ffn_chain(const OpKernels& K, const void* A, const void* B1, const void* B2, const float* bias1, const float* bias2, const float* resid,
               const void* aux, void* save_gp, void* save_h, float* C, void* C2, int M, int H, int I, int mode,
               const float* gamma, const float* beta, float eps, void* xhat, float* rstd, float* partials, hipStream_t st) {
     QstFfnArgs g{};
@@ -475,7 +494,7 @@ int ffn_chain(const void* A, const void* B1, const void* B2, const float* bias1,
     g.save_gp = save_gp; g.save_h = save_h; g.C = C; g.C2 = C2; g.M = M; g.H = H; g.I = I;
     QstLnEpi e{};
     e.gamma = gamma; e.beta = beta; e.eps = eps; e.xhat = xhat; e.rstd = rstd; e.partials = partials;
-    return qst_ffn_chain(&g, &e, mode, st);
+    return K.ffn_chain(&g, &e, mode, st);
 }
 
 constexpr int kFuseLnMinRows = 16384;      // token rows from which the fused GEMM+LayerNorm kernels win (see forward)
@@ -513,7 +532,8 @@ extern "C" size_t qst_encoder_bwd_workspace_bytes(const qst_encoder* e, int nseq
 
 extern "C" int qst_refresh_shadow(const qst_encoder* e, const float* params, void* shadow, void* stream) {
     if (!e || !params || !shadow) return QST_ERR_BAD_ARG;
-    return qst_shadow_all(params, shadow, e->shadow_tab, e->shadow_nseg, e->shadow_blocks, stream);
+    // (a QST_PREC_F16 handle fills the same layout with IEEE half; every other handle with bf16)
+    return op_kernels(e->cfg).shadow_all(params, shadow, e->shadow_tab, e->shadow_nseg, e->shadow_blocks, stream);
 }
 
 // QST_PREC_FP8: every GEMM weight as MXFP8 -- e4m3 bytes at the segment's shadow offset, E8M0 block scales (one per 32
@@ -892,13 +912,14 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     if (saved_bytes < p.total) return QST_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char* sv = (char*)saved;
-    const bf16* sh = (const bf16*)shadow;
+    const uint16_t* sh = (const uint16_t*)shadow;          // bf16, or IEEE half on a QST_PREC_F16 handle
+    const OpKernels& K = op_kernels(c);
     const int M = nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads, d = H / A;
     const Layout& lay = e->lay;
     auto P = [&](int seg) { return params + lay.segs[seg].off; };
     auto W = [&](int seg) { return sh + lay.segs[seg].shadow_off; };
-    auto linear = [&](const void* Ain, int K, int wseg, void* Cout, int N, void* C2, int bseg, const float* resid, int epi) {
-        return nt(Ain, K, W(wseg), K, Cout, N, C2, nullptr, P(bseg), resid, N, M, N, K, epi, st);
+    auto linear = [&](const void* Ain, int Kd, int wseg, void* Cout, int N, void* C2, int bseg, const float* resid, int epi) {
+        return nt(K, Ain, Kd, W(wseg), Kd, Cout, N, C2, nullptr, P(bseg), resid, N, M, N, Kd, epi, true, st);
     };
 
     int32_t* pos_ids = (int32_t*)(sv + p.pos_ids);
@@ -910,11 +931,11 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     QST_TRY(qst_forward_prologue(ids, nseq, L, c.arch, c.pad_token_id, pos_ids, dropping ? e->drop_state : nullptr,
                                  dropping ? (uint32_t*)(sv + p.dropst) : nullptr, st));
     if (training) {                                   // remember what this forward did, for the backward over the same arena
-        rec_put(saved, thr.hidden, thr.attn, ARENA_BF16);
+        rec_put(saved, thr.hidden, thr.attn, K.arena_kind);
     }
     {
         const QstDrop de = drop_of(thr, dst8, false, QST_DROP_SITE_EMBED);
-        QST_TRY(qst_embed_ln_fwd_drop(ids, type_ids, pos_ids, P(lay.word), P(lay.pos), lay.type >= 0 ? P(lay.type) : nullptr,
+        QST_TRY(K.embed_ln_fwd_drop(ids, type_ids, pos_ids, P(lay.word), P(lay.pos), lay.type >= 0 ? P(lay.type) : nullptr,
                                       P(lay.eg), P(lay.eb), c.layer_norm_eps, M, H, (float*)(sv + p.x0), sv + p.x0b,
                                       sv + p.xh0, (float*)(sv + p.rs0), dropping ? &de : nullptr, st));
     }
@@ -942,19 +963,19 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
             q.qkv = sv + a.qkv; q.mask = mask; q.rel_pos = rel; q.nseq = nseq; q.L = L; q.A = A; q.d = d;
             q.ctx = sv + a.ctx; q.lse = (float*)(sv + a.lse);
             if (dropping) q.drop = drop_of(thr, dst8, true, QST_DROP_SITE_PROBS(l));
-            QST_TRY(qst_attention_fwd_ex(&q, st));
+            QST_TRY(K.attention_fwd_ex(&q, st));
         }
         drop_next(thr, dst8, dropping, QST_DROP_SITE_ATTN_OUT(l), 1);
         if (fuse_ln) {
-            QST_TRY(nt_ln(sv + a.ctx, H, W(b + W_O), H, (float*)(sv + a.y1), sv + a.y1b, P(b + B_O), x, M, H, H, 0,
+            QST_TRY(nt_ln(K, sv + a.ctx, H, W(b + W_O), H, (float*)(sv + a.y1), sv + a.y1b, P(b + B_O), x, M, H, H, 0,
                           P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, sv + a.xh1, (float*)(sv + a.rs1), nullptr, st));
         } else {
             QST_TRY(linear(sv + a.ctx, H, b + W_O, s, H, nullptr, b + B_O, x, QST_EPI_F32_RESID));
-            QST_TRY(qst_ln_fwd(s, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, (float*)(sv + a.y1), sv + a.y1b,
+            QST_TRY(K.ln_fwd(s, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, (float*)(sv + a.y1), sv + a.y1b,
                                sv + a.xh1, (float*)(sv + a.rs1), st));
         }
         if (fuse_ffn) {
-            QST_TRY(ffn_chain(sv + a.y1b, W(b + W_1), W(b + W_2), P(b + B_1), P(b + B_2), (const float*)(sv + a.y1), nullptr,
+            QST_TRY(ffn_chain(K, sv + a.y1b, W(b + W_1), W(b + W_2), P(b + B_1), P(b + B_2), (const float*)(sv + a.y1), nullptr,
                               training ? sv + a.u : nullptr, training ? sv + a.hact : nullptr, (float*)(sv + a.x), sv + a.xb,
                               M, H, I, 0, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, sv + a.xh2, (float*)(sv + a.rs2),
                               nullptr, st));
@@ -965,12 +986,12 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
         QST_TRY(linear(sv + a.y1b, H, b + W_1, sv + a.u, I, sv + a.hact, b + B_1, nullptr, QST_EPI_GELU));
         drop_next(thr, dst8, dropping, QST_DROP_SITE_FFN_OUT(l), 1);
         if (fuse_ln) {
-            QST_TRY(nt_ln(sv + a.hact, I, W(b + W_2), I, (float*)(sv + a.x), sv + a.xb, P(b + B_2),
+            QST_TRY(nt_ln(K, sv + a.hact, I, W(b + W_2), I, (float*)(sv + a.x), sv + a.xb, P(b + B_2),
                           (const float*)(sv + a.y1), M, H, I, 0, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, sv + a.xh2,
                           (float*)(sv + a.rs2), nullptr, st));
         } else {
             QST_TRY(linear(sv + a.hact, I, b + W_2, s, H, nullptr, b + B_2, (const float*)(sv + a.y1), QST_EPI_F32_RESID));
-            QST_TRY(qst_ln_fwd(s, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, M, H, (float*)(sv + a.x), sv + a.xb,
+            QST_TRY(K.ln_fwd(s, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, M, H, (float*)(sv + a.x), sv + a.xb,
                                sv + a.xh2, (float*)(sv + a.rs2), st));
         }
         x = (const float*)(sv + a.x);
@@ -1021,7 +1042,8 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
     hipStream_t st = (hipStream_t)stream;
     char* sv = (char*)saved;
     char* ws = (char*)workspace;
-    const bf16* sh = (const bf16*)shadow;
+    const uint16_t* sh = (const uint16_t*)shadow;
+    const OpKernels& K = op_kernels(c);
     const int M = nseq * L, H = c.hidden_size, I = c.intermediate_size, A = c.num_heads, d = H / A;
     const Layout& lay = e->lay;
     auto P = [&](int seg) { return params + lay.segs[seg].off; };
@@ -1047,7 +1069,7 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
     // dropout: the masks of the forward that filled `saved` are recomputed from its (seed, step) snapshot in the arena and
     // ITS thresholds (recorded by that forward, process-wide: any handle of the same model may run the backward)
     FwdRec fr;
-    if (!rec_get(saved, ARENA_BF16, &fr)) return QST_ERR_BAD_ARG;    // not an arena a bf16 / fp8 training forward has filled
+    if (!rec_get(saved, K.arena_kind, &fr)) return QST_ERR_BAD_ARG;  // not an arena a training forward of this operand type has filled
     const DropThr thr = {fr.hidden, fr.attn};
     const bool dropping = thr.hidden != 0 || thr.attn != 0;
     const void* dst8 = sv + p.dropst;
@@ -1091,7 +1113,7 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
         set(1, du, I, sv + a.y1b, H, b + W_1, b + B_1);            // dW1 [I, H]
         set(2, dsb1, H, sv + a.ctx, H, b + W_O, b + B_O);          // dWo [H, H]
         set(3, dqkv, 3 * H, xin_b, H, b + W_QKV, b + B_QKV);       // dWqkv [3H, H]
-        return qst_gemm_tn_group(&grp, st);
+        return K.gemm_tn_group(&grp, st);
     };
     if (wgrad_only) {
         // the dY tensors of exactly one layer live in the workspace: the one whose stage ran with QST_BWD_SKIP_WGRAD
@@ -1106,41 +1128,41 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
         // row kernel; below, (ds, dsb) were written by the QKV dgrad of layer l+1.
         if (!fuse_ln || l == c.num_layers - 1) {
             QstDrop dd;
-            QST_TRY(qst_ln_bwd_drop(dxa, sv + a.xh2, (const float*)(sv + a.rs2), P(b + LN2_G), M, H, ds, dsb, nullptr, nullptr,
+            QST_TRY(K.ln_bwd_drop(dxa, sv + a.xh2, (const float*)(sv + a.rs2), P(b + LN2_G), M, H, ds, dsb, nullptr, nullptr,
                                     ln_slot(2 * l + 1, G(b + LN2_G), G(b + LN2_B)), nullptr, hdrop(QST_DROP_SITE_FFN_OUT(l), dd), st));
         }
         // FFN2 dgrad through GELU: du = (ds2 . W2) * gelu'(u)   (a.u holds gelu'(u), written by the forward epilogue)
         if (!fuse_ffn)
-            QST_TRY(nt(dsb, H, WT(b + W_2), H, du, I, nullptr, sv + a.u, nullptr, nullptr, 0, M, I, H, QST_EPI_GELU_BWD, st));
+            QST_TRY(nt(K, dsb, H, WT(b + W_2), H, du, I, nullptr, sv + a.u, nullptr, nullptr, 0, M, I, H, QST_EPI_GELU_BWD, false, st));
         // FFN1 dgrad + residual: dy1 = du . W1 + ds2 ; LN1 backward -> ds1 (fp32 in `ds1`, bf16 in dsb1)
         const float* ds1 = ds;
         if (fuse_ffn) {
             // both dgrads of the feed-forward block and the LayerNorm-1 backward in one kernel; du is written once
             // (the weight gradients need it) and never read back by this chain
-            QST_TRY(ffn_chain(dsb, WT(b + W_2), WT(b + W_1), nullptr, nullptr, ds, sv + a.u, nullptr, du, dxb, dsb1, M, H, I, 1,
+            QST_TRY(ffn_chain(K, dsb, WT(b + W_2), WT(b + W_1), nullptr, nullptr, ds, sv + a.u, nullptr, du, dxb, dsb1, M, H, I, 1,
                               P(b + LN1_G), nullptr, 0.f, sv + a.xh1, (float*)(sv + a.rs1),
                               ln_slot(2 * l, G(b + LN1_G), G(b + LN1_B), fused_rows), st));
             ds1 = dxb;
         } else if (fuse_ln) {
             drop_next(thr, dst8, dropping, QST_DROP_SITE_ATTN_OUT(l), 2);
-            QST_TRY(nt_ln(du, I, WT(b + W_1), I, dxb, dsb1, nullptr, ds, M, H, I, 1, P(b + LN1_G), nullptr, 0.f, sv + a.xh1,
+            QST_TRY(nt_ln(K, du, I, WT(b + W_1), I, dxb, dsb1, nullptr, ds, M, H, I, 1, P(b + LN1_G), nullptr, 0.f, sv + a.xh1,
                           (float*)(sv + a.rs1), ln_slot(2 * l, G(b + LN1_G), G(b + LN1_B), fused_rows), st));
             ds1 = dxb;
         } else {
             QstDrop dd;
-            QST_TRY(nt(du, I, WT(b + W_1), I, dxb, H, nullptr, nullptr, nullptr, ds, H, M, H, I, QST_EPI_F32_RESID, st));
-            QST_TRY(qst_ln_bwd_drop(dxb, sv + a.xh1, (const float*)(sv + a.rs1), P(b + LN1_G), M, H, ds, dsb1, nullptr, nullptr,
+            QST_TRY(nt(K, du, I, WT(b + W_1), I, dxb, H, nullptr, nullptr, nullptr, ds, H, M, H, I, QST_EPI_F32_RESID, false, st));
+            QST_TRY(K.ln_bwd_drop(dxb, sv + a.xh1, (const float*)(sv + a.rs1), P(b + LN1_G), M, H, ds, dsb1, nullptr, nullptr,
                                     ln_slot(2 * l, G(b + LN1_G), G(b + LN1_B)), nullptr, hdrop(QST_DROP_SITE_ATTN_OUT(l), dd), st));
         }
         // attention output projection dgrad, attention core
-        QST_TRY(nt(dsb1, H, WT(b + W_O), H, dctx, H, nullptr, nullptr, nullptr, nullptr, 0, M, H, H, QST_EPI_BF16, st));
+        QST_TRY(nt(K, dsb1, H, WT(b + W_O), H, dctx, H, nullptr, nullptr, nullptr, nullptr, 0, M, H, H, QST_EPI_BF16, false, st));
         {
             QstAttnDesc q{};
             q.qkv = sv + a.qkv; q.mask = mask; q.rel_pos = rel; q.nseq = nseq; q.L = L; q.A = A; q.d = d;
             q.ctx = sv + a.ctx; q.lse = (float*)(sv + a.lse); q.dctx = dctx; q.dqkv = dqkv; q.drel = drel;
             q.delta_scratch = (float*)(ws + w.delta);
             if (dropping) q.drop = drop_of(thr, dst8, true, QST_DROP_SITE_PROBS(l));
-            QST_TRY(qst_attention_bwd_ex(&q, st));
+            QST_TRY(K.attention_bwd_ex(&q, st));
         }
         if (!skip_wgrad) QST_TRY(wgrad(l));
         // QKV projection dgrad + residual: dx_in = dqkv . Wqkv + ds1. Fused mode: followed in the same kernel by the
@@ -1150,20 +1172,20 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
         if (fuse_ln && l > 0) {
             const LayerAct& lo = p.layers[l - 1];
             const int bl = lay.layer0[l - 1];
-            QST_TRY(nt_ln(dqkv, 3 * H, WT(b + W_QKV), 3 * H, ds, dsb, nullptr, ds1, M, H, 3 * H, 1, P(bl + LN2_G), nullptr, 0.f,
+            QST_TRY(nt_ln(K, dqkv, 3 * H, WT(b + W_QKV), 3 * H, ds, dsb, nullptr, ds1, M, H, 3 * H, 1, P(bl + LN2_G), nullptr, 0.f,
                           sv + lo.xh2, (float*)(sv + lo.rs2),
                           ln_slot(2 * (l - 1) + 1, G(bl + LN2_G), G(bl + LN2_B), fused_rows), st));
         } else if (fuse_ln) {
-            QST_TRY(nt_ln(dqkv, 3 * H, WT(b + W_QKV), 3 * H, ds, nullptr, nullptr, ds1, M, H, 3 * H, 1, P(lay.eg), nullptr, 0.f,
+            QST_TRY(nt_ln(K, dqkv, 3 * H, WT(b + W_QKV), 3 * H, ds, nullptr, nullptr, ds1, M, H, 3 * H, 1, P(lay.eg), nullptr, 0.f,
                           sv + p.xh0, (float*)(sv + p.rs0), ln_slot(2 * c.num_layers, G(lay.eg), G(lay.eb), fused_rows), st));
         } else {
-            QST_TRY(nt(dqkv, 3 * H, WT(b + W_QKV), 3 * H, dxa, H, nullptr, nullptr, nullptr, ds1, H, M, H, 3 * H,
-                       QST_EPI_F32_RESID, st));
+            QST_TRY(nt(K, dqkv, 3 * H, WT(b + W_QKV), 3 * H, dxa, H, nullptr, nullptr, nullptr, ds1, H, M, H, 3 * H,
+                       QST_EPI_F32_RESID, false, st));
         }
     }
     if (do_embed && !fuse_ln) {
         QstDrop dd;
-        QST_TRY(qst_ln_bwd_drop(dxa, sv + p.xh0, (const float*)(sv + p.rs0), P(lay.eg), M, H, ds, nullptr, nullptr, nullptr,
+        QST_TRY(K.ln_bwd_drop(dxa, sv + p.xh0, (const float*)(sv + p.rs0), P(lay.eg), M, H, ds, nullptr, nullptr, nullptr,
                                 ln_slot(2 * c.num_layers, G(lay.eg), G(lay.eb)), hdrop(QST_DROP_SITE_EMBED, dd), nullptr, st));
     }
     if (lnb.count > 0) {
@@ -1214,6 +1236,24 @@ extern "C" int qst_clip_adamw_step_sched(const qst_encoder* e, float* params, fl
     return qst_adamw_launch_sched(params, grads, exp_avg, exp_avg_sq, e->chunk_decay, e->lay.total, base_lr, beta1, beta2,
                                   eps, weight_decay, max_grad_norm, grad_scale, warmup_steps, total_steps, step_dev,
                                   norm_out, scratch, (hipStream_t)stream);
+}
+
+extern "C" int qst_adamw_launch_amp(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                                    const uint8_t* chunk_decay, int64_t n, float base_lr, float beta1, float beta2,
+                                    float eps, float weight_decay, float max_grad_norm, float grad_scale,
+                                    int64_t warmup_steps, int64_t total_steps, int64_t* step_dev, float* scaler_dev,
+                                    float growth, float backoff, int growth_interval, float* norm_out, float* scratch,
+                                    hipStream_t st);
+
+extern "C" int qst_clip_adamw_step_amp(const qst_encoder* e, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                                       float base_lr, float beta1, float beta2, float eps, float weight_decay,
+                                       float max_grad_norm, float grad_scale, int64_t warmup_steps, int64_t total_steps,
+                                       int64_t* step_dev, float* scaler_dev, float growth_factor, float backoff_factor,
+                                       int32_t growth_interval, float* norm_out, float* scratch, void* stream) {
+    if (!e) return QST_ERR_BAD_ARG;
+    return qst_adamw_launch_amp(params, grads, exp_avg, exp_avg_sq, e->chunk_decay, e->lay.total, base_lr, beta1, beta2, eps,
+                                weight_decay, max_grad_norm, grad_scale, warmup_steps, total_steps, step_dev, scaler_dev,
+                                growth_factor, backoff_factor, growth_interval, norm_out, scratch, (hipStream_t)stream);
 }
 
 extern "C" int qst_clip_adamw_step(const qst_encoder* e, float* params, float* grads, float* exp_avg,

@@ -16,6 +16,28 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 #define QST_WAVE 64
 
+// ---------------------------------------------------------------- the 16-bit matrix-core operand type of a translation unit
+// gemm.hip, gemm8.hip (gemm8p.h), ffn.hip, attention.hip and rowops.hip are written once on `op16` and compiled twice (csrc/Makefile):
+//   QST_OP_F16 = 0 (default): op16 = bfloat16 -- QST_PREC_BF16, v_mfma_f32_32x32x16_bf16 / 16x16x32_bf16; entry points qst_*.
+//   QST_OP_F16 = 1: op16 = IEEE half -- QST_PREC_F16, v_mfma_f32_32x32x16_f16 / 16x16x32_f16 (same issue rate, same bytes);
+//                   the same entry points with the suffix _f16 (QST_K). Conversions round to nearest even (v_cvt_pk_f16_f32);
+//                   forward kernels saturate at +-65,504 instead of overflowing to inf (op_saturate), backward kernels keep IEEE
+//                   inf so that an overflowed gradient reaches the global norm, where the loss scaler looks for it (optim.hip).
+// LDS-DMA staging, swizzles and transposing LDS reads move 16-bit lanes and do not care which of the two it is.
+#ifndef QST_OP_F16
+#define QST_OP_F16 0
+#endif
+#if QST_OP_F16
+typedef _Float16 op16;
+#define QST_K(name) name##_f16
+#else
+typedef __bf16 op16;
+#define QST_K(name) name
+#endif
+typedef __attribute__((ext_vector_type(2))) op16 op16x2;
+typedef __attribute__((ext_vector_type(4))) op16 op16x4;
+typedef __attribute__((ext_vector_type(8))) op16 op16x8;
+
 extern "C" int qst_set_hip_error(int code);
 
 #define QST_HIP_CHECK(expr)                                 \
@@ -143,6 +165,46 @@ __device__ __forceinline__ T ld_stream(const T* p) {
 #else
     return *p;
 #endif
+}
+
+// (static: these differ between the two builds of a file)
+static __device__ __forceinline__ float op2f(op16 x) { return (float)x; }
+static __device__ __forceinline__ op16 f2op(float x) { return (op16)x; }
+static __device__ __forceinline__ uint32_t pack_op2(float lo, float hi) {          // v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32: RNE
+    op16x2 v;
+    v[0] = (op16)lo;
+    v[1] = (op16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
+#if QST_OP_F16
+static __device__ __forceinline__ float op_lo(uint32_t u) { return (float)__builtin_bit_cast(op16x2, u)[0]; }
+static __device__ __forceinline__ float op_hi(uint32_t u) { return (float)__builtin_bit_cast(op16x2, u)[1]; }    // v_cvt_f32_f16 sdwa WORD_1
+// MODE.FP16_OVFL (hwreg 1, bit 23): an overflowed f16 VALU result is clamped to +-MAX_F16 instead of becoming inf (true
+// infinities pass). Set at the top of a FORWARD kernel; backward kernels leave it clear.
+static __device__ __forceinline__ void op_saturate(bool on) { if (on) __builtin_amdgcn_s_setreg(1 | (23 << 6), 1); }
+#else
+static __device__ __forceinline__ float op_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+static __device__ __forceinline__ float op_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
+static __device__ __forceinline__ void op_saturate(bool) {}                        // bf16 has fp32's exponent range
+#endif
+static __device__ __forceinline__ f32x16 mfma32_op(op16x8 a, op16x8 b, f32x16 c) {
+#if QST_OP_F16
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+static __device__ __forceinline__ f32x4 mfma16_op(op16x8 a, op16x8 b, f32x4 c) {
+#if QST_OP_F16
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+// ds_read_b64_tr_b16: a transposing LDS read of four 16-bit values (type-agnostic in hardware; the builtin is typed)
+static __device__ __forceinline__ op16x4 lds_tr16_op(const char* p) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 raw4;
+    return __builtin_bit_cast(op16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) raw4*)(p)));
 }
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {

@@ -24,7 +24,7 @@ __device__ __forceinline__ int mx_exponent_r(float amax) {
 template <int VPL>
 __device__ __forceinline__ void ln_row_finish(const f32x2 (&v)[VPL], int lane, int H, int row,
                                               const float* gamma, const float* beta, float eps,
-                                              float* y, bf16* yb, bf16* xh, float* rstd_out,
+                                              float* y, op16* yb, op16* xh, float* rstd_out,
                                               uint8_t* yq = nullptr, uint8_t* ys = nullptr, int M = 0,
                                               DropCtx dc = DropCtx{0u, 0u, 1.f}) {
     const int nv = H >> 1;
@@ -59,8 +59,8 @@ __device__ __forceinline__ void ln_row_finish(const f32x2 (&v)[VPL], int lane, i
                 o[0] *= m0; o[1] *= m1;
             }
             *(f32x2*)(y + base + 2 * c) = o;
-            if (yb) *(uint32_t*)(yb + base + 2 * c) = pack_bf16x2(o[0], o[1]);
-            if (xh) *(uint32_t*)(xh + base + 2 * c) = pack_bf16x2(h0, h1);
+            if (yb) *(uint32_t*)(yb + base + 2 * c) = pack_op2(o[0], o[1]);
+            if (xh) *(uint32_t*)(xh + base + 2 * c) = pack_op2(h0, h1);
         }
     }
     if (yq) {
@@ -80,8 +80,8 @@ __device__ __forceinline__ void ln_row_finish(const f32x2 (&v)[VPL], int lane, i
                     drop_pair(dc, (uint32_t)(base + 2 * c), m0, m1);
                     f0 *= m0; f1 *= m1;
                 }
-                const uint32_t pk = pack_bf16x2(f0, f1);
-                o0 = bf16lo(pk); o1 = bf16hi(pk);
+                const uint32_t pk = pack_op2(f0, f1);
+                o0 = op_lo(pk); o1 = op_hi(pk);
             }
             const float amax = row16_max(fmaxf(fabsf(o0), fabsf(o1)));
             const int ex = mx_exponent_r(amax);
@@ -107,8 +107,9 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, c
                                                            const int32_t* pos_ids, const float* word,
                                                            const float* pos, const float* type,
                                                            const float* gamma, const float* beta, float eps,
-                                                           int M, int H, float* y, bf16* yb, bf16* xh, float* rstd,
+                                                           int M, int H, float* y, op16* yb, op16* xh, float* rstd,
                                                            uint8_t* yq, uint8_t* ys, QstDrop drop) {
+    op_saturate(true);
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * EMB_ROWS;
     if (row0 >= M) return;
@@ -142,8 +143,9 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, c
 
 template <int VPL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* s, const float* gamma, const float* beta, float eps,
-                                                     int M, int H, float* y, bf16* yb, bf16* xh, float* rstd,
+                                                     int M, int H, float* y, op16* yb, op16* xh, float* rstd,
                                                      uint8_t* yq, uint8_t* ys) {
+    op_saturate(true);
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -163,8 +165,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* s, const float
 constexpr int LN_BWD_ROWS_PER_WAVE = 8;
 
 template <int VPL>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const bf16* xh, const float* rstd,
-                                                     const float* gamma, int M, int H, float* ds, bf16* dsb,
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const op16* xh, const float* rstd,
+                                                     const float* gamma, int M, int H, float* ds, op16* dsb,
                                                      float* dgamma, float* dbeta, float* partials,
                                                      QstDrop drop_in, QstDrop drop_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [4 waves][2][H] floats
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const bf16
         f32x2 d[VPL], x[VPL];
         const float rs = rsn;
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) { d[i] = dn[i]; x[i][0] = bf16lo(xn[i]); x[i][1] = bf16hi(xn[i]); }
+        for (int i = 0; i < VPL; ++i) { d[i] = dn[i]; x[i][0] = op_lo(xn[i]); x[i][1] = op_hi(xn[i]); }
         if (dci.thr) {                   // the dropout that followed this LayerNorm: its mask on the incoming gradient
 #pragma unroll
             for (int i = 0; i < VPL; ++i) {
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const bf16
                         drop_pair(dco, (uint32_t)(base + 2 * c), m0, m1);
                         o[0] *= m0; o[1] *= m1;
                     }
-                    *(uint32_t*)(dsb + base + 2 * c) = pack_bf16x2(o[0], o[1]);
+                    *(uint32_t*)(dsb + base + 2 * c) = pack_op2(o[0], o[1]);
                 }
             }
         }
@@ -563,7 +565,8 @@ __global__ void rel_pos_bwd_kernel(const float* drelpos, const int32_t* lut, int
 }
 
 // bf16 shadow of a [rows, cols] fp32 matrix and its transpose, via a 32x32 LDS tile
-__global__ __launch_bounds__(256) void shadow_kernel(const float* src, int rows, int cols, bf16* dst, bf16* dstT) {
+__global__ __launch_bounds__(256) void shadow_kernel(const float* src, int rows, int cols, op16* dst, op16* dstT) {
+    op_saturate(true);
     __shared__ float tile[32][33];
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(256) void shadow_kernel(const float* src, int rows,
         float v = 0.f;
         if (r < rows && c < cols) {
             v = src[(size_t)r * cols + c];
-            if (dst) dst[(size_t)r * cols + c] = f2bf(v);
+            if (dst) dst[(size_t)r * cols + c] = f2op(v);
         }
         tile[ty + 8 * k][tx] = v;
     }
@@ -580,12 +583,13 @@ __global__ __launch_bounds__(256) void shadow_kernel(const float* src, int rows,
     if (dstT)
         for (int k = 0; k < 4; ++k) {
             const int c = c0 + ty + 8 * k, r = r0 + tx;
-            if (r < rows && c < cols) dstT[(size_t)c * rows + r] = f2bf(tile[tx][ty + 8 * k]);
+            if (r < rows && c < cols) dstT[(size_t)c * rows + r] = f2op(tile[tx][ty + 8 * k]);
         }
 }
 
 // all GEMM weights in ONE launch: table entry = {src offset, rows, cols, dst offset, dstT offset, first block}
-__global__ __launch_bounds__(256) void shadow_all_kernel(const float* params, bf16* shadow, const int64_t* tab, int nseg) {
+__global__ __launch_bounds__(256) void shadow_all_kernel(const float* params, op16* shadow, const int64_t* tab, int nseg) {
+    op_saturate(true);
     __shared__ float tile[32][33];
     int lo = 0, hi = nseg - 1;
     while (lo < hi) {                                   // last segment whose first block <= blockIdx.x
@@ -595,8 +599,8 @@ __global__ __launch_bounds__(256) void shadow_all_kernel(const float* params, bf
     const int64_t* e = tab + lo * 6;
     const float* src = params + e[0];
     const int rows = (int)e[1], cols = (int)e[2];
-    bf16* dst = shadow + e[3];
-    bf16* dstT = shadow + e[4];
+    op16* dst = shadow + e[3];
+    op16* dstT = shadow + e[4];
     const int b = blockIdx.x - (int)e[5];
     const int tiles_x = (cols + 31) / 32;
     const int c0 = (b % tiles_x) * 32, r0 = (b / tiles_x) * 32;
@@ -606,14 +610,14 @@ __global__ __launch_bounds__(256) void shadow_all_kernel(const float* params, bf
         float v = 0.f;
         if (r < rows && c < cols) {
             v = src[(size_t)r * cols + c];
-            dst[(size_t)r * cols + c] = f2bf(v);
+            dst[(size_t)r * cols + c] = f2op(v);
         }
         tile[ty + 8 * k][tx] = v;
     }
     __syncthreads();
     for (int k = 0; k < 4; ++k) {
         const int c = c0 + ty + 8 * k, r = r0 + tx;
-        if (r < rows && c < cols) dstT[(size_t)c * rows + r] = f2bf(tile[tx][ty + 8 * k]);
+        if (r < rows && c < cols) dstT[(size_t)c * rows + r] = f2op(tile[tx][ty + 8 * k]);
     }
 }
 
@@ -633,10 +637,13 @@ __global__ __launch_bounds__(256) void shadow_all_kernel(const float* params, bf
 
 }  // namespace
 
+#if !QST_OP_F16
 extern "C" int qst_embed_ln_fwd_mx(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
                                    const float* word_emb, const float* pos_emb, const float* type_emb,
                                    const float* gamma, const float* beta, float eps, int M, int H,
                                    float* y, void* y_bf16, void* yq, void* ys, void* stream);
+#endif  // !QST_OP_F16
+
 static const QstDrop kNoDrop = {nullptr, 0u, 0u};
 static int drop_ok(const QstDrop* d, int64_t elems) {
     if (!d) return QST_OK;
@@ -644,7 +651,7 @@ static int drop_ok(const QstDrop* d, int64_t elems) {
     if (d->thr16 && d->state && elems >= (int64_t)1 << 32) return QST_ERR_UNSUPPORTED;       // 32-bit element counters
     return QST_OK;
 }
-extern "C" int qst_embed_ln_fwd_drop(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
+extern "C" int QST_K(qst_embed_ln_fwd_drop)(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
                                      const float* word_emb, const float* pos_emb, const float* type_emb,
                                      const float* gamma, const float* beta, float eps, int M, int H,
                                      float* y, void* y_bf16, void* xhat_bf16, float* rstd, const QstDrop* drop, void* stream) {
@@ -654,18 +661,19 @@ extern "C" int qst_embed_ln_fwd_drop(const int64_t* ids, const int64_t* type_ids
     hipStream_t st = (hipStream_t)stream;
     QST_VPL_DISPATCH(H, (embed_ln_fwd_kernel<VPL><<<(M + 4 * EMB_ROWS - 1) / (4 * EMB_ROWS), 256, 0, st>>>(
                             ids, type_ids, pos_ids, word_emb, pos_emb, type_emb, gamma, beta, eps, M, H, y,
-                            (bf16*)y_bf16, (bf16*)xhat_bf16, rstd, nullptr, nullptr, drop ? *drop : kNoDrop)));
+                            (op16*)y_bf16, (op16*)xhat_bf16, rstd, nullptr, nullptr, drop ? *drop : kNoDrop)));
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
-extern "C" int qst_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
+extern "C" int QST_K(qst_embed_ln_fwd)(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
                                 const float* word_emb, const float* pos_emb, const float* type_emb,
                                 const float* gamma, const float* beta, float eps, int M, int H,
                                 float* y, void* y_bf16, void* xhat_bf16, float* rstd, void* stream) {
-    return qst_embed_ln_fwd_drop(ids, type_ids, pos_ids, word_emb, pos_emb, type_emb, gamma, beta, eps, M, H, y, y_bf16,
+    return QST_K(qst_embed_ln_fwd_drop)(ids, type_ids, pos_ids, word_emb, pos_emb, type_emb, gamma, beta, eps, M, H, y, y_bf16,
                                  xhat_bf16, rstd, nullptr, stream);
 }
 
+#if !QST_OP_F16
 extern "C" int qst_embed_ln_fwd_mx(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
                                    const float* word_emb, const float* pos_emb, const float* type_emb,
                                    const float* gamma, const float* beta, float eps, int M, int H,
@@ -675,7 +683,7 @@ extern "C" int qst_embed_ln_fwd_mx(const int64_t* ids, const int64_t* type_ids, 
     hipStream_t st = (hipStream_t)stream;
     QST_VPL_DISPATCH(H, (embed_ln_fwd_kernel<VPL><<<(M + 4 * EMB_ROWS - 1) / (4 * EMB_ROWS), 256, 0, st>>>(
                             ids, type_ids, pos_ids, word_emb, pos_emb, type_emb, gamma, beta, eps, M, H, y,
-                            (bf16*)y_bf16, nullptr, nullptr, (uint8_t*)yq, (uint8_t*)ys, kNoDrop)));
+                            (op16*)y_bf16, nullptr, nullptr, (uint8_t*)yq, (uint8_t*)ys, kNoDrop)));
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
@@ -685,7 +693,7 @@ extern "C" int qst_ln_fwd_mx(const float* s, const float* gamma, const float* be
     if (!s || !gamma || !beta || !y || !yq || !ys || M <= 0 || H <= 0) return QST_ERR_BAD_ARG;
     if (H % 64 != 0) return QST_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    QST_VPL_DISPATCH(H, (ln_fwd_kernel<VPL><<<(M + 3) / 4, 256, 0, st>>>(s, gamma, beta, eps, M, H, y, (bf16*)y_bf16, nullptr,
+    QST_VPL_DISPATCH(H, (ln_fwd_kernel<VPL><<<(M + 3) / 4, 256, 0, st>>>(s, gamma, beta, eps, M, H, y, (op16*)y_bf16, nullptr,
                                                                          nullptr, (uint8_t*)yq, (uint8_t*)ys)));
     QST_LAUNCH_CHECK();
     return QST_OK;
@@ -706,7 +714,7 @@ extern "C" int qst_embed_ln_fwd_mx_train(const int64_t* ids, const int64_t* type
     hipStream_t st = (hipStream_t)stream;
     QST_VPL_DISPATCH(H, (embed_ln_fwd_kernel<VPL><<<(M + 4 * EMB_ROWS - 1) / (4 * EMB_ROWS), 256, 0, st>>>(
                             ids, type_ids, pos_ids, word_emb, pos_emb, type_emb, gamma, beta, eps, M, H, y,
-                            (bf16*)y_bf16, (bf16*)xhat_bf16, rstd, (uint8_t*)yq, (uint8_t*)ys, drop ? *drop : kNoDrop)));
+                            (op16*)y_bf16, (op16*)xhat_bf16, rstd, (uint8_t*)yq, (uint8_t*)ys, drop ? *drop : kNoDrop)));
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
@@ -715,22 +723,24 @@ extern "C" int qst_ln_fwd_mx_train(const float* s, const float* gamma, const flo
     if (!s || !gamma || !beta || !y || !y_bf16 || !xhat_bf16 || !rstd || !yq || !ys || M <= 0 || H <= 0) return QST_ERR_BAD_ARG;
     if (H % 64 != 0) return QST_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    QST_VPL_DISPATCH(H, (ln_fwd_kernel<VPL><<<(M + 3) / 4, 256, 0, st>>>(s, gamma, beta, eps, M, H, y, (bf16*)y_bf16,
-                                                                         (bf16*)xhat_bf16, rstd, (uint8_t*)yq, (uint8_t*)ys)));
+    QST_VPL_DISPATCH(H, (ln_fwd_kernel<VPL><<<(M + 3) / 4, 256, 0, st>>>(s, gamma, beta, eps, M, H, y, (op16*)y_bf16,
+                                                                         (op16*)xhat_bf16, rstd, (uint8_t*)yq, (uint8_t*)ys)));
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
+#endif  // !QST_OP_F16
 
-extern "C" int qst_ln_fwd(const float* s, const float* gamma, const float* beta, float eps, int M, int H,
+extern "C" int QST_K(qst_ln_fwd)(const float* s, const float* gamma, const float* beta, float eps, int M, int H,
                           float* y, void* y_bf16, void* xhat_bf16, float* rstd, void* stream) {
     if (!s || !gamma || !beta || !y || M <= 0 || H <= 0 || (H & 1)) return QST_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    QST_VPL_DISPATCH(H, (ln_fwd_kernel<VPL><<<(M + 3) / 4, 256, 0, st>>>(s, gamma, beta, eps, M, H, y, (bf16*)y_bf16,
-                                                                         (bf16*)xhat_bf16, rstd, nullptr, nullptr)));
+    QST_VPL_DISPATCH(H, (ln_fwd_kernel<VPL><<<(M + 3) / 4, 256, 0, st>>>(s, gamma, beta, eps, M, H, y, (op16*)y_bf16,
+                                                                         (op16*)xhat_bf16, rstd, nullptr, nullptr)));
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
 
+#if !QST_OP_F16
 // Batched second stage for several LayerNorms at once (one launch per backward call instead of one per LayerNorm)
 __global__ __launch_bounds__(256) void ln_bwd_reduce_batch_kernel(QstLnReduceBatch b) {
     const int which = blockIdx.z;
@@ -765,12 +775,13 @@ extern "C" size_t qst_ln_bwd_scratch_bytes(int M, int H) {
     const int rows_per_block = 4 * LN_BWD_ROWS_PER_WAVE;
     return (size_t)((M + rows_per_block - 1) / rows_per_block) * 2 * H * sizeof(float);
 }
+#endif  // !QST_OP_F16
 
-extern "C" int qst_ln_bwd(const float* dy, const void* xhat_bf16, const float* rstd, const float* gamma, int M, int H,
+extern "C" int QST_K(qst_ln_bwd)(const float* dy, const void* xhat_bf16, const float* rstd, const float* gamma, int M, int H,
                           float* ds, void* ds_bf16, float* dgamma, float* dbeta, float* scratch, void* stream) {
-    return qst_ln_bwd_drop(dy, xhat_bf16, rstd, gamma, M, H, ds, ds_bf16, dgamma, dbeta, scratch, nullptr, nullptr, stream);
+    return QST_K(qst_ln_bwd_drop)(dy, xhat_bf16, rstd, gamma, M, H, ds, ds_bf16, dgamma, dbeta, scratch, nullptr, nullptr, stream);
 }
-extern "C" int qst_ln_bwd_drop(const float* dy, const void* xhat_bf16, const float* rstd, const float* gamma, int M, int H,
+extern "C" int QST_K(qst_ln_bwd_drop)(const float* dy, const void* xhat_bf16, const float* rstd, const float* gamma, int M, int H,
                                float* ds, void* ds_bf16, float* dgamma, float* dbeta, float* scratch,
                                const QstDrop* drop_in, const QstDrop* drop_out, void* stream) {
     if (int rc = drop_ok(drop_in, (int64_t)M * H)) return rc;
@@ -784,8 +795,8 @@ extern "C" int qst_ln_bwd_drop(const float* dy, const void* xhat_bf16, const flo
     const int rows_per_block = 4 * LN_BWD_ROWS_PER_WAVE;
     const int grid = (M + rows_per_block - 1) / rows_per_block;
     const size_t lds = (size_t)8 * H * sizeof(float);
-    QST_VPL_DISPATCH(H, (ln_bwd_kernel<VPL><<<grid, 256, lds, st>>>(dy, (const bf16*)xhat_bf16, rstd, gamma, M, H, ds,
-                                                                   (bf16*)ds_bf16, dgamma, dbeta, scratch,
+    QST_VPL_DISPATCH(H, (ln_bwd_kernel<VPL><<<grid, 256, lds, st>>>(dy, (const op16*)xhat_bf16, rstd, gamma, M, H, ds,
+                                                                   (op16*)ds_bf16, dgamma, dbeta, scratch,
                                                                    drop_in ? *drop_in : kNoDrop, drop_out ? *drop_out : kNoDrop)));
     QST_LAUNCH_CHECK();
     if (scratch && !deferred) {
@@ -795,6 +806,7 @@ extern "C" int qst_ln_bwd_drop(const float* dy, const void* xhat_bf16, const flo
     return QST_OK;
 }
 
+#if !QST_OP_F16
 extern "C" int qst_embed_bwd(const float* ds, const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
                              int nseq, int L, int H, int num_types, float* dword, float* dpos, float* dtype_,
                              void* stream) {
@@ -874,22 +886,24 @@ extern "C" int qst_rel_pos_bwd(const float* drel_pos, const int32_t* lut, int bu
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
+#endif  // !QST_OP_F16
 
-extern "C" int qst_shadow_all(const float* params, void* shadow, const int64_t* table_dev, int nseg, int nblocks, void* stream) {
+extern "C" int QST_K(qst_shadow_all)(const float* params, void* shadow, const int64_t* table_dev, int nseg, int nblocks, void* stream) {
     if (!params || !shadow || !table_dev || nseg <= 0 || nblocks <= 0) return QST_ERR_BAD_ARG;
-    shadow_all_kernel<<<nblocks, 256, 0, (hipStream_t)stream>>>(params, (bf16*)shadow, table_dev, nseg);
+    shadow_all_kernel<<<nblocks, 256, 0, (hipStream_t)stream>>>(params, (op16*)shadow, table_dev, nseg);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
 
-extern "C" int qst_shadow_matrix(const float* src, int rows, int cols, void* dst_bf16, void* dstT_bf16, void* stream) {
+extern "C" int QST_K(qst_shadow_matrix)(const float* src, int rows, int cols, void* dst_bf16, void* dstT_bf16, void* stream) {
     if (!src || rows <= 0 || cols <= 0) return QST_ERR_BAD_ARG;
     shadow_kernel<<<dim3((cols + 31) / 32, (rows + 31) / 32), 256, 0, (hipStream_t)stream>>>(
-        src, rows, cols, (bf16*)dst_bf16, (bf16*)dstT_bf16);
+        src, rows, cols, (op16*)dst_bf16, (op16*)dstT_bf16);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
 
+#if !QST_OP_F16
 // ---------------------------------------------------------------- dropout state (include/qst.h, qst_kernels.h: QstDrop)
 namespace {
 __global__ void drop_init_kernel(uint32_t* st, uint32_t lo, uint32_t hi) { st[0] = lo; st[1] = hi; st[2] = 0u; st[3] = 0u; }
@@ -955,3 +969,5 @@ extern "C" int qst_dropout_multipliers(const QstDrop* d, int probs, int64_t n, f
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
+#endif  // !QST_OP_F16
+

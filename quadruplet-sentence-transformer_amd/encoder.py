@@ -41,6 +41,11 @@ class HipEncoder:
         self.drop_state = None
         self.handle_x3 = None         # QST_PREC_BF16X3 handle over the SAME arenas, created on first use
         self.handle_mx = None         # QST_PREC_FP8 handle (MXFP8 weights and activations on the fp8 matrix cores, inference)
+        self.handle_f16 = None        # QST_PREC_F16 handle: the bf16 kernels compiled on IEEE half (round 5), its own shadow
+        self.shadow_f16: Optional[torch.Tensor] = None
+        self.shadow_f16_stale = True
+        self.amp_scaler: Optional[torch.Tensor] = None   # device fp32 [4] {loss scale, growth tracker, last skipped, #skipped}
+        self._step2_dev: Optional[torch.Tensor] = None   # device int64 [2] {optimiser steps, scheduler steps} of the amp step
         self.shadow_mx: Optional[torch.Tensor] = None
         self.shadow_mx_stale = True
         self.params = torch.zeros(self.total, dtype=torch.float32, device=self.device)
@@ -60,7 +65,7 @@ class HipEncoder:
 
     def __del__(self):
         try:
-            for attr in ("handle", "handle_x3", "handle_mx"):
+            for attr in ("handle", "handle_x3", "handle_mx", "handle_f16"):
                 if getattr(self, attr, None):
                     self.lib.qst_encoder_destroy(getattr(self, attr))
                     setattr(self, attr, None)
@@ -75,6 +80,7 @@ class HipEncoder:
         self.params.copy_(t.to(self.device))
         self.shadow_stale = True
         self.shadow_mx_stale = True
+        self.shadow_f16_stale = True
 
     def named_views(self) -> Dict[str, torch.Tensor]:
         """HF-named views into the parameter arena (no copies)."""
@@ -117,7 +123,7 @@ class HipEncoder:
                 self.drop_state = torch.zeros(4, dtype=torch.int32, device=self.device)
             _lib.check(self.lib.qst_dropout_init(self.drop_state.data_ptr(), int(seed) & 0xFFFFFFFFFFFFFFFF,
                                                  _lib.current_stream_ptr()), "qst_dropout_init")
-        for h in (self.handle, self.handle_mx, self.handle_x3):      # every precision's training forward drops at the same places
+        for h in (self.handle, self.handle_mx, self.handle_x3, self.handle_f16):      # every precision's training forward drops at the same places
             if h is not None:
                 _lib.check(self.lib.qst_encoder_set_dropout(h, float(p_hidden), float(p_attn),
                                                             self.drop_state.data_ptr() if on else None), "qst_encoder_set_dropout")
@@ -140,6 +146,12 @@ class HipEncoder:
         _lib.check(self.lib.qst_refresh_shadow_mx(self.handle_mx, self.params.data_ptr(), self.shadow_mx.data_ptr(),
                                                   _lib.current_stream_ptr()), "qst_refresh_shadow_mx")
         self.shadow_mx_stale = False
+
+    def refresh_shadow_f16(self) -> None:
+        """[W | W^T] of every Linear weight as IEEE half (QST_PREC_F16: qst_refresh_shadow on that handle)."""
+        _lib.check(self.lib.qst_refresh_shadow(self.handle_f16, self.params.data_ptr(), self.shadow_f16.data_ptr(),
+                                               _lib.current_stream_ptr()), "qst_refresh_shadow(f16)")
+        self.shadow_f16_stale = False
 
     def refresh_shadow(self) -> None:
         _lib.check(self.lib.qst_refresh_shadow(self.handle, self.params.data_ptr(), self.shadow.data_ptr(),
@@ -182,8 +194,19 @@ class HipEncoder:
                     _lib.check(self.lib.qst_encoder_set_dropout(h, self.dropout[0], self.dropout[1], self.drop_state.data_ptr()),
                                "qst_encoder_set_dropout")
             return self.handle_mx
+        if precision in ("f16", "fp16", 4):
+            if self.handle_f16 is None:
+                h = _lib.vp()
+                _lib.check(self.lib.qst_encoder_create(_lib.make_config(self.cfg, 4), h), "qst_encoder_create(f16)")
+                self.handle_f16 = h
+                self.shadow_f16 = torch.zeros(self.lib.qst_shadow_elems(self.ccfg), dtype=torch.float16, device=self.device)
+                self.shadow_f16_stale = True
+                if self.dropout is not None:
+                    _lib.check(self.lib.qst_encoder_set_dropout(h, self.dropout[0], self.dropout[1], self.drop_state.data_ptr()),
+                               "qst_encoder_set_dropout")
+            return self.handle_f16
         if precision not in ("bf16x3", 1):
-            raise ValueError(f"unknown precision {precision!r} (bf16 | bf16x3 | fp8)")
+            raise ValueError(f"unknown precision {precision!r} (bf16 | f16 | bf16x3 | fp8)")
         if self.handle_x3 is None:
             h = _lib.vp()
             _lib.check(self.lib.qst_encoder_create(_lib.make_config(self.cfg, 1), h), "qst_encoder_create(x3)")
@@ -209,11 +232,15 @@ class HipEncoder:
             if self.shadow_mx_stale:
                 self.refresh_shadow_mx()
             shadow = self.shadow_mx
+        if handle is self.handle_f16 and handle is not None:
+            if self.shadow_f16_stale:
+                self.refresh_shadow_f16()
+            shadow = self.shadow_f16
         nbytes = self.lib.qst_encoder_saved_bytes(handle, n, L, int(training))
         if nbytes == 0:
             raise _lib.QstError(f"unsupported shape nseq={n} L={L} for this encoder (L % 32 == 0, L <= 512)")
         if saved is None:
-            saved = self._arena("_saved_x3" if handle is not self.handle and training else "_saved", nbytes)
+            saved = self._arena("_saved_x3" if handle in (self.handle_x3, self.handle_mx) and training else "_saved", nbytes)
         emb = torch.empty(n, self.cfg.hidden_size, dtype=torch.float32, device=self.device)
         tok = torch.empty(n, L, self.cfg.hidden_size, dtype=torch.float32, device=self.device) if want_tokens else None
         _lib.check(self.lib.qst_encoder_forward(
@@ -223,6 +250,10 @@ class HipEncoder:
         if training and self.dropout is not None:
             self.dropout_step += 1           # mirrors the device counter (tests rebuild this step's masks from it)
         return emb, tok, saved
+
+    def shadow_for(self, handle) -> torch.Tensor:
+        """The [W | W^T] operand shadow a BACKWARD on `handle` reads: IEEE half for the f16 handle, bf16 otherwise."""
+        return self.shadow_f16 if (handle is self.handle_f16 and handle is not None) else self.shadow
 
     def backward(self, ids, mask, type_ids, grad_emb: torch.Tensor, saved: torch.Tensor, precision: str = "bf16") -> None:
         """Accumulate d(loss)/d(params) into self.grads given d(loss)/d(emb). precision="bf16x3": the fp32-class backward
@@ -238,7 +269,7 @@ class HipEncoder:
         grad_emb = grad_emb.contiguous()
         _lib.check(self.lib.qst_encoder_backward(
             handle, ids.data_ptr(), mask.data_ptr(), _lib.ptr(type_ids), n, L, self.params.data_ptr(),
-            self.shadow.data_ptr(), grad_emb.data_ptr(), self.grads.data_ptr(), saved.data_ptr(), saved.numel(),
+            self.shadow_for(handle).data_ptr(), grad_emb.data_ptr(), self.grads.data_ptr(), saved.data_ptr(), saved.numel(),
             ws.data_ptr(), ws.numel(), _lib.current_stream_ptr()), "qst_encoder_backward")
 
     def adamw_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
@@ -253,6 +284,7 @@ class HipEncoder:
             "qst_clip_adamw_step")
         self.shadow_stale = True
         self.shadow_mx_stale = True
+        self.shadow_f16_stale = True
 
 
     # ------------------------------------------------------------------ optimiser state (true resume)
@@ -289,6 +321,39 @@ class HipEncoder:
             self._scratch.data_ptr(), _lib.current_stream_ptr()), "qst_clip_adamw_step_sched")
         self.shadow_stale = True
         self.shadow_mx_stale = True
+        self.shadow_f16_stale = True
+
+
+    # ------------------------------------------------------------------ mixed precision (QST_PREC_F16 training)
+    def ensure_amp_scaler(self, init_scale: float = 65536.0) -> torch.Tensor:
+        """The loss scaler of f16 training on the device (include/qst.h qst_amp_scaler_init): fp32 [4] {scale, growth
+        tracker, last step skipped, skipped steps}. torch.cuda.amp.GradScaler's default init_scale, as ST fit(use_amp=True)."""
+        if self.amp_scaler is None:
+            self.amp_scaler = torch.zeros(4, dtype=torch.float32, device=self.device)
+            _lib.check(self.lib.qst_amp_scaler_init(self.amp_scaler.data_ptr(), float(init_scale), _lib.current_stream_ptr()),
+                       "qst_amp_scaler_init")
+        return self.amp_scaler
+
+    def adamw_step_amp(self, base_lr: float, warmup_steps: int, total_steps: int, betas=(0.9, 0.999), eps: float = 1e-8,
+                       weight_decay: float = 0.01, max_grad_norm: float = 1.0, grad_scale: float = 1.0,
+                       growth_factor: float = 2.0, backoff_factor: float = 0.5, growth_interval: int = 2000) -> None:
+        """GradScaler.unscale_ + clip_grad_norm_ + GradScaler.step(AdamW) + update + zero_grad on the device
+        (qst_clip_adamw_step_amp): the gradients in the arena carry the loss scale; a step whose gradients overflowed is
+        skipped and halves the scale. total_steps <= 0: constant base_lr. No host value of the step depends on the outcome,
+        so the call can sit inside a captured graph; self.opt_step counts CALLS (skipped steps are in amp_scaler[3])."""
+        self.ensure_train_state()
+        self.ensure_amp_scaler()
+        if self._step2_dev is None:
+            self._step2_dev = torch.tensor([self.opt_step, self.opt_step], dtype=torch.int64, device=self.device)
+        self.opt_step += 1
+        _lib.check(self.lib.qst_clip_adamw_step_amp(
+            self.handle, self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+            base_lr, betas[0], betas[1], eps, weight_decay, max_grad_norm, grad_scale, int(warmup_steps), int(total_steps),
+            self._step2_dev.data_ptr(), self.amp_scaler.data_ptr(), growth_factor, backoff_factor, int(growth_interval),
+            self.grad_norm.data_ptr(), self._scratch.data_ptr(), _lib.current_stream_ptr()), "qst_clip_adamw_step_amp")
+        self.shadow_stale = True
+        self.shadow_mx_stale = True
+        self.shadow_f16_stale = True
 
 
 def quadruplet_loss_raw(xa, xp, xq, xn, gamma, m_pn, m_pq, m_qn, p, swap, reduction: int,

@@ -393,7 +393,8 @@ class SentenceTransformer(nn.Module):
         """Same keyword set as sentence-transformers 2.2.2 `fit` (the reference passes all of them,
         training/main.py:128-148) plus `resume_from_checkpoint`: a checkpoint directory written by this method
         (weights + Adam moments + step counters; the reference's checkpoints hold weights only)
-        from which training continues with the schedule where it stopped; and `precision`: "bf16" (default) or "bf16x3", the
+        from which training continues with the schedule where it stopped; and `precision`: "bf16" (default), "f16" (what
+        use_amp=True selects: IEEE-half operands under a device-side GradScaler) or "bf16x3", the
         parity path -- forward and backward as split-bf16 x3 products with fp32 activations, gradients within 1e-4 of fp32
         autograd (the reference trains in fp32, training/main.py:142), dropout as on the bf16 path; single process; or "fp8"
         (BASELINE configs[4]): the forward's Linears on the fp8 matrix cores, the bf16 backward (dropout as in bf16).
@@ -423,8 +424,11 @@ class SentenceTransformer(nn.Module):
         lr = float(optimizer_params.get("lr", 2e-5))
         betas = tuple(optimizer_params.get("betas", (0.9, 0.999)))
         eps = float(optimizer_params.get("eps", 1e-8))
-        if use_amp:
-            logger.info("use_amp is a no-op: the HIP path already runs bf16 MFMA operands with fp32 accumulation")
+        # use_amp: the reference's reduced precision is fp16 autocast + GradScaler (training/main.py:142 passes the flag on); here
+        # that is precision="f16" -- IEEE-half matrix-core operands, fp32 accumulation / residual stream / LayerNorm / softmax /
+        # loss, and GradScaler's scale / unscale / skip / grow rules on the device (qst_clip_adamw_step_amp)
+        if use_amp and precision == "bf16":
+            precision = "f16"
         dataloaders = [dl for dl, _ in train_objectives]
         loss_models = [lm for _, lm in train_objectives]
         for dl in dataloaders:
@@ -446,8 +450,10 @@ class SentenceTransformer(nn.Module):
                 return lr * min(1.0, float(step) / float(max(1, warmup_steps)))
             return warmup_linear_lr(lr, step, warmup_steps, t_total)
 
-        if precision not in ("bf16", "bf16x3", "fp8"):
-            raise ValueError("fit(precision=...) is 'bf16', 'bf16x3' or 'fp8'")
+        if precision not in ("bf16", "f16", "bf16x3", "fp8"):
+            raise ValueError("fit(precision=...) is 'bf16', 'f16', 'bf16x3' or 'fp8'")
+        if precision == "f16" and sched != "warmuplinear" and sched != "constantlr":
+            raise ValueError("precision='f16' / use_amp drives the device-side schedule: 'WarmupLinear' or 'constantlr'")
         if data_parallel not in (None, "off", "split_batch", "per_rank_batches"):
             raise ValueError(f"data_parallel={data_parallel!r}: expected 'split_batch', 'per_rank_batches' or 'off'")
         enc = self._enc
@@ -479,6 +485,8 @@ class SentenceTransformer(nn.Module):
         self.training_precision = precision
         try:
             enc.set_dropout(p_hidden, p_attn, int(dropout_seed) + rank)
+            if precision == "f16":
+                enc.ensure_amp_scaler()
             global_step = 0
             if resume_from_checkpoint is not None:
                 global_step = self._load_training_state(resume_from_checkpoint)
@@ -514,7 +522,10 @@ class SentenceTransformer(nn.Module):
                             labels = labels.to(self._target_device)
                             features = [batch_to_device(f, self._target_device) for f in features]
                             loss_value = lm(features, labels)
-                            (loss_value if weight == 1.0 else loss_value * weight).backward()
+                            if precision == "f16":          # GradScaler.scale(loss): the scale is a device scalar
+                                (loss_value * (enc.amp_scaler[0] * weight)).backward()
+                            else:
+                                (loss_value if weight == 1.0 else loss_value * weight).backward()
                         if world > 1:
                             if not self._dp_reduced:
                                 # empty shard (the last batch had fewer rows than ranks), or a loss model that bypassed
@@ -527,7 +538,13 @@ class SentenceTransformer(nn.Module):
                                 w.wait()
                             self._dp_works, self._dp_reduced, self._live_graphs = [], False, 0
                         # clip_grad_norm_ + AdamW.step + zero_grad, one pass over the arena, norm stays on the device
-                        enc.adamw_step(lr_at(global_step), betas, eps, weight_decay, float(max_grad_norm), 1.0 / world)
+                        if precision == "f16":
+                            # scaler.unscale_ + clip + scaler.step + scaler.update; the learning rate follows the device's
+                            # scheduler count (ST skips scheduler.step() whenever the scale changed)
+                            enc.adamw_step_amp(lr, int(warmup_steps), t_total if sched == "warmuplinear" else 0, betas, eps,
+                                               weight_decay, float(max_grad_norm), 1.0 / world)
+                        else:
+                            enc.adamw_step(lr_at(global_step), betas, eps, weight_decay, float(max_grad_norm), 1.0 / world)
                     training_steps += 1
                     global_step += 1
                     if evaluation_steps > 0 and training_steps % evaluation_steps == 0:

@@ -83,13 +83,14 @@ def staged_backward(enc: HipEncoder, ids, mask, types, grad_emb, saved, ws=None,
     optimiser step (the global-norm clip needs every reduced gradient, so replicas stay bit-identical).
 
     buckets=None (single process): one call, no exchange.
-    precision: "bf16", or "fp8" when `saved` was filled by forward(training=True, precision="fp8") -- the same bf16 stages
-    on that handle. What a training forward did with dropout is recorded per activation arena, process-wide, so either
+    precision: "bf16"; "f16" (the same stages on IEEE-half operands: `saved` from forward(training=True, precision="f16"),
+    grad_emb carrying the loss scale); or "fp8" when `saved` was filled by forward(training=True, precision="fp8") -- the
+    bf16 stages on that handle. What a training forward did with dropout is recorded per activation arena, process-wide, so either
     handle rebuilds the masks of the forward that filled `saved` (an arena no training forward has filled is refused)."""
     lib, st = enc.lib, _lib.current_stream_ptr()
     n, L = ids.shape
-    if precision not in ("bf16", "fp8"):
-        raise ValueError("the staged backward runs the bf16 stages (precision 'bf16' or 'fp8')")
+    if precision not in ("bf16", "fp8", "f16"):
+        raise ValueError("the staged backward runs the 16-bit stages (precision 'bf16', 'f16' or 'fp8')")
     handle = enc._handle_for(precision)
     if ws is None:
         ws = enc._arena("_ws", lib.qst_encoder_bwd_workspace_bytes(handle, n, L))
@@ -99,7 +100,7 @@ def staged_backward(enc: HipEncoder, ids, mask, types, grad_emb, saved, ws=None,
     def stage(flags, hi, lo):
         _lib.check(lib.qst_encoder_backward_stage(
             handle, ids.data_ptr(), mask.data_ptr(), _lib.ptr(types), n, L, enc.params.data_ptr(),
-            enc.shadow.data_ptr(), grad_emb.data_ptr(), enc.grads.data_ptr(), saved.data_ptr(), saved.numel(),
+            enc.shadow_for(handle).data_ptr(), grad_emb.data_ptr(), enc.grads.data_ptr(), saved.data_ptr(), saved.numel(),
             ws.data_ptr(), ws.numel(), int(flags), hi, lo, st), "qst_encoder_backward_stage")
 
     if buckets is None:
@@ -136,8 +137,11 @@ class QuadrupletTrainer:
                  betas=(0.9, 0.999), eps: float = 1e-8, warmup_steps: int = 0, total_steps: int = 0,
                  process_group=None, world_size: int = 1, overlap: bool = True, encoder: Optional[HipEncoder] = None,
                  use_graph: bool = False, dropout=None, dropout_seed: int = 0, force_dp: bool = False,
-                 precision: str = "bf16"):
-        """precision: "bf16" (the throughput path); "fp8" -- BASELINE configs[4]: the forward's Linears on the fp8 matrix
+                 precision: str = "bf16", amp_init_scale: float = 65536.0, amp_growth_interval: int = 2000):
+        """precision: "bf16" (the throughput path); "f16" -- the same kernels on IEEE-half operands (11 significand bits:
+        embeddings inside the north-star tolerance for the six-layer models) under a dynamic loss scale on the device, i.e.
+        what the reference's `use_amp=True` is (autocast + GradScaler, training/main.py:142): amp_init_scale and
+        amp_growth_interval are GradScaler's init_scale / growth_interval (<= 0: a static scale); "fp8" -- BASELINE configs[4]: the forward's Linears on the fp8 matrix
         cores (MXFP8 weights and activations), dgrad / wgrad in bf16 from the fp32 master weights (H and I multiples of 128;
         dropout as on the bf16 path); or "bf16x3" -- the parity path: fp32 activations, every product as three
         split-bf16 MFMAs, gradients fp32-class (the reference trains in fp32, training/main.py:142). Several times slower;
@@ -147,8 +151,8 @@ class QuadrupletTrainer:
         (p_hidden, p_attn). The reference's fit() trains with 0.1 (HF config defaults, train() mode). Ranks of a
         data-parallel job should pass different dropout_seed values (fit() adds the rank)."""
         self.cfg = cfg
-        if precision not in ("bf16", "bf16x3", "fp8"):
-            raise ValueError("training precision is 'bf16', 'bf16x3' or 'fp8'")
+        if precision not in ("bf16", "f16", "bf16x3", "fp8"):
+            raise ValueError("training precision is 'bf16', 'f16', 'bf16x3' or 'fp8'")
         if precision == "bf16x3" and use_graph:
             raise ValueError("precision='bf16x3' (the parity path) trains without a graph")
         if precision == "fp8" and use_graph:
@@ -158,6 +162,9 @@ class QuadrupletTrainer:
         if arena is not None:
             self.enc.load_arena(arena)
         self.enc.ensure_train_state()
+        self.amp_growth_interval = int(amp_growth_interval)
+        if precision == "f16":
+            self.enc.ensure_amp_scaler(amp_init_scale)
         if dropout is not None:
             ph, pa = (dropout, dropout) if isinstance(dropout, (int, float)) else dropout
             self.enc.set_dropout(float(ph), float(pa), int(dropout_seed))
@@ -196,8 +203,11 @@ class QuadrupletTrainer:
         types = types4.reshape(4 * B, L) if (types4 is not None and self.cfg.type_vocab_size > 0) else None
         emb, _, saved = self.enc.forward(ids, mask, types, training=training, saved=saved, precision=precision)
         e4 = emb.view(4, B, -1)
+        # f16 training: the loss gradient leaves the loss kernel multiplied by the device-resident loss scale (grad_out = the
+        # scaler's first word), so every f16 gradient tensor of the backward sits inside half's range
+        gout = self.enc.amp_scaler if (want_grads and precision == "f16") else None
         loss, g = quadruplet_loss_raw(e4[0], e4[1], e4[2], e4[3], *self.loss_args, _REDUCTION["mean"],
-                                      want_grads=want_grads)
+                                      grad_out=gout, want_grads=want_grads)
         return loss, e4, g, saved, (ids, mask, types)
 
     def step(self, ids4: torch.Tensor, mask4: torch.Tensor, types4: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -216,8 +226,8 @@ class QuadrupletTrainer:
             n, L = 4 * ids4.shape[1], ids4.shape[2]
             enc = self.enc
             bufs = dict(
-                saved=torch.empty(enc.lib.qst_encoder_saved_bytes(enc.handle, n, L, 1), dtype=torch.uint8, device=enc.device),
-                ws=torch.empty(enc.lib.qst_encoder_bwd_workspace_bytes(enc.handle, n, L), dtype=torch.uint8, device=enc.device))
+                saved=torch.empty(enc.lib.qst_encoder_saved_bytes(enc._handle_for(self.precision), n, L, 1), dtype=torch.uint8, device=enc.device),
+                ws=torch.empty(enc.lib.qst_encoder_bwd_workspace_bytes(enc._handle_for(self.precision), n, L), dtype=torch.uint8, device=enc.device))
             loss = self._step_eager(*static, sched_on_device=True, **bufs)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
@@ -232,7 +242,9 @@ class QuadrupletTrainer:
             static[2].copy_(types4, non_blocking=True)
         graph.replay()
         self.enc.opt_step += 1
-        self.enc.shadow_stale = False        # the captured step ends with the shadow refresh
+        # the captured step ends with the refresh of the operand shadow it trains on (the other one is stale)
+        self.enc.shadow_stale = self.precision == "f16"
+        self.enc.shadow_f16_stale = self.precision != "f16"
         self.sched_step += 1
         return static_loss
 
@@ -257,7 +269,15 @@ class QuadrupletTrainer:
                                     precision=self.precision)
         for w in works:
             w.wait()
-        if sched_on_device:
+        if self.precision == "f16":
+            opt0 = enc.opt_step
+            enc.adamw_step_amp(self.lr, self.warmup_steps, self.total_steps, self.betas, self.eps, self.wd,
+                               self.max_grad_norm, 1.0 / self.world, growth_interval=self.amp_growth_interval)
+            if sched_on_device:
+                enc.refresh_shadow_f16()     # a graph replays the whole step: the next forward's operand refresh belongs inside it
+            if not count:
+                enc.opt_step = opt0
+        elif sched_on_device:
             opt0 = enc.opt_step
             enc.adamw_step_sched(self.lr, self.warmup_steps, self.total_steps, self.betas, self.eps, self.wd,
                                  self.max_grad_norm, 1.0 / self.world)

@@ -37,6 +37,25 @@ def bfr(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
 
+# The kernels with 16-bit matrix-core operands exist on bf16 (qst_*) and on IEEE half (qst_*_f16: QST_PREC_F16, the same
+# sources compiled on the other operand type); their tests run on both.
+OPDT = {"bf16": torch.bfloat16, "f16": torch.float16}
+
+
+@pytest.fixture(params=["bf16", "f16"])
+def op(request):
+    return request.param
+
+
+def opr(op, t):
+    """t rounded to the operand type and back (what the kernel's operand holds)."""
+    return t.to(OPDT[op]).to(torch.float32)
+
+
+def kf(lib, name, op):
+    return _lib.kfn(lib, name, op)
+
+
 # ------------------------------------------------------------------ loss
 @pytest.mark.parametrize("B,D", [(1, 10), (5, 10), (8, 384), (64, 384), (32, 768), (7, 33), (3, 2052)])
 @pytest.mark.parametrize("p", [2.0, 1.0, 3.0])
@@ -104,38 +123,38 @@ def gemm_args(**kw):
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 384), (200, 192, 128), (1000, 1152, 384), (64, 64, 64),
                                    (4096, 384, 1536), (5000, 1536, 384), (20000, 1152, 384), (12000, 768, 768),
                                    (33000, 384, 448)])
-def test_gemm_nt_epilogues(lib, M, N, K, form):
+def test_gemm_nt_epilogues(lib, op, M, N, K, form):
     """form: QstGemmArgs.splits selects the nt tiling (0 = automatic; 1 = 128-row tiles, two workgroups per CU; 2 = 256-row
     tiles, one 8-wave workgroup per CU; 4 = 256-row tiles of four waves owning 128 x 96 each, bf16-output epilogues only --
     the fp32 one falls back to form 1; 0x20 / 0x40 = the 8-wave, 8-phase K loop of csrc/gemm8.hip with its 128 x 384 / 256 x 256
     workgroup tile, register-only epilogues -- K = 448 is an odd number of K-tiles, M = 33000 / 5000 / 200 ragged row tiles);
     all must give the same results."""
     g = torch.Generator().manual_seed(M + N + K)
-    A = bfr(torch.randn(M, K, generator=g))
-    B = bfr(torch.randn(N, K, generator=g) * 0.05)
+    A = opr(op, torch.randn(M, K, generator=g))
+    B = opr(op, torch.randn(N, K, generator=g) * 0.05)
     bias = torch.randn(N, generator=g)
     resid = torch.randn(M, N, generator=g)
     ref = A @ B.t() + bias
-    Ad, Bd = dev(A.to(torch.bfloat16)), dev(B.to(torch.bfloat16))
+    Ad, Bd = dev(A.to(OPDT[op])), dev(B.to(OPDT[op]))
     # EPI_BF16
-    Cb = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-    _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=Cb, bias=dev(bias), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, splits=form), 0, stream()))
+    Cb = torch.empty(M, N, dtype=OPDT[op], device="cuda")
+    _lib.check(kf(lib, "qst_gemm_nt", op)(gemm_args(A=Ad, B=Bd, C=Cb, bias=dev(bias), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, splits=form), 0, stream()))
     torch.testing.assert_close(Cb.float().cpu(), ref, rtol=8e-3, atol=2e-2)
     # EPI_F32_RESID
     Cf = torch.empty(M, N, dtype=torch.float32, device="cuda")
-    _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=Cf, bias=dev(bias), resid=dev(resid), M=M, N=N, K=K, lda=K, ldb=K,
+    _lib.check(kf(lib, "qst_gemm_nt", op)(gemm_args(A=Ad, B=Bd, C=Cf, bias=dev(bias), resid=dev(resid), M=M, N=N, K=K, lda=K, ldb=K,
                                          ldc=N, ldr=N, splits=form), 1, stream()))
     torch.testing.assert_close(Cf.cpu(), ref + resid, rtol=1e-4, atol=1e-3)
     # EPI_GELU: C = gelu'(u) (saved for backward), C2 = gelu(u)
-    C2 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-    _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=Cb, C2=C2, bias=dev(bias), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, splits=form), 2, stream()))
+    C2 = torch.empty(M, N, dtype=OPDT[op], device="cuda")
+    _lib.check(kf(lib, "qst_gemm_nt", op)(gemm_args(A=Ad, B=Bd, C=Cb, C2=C2, bias=dev(bias), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, splits=form), 2, stream()))
     ur = ref.clone().requires_grad_(True)
     torch.nn.functional.gelu(ur).sum().backward()
     torch.testing.assert_close(Cb.float().cpu(), ur.grad, rtol=8e-3, atol=2e-2)
     torch.testing.assert_close(C2.float().cpu(), torch.nn.functional.gelu(ref), rtol=8e-3, atol=2e-2)
     # EPI_GELU_BWD: C = acc * aux
-    gp = bfr(torch.rand(M, N, generator=g) * 1.2 - 0.1)
-    _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=Cb, aux=dev(gp.to(torch.bfloat16)), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, splits=form), 3, stream()))
+    gp = opr(op, torch.rand(M, N, generator=g) * 1.2 - 0.1)
+    _lib.check(kf(lib, "qst_gemm_nt", op)(gemm_args(A=Ad, B=Bd, C=Cb, aux=dev(gp.to(OPDT[op])), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, splits=form), 3, stream()))
     torch.testing.assert_close(Cb.float().cpu(), (A @ B.t()) * gp, rtol=8e-3, atol=2e-2)
 
 
@@ -149,29 +168,29 @@ def tn_mode(request, lib):
 
 @pytest.mark.parametrize("M,N,K", [(64, 128, 128), (512, 384, 384), (1000, 1152, 384), (300, 64, 256), (4096, 384, 1536),
                                    (96, 192, 64), (16384, 384, 384), (32768, 768, 768), (8256, 192, 384), (777, 200, 136)])
-def test_gemm_tn_wgrad(lib, tn_mode, M, N, K):
+def test_gemm_tn_wgrad(lib, op, tn_mode, M, N, K):
     """Single-problem weight gradient. The large cases have fewer tiles than workgroups per M-range (every tile is cut into
     stage pieces: VERDICT r02 weak point 9 -- tools/gemm_bench.py died on (32768, 768, 768) with no test at that size) and an
     M that leaves a ragged last 64-row stage."""
     g = torch.Generator().manual_seed(M * 3 + N + K)
-    A = bfr(torch.randn(M, N, generator=g))      # dY
-    B = bfr(torch.randn(M, K, generator=g))      # X
+    A = opr(op, torch.randn(M, N, generator=g))      # dY
+    B = opr(op, torch.randn(M, K, generator=g))      # X
     ref = A.t() @ B
     C = torch.zeros(N, K, dtype=torch.float32, device="cuda")
     cs = torch.zeros(N, dtype=torch.float32, device="cuda")
-    _lib.check(lib.qst_gemm_tn(gemm_args(A=dev(A.to(torch.bfloat16)), B=dev(B.to(torch.bfloat16)), C=C, colsum=cs, M=M, N=N,
+    _lib.check(kf(lib, "qst_gemm_tn", op)(gemm_args(A=dev(A.to(OPDT[op])), B=dev(B.to(OPDT[op])), C=C, colsum=cs, M=M, N=N,
                                          K=K, lda=N, ldb=K, ldc=K, splits=0), stream()))
     scale = math.sqrt(M)
     torch.testing.assert_close(C.cpu(), ref, rtol=1e-3, atol=1e-3 * scale)
     torch.testing.assert_close(cs.cpu(), A.sum(0), rtol=1e-3, atol=1e-3 * scale)
     # accumulation semantics: a second call doubles the result
-    _lib.check(lib.qst_gemm_tn(gemm_args(A=dev(A.to(torch.bfloat16)), B=dev(B.to(torch.bfloat16)), C=C, colsum=cs, M=M, N=N,
+    _lib.check(kf(lib, "qst_gemm_tn", op)(gemm_args(A=dev(A.to(OPDT[op])), B=dev(B.to(OPDT[op])), C=C, colsum=cs, M=M, N=N,
                                          K=K, lda=N, ldb=K, ldc=K, splits=3), stream()))
     torch.testing.assert_close(C.cpu(), 2 * ref, rtol=1e-3, atol=2e-3 * scale)
 
 
 @pytest.mark.parametrize("M", [1000, 4096, 32 * 70 + 32, 96])
-def test_gemm_tn_group_matches_individual(lib, tn_mode, M):
+def test_gemm_tn_group_matches_individual(lib, op, tn_mode, M):
     """All four weight gradients of a MiniLM-shaped layer in one grouped launch -- incl. a last M-range shorter than
     the others and M too small for eight ranges."""
     H, I = 384, 1536
@@ -181,9 +200,9 @@ def test_gemm_tn_group_matches_individual(lib, tn_mode, M):
     grp.nprob, grp.splits = 4, 0
     keep, refs, outs = [], [], []
     for i, (N, K) in enumerate(shapes):
-        A = bfr(torch.randn(M, N, generator=g))
-        B = bfr(torch.randn(M, K, generator=g))
-        Ad, Bd = dev(A.to(torch.bfloat16)), dev(B.to(torch.bfloat16))
+        A = opr(op, torch.randn(M, N, generator=g))
+        B = opr(op, torch.randn(M, K, generator=g))
+        Ad, Bd = dev(A.to(OPDT[op])), dev(B.to(OPDT[op]))
         C = torch.ones(N, K, device="cuda")                    # accumulation semantics: C += A^T.B
         cs = torch.zeros(N, device="cuda")
         q = grp.prob[i]
@@ -192,7 +211,7 @@ def test_gemm_tn_group_matches_individual(lib, tn_mode, M):
         keep += [Ad, Bd]
         refs.append((A.t() @ B + 1.0, A.sum(0)))
         outs.append((C, cs))
-    _lib.check(lib.qst_gemm_tn_group(grp, stream()))
+    _lib.check(kf(lib, "qst_gemm_tn_group", op)(grp, stream()))
     torch.cuda.synchronize()
     for (C, cs), (rC, rcs) in zip(outs, refs):
         torch.testing.assert_close(C.cpu(), rC, rtol=1e-3, atol=1e-3 * math.sqrt(M))
@@ -201,7 +220,7 @@ def test_gemm_tn_group_matches_individual(lib, tn_mode, M):
 
 # ------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("M,H", [(37, 64), (128, 128), (300, 384), (129, 768), (5, 1024)])
-def test_layernorm_fwd_bwd(lib, M, H):
+def test_layernorm_fwd_bwd(lib, op, M, H):
     g = torch.Generator().manual_seed(M + H)
     s = torch.randn(M, H, generator=g) * 2 + 0.3
     gamma = 1 + 0.1 * torch.randn(H, generator=g)
@@ -212,24 +231,24 @@ def test_layernorm_fwd_bwd(lib, M, H):
     yref = torch.nn.functional.layer_norm(sr, (H,), gr, br, 1e-12)
     (yref * dy).sum().backward()
     y = torch.empty(M, H, device="cuda")
-    yb = torch.empty(M, H, dtype=torch.bfloat16, device="cuda")
-    xh = torch.empty(M, H, dtype=torch.bfloat16, device="cuda")
+    yb = torch.empty(M, H, dtype=OPDT[op], device="cuda")
+    xh = torch.empty(M, H, dtype=OPDT[op], device="cuda")
     rs = torch.empty(M, device="cuda")
     sd, gd, bd, dyd = dev(s), dev(gamma), dev(beta), dev(dy)      # keep the device tensors alive across the launches
-    _lib.check(lib.qst_ln_fwd(sd.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-12, M, H, y.data_ptr(),
+    _lib.check(kf(lib, "qst_ln_fwd", op)(sd.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-12, M, H, y.data_ptr(),
                               yb.data_ptr(), xh.data_ptr(), rs.data_ptr(), stream()))
     torch.testing.assert_close(y.cpu(), yref.detach(), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(yb.float().cpu(), yref.detach(), rtol=8e-3, atol=1e-2)
     ds = torch.empty(M, H, device="cuda")
-    dsb = torch.empty(M, H, dtype=torch.bfloat16, device="cuda")
+    dsb = torch.empty(M, H, dtype=OPDT[op], device="cuda")
     dg = torch.zeros(H, device="cuda")
     db = torch.zeros(H, device="cuda")
     scratch = torch.empty(lib.qst_ln_bwd_scratch_bytes(M, H) // 4, device="cuda")
-    _lib.check(lib.qst_ln_bwd(dyd.data_ptr(), xh.data_ptr(), rs.data_ptr(), gd.data_ptr(), M, H, ds.data_ptr(),
+    _lib.check(kf(lib, "qst_ln_bwd", op)(dyd.data_ptr(), xh.data_ptr(), rs.data_ptr(), gd.data_ptr(), M, H, ds.data_ptr(),
                               dsb.data_ptr(), dg.data_ptr(), db.data_ptr(), scratch.data_ptr(), stream()))
     dg2 = torch.zeros(H, device="cuda")
     db2 = torch.zeros(H, device="cuda")
-    _lib.check(lib.qst_ln_bwd(dyd.data_ptr(), xh.data_ptr(), rs.data_ptr(), gd.data_ptr(), M, H, ds.data_ptr(),
+    _lib.check(kf(lib, "qst_ln_bwd", op)(dyd.data_ptr(), xh.data_ptr(), rs.data_ptr(), gd.data_ptr(), M, H, ds.data_ptr(),
                               dsb.data_ptr(), dg2.data_ptr(), db2.data_ptr(), None, stream()))      # atomic fallback
     torch.testing.assert_close(dg2, dg, rtol=1e-4, atol=1e-4 * math.sqrt(M))
     torch.testing.assert_close(db2, db, rtol=1e-4, atol=1e-4 * math.sqrt(M))
@@ -240,14 +259,14 @@ def test_layernorm_fwd_bwd(lib, M, H):
 
 
 @pytest.mark.parametrize("M,K", [(128, 64), (300, 384), (1000, 1536), (4096, 1152)])
-def test_gemm_nt_fused_layernorm(lib, M, K):
+def test_gemm_nt_fused_layernorm(lib, op, M, K):
     """qst_gemm_nt_ln (N = 384 full-row tiles) against the unfused pair it replaces: qst_gemm_nt(F32_RESID) followed
     by qst_ln_fwd / qst_ln_bwd -- same arithmetic, so fp32 outputs agree to accumulation-order noise."""
     N = 384
     assert lib.qst_gemm_nt_ln_supported(N) == 1 and lib.qst_gemm_nt_ln_supported(768) == 0
     g = torch.Generator().manual_seed(M + K)
-    Ad = dev(bfr(torch.randn(M, K, generator=g)).to(torch.bfloat16))
-    Bd = dev(bfr(torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16))
+    Ad = dev(opr(op, torch.randn(M, K, generator=g)).to(OPDT[op]))
+    Bd = dev(opr(op, torch.randn(N, K, generator=g) * 0.05).to(OPDT[op]))
     bias, resid = dev(torch.randn(N, generator=g)), dev(torch.randn(M, N, generator=g))
     gamma, beta = dev(1 + 0.1 * torch.randn(N, generator=g)), dev(0.1 * torch.randn(N, generator=g))
     eps = 1e-12
@@ -263,17 +282,17 @@ def test_gemm_nt_fused_layernorm(lib, M, K):
         return torch.empty(*shape, dtype=torch.float32, device="cuda")
 
     def b16(*shape):
-        return torch.empty(*shape, dtype=torch.bfloat16, device="cuda")
+        return torch.empty(*shape, dtype=OPDT[op], device="cuda")
 
     # ---- forward: y = LN(A.B^T + bias + resid)
     s = f32(M, N)
-    _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=s, bias=bias, resid=resid, M=M, N=N, K=K, lda=K, ldb=K, ldc=N,
+    _lib.check(kf(lib, "qst_gemm_nt", op)(gemm_args(A=Ad, B=Bd, C=s, bias=bias, resid=resid, M=M, N=N, K=K, lda=K, ldb=K, ldc=N,
                                          ldr=N), 1, stream()))
     y0, yb0, xh0, rs0 = f32(M, N), b16(M, N), b16(M, N), f32(M)
-    _lib.check(lib.qst_ln_fwd(s.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, M, N, y0.data_ptr(), yb0.data_ptr(),
+    _lib.check(kf(lib, "qst_ln_fwd", op)(s.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, M, N, y0.data_ptr(), yb0.data_ptr(),
                               xh0.data_ptr(), rs0.data_ptr(), stream()))
     y1, yb1, xh1, rs1 = f32(M, N), b16(M, N), b16(M, N), f32(M)
-    _lib.check(lib.qst_gemm_nt_ln(gemm_args(A=Ad, B=Bd, C=y1, C2=yb1, bias=bias, resid=resid, M=M, N=N, K=K, lda=K, ldb=K,
+    _lib.check(kf(lib, "qst_gemm_nt_ln", op)(gemm_args(A=Ad, B=Bd, C=y1, C2=yb1, bias=bias, resid=resid, M=M, N=N, K=K, lda=K, ldb=K,
                                             ldc=N, ldr=N),
                                   ln_epi(gamma=gamma, beta=beta, eps=eps, xhat=xh1, rstd=rs1), 0, stream()))
     torch.testing.assert_close(y1, y0, rtol=1e-4, atol=1e-4)
@@ -284,23 +303,23 @@ def test_gemm_nt_fused_layernorm(lib, M, K):
     torch.testing.assert_close(y1, ref, rtol=1e-4, atol=2e-4)
     # outputs that the caller does not want may be NULL (inference)
     y2 = f32(M, N)
-    _lib.check(lib.qst_gemm_nt_ln(gemm_args(A=Ad, B=Bd, C=y2, bias=bias, resid=resid, M=M, N=N, K=K, lda=K, ldb=K, ldc=N,
+    _lib.check(kf(lib, "qst_gemm_nt_ln", op)(gemm_args(A=Ad, B=Bd, C=y2, bias=bias, resid=resid, M=M, N=N, K=K, lda=K, ldb=K, ldc=N,
                                             ldr=N), ln_epi(gamma=gamma, beta=beta, eps=eps), 0, stream()))
     torch.testing.assert_close(y2, y1, rtol=0, atol=0)
 
     # ---- backward: ds = LN_bwd(A.B^T + resid), dgamma/dbeta through per-tile partial sums
     dy = f32(M, N)
-    _lib.check(lib.qst_gemm_nt(gemm_args(A=Ad, B=Bd, C=dy, resid=resid, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, ldr=N), 1,
+    _lib.check(kf(lib, "qst_gemm_nt", op)(gemm_args(A=Ad, B=Bd, C=dy, resid=resid, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, ldr=N), 1,
                                stream()))
     ds0, dsb0 = f32(M, N), b16(M, N)
     dg0, db0 = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
     scratch = torch.empty(lib.qst_ln_bwd_scratch_bytes(M, N) // 4, device="cuda")
-    _lib.check(lib.qst_ln_bwd(dy.data_ptr(), xh0.data_ptr(), rs0.data_ptr(), gamma.data_ptr(), M, N, ds0.data_ptr(),
+    _lib.check(kf(lib, "qst_ln_bwd", op)(dy.data_ptr(), xh0.data_ptr(), rs0.data_ptr(), gamma.data_ptr(), M, N, ds0.data_ptr(),
                               dsb0.data_ptr(), dg0.data_ptr(), db0.data_ptr(), scratch.data_ptr(), stream()))
     ds1, dsb1 = f32(M, N), b16(M, N)
     ntile = (M + 127) // 128
     part = torch.full((ntile, 2, N), float("nan"), device="cuda")
-    _lib.check(lib.qst_gemm_nt_ln(gemm_args(A=Ad, B=Bd, C=ds1, C2=dsb1, resid=resid, M=M, N=N, K=K, lda=K, ldb=K, ldc=N,
+    _lib.check(kf(lib, "qst_gemm_nt_ln", op)(gemm_args(A=Ad, B=Bd, C=ds1, C2=dsb1, resid=resid, M=M, N=N, K=K, lda=K, ldb=K, ldc=N,
                                             ldr=N),
                                   ln_epi(gamma=gamma, xhat=xh0, rstd=rs0, partials=part), 1, stream()))
     scale = ds0.abs().max().item()
@@ -309,12 +328,12 @@ def test_gemm_nt_fused_layernorm(lib, M, K):
     torch.testing.assert_close(part[:, 0].sum(0), dg0, rtol=1e-4, atol=1e-4 * math.sqrt(M) * dy.abs().max().item())
     torch.testing.assert_close(part[:, 1].sum(0), db0, rtol=1e-4, atol=1e-4 * math.sqrt(M) * dy.abs().max().item())
     # bad shapes are refused, not mis-computed
-    assert lib.qst_gemm_nt_ln(gemm_args(A=Ad, B=Bd, C=ds1, M=M, N=192, K=K, lda=K, ldb=K, ldc=192),
+    assert kf(lib, "qst_gemm_nt_ln", op)(gemm_args(A=Ad, B=Bd, C=ds1, M=M, N=192, K=K, lda=K, ldb=K, ldc=192),
                               ln_epi(gamma=gamma, xhat=xh0, rstd=rs0), 1, stream()) == -2
 
 
 @pytest.mark.parametrize("M,I", [(128, 192), (416, 768), (1000, 1536), (4096, 1536)])
-def test_ffn_chain_matches_the_two_kernel_path(lib, M, I):
+def test_ffn_chain_matches_the_two_kernel_path(lib, op, M, I):
     """qst_ffn_chain (csrc/ffn.hip: the feed-forward block as one kernel) against the launches it replaces --
     forward: qst_gemm_nt(GELU) + qst_gemm_nt_ln(mode 0); backward: qst_gemm_nt(GELU_BWD) + qst_gemm_nt_ln(mode 1).
     The rounding points are the same (h / du are rounded to bf16 before the second product in both forms), so fp32
@@ -322,10 +341,10 @@ def test_ffn_chain_matches_the_two_kernel_path(lib, M, I):
     H = 384
     assert lib.qst_ffn_chain_supported(H, I) == 1 and lib.qst_ffn_chain_supported(768, 3072) == 0
     g = torch.Generator().manual_seed(M + I)
-    bf = torch.bfloat16
-    A = dev(bfr(torch.randn(M, H, generator=g)).to(bf))
-    W1 = dev(bfr(torch.randn(I, H, generator=g) * 0.05).to(bf))
-    W2 = dev(bfr(torch.randn(H, I, generator=g) * 0.05).to(bf))
+    bf = OPDT[op]
+    A = dev(opr(op, torch.randn(M, H, generator=g)).to(bf))
+    W1 = dev(opr(op, torch.randn(I, H, generator=g) * 0.05).to(bf))
+    W2 = dev(opr(op, torch.randn(H, I, generator=g) * 0.05).to(bf))
     W1t, W2t = W1.t().contiguous(), W2.t().contiguous()                 # the "W^T shadows" the dgrads read
     b1, b2 = dev(0.3 * torch.randn(I, generator=g)), dev(0.3 * torch.randn(H, generator=g))
     resid = dev(torch.randn(M, H, generator=g))
@@ -354,15 +373,15 @@ def test_ffn_chain_matches_the_two_kernel_path(lib, M, I):
 
     # ---- forward, two kernels
     gp0, h0 = b16(M, I), b16(M, I)
-    _lib.check(lib.qst_gemm_nt(gemm_args(A=A, B=W1, C=gp0, C2=h0, bias=b1, M=M, N=I, K=H, lda=H, ldb=H, ldc=I), 2, stream()))
+    _lib.check(kf(lib, "qst_gemm_nt", op)(gemm_args(A=A, B=W1, C=gp0, C2=h0, bias=b1, M=M, N=I, K=H, lda=H, ldb=H, ldc=I), 2, stream()))
     y0, yb0, xh0, rs0 = f32(M, H), b16(M, H), b16(M, H), f32(M)
-    _lib.check(lib.qst_gemm_nt_ln(gemm_args(A=h0, B=W2, C=y0, C2=yb0, bias=b2, resid=resid, M=M, N=H, K=I, lda=I, ldb=I,
+    _lib.check(kf(lib, "qst_gemm_nt_ln", op)(gemm_args(A=h0, B=W2, C=y0, C2=yb0, bias=b2, resid=resid, M=M, N=H, K=I, lda=I, ldb=I,
                                             ldc=H, ldr=H), ln_epi(gamma=gamma, beta=beta, eps=eps, xhat=xh0, rstd=rs0), 0,
                                   stream()))
     # ---- forward, one kernel (training: side outputs; inference: none)
     gp1, h1 = torch.full((M, I), 7.0, dtype=bf, device="cuda"), torch.full((M, I), 7.0, dtype=bf, device="cuda")
     y1, yb1, xh1, rs1 = f32(M, H), b16(M, H), b16(M, H), f32(M)
-    _lib.check(lib.qst_ffn_chain(ffn_args(A=A, B1=W1, B2=W2, bias1=b1, bias2=b2, resid=resid, save_gp=gp1, save_h=h1, C=y1,
+    _lib.check(kf(lib, "qst_ffn_chain", op)(ffn_args(A=A, B1=W1, B2=W2, bias1=b1, bias2=b2, resid=resid, save_gp=gp1, save_h=h1, C=y1,
                                           C2=yb1, M=M, H=H, I=I),
                                  ln_epi(gamma=gamma, beta=beta, eps=eps, xhat=xh1, rstd=rs1), 0, stream()))
     torch.cuda.synchronize()
@@ -374,11 +393,11 @@ def test_ffn_chain_matches_the_two_kernel_path(lib, M, I):
     torch.testing.assert_close(yb1.float(), yb0.float(), rtol=8e-3, atol=1e-2)
     torch.testing.assert_close(xh1.float(), xh0.float(), rtol=8e-3, atol=1e-2)
     u = A.float() @ W1.float().t() + b1
-    href = bfr(torch.nn.functional.gelu(u))
+    href = opr(op, torch.nn.functional.gelu(u))
     ref = torch.nn.functional.layer_norm(href @ W2.float().t() + b2 + resid, (H,), gamma, beta, eps)
     torch.testing.assert_close(y1, ref, rtol=1e-3, atol=2e-3)
     y2 = f32(M, H)
-    _lib.check(lib.qst_ffn_chain(ffn_args(A=A, B1=W1, B2=W2, bias1=b1, bias2=b2, resid=resid, C=y2, M=M, H=H, I=I),
+    _lib.check(kf(lib, "qst_ffn_chain", op)(ffn_args(A=A, B1=W1, B2=W2, bias1=b1, bias2=b2, resid=resid, C=y2, M=M, H=H, I=I),
                                  ln_epi(gamma=gamma, beta=beta, eps=eps), 0, stream()))
     torch.testing.assert_close(y2, y1, rtol=0, atol=0)                  # inference variant: same arithmetic
 
@@ -386,14 +405,14 @@ def test_ffn_chain_matches_the_two_kernel_path(lib, M, I):
     ds2 = dev(torch.randn(M, H, generator=g))
     ds2b = ds2.to(bf)
     du0 = b16(M, I)
-    _lib.check(lib.qst_gemm_nt(gemm_args(A=ds2b, B=W2t, C=du0, aux=gp0, M=M, N=I, K=H, lda=H, ldb=H, ldc=I), 3, stream()))
+    _lib.check(kf(lib, "qst_gemm_nt", op)(gemm_args(A=ds2b, B=W2t, C=du0, aux=gp0, M=M, N=I, K=H, lda=H, ldb=H, ldc=I), 3, stream()))
     ntile = (M + 127) // 128
     o0, ob0, part0 = f32(M, H), b16(M, H), f32(ntile, 2, H)
-    _lib.check(lib.qst_gemm_nt_ln(gemm_args(A=du0, B=W1t, C=o0, C2=ob0, resid=ds2, M=M, N=H, K=I, lda=I, ldb=I, ldc=H, ldr=H),
+    _lib.check(kf(lib, "qst_gemm_nt_ln", op)(gemm_args(A=du0, B=W1t, C=o0, C2=ob0, resid=ds2, M=M, N=H, K=I, lda=I, ldb=I, ldc=H, ldr=H),
                                   ln_epi(gamma=gamma, xhat=xh0, rstd=rs0, partials=part0), 1, stream()))
     du1 = torch.full((M, I), 7.0, dtype=bf, device="cuda")
     o1, ob1, part1 = f32(M, H), b16(M, H), torch.full((ntile, 2, H), float("nan"), device="cuda")
-    _lib.check(lib.qst_ffn_chain(ffn_args(A=ds2b, B1=W2t, B2=W1t, resid=ds2, aux=gp0, save_h=du1, C=o1, C2=ob1, M=M, H=H, I=I),
+    _lib.check(kf(lib, "qst_ffn_chain", op)(ffn_args(A=ds2b, B1=W2t, B2=W1t, resid=ds2, aux=gp0, save_h=du1, C=o1, C2=ob1, M=M, H=H, I=I),
                                  ln_epi(gamma=gamma, xhat=xh0, rstd=rs0, partials=part1), 1, stream()))
     torch.cuda.synchronize()
     sc = du0.float().abs().max().item()
@@ -403,8 +422,8 @@ def test_ffn_chain_matches_the_two_kernel_path(lib, M, I):
     torch.testing.assert_close(ob1.float(), ob0.float(), rtol=8e-3, atol=1e-2 * scale)
     torch.testing.assert_close(part1.sum(0), part0.sum(0), rtol=1e-3, atol=1e-3 * math.sqrt(M) * scale)
     # refused, not mis-computed
-    assert lib.qst_ffn_chain(ffn_args(A=A, B1=W1, B2=W2, C=y2, M=M, H=768, I=I), ln_epi(gamma=gamma, beta=beta), 0, stream()) == -2
-    assert lib.qst_ffn_chain(ffn_args(A=A, B1=W1, B2=W2, C=y2, save_h=h1, M=M, H=H, I=I), ln_epi(gamma=gamma, beta=beta), 0,
+    assert kf(lib, "qst_ffn_chain", op)(ffn_args(A=A, B1=W1, B2=W2, C=y2, M=M, H=768, I=I), ln_epi(gamma=gamma, beta=beta), 0, stream()) == -2
+    assert kf(lib, "qst_ffn_chain", op)(ffn_args(A=A, B1=W1, B2=W2, C=y2, save_h=h1, M=M, H=H, I=I), ln_epi(gamma=gamma, beta=beta), 0,
                              stream()) == -1                            # save_h without save_gp
 
 
@@ -425,35 +444,35 @@ def attn_ref(qkv, mask, rel, n, L, A, d):
                                               (5, 96, 3, 32, False), (2, 160, 2, 32, True), (2, 512, 2, 64, False),
                                               (3, 288, 2, 64, True), (1, 512, 1, 64, True), (2, 32, 1, 64, False),
                                               (2, 384, 3, 64, False)])
-def test_attention_fwd_bwd(lib, n, L, A, d, use_rel):
+def test_attention_fwd_bwd(lib, op, n, L, A, d, use_rel):
     H = A * d
     g = torch.Generator().manual_seed(n * L + A + d)
-    qkv = bfr(torch.randn(n * L, 3 * H, generator=g))
+    qkv = opr(op, torch.randn(n * L, 3 * H, generator=g))
     lens = torch.randint(max(1, L // 8), L + 1, (n,), generator=g)
     lens[0] = L
     mask = (torch.arange(L)[None, :] < lens[:, None]).long()
     # MPNet's bias depends on j - i only: the kernels take it as relative-position vectors [A, 2L] (entry j - i + L)
     relpos = (0.5 * torch.randn(A, 2 * L, generator=g)) if use_rel else None
     ridx = (torch.arange(L)[None, :] - torch.arange(L)[:, None]) + L          # [i, j] -> j - i + L
-    dctx = bfr(torch.randn(n * L, H, generator=g))
+    dctx = opr(op, torch.randn(n * L, H, generator=g))
     qr = qkv.clone().requires_grad_(True)
     relr = relpos.clone().requires_grad_(True) if use_rel else None
     ref = attn_ref(qr, mask, relr[:, ridx] if use_rel else None, n, L, A, d)
     (ref * dctx).sum().backward()
 
-    qd = dev(qkv.to(torch.bfloat16))
+    qd = dev(qkv.to(OPDT[op]))
     md = dev(mask)
     reld = dev(relpos) if use_rel else None
-    ctx = torch.empty(n * L, H, dtype=torch.bfloat16, device="cuda")
+    ctx = torch.empty(n * L, H, dtype=OPDT[op], device="cuda")
     lse = torch.empty(n, A, L, device="cuda")
-    _lib.check(lib.qst_attention_fwd(qd.data_ptr(), md.data_ptr(), _lib.ptr(reld), n, L, A, d, ctx.data_ptr(), lse.data_ptr(), stream()))
+    _lib.check(kf(lib, "qst_attention_fwd", op)(qd.data_ptr(), md.data_ptr(), _lib.ptr(reld), n, L, A, d, ctx.data_ptr(), lse.data_ptr(), stream()))
     torch.testing.assert_close(ctx.float().cpu(), ref.detach(), rtol=2e-2, atol=2e-2)
 
-    dq = torch.empty(n * L, 3 * H, dtype=torch.bfloat16, device="cuda")
+    dq = torch.empty(n * L, 3 * H, dtype=OPDT[op], device="cuda")
     drel = torch.zeros(A, 2 * L, device="cuda") if use_rel else None
-    dcd = dev(dctx.to(torch.bfloat16))
+    dcd = dev(dctx.to(OPDT[op]))
     delta = torch.empty(n, A, L, device="cuda")
-    _lib.check(lib.qst_attention_bwd(qd.data_ptr(), ctx.data_ptr(), dcd.data_ptr(), lse.data_ptr(),
+    _lib.check(kf(lib, "qst_attention_bwd", op)(qd.data_ptr(), ctx.data_ptr(), dcd.data_ptr(), lse.data_ptr(),
                                      md.data_ptr(), _lib.ptr(reld), n, L, A, d, dq.data_ptr(), _lib.ptr(drel),
                                      delta.data_ptr(), stream()))
     gref = qr.grad
@@ -475,7 +494,7 @@ def test_attention_fwd_bwd(lib, n, L, A, d, use_rel):
         q.ctx, q.lse, q.dctx, q.dqkv, q.drel = ctx.data_ptr(), lse.data_ptr(), dcd.data_ptr(), dq2.data_ptr(), _lib.ptr(drel2)
         # force_split = 1: the two-kernel path (the first call above ran the one-workgroup kernel where there is one)
         q.delta_scratch, q.force_split = delta.data_ptr(), 1
-        _lib.check(lib.qst_attention_bwd_ex(q, stream()))
+        _lib.check(kf(lib, "qst_attention_bwd_ex", op)(q, stream()))
         torch.cuda.synchronize()
         torch.testing.assert_close(dq.float(), dq2.float(), rtol=2e-2, atol=2e-2 * max(1.0, gref.abs().max().item()))
         if use_rel:

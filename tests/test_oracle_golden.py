@@ -96,7 +96,10 @@ ENC_CASES = [("tinybert_hfinit", "tiny-bert", 2, 32, dict(std=0.02), "full"),
              ("tinympnet_maskedge", "tiny-mpnet", 3, 64, dict(std=0.08, bias_std=0.05, ln_jitter=0.1), "full"),
              # 16,384 token rows: the size the fused GEMM + LayerNorm kernels, the 8-range wgrad and the single-workgroup
              # attention backward run from (the HIP side of this case: tests/test_gpu_golden.py)
-             ("minilm2l_fused", "minilm-2l", 32, 128, dict(std=0.04, bias_std=0.02, ln_jitter=0.05), "norms")]
+             ("minilm2l_fused", "minilm-2l", 32, 128, dict(std=0.04, bias_std=0.02, ln_jitter=0.05), "norms"),
+             # full dims of BASELINE configs[2] / configs[4], trained-like weights (round 5)
+             ("mpnetbase_trained", "all-mpnet-base-v2", 1, 64, dict(std=0.04, bias_std=0.02, ln_jitter=0.05), "norms"),
+             ("bertbase_trained", "bert-base-uncased", 1, 64, dict(std=0.04, bias_std=0.02, ln_jitter=0.05), "norms")]
 
 
 def golden_inputs(key, cfg, B, L):
