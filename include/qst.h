@@ -25,6 +25,12 @@
  * are not -- and a 5-bit exponent: forward kernels saturate at +-65,504, and a training step runs under a loss scale
  * (qst_amp_scaler_init / qst_clip_adamw_step_amp), which is what the reference's own reduced precision does:
  * torch.cuda.amp.autocast + GradScaler, /root/reference/training/main.py:142 (`use_amp`), models/evaluators.py:92-94.
+ * QST_PREC_F16W is QST_PREC_F16 with SPLIT WEIGHTS in the forward: every Linear multiplies its f16 activations by hi + lo
+ * of the weight (two f16 values, W to ~2^-22), as a second pass over K in the same kernel -- the rounding of the weights is
+ * the same for every token of a sequence and does not average out in the pooled embedding, the rounding of the activations
+ * does: measured, it is 85-95% of plain f16's embedding error. With it the twelve-layer mpnet-base case is inside the
+ * north-star tolerance too. Backward as QST_PREC_F16 (gradients need no more). Its shadow is qst_shadow_elems() long: the f16
+ * arena and behind it a second one with the low halves.
  * The shadow of a QST_PREC_F16 handle holds IEEE half (qst_refresh_shadow on that handle), its activation arena f16
  * tensors of the bf16 arena's sizes; its backward is refused on another precision's arena and vice versa.
  */
@@ -49,7 +55,7 @@ typedef enum {
 } qst_status;
 
 enum { QST_ARCH_BERT = 0, QST_ARCH_MPNET = 1 };
-enum { QST_PREC_BF16 = 0, QST_PREC_BF16X3 = 1, QST_PREC_FP8 = 3, QST_PREC_F16 = 4 };   /* 2 was an fp8-weights-only mode (removed) */
+enum { QST_PREC_BF16 = 0, QST_PREC_BF16X3 = 1, QST_PREC_FP8 = 3, QST_PREC_F16 = 4, QST_PREC_F16W = 5 };   /* 2 was an fp8-weights-only mode (removed) */
 enum { QST_REDUCE_NONE = 0, QST_REDUCE_SUM = 1, QST_REDUCE_MEAN = 2 };
 
 /* Encoder architecture. Mirrors HF BertConfig / MPNetConfig fields that the

@@ -70,6 +70,8 @@ typedef struct {
     int32_t drop_where;
     void* C3;             // QST_EPI_GELU_MX_TRAIN only (see the enum)
     void* C4;
+    const void* B2;       // qst_gemm_nt / qst_gemm_nt_ln (tiled kernels): C = A . (B + B2)^T -- a second pass over K against B2, same
+                          // shape and ldb as B (QST_PREC_F16W: the low halves of split-f16 weights); NULL = none
     int32_t sat16;        // f16 twins only (qst_gemm_nt_f16 / qst_gemm_nt8_f16): != 0 = 16-bit outputs saturate at +-65,504
                           // instead of overflowing to inf (forward launches); 0 = IEEE overflow (backward launches)
 } QstGemmArgs;
@@ -370,6 +372,11 @@ int qst_attention_fwd_ex_f16(const QstAttnDesc* a, void* stream);
 int qst_attention_bwd_ex_f16(const QstAttnDesc* a, void* stream);
 int qst_shadow_all_f16(const float* params, void* shadow, const int64_t* table_dev, int nseg, int nblocks, void* stream);
 int qst_shadow_matrix_f16(const float* src, int rows, int cols, void* dst_f16, void* dstT_f16, void* stream);
+/* QST_PREC_F16W: qst_shadow_all_f16 plus the low halves of the split weights, lo = f16(w - f16(w)), written at the offsets of the
+ * W copies in shadow_lo, an arena of the same layout as `shadow` (W = hi + lo to about 2^-22 relative; the halves are mostly
+ * subnormal, which v_mfma_f32_*_f16 keeps). The forward GEMMs take them as QstGemmArgs.B2. */
+int qst_shadow_all_split_f16(const float* params, void* shadow, void* shadow_lo, const int64_t* table_dev, int nseg, int nblocks,
+                             void* stream);
 
 /* sizeof() of the argument structs above as this library was compiled, for bindings to check their mirror of the layout:
  * which = 0 QstGemmArgs, 1 QstLnEpi, 2 QstFfnArgs, 3 QstTnGroup, 4 QstLnReduceBatch, 5 QstDrop, 6 QstAttnDesc. */

@@ -46,7 +46,7 @@ class QstGemmArgs(C.Structure):
     _fields_ = [("A", vp), ("B", vp), ("C", vp), ("C2", vp), ("aux", vp), ("bias", vp), ("resid", vp),
                 ("colsum", vp), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32),
                 ("ldb", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32), ("splits", C.c_int32), ("bscale", vp),
-                ("drop", QstDrop), ("drop_where", C.c_int32), ("C3", vp), ("C4", vp), ("sat16", C.c_int32)]
+                ("drop", QstDrop), ("drop_where", C.c_int32), ("C3", vp), ("C4", vp), ("B2", vp), ("sat16", C.c_int32)]
 
 
 class QstLnEpi(C.Structure):
@@ -187,6 +187,7 @@ F16_TWINS = ["qst_gemm_nt", "qst_gemm_nt_ln", "qst_ffn_chain", "qst_gemm_tn", "q
              "qst_shadow_all", "qst_shadow_matrix"]
 for _n in F16_TWINS:
     SIGNATURES[_n + "_f16"] = SIGNATURES[_n]
+SIGNATURES["qst_shadow_all_split_f16"] = (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp])
 SIGNATURES["qst_amp_scaler_init"] = (C.c_int, [vp, C.c_float, vp])
 SIGNATURES["qst_clip_adamw_step_amp"] = (C.c_int, [vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                                   C.c_float, C.c_float, C.c_int64, C.c_int64, vp, vp, C.c_float, C.c_float,

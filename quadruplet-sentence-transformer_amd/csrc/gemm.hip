@@ -111,6 +111,12 @@ __device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, in
     const op16* Bb = (const op16*)g.B + (size_t)n0 * g.ldb;
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(Ab, (uint32_t)rows_a * g.lda * 2u);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(Bb, (uint32_t)rows_b * g.ldb * 2u);
+    // Split weights (QstGemmArgs.B2, QST_PREC_F16W): C = A . (B + B2)^T as a second pass over K -- K-tile kt >= K / 64 takes
+    // the A rows of K-tile kt - K / 64 again and the B rows from B2 (same shape and leading dimension as B): the loop below
+    // simply runs twice as many stages; fragments, ring and epilogue do not know.
+    const bool split = g.B2 != nullptr;
+    const __amdgpu_buffer_rsrc_t rb2 = split ? make_rsrc((const op16*)g.B2 + (size_t)n0 * g.ldb, (uint32_t)rows_b * g.ldb * 2u) : rb;
+    const int nk1 = g.K / NBK;
 
     // DMA map: one wave-instruction = 1 KB = 8 rows x 128 B. LDS position p (16-B units) = q*64 + lane -> row p/8,
     // chunk position p%8 -> logical chunk = pos ^ swz(row).
@@ -130,15 +136,17 @@ __device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, in
     auto slot_b = [&](int kt) { return smem + (DEEP ? 3 * NT_A_BYTES + (kt & 1) * NT_B_BYTES : (kt & 1) * NT_STAGE + NT_A_BYTES); };
     auto issue_a = [&](int kt) {
         char* st = slot_a(kt);
-        const uint32_t ko = (uint32_t)kt * (NBK * 2);
+        const uint32_t ko = (uint32_t)(kt >= nk1 ? kt - nk1 : kt) * (NBK * 2);
 #pragma unroll
         for (int t = 0; t < A_PER_WAVE; ++t) dma16<A_ONCE>(ra, st + (wave * A_PER_WAVE + t) * 1024, va[t], ko);
     };
     auto issue_b = [&](int kt) {
         char* st = slot_b(kt);
-        const uint32_t ko = (uint32_t)kt * (NBK * 2);
+        const bool lo = kt >= nk1;
+        const uint32_t ko = (uint32_t)(lo ? kt - nk1 : kt) * (NBK * 2);
+        const __amdgpu_buffer_rsrc_t r = lo ? rb2 : rb;
 #pragma unroll
-        for (int t = 0; t < B_PER_WAVE; ++t) dma16(rb, st + (wave * B_PER_WAVE + t) * 1024, vb[t], ko);
+        for (int t = 0; t < B_PER_WAVE; ++t) dma16(r, st + (wave * B_PER_WAVE + t) * 1024, vb[t], ko);
     };
     auto issue = [&](int kt) { issue_a(kt); issue_b(kt); };
 
@@ -149,7 +157,7 @@ __device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, in
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = g.K / NBK;
+    const int nk = split ? 2 * nk1 : nk1;
     const int fr = lane & 31, fh = lane >> 5;
     issue(0);
     after_first_issue();
@@ -203,6 +211,9 @@ __device__ __forceinline__ void nt_mainloop_tall(const QstGemmArgs& g, char* sme
     const int rows_a = min(NBM, g.M - m0), rows_b = min(NBN, g.N - n0);
     const __amdgpu_buffer_rsrc_t ra = make_rsrc((const op16*)g.A + (size_t)m0 * g.lda, (uint32_t)rows_a * g.lda * 2u);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc((const op16*)g.B + (size_t)n0 * g.ldb, (uint32_t)rows_b * g.ldb * 2u);
+    const bool split = g.B2 != nullptr;                  // (see nt_mainloop)
+    const __amdgpu_buffer_rsrc_t rb2 = split ? make_rsrc((const op16*)g.B2 + (size_t)n0 * g.ldb, (uint32_t)rows_b * g.ldb * 2u) : rb;
+    const int nk1 = g.K / BK;
     uint32_t va[A_PER_WAVE], vb[B_PER_WAVE];
 #pragma unroll
     for (int t = 0; t < A_PER_WAVE; ++t) {
@@ -216,11 +227,13 @@ __device__ __forceinline__ void nt_mainloop_tall(const QstGemmArgs& g, char* sme
     }
     auto issue = [&](int kt) {
         char* st = smem + (kt & 1) * STAGE;
-        const uint32_t ko = (uint32_t)kt * (BK * 2);
+        const bool lo = kt >= nk1;
+        const uint32_t ko = (uint32_t)(lo ? kt - nk1 : kt) * (BK * 2);
+        const __amdgpu_buffer_rsrc_t r = lo ? rb2 : rb;
 #pragma unroll
         for (int t = 0; t < A_PER_WAVE; ++t) dma16(ra, st + (wave * A_PER_WAVE + t) * 1024, va[t], ko);
 #pragma unroll
-        for (int t = 0; t < B_PER_WAVE; ++t) dma16(rb, st + A_BYTES + (wave * B_PER_WAVE + t) * 1024, vb[t], ko);
+        for (int t = 0; t < B_PER_WAVE; ++t) dma16(r, st + A_BYTES + (wave * B_PER_WAVE + t) * 1024, vb[t], ko);
     };
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -228,7 +241,7 @@ __device__ __forceinline__ void nt_mainloop_tall(const QstGemmArgs& g, char* sme
         for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int nk = g.K / BK;
+    const int nk = split ? 2 * nk1 : nk1;
     const int fr = lane & 31, fh = lane >> 5;
     issue(0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -1169,8 +1182,9 @@ extern "C" int QST_K(qst_gemm_nt)(const QstGemmArgs* a, int epi, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     // The 8-wave, 8-phase K loop (gemm8.hip): a->splits bit 5 forces its 128 x 384 tile, bit 6 its 256 x 256 tile, bit 7
     // forbids it; otherwise qst_gemm8_mode / the shape decide (nt8_auto).
-    if ((a->splits & 0x60) && QST_K(qst_gemm_nt8_supported)(a, epi)) return QST_K(qst_gemm_nt8)(a, epi, (a->splits & 0x40) ? 1 : 0, stream);
-    if (!(a->splits & 0xFE7) && QST_K(qst_gemm_nt8_supported)(a, epi)) {
+    const bool no8 = a->B2 != nullptr;                 // split weights: the tiled kernels only
+    if (!no8 && (a->splits & 0x60) && QST_K(qst_gemm_nt8_supported)(a, epi)) return QST_K(qst_gemm_nt8)(a, epi, (a->splits & 0x40) ? 1 : 0, stream);
+    if (!no8 && !(a->splits & 0xFE7) && QST_K(qst_gemm_nt8_supported)(a, epi)) {
         const int mode = qst_gemm8_mode_get();
         if (mode >= 0 ? (mode & 1) != 0 : nt8_auto(a, epi)) return QST_K(qst_gemm_nt8)(a, epi, mode >= 0 ? 0 : 1, stream);
     }

@@ -153,7 +153,12 @@ struct qst_encoder {
 };
 
 extern "C" int64_t qst_arena_elems(const qst_config* cfg) { return cfg_ok(cfg) ? build_layout(cfg).total : QST_ERR_BAD_ARG; }
-extern "C" int64_t qst_shadow_elems(const qst_config* cfg) { return cfg_ok(cfg) ? build_layout(cfg).shadow_total : QST_ERR_BAD_ARG; }
+// (QST_PREC_F16W: a second arena of the same layout behind the first holds the low halves of the split weights)
+extern "C" int64_t qst_shadow_elems(const qst_config* cfg) {
+    if (!cfg_ok(cfg)) return QST_ERR_BAD_ARG;
+    const int64_t n = build_layout(cfg).shadow_total;
+    return cfg->precision == QST_PREC_F16W ? 2 * n : n;
+}
 // fp8 shadow: the weight bytes of segment s sit at byte offset s.shadow_off (inside the first half of what is the [W | W^T]
 // region in bf16-element units), its fp32 row scales at byte offset s.shadow_off + align(numel): same total, in bytes.
 extern "C" int64_t qst_shadow8_bytes(const qst_config* cfg) { return cfg_ok(cfg) ? build_layout(cfg).shadow_total : QST_ERR_BAD_ARG; }
@@ -199,7 +204,7 @@ extern "C" int qst_encoder_create(const qst_config* cfg, qst_encoder** out) {
     if (cfg->hidden_size % 64 != 0 || cfg->intermediate_size % 64 != 0 || cfg->hidden_size > 1024) return QST_ERR_UNSUPPORTED;
     if (cfg->type_vocab_size > 2) return QST_ERR_UNSUPPORTED;
     if (cfg->precision != QST_PREC_BF16 && cfg->precision != QST_PREC_BF16X3 && cfg->precision != QST_PREC_FP8 &&
-        cfg->precision != QST_PREC_F16)
+        cfg->precision != QST_PREC_F16 && cfg->precision != QST_PREC_F16W)
         return QST_ERR_UNSUPPORTED;
     if (cfg->precision == QST_PREC_FP8 && (cfg->hidden_size % 128 != 0 || cfg->intermediate_size % 128 != 0))
         return QST_ERR_UNSUPPORTED;                      // the fp8 K loop takes 128-deep stages
@@ -460,13 +465,17 @@ const OpKernels kOpBf16 = {qst_gemm_nt, qst_gemm_nt_ln, qst_ffn_chain, qst_gemm_
 const OpKernels kOpF16 = {qst_gemm_nt_f16, qst_gemm_nt_ln_f16, qst_ffn_chain_f16, qst_gemm_tn_group_f16,
                           qst_embed_ln_fwd_drop_f16, qst_ln_fwd_f16, qst_ln_bwd_drop_f16, qst_attention_fwd_ex_f16,
                           qst_attention_bwd_ex_f16, qst_shadow_all_f16, ARENA_F16};
-const OpKernels& op_kernels(const qst_config& c) { return c.precision == QST_PREC_F16 ? kOpF16 : kOpBf16; }
+const OpKernels& op_kernels(const qst_config& c) {
+    return (c.precision == QST_PREC_F16 || c.precision == QST_PREC_F16W) ? kOpF16 : kOpBf16;
+}
 
 // sat: forward launches of the f16 build saturate their 16-bit outputs (QstGemmArgs.sat16); the bf16 build ignores it
+// B2: the low halves of split weights (QST_PREC_F16W forward), or null
 int nt(const OpKernels& K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* C2, const void* aux,
-       const float* bias, const float* resid, int ldr, int M, int N, int K_, int epi, bool sat, hipStream_t st) {
+       const float* bias, const float* resid, int ldr, int M, int N, int K_, int epi, bool sat, hipStream_t st,
+       const void* B2 = nullptr) {
     QstGemmArgs g{};
-    g.A = A; g.B = B; g.C = C; g.C2 = C2; g.aux = aux; g.bias = bias; g.resid = resid;
+    g.A = A; g.B = B; g.B2 = B2; g.C = C; g.C2 = C2; g.aux = aux; g.bias = bias; g.resid = resid;
     g.M = M; g.N = N; g.K = K_; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
     g.sat16 = sat ? 1 : 0;
     take_drop(g);
@@ -475,9 +484,9 @@ int nt(const OpKernels& K, const void* A, int lda, const void* B, int ldb, void*
 // GEMM with the following LayerNorm (mode 0) / LayerNorm backward (mode 1) fused into its epilogue (N = H = 384)
 int nt_ln(const OpKernels& K, const void* A, int lda, const void* B, int ldb, float* C, void* C2, const float* bias,
           const float* resid, int M, int H, int K_, int mode, const float* gamma, const float* beta, float eps, void* xhat,
-          float* rstd, float* partials, hipStream_t st) {
+          float* rstd, float* partials, hipStream_t st, const void* B2 = nullptr) {
     QstGemmArgs g{};
-    g.A = A; g.B = B; g.C = C; g.C2 = C2; g.bias = bias; g.resid = resid;
+    g.A = A; g.B = B; g.B2 = B2; g.C = C; g.C2 = C2; g.bias = bias; g.resid = resid;
     g.M = M; g.N = H; g.K = K_; g.lda = lda; g.ldb = ldb; g.ldc = H; g.ldr = H;
     take_drop(g);
     QstLnEpi e{};
@@ -532,7 +541,10 @@ extern "C" size_t qst_encoder_bwd_workspace_bytes(const qst_encoder* e, int nseq
 
 extern "C" int qst_refresh_shadow(const qst_encoder* e, const float* params, void* shadow, void* stream) {
     if (!e || !params || !shadow) return QST_ERR_BAD_ARG;
-    // (a QST_PREC_F16 handle fills the same layout with IEEE half; every other handle with bf16)
+    // (a QST_PREC_F16 / F16W handle fills the same layout with IEEE half; every other handle with bf16)
+    if (e->cfg.precision == QST_PREC_F16W)
+        return qst_shadow_all_split_f16(params, shadow, (uint16_t*)shadow + e->lay.shadow_total, e->shadow_tab, e->shadow_nseg,
+                                        e->shadow_blocks, stream);
     return op_kernels(e->cfg).shadow_all(params, shadow, e->shadow_tab, e->shadow_nseg, e->shadow_blocks, stream);
 }
 
@@ -918,8 +930,11 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     const Layout& lay = e->lay;
     auto P = [&](int seg) { return params + lay.segs[seg].off; };
     auto W = [&](int seg) { return sh + lay.segs[seg].shadow_off; };
+    // QST_PREC_F16W: every forward Linear multiplies by hi + lo of the weight (a second pass over K: QstGemmArgs.B2)
+    const bool splitw = c.precision == QST_PREC_F16W;
+    auto WL = [&](int seg) -> const void* { return splitw ? sh + lay.shadow_total + lay.segs[seg].shadow_off : nullptr; };
     auto linear = [&](const void* Ain, int Kd, int wseg, void* Cout, int N, void* C2, int bseg, const float* resid, int epi) {
-        return nt(K, Ain, Kd, W(wseg), Kd, Cout, N, C2, nullptr, P(bseg), resid, N, M, N, Kd, epi, true, st);
+        return nt(K, Ain, Kd, W(wseg), Kd, Cout, N, C2, nullptr, P(bseg), resid, N, M, N, Kd, epi, true, st, WL(wseg));
     };
 
     int32_t* pos_ids = (int32_t*)(sv + p.pos_ids);
@@ -953,7 +968,7 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     const bool fuse_ln = qst_gemm_nt_ln_supported(H) != 0 && M >= kFuseLnMinRows;
     // ... and the whole feed-forward block (FFN-1, GELU, FFN-2, LayerNorm) is ONE kernel: h never returns from HBM, and
     // an inference forward does not write it at all
-    const bool fuse_ffn = fuse_ln && !dropping && (e->ffn_chain & (training ? 2 : 1)) && qst_ffn_chain_supported(H, I) != 0;
+    const bool fuse_ffn = fuse_ln && !dropping && !splitw && (e->ffn_chain & (training ? 2 : 1)) && qst_ffn_chain_supported(H, I) != 0;
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerAct& a = p.layers[l];
         const int b = lay.layer0[l];
@@ -968,7 +983,7 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
         drop_next(thr, dst8, dropping, QST_DROP_SITE_ATTN_OUT(l), 1);
         if (fuse_ln) {
             QST_TRY(nt_ln(K, sv + a.ctx, H, W(b + W_O), H, (float*)(sv + a.y1), sv + a.y1b, P(b + B_O), x, M, H, H, 0,
-                          P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, sv + a.xh1, (float*)(sv + a.rs1), nullptr, st));
+                          P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, sv + a.xh1, (float*)(sv + a.rs1), nullptr, st, WL(b + W_O)));
         } else {
             QST_TRY(linear(sv + a.ctx, H, b + W_O, s, H, nullptr, b + B_O, x, QST_EPI_F32_RESID));
             QST_TRY(K.ln_fwd(s, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, (float*)(sv + a.y1), sv + a.y1b,
@@ -988,7 +1003,7 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
         if (fuse_ln) {
             QST_TRY(nt_ln(K, sv + a.hact, I, W(b + W_2), I, (float*)(sv + a.x), sv + a.xb, P(b + B_2),
                           (const float*)(sv + a.y1), M, H, I, 0, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, sv + a.xh2,
-                          (float*)(sv + a.rs2), nullptr, st));
+                          (float*)(sv + a.rs2), nullptr, st, WL(b + W_2)));
         } else {
             QST_TRY(linear(sv + a.hact, I, b + W_2, s, H, nullptr, b + B_2, (const float*)(sv + a.y1), QST_EPI_F32_RESID));
             QST_TRY(K.ln_fwd(s, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, M, H, (float*)(sv + a.x), sv + a.xb,

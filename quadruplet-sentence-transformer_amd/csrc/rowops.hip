@@ -588,7 +588,11 @@ __global__ __launch_bounds__(256) void shadow_kernel(const float* src, int rows,
 }
 
 // all GEMM weights in ONE launch: table entry = {src offset, rows, cols, dst offset, dstT offset, first block}
-__global__ __launch_bounds__(256) void shadow_all_kernel(const float* params, op16* shadow, const int64_t* tab, int nseg) {
+// shadow_lo (nullable, QST_PREC_F16W): the low halves of the split weights, lo = op16(w - float(op16(w))), at the offsets of the W
+// copies in a second arena of the same layout (W = hi + lo to ~2^-22: mostly SUBNORMAL halves, which the f16 MFMA keeps --
+// tools/probe/mfma_f16_denorm_probe.hip)
+__global__ __launch_bounds__(256) void shadow_all_kernel(const float* params, op16* shadow, const int64_t* tab, int nseg,
+                                                         op16* shadow_lo) {
     op_saturate(true);
     __shared__ float tile[32][33];
     int lo = 0, hi = nseg - 1;
@@ -610,7 +614,9 @@ __global__ __launch_bounds__(256) void shadow_all_kernel(const float* params, op
         float v = 0.f;
         if (r < rows && c < cols) {
             v = src[(size_t)r * cols + c];
-            dst[(size_t)r * cols + c] = f2op(v);
+            const op16 h = f2op(v);
+            dst[(size_t)r * cols + c] = h;
+            if (shadow_lo) shadow_lo[e[3] + (size_t)r * cols + c] = f2op(v - op2f(h));
         }
         tile[ty + 8 * k][tx] = v;
     }
@@ -890,10 +896,20 @@ extern "C" int qst_rel_pos_bwd(const float* drel_pos, const int32_t* lut, int bu
 
 extern "C" int QST_K(qst_shadow_all)(const float* params, void* shadow, const int64_t* table_dev, int nseg, int nblocks, void* stream) {
     if (!params || !shadow || !table_dev || nseg <= 0 || nblocks <= 0) return QST_ERR_BAD_ARG;
-    shadow_all_kernel<<<nblocks, 256, 0, (hipStream_t)stream>>>(params, (op16*)shadow, table_dev, nseg);
+    shadow_all_kernel<<<nblocks, 256, 0, (hipStream_t)stream>>>(params, (op16*)shadow, table_dev, nseg, nullptr);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
+#if QST_OP_F16
+// ... and the low halves of the split weights into shadow_lo (QST_PREC_F16W; an arena of the same layout as `shadow`)
+extern "C" int qst_shadow_all_split_f16(const float* params, void* shadow, void* shadow_lo, const int64_t* table_dev, int nseg,
+                                        int nblocks, void* stream) {
+    if (!params || !shadow || !shadow_lo || !table_dev || nseg <= 0 || nblocks <= 0) return QST_ERR_BAD_ARG;
+    shadow_all_kernel<<<nblocks, 256, 0, (hipStream_t)stream>>>(params, (op16*)shadow, table_dev, nseg, (op16*)shadow_lo);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+#endif
 
 extern "C" int QST_K(qst_shadow_matrix)(const float* src, int rows, int cols, void* dst_bf16, void* dstT_bf16, void* stream) {
     if (!src || rows <= 0 || cols <= 0) return QST_ERR_BAD_ARG;

@@ -44,6 +44,9 @@ class HipEncoder:
         self.handle_f16 = None        # QST_PREC_F16 handle: the bf16 kernels compiled on IEEE half (round 5), its own shadow
         self.shadow_f16: Optional[torch.Tensor] = None
         self.shadow_f16_stale = True
+        self.handle_f16w = None       # QST_PREC_F16W: f16 with split weights (hi + lo) in the forward; shadow = [f16 arena | low halves]
+        self.shadow_f16w: Optional[torch.Tensor] = None
+        self.shadow_f16w_stale = True
         self.amp_scaler: Optional[torch.Tensor] = None   # device fp32 [4] {loss scale, growth tracker, last skipped, #skipped}
         self._step2_dev: Optional[torch.Tensor] = None   # device int64 [2] {optimiser steps, scheduler steps} of the amp step
         self.shadow_mx: Optional[torch.Tensor] = None
@@ -65,7 +68,7 @@ class HipEncoder:
 
     def __del__(self):
         try:
-            for attr in ("handle", "handle_x3", "handle_mx", "handle_f16"):
+            for attr in ("handle", "handle_x3", "handle_mx", "handle_f16", "handle_f16w"):
                 if getattr(self, attr, None):
                     self.lib.qst_encoder_destroy(getattr(self, attr))
                     setattr(self, attr, None)
@@ -81,6 +84,7 @@ class HipEncoder:
         self.shadow_stale = True
         self.shadow_mx_stale = True
         self.shadow_f16_stale = True
+        self.shadow_f16w_stale = True
 
     def named_views(self) -> Dict[str, torch.Tensor]:
         """HF-named views into the parameter arena (no copies)."""
@@ -123,7 +127,7 @@ class HipEncoder:
                 self.drop_state = torch.zeros(4, dtype=torch.int32, device=self.device)
             _lib.check(self.lib.qst_dropout_init(self.drop_state.data_ptr(), int(seed) & 0xFFFFFFFFFFFFFFFF,
                                                  _lib.current_stream_ptr()), "qst_dropout_init")
-        for h in (self.handle, self.handle_mx, self.handle_x3, self.handle_f16):      # every precision's training forward drops at the same places
+        for h in (self.handle, self.handle_mx, self.handle_x3, self.handle_f16, self.handle_f16w):      # every precision's training forward drops at the same places
             if h is not None:
                 _lib.check(self.lib.qst_encoder_set_dropout(h, float(p_hidden), float(p_attn),
                                                             self.drop_state.data_ptr() if on else None), "qst_encoder_set_dropout")
@@ -152,6 +156,12 @@ class HipEncoder:
         _lib.check(self.lib.qst_refresh_shadow(self.handle_f16, self.params.data_ptr(), self.shadow_f16.data_ptr(),
                                                _lib.current_stream_ptr()), "qst_refresh_shadow(f16)")
         self.shadow_f16_stale = False
+
+    def refresh_shadow_f16w(self) -> None:
+        """QST_PREC_F16W: the f16 [W | W^T] arena and, behind it, the low halves of the split weights."""
+        _lib.check(self.lib.qst_refresh_shadow(self.handle_f16w, self.params.data_ptr(), self.shadow_f16w.data_ptr(),
+                                               _lib.current_stream_ptr()), "qst_refresh_shadow(f16w)")
+        self.shadow_f16w_stale = False
 
     def refresh_shadow(self) -> None:
         _lib.check(self.lib.qst_refresh_shadow(self.handle, self.params.data_ptr(), self.shadow.data_ptr(),
@@ -205,8 +215,20 @@ class HipEncoder:
                     _lib.check(self.lib.qst_encoder_set_dropout(h, self.dropout[0], self.dropout[1], self.drop_state.data_ptr()),
                                "qst_encoder_set_dropout")
             return self.handle_f16
+        if precision in ("f16w", 5):
+            if self.handle_f16w is None:
+                h = _lib.vp()
+                c5 = _lib.make_config(self.cfg, 5)
+                _lib.check(self.lib.qst_encoder_create(c5, h), "qst_encoder_create(f16w)")
+                self.handle_f16w = h
+                self.shadow_f16w = torch.zeros(self.lib.qst_shadow_elems(c5), dtype=torch.float16, device=self.device)
+                self.shadow_f16w_stale = True
+                if self.dropout is not None:
+                    _lib.check(self.lib.qst_encoder_set_dropout(h, self.dropout[0], self.dropout[1], self.drop_state.data_ptr()),
+                               "qst_encoder_set_dropout")
+            return self.handle_f16w
         if precision not in ("bf16x3", 1):
-            raise ValueError(f"unknown precision {precision!r} (bf16 | f16 | bf16x3 | fp8)")
+            raise ValueError(f"unknown precision {precision!r} (bf16 | f16 | f16w | bf16x3 | fp8)")
         if self.handle_x3 is None:
             h = _lib.vp()
             _lib.check(self.lib.qst_encoder_create(_lib.make_config(self.cfg, 1), h), "qst_encoder_create(x3)")
@@ -236,6 +258,10 @@ class HipEncoder:
             if self.shadow_f16_stale:
                 self.refresh_shadow_f16()
             shadow = self.shadow_f16
+        if handle is self.handle_f16w and handle is not None:
+            if self.shadow_f16w_stale:
+                self.refresh_shadow_f16w()
+            shadow = self.shadow_f16w
         nbytes = self.lib.qst_encoder_saved_bytes(handle, n, L, int(training))
         if nbytes == 0:
             raise _lib.QstError(f"unsupported shape nseq={n} L={L} for this encoder (L % 32 == 0, L <= 512)")
@@ -253,6 +279,8 @@ class HipEncoder:
 
     def shadow_for(self, handle) -> torch.Tensor:
         """The [W | W^T] operand shadow a BACKWARD on `handle` reads: IEEE half for the f16 handle, bf16 otherwise."""
+        if handle is not None and handle is self.handle_f16w:
+            return self.shadow_f16w
         return self.shadow_f16 if (handle is self.handle_f16 and handle is not None) else self.shadow
 
     def backward(self, ids, mask, type_ids, grad_emb: torch.Tensor, saved: torch.Tensor, precision: str = "bf16") -> None:
@@ -285,6 +313,7 @@ class HipEncoder:
         self.shadow_stale = True
         self.shadow_mx_stale = True
         self.shadow_f16_stale = True
+        self.shadow_f16w_stale = True
 
 
     # ------------------------------------------------------------------ optimiser state (true resume)
@@ -322,6 +351,7 @@ class HipEncoder:
         self.shadow_stale = True
         self.shadow_mx_stale = True
         self.shadow_f16_stale = True
+        self.shadow_f16w_stale = True
 
 
     # ------------------------------------------------------------------ mixed precision (QST_PREC_F16 training)
@@ -354,6 +384,7 @@ class HipEncoder:
         self.shadow_stale = True
         self.shadow_mx_stale = True
         self.shadow_f16_stale = True
+        self.shadow_f16w_stale = True
 
 
 def quadruplet_loss_raw(xa, xp, xq, xn, gamma, m_pn, m_pq, m_qn, p, swap, reduction: int,

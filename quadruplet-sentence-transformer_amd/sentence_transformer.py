@@ -450,9 +450,10 @@ class SentenceTransformer(nn.Module):
                 return lr * min(1.0, float(step) / float(max(1, warmup_steps)))
             return warmup_linear_lr(lr, step, warmup_steps, t_total)
 
-        if precision not in ("bf16", "f16", "bf16x3", "fp8"):
-            raise ValueError("fit(precision=...) is 'bf16', 'f16', 'bf16x3' or 'fp8'")
-        if precision == "f16" and sched != "warmuplinear" and sched != "constantlr":
+        if precision not in ("bf16", "f16", "f16w", "bf16x3", "fp8"):
+            raise ValueError("fit(precision=...) is 'bf16', 'f16', 'f16w', 'bf16x3' or 'fp8'")
+        amp = precision in ("f16", "f16w")
+        if amp and sched != "warmuplinear" and sched != "constantlr":
             raise ValueError("precision='f16' / use_amp drives the device-side schedule: 'WarmupLinear' or 'constantlr'")
         if data_parallel not in (None, "off", "split_batch", "per_rank_batches"):
             raise ValueError(f"data_parallel={data_parallel!r}: expected 'split_batch', 'per_rank_batches' or 'off'")
@@ -485,7 +486,7 @@ class SentenceTransformer(nn.Module):
         self.training_precision = precision
         try:
             enc.set_dropout(p_hidden, p_attn, int(dropout_seed) + rank)
-            if precision == "f16":
+            if amp:
                 enc.ensure_amp_scaler()
             global_step = 0
             if resume_from_checkpoint is not None:
@@ -522,7 +523,7 @@ class SentenceTransformer(nn.Module):
                             labels = labels.to(self._target_device)
                             features = [batch_to_device(f, self._target_device) for f in features]
                             loss_value = lm(features, labels)
-                            if precision == "f16":          # GradScaler.scale(loss): the scale is a device scalar
+                            if amp:                         # GradScaler.scale(loss): the scale is a device scalar
                                 (loss_value * (enc.amp_scaler[0] * weight)).backward()
                             else:
                                 (loss_value if weight == 1.0 else loss_value * weight).backward()
@@ -538,7 +539,7 @@ class SentenceTransformer(nn.Module):
                                 w.wait()
                             self._dp_works, self._dp_reduced, self._live_graphs = [], False, 0
                         # clip_grad_norm_ + AdamW.step + zero_grad, one pass over the arena, norm stays on the device
-                        if precision == "f16":
+                        if amp:
                             # scaler.unscale_ + clip + scaler.step + scaler.update; the learning rate follows the device's
                             # scheduler count (ST skips scheduler.step() whenever the scale changed)
                             enc.adamw_step_amp(lr, int(warmup_steps), t_total if sched == "warmuplinear" else 0, betas, eps,

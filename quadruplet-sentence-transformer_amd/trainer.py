@@ -89,8 +89,8 @@ def staged_backward(enc: HipEncoder, ids, mask, types, grad_emb, saved, ws=None,
     handle rebuilds the masks of the forward that filled `saved` (an arena no training forward has filled is refused)."""
     lib, st = enc.lib, _lib.current_stream_ptr()
     n, L = ids.shape
-    if precision not in ("bf16", "fp8", "f16"):
-        raise ValueError("the staged backward runs the 16-bit stages (precision 'bf16', 'f16' or 'fp8')")
+    if precision not in ("bf16", "fp8", "f16", "f16w"):
+        raise ValueError("the staged backward runs the 16-bit stages (precision 'bf16', 'f16', 'f16w' or 'fp8')")
     handle = enc._handle_for(precision)
     if ws is None:
         ws = enc._arena("_ws", lib.qst_encoder_bwd_workspace_bytes(handle, n, L))
@@ -141,7 +141,9 @@ class QuadrupletTrainer:
         """precision: "bf16" (the throughput path); "f16" -- the same kernels on IEEE-half operands (11 significand bits:
         embeddings inside the north-star tolerance for the six-layer models) under a dynamic loss scale on the device, i.e.
         what the reference's `use_amp=True` is (autocast + GradScaler, training/main.py:142): amp_init_scale and
-        amp_growth_interval are GradScaler's init_scale / growth_interval (<= 0: a static scale); "fp8" -- BASELINE configs[4]: the forward's Linears on the fp8 matrix
+        amp_growth_interval are GradScaler's init_scale / growth_interval (<= 0: a static scale); "f16w" -- f16 whose forward
+        Linears multiply by hi + lo of every weight (split-f16 weights: the weight rounding, which does not average out over
+        the tokens of a sequence, is gone; a second pass over K per forward GEMM); "fp8" -- BASELINE configs[4]: the forward's Linears on the fp8 matrix
         cores (MXFP8 weights and activations), dgrad / wgrad in bf16 from the fp32 master weights (H and I multiples of 128;
         dropout as on the bf16 path); or "bf16x3" -- the parity path: fp32 activations, every product as three
         split-bf16 MFMAs, gradients fp32-class (the reference trains in fp32, training/main.py:142). Several times slower;
@@ -151,8 +153,8 @@ class QuadrupletTrainer:
         (p_hidden, p_attn). The reference's fit() trains with 0.1 (HF config defaults, train() mode). Ranks of a
         data-parallel job should pass different dropout_seed values (fit() adds the rank)."""
         self.cfg = cfg
-        if precision not in ("bf16", "f16", "bf16x3", "fp8"):
-            raise ValueError("training precision is 'bf16', 'f16', 'bf16x3' or 'fp8'")
+        if precision not in ("bf16", "f16", "f16w", "bf16x3", "fp8"):
+            raise ValueError("training precision is 'bf16', 'f16', 'f16w', 'bf16x3' or 'fp8'")
         if precision == "bf16x3" and use_graph:
             raise ValueError("precision='bf16x3' (the parity path) trains without a graph")
         if precision == "fp8" and use_graph:
@@ -163,7 +165,8 @@ class QuadrupletTrainer:
             self.enc.load_arena(arena)
         self.enc.ensure_train_state()
         self.amp_growth_interval = int(amp_growth_interval)
-        if precision == "f16":
+        self.amp = precision in ("f16", "f16w")      # IEEE-half operands: the step runs under the device-side loss scaler
+        if self.amp:
             self.enc.ensure_amp_scaler(amp_init_scale)
         if dropout is not None:
             ph, pa = (dropout, dropout) if isinstance(dropout, (int, float)) else dropout
@@ -205,7 +208,7 @@ class QuadrupletTrainer:
         e4 = emb.view(4, B, -1)
         # f16 training: the loss gradient leaves the loss kernel multiplied by the device-resident loss scale (grad_out = the
         # scaler's first word), so every f16 gradient tensor of the backward sits inside half's range
-        gout = self.enc.amp_scaler if (want_grads and precision == "f16") else None
+        gout = self.enc.amp_scaler if (want_grads and precision in ("f16", "f16w")) else None
         loss, g = quadruplet_loss_raw(e4[0], e4[1], e4[2], e4[3], *self.loss_args, _REDUCTION["mean"],
                                       grad_out=gout, want_grads=want_grads)
         return loss, e4, g, saved, (ids, mask, types)
@@ -243,8 +246,9 @@ class QuadrupletTrainer:
         graph.replay()
         self.enc.opt_step += 1
         # the captured step ends with the refresh of the operand shadow it trains on (the other one is stale)
-        self.enc.shadow_stale = self.precision == "f16"
+        self.enc.shadow_stale = self.precision != "bf16"
         self.enc.shadow_f16_stale = self.precision != "f16"
+        self.enc.shadow_f16w_stale = self.precision != "f16w"
         self.sched_step += 1
         return static_loss
 
@@ -269,12 +273,13 @@ class QuadrupletTrainer:
                                     precision=self.precision)
         for w in works:
             w.wait()
-        if self.precision == "f16":
+        if self.amp:
             opt0 = enc.opt_step
             enc.adamw_step_amp(self.lr, self.warmup_steps, self.total_steps, self.betas, self.eps, self.wd,
                                self.max_grad_norm, 1.0 / self.world, growth_interval=self.amp_growth_interval)
             if sched_on_device:
-                enc.refresh_shadow_f16()     # a graph replays the whole step: the next forward's operand refresh belongs inside it
+                # a graph replays the whole step: the next forward's operand refresh belongs inside it
+                enc.refresh_shadow_f16() if self.precision == "f16" else enc.refresh_shadow_f16w()
             if not count:
                 enc.opt_step = opt0
         elif sched_on_device:
