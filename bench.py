@@ -562,11 +562,56 @@ def time_dp_rccl_ws1(trainer, cfg, batches, steps, B, ms_dp1):
             tr.step(*batches[i % len(batches)])
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
+        out = {"value": round(B / ms * 1e3, 1), "unit": "quadruplets/s", "ms_per_step": round(ms, 4),
+               "overhead_vs_dp1_ms": round(ms - ms_dp1, 4),
+               "what": "the same step through the data-parallel path: staged backward + 7 async RCCL all-reduces "
+                       "(world_size 1 on this GPU; the 1 -> 8 GPU curve itself needs an 8-GPU node)"}
+        # the other training precisions through the same path (f16: scaled gradients are exchanged, GradScaler decides after the
+        # exchange; bf16x3: staged since round 5) -- a handful of steps each, against their own single-process step
+        for prec, nst in (("f16", steps), ("bf16x3", max(3, steps // 5))):
+            try:
+                t1 = QuadrupletTrainer(cfg, encoder=trainer.enc, lr=2e-5, weight_decay=0.01, max_grad_norm=1.0, warmup_steps=10000,
+                                       total_steps=1000000, precision=prec)
+                t2 = QuadrupletTrainer(cfg, encoder=trainer.enc, lr=2e-5, weight_decay=0.01, max_grad_norm=1.0, warmup_steps=10000,
+                                       total_steps=1000000, world_size=1, overlap=True, force_dp=True, precision=prec)
+                res = []
+                for t in (t1, t2):
+                    for i in range(2):
+                        t.step(*batches[i % len(batches)])
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for i in range(nst):
+                        t.step(*batches[i % len(batches)])
+                    torch.cuda.synchronize()
+                    res.append((time.perf_counter() - t0) / nst * 1e3)
+                out[prec] = {"ms_per_step_single": round(res[0], 4), "ms_per_step_dp_ws1": round(res[1], 4),
+                             "overhead_ms": round(res[1] - res[0], 4)}
+            except Exception as e:
+                out[prec] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        # the exchange itself on the gradient arena: fp32 as the step does it, and as bf16 (QST_COMM_BF16: half the bytes on the
+        # wire, paid for with two conversion passes over the arena and 8-bit gradient sums -- DESIGN.md section 5)
+        try:
+            g = trainer.enc.grads
+            gb = torch.empty_like(g, dtype=torch.bfloat16)
+            def t_of(fn, n=10):
+                for _ in range(2):
+                    fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n * 1e3
+            def x32():
+                dist.all_reduce(g)
+            def x16():
+                gb.copy_(g); dist.all_reduce(gb); g.copy_(gb)
+            out["exchange_whole_arena_ms"] = {"fp32": round(t_of(x32), 4), "bf16_with_conversions": round(t_of(x16), 4),
+                                              "mb_fp32": round(g.numel() * 4 / 1e6, 1)}
+        except Exception as e:
+            out["exchange_whole_arena_ms"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         dist.destroy_process_group()
-        return {"value": round(B / ms * 1e3, 1), "unit": "quadruplets/s", "ms_per_step": round(ms, 4),
-                "overhead_vs_dp1_ms": round(ms - ms_dp1, 4),
-                "what": "the same step through the data-parallel path: staged backward + 7 async RCCL all-reduces "
-                        "(world_size 1 on this GPU; the 1 -> 8 GPU curve itself needs an 8-GPU node)"}
+        return out
     except Exception as e:                           # RCCL unavailable on this box: say so, do not fail the bench line
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 

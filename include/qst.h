@@ -51,7 +51,8 @@ typedef enum {
     QST_ERR_WORKSPACE = -3,    /* workspace/saved arena smaller than qst_*_bytes() says */
     QST_ERR_HIP = -4,          /* a HIP runtime call failed; qst_last_hip_error() has the code */
     QST_ERR_NO_DEVICE = -5,
-    QST_ERR_COMM = -6          /* RCCL could not be loaded, or one of its calls failed; qst_comm_last_error() has the text */
+    QST_ERR_COMM = -6,         /* RCCL could not be loaded, or one of its calls failed; qst_comm_last_error() has the text */
+    QST_ERR_NO_FORWARD = -7    /* backward over an arena that no training forward of this precision and shape has filled */
 } qst_status;
 
 enum { QST_ARCH_BERT = 0, QST_ARCH_MPNET = 1 };
@@ -153,8 +154,9 @@ int qst_dropout_advance(uint32_t* state_dev, void* stream);
  *   workspace  : qst_encoder_bwd_workspace_bytes
  *   saved      : the arena a TRAINING forward of this process filled (any handle of the same model and arena kind: the
  *                dropout rates that forward ran under are remembered per arena, so the masks rebuilt here are its masks
- *                whatever qst_encoder_set_dropout has been told since); an arena without such a forward, or the fp32
- *                arena of QST_PREC_BF16X3 given to a bf16 / fp8 handle (or the reverse), is refused with QST_ERR_BAD_ARG.
+ *                whatever qst_encoder_set_dropout has been told since); an arena without such a forward, one filled for another
+ *                (nseq, L), or an arena of another kind -- the fp32 one of QST_PREC_BF16X3, the f16 one of QST_PREC_F16 / F16W,
+ *                the bf16 one of QST_PREC_BF16 / FP8 -- is refused with QST_ERR_NO_FORWARD.
  */
 int qst_encoder_backward(qst_encoder* enc, const int64_t* ids, const int64_t* mask, const int64_t* type_ids,
                          int nseq, int L, const float* params, const void* shadow_bf16,

@@ -1256,7 +1256,13 @@ extern "C" int qst_gemm_nt_f8(const QstGemmArgs* a, int epi, void* stream) {
     const bool mxt_ok = epi == QST_EPI_GELU_MX_TRAIN && a->C2 && a->C3 && a->C4 && a->ldc == a->N && a->N % 32 == 0;
     if (!(a->splits & 0x80) && (epi == QST_EPI_BF16 || epi == QST_EPI_F32_RESID || epi == QST_EPI_GELU || mxt_ok) && a->N % 8 == 0 && a->ldc % 8 == 0) {
         const int mode = qst_gemm8_mode_get();
-        if ((a->splits & 0x40) || (mode >= 0 ? (mode & 1) != 0 : f8_auto(a, epi))) return qst_gemm_nt8_f8(a, epi, 1, stream);
+        // the 8-phase entry point has stricter limits than the tiled kernel (32-bit scale offsets, 256 / 384-row descriptors): a
+        // shape it would refuse falls through to the tiled launch unless the caller FORCED the form
+        const bool fits8 = (int64_t)256 * a->lda < 0x7FFFFF00LL && (int64_t)384 * a->ldb < 0x7FFFFF00LL &&
+                           (int64_t)(a->K / 128) * (a->M > a->N ? a->M : a->N) * 4 < 0x7FFFFF00LL &&
+                           !(epi == QST_EPI_F32_RESID && a->resid && a->ldr % 4 != 0);
+        if (a->splits & 0x40) return qst_gemm_nt8_f8(a, epi, 1, stream);
+        if (fits8 && (mode >= 0 ? (mode & 1) != 0 : f8_auto(a, epi))) return qst_gemm_nt8_f8(a, epi, 1, stream);
     }
     switch (epi) {
         case QST_EPI_BF16: return a->ldc % 4 ? QST_ERR_UNSUPPORTED : launch_nt_f8<QST_EPI_BF16>(a, st);

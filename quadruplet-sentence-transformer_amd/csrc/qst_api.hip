@@ -7,6 +7,7 @@
 #include <vector>
 #include <mutex>
 #include <unordered_map>
+#include <algorithm>
 
 #include "qst_common.h"
 #include "qst_kernels.h"
@@ -28,6 +29,8 @@ extern "C" const char* qst_strerror(int s) {
         case QST_ERR_HIP: return "HIP runtime error (see qst_last_hip_error)";
         case QST_ERR_NO_DEVICE: return "no HIP device";
         case QST_ERR_COMM: return "RCCL error (see qst_comm_last_error)";
+        case QST_ERR_NO_FORWARD: return "no matching training forward: `saved` is not an activation arena that a training forward of this "
+                                        "precision and shape (nseq, L) has filled in this process";
         default: return "unknown qst status";
     }
 }
@@ -112,22 +115,30 @@ enum { W_QKV = 0, B_QKV, W_O, B_O, LN1_G, LN1_B, W_1, B_1, W_2, B_2, LN2_G, LN2_
 // gradients without an error once the ring wrapped or a backward ran on another handle -- ADVICE r03.)
 namespace {
 enum { ARENA_BF16 = 0, ARENA_X3 = 1, ARENA_F16 = 2 };   // the bf16 activation arena (bf16 and fp8 forwards) / the fp32 one of bf16x3 / the f16 one
-struct FwdRec { uint32_t hidden = 0, attn = 0; int kind = ARENA_BF16; uint64_t seq = 0; };
+// A record also holds the shape of its forward: an arena whose address was reused by a later allocation of another shape (or a
+// backward called with another nseq / L than its forward) is refused instead of read with the wrong plan.
+struct FwdRec { uint32_t hidden = 0, attn = 0; int kind = ARENA_BF16; uint64_t seq = 0; int nseq = 0, L = 0; };
 std::mutex g_rec_mu;
 std::unordered_map<const void*, FwdRec> g_recs;
 uint64_t g_rec_seq = 0;
-void rec_put(const void* saved, uint32_t hidden, uint32_t attn, int kind) {
+void rec_put(const void* saved, uint32_t hidden, uint32_t attn, int kind, int nseq, int L) {
     std::lock_guard<std::mutex> lk(g_rec_mu);
-    g_recs[saved] = FwdRec{hidden, attn, kind, ++g_rec_seq};
-    if (g_recs.size() > 4096) {                 // arenas that were freed long ago: drop the older half
-        const uint64_t cut = g_rec_seq - 2048;
+    g_recs[saved] = FwdRec{hidden, attn, kind, ++g_rec_seq, nseq, L};
+    if (g_recs.size() > 4096) {
+        // arenas that were freed long ago: keep the 2048 most recently WRITTEN records (by count -- a cut at "sequence number -
+        // 2048" dropped live arenas once hot ones had been re-put often enough)
+        std::vector<uint64_t> seqs;
+        seqs.reserve(g_recs.size());
+        for (const auto& kv : g_recs) seqs.push_back(kv.second.seq);
+        std::nth_element(seqs.begin(), seqs.end() - 2048, seqs.end());
+        const uint64_t cut = *(seqs.end() - 2048);
         for (auto it = g_recs.begin(); it != g_recs.end();) it = it->second.seq < cut ? g_recs.erase(it) : std::next(it);
     }
 }
-bool rec_get(const void* saved, int kind, FwdRec* out) {
+bool rec_get(const void* saved, int kind, int nseq, int L, FwdRec* out) {
     std::lock_guard<std::mutex> lk(g_rec_mu);
     const auto it = g_recs.find(saved);
-    if (it == g_recs.end() || it->second.kind != kind) return false;
+    if (it == g_recs.end() || it->second.kind != kind || it->second.nseq != nseq || it->second.L != L) return false;
     *out = it->second;
     return true;
 }
@@ -653,7 +664,7 @@ static int forward_mx_train(qst_encoder* e, const int64_t* ids, const int64_t* m
         return qst_gemm_nt_f8(&g, epi, st);
     };
     {
-        rec_put(saved, thr.hidden, thr.attn, ARENA_BF16);
+        rec_put(saved, thr.hidden, thr.attn, ARENA_BF16, nseq, L);
     }
     int32_t* pos_ids = (int32_t*)(sv + p.pos_ids);
     QST_TRY(qst_forward_prologue(ids, nseq, L, c.arch, c.pad_token_id, pos_ids, dropping ? e->drop_state : nullptr,
@@ -766,7 +777,7 @@ static int forward_x3_train(qst_encoder* e, const int64_t* ids, const int64_t* m
     QST_TRY(qst_forward_prologue(ids, nseq, L, c.arch, c.pad_token_id, pos_ids, dropping ? e->drop_state : nullptr,
                                  dropping ? (uint32_t*)(sv + p.dropst) : nullptr, st));
     {
-        rec_put(saved, thr.hidden, thr.attn, ARENA_X3);
+        rec_put(saved, thr.hidden, thr.attn, ARENA_X3, nseq, L);
     }
     const bool hdrop = dropping && thr.hidden != 0;
     // out = (A . W^T + bias) * mask(site) + resid   (BertSelfOutput / BertOutput: LayerNorm(dropout(dense(x)) + input))
@@ -816,9 +827,13 @@ static int forward_x3_train(qst_encoder* e, const int64_t* ids, const int64_t* m
 
 // ... and its backward: fp32-class gradients ACCUMULATED into `grads`. Every contraction runs on split-bf16 x3 products: a
 // dgrad is gemm_nt_x3 against the transposed weight, a wgrad (+ bias gradient) one gemm_tn_x3 launch over the token rows.
+// Stages as the bf16 backward has them (head -> layers [layer_lo, layer_hi) top-down -> embeddings; the running d(loss)/d(x)
+// lives in the workspace between calls), so that a data-parallel step can hand a finished layer's gradients to the all-reduce
+// while the layers below are still running (round 5; rounds 3-4 ran it as one call and reduced afterwards).
 static int backward_x3(qst_encoder* e, const int64_t* ids, const int64_t* mask, const int64_t* type_ids, int nseq, int L,
                        const float* params, const float* grad_emb, float* grads, void* saved, size_t saved_bytes,
-                       void* workspace, size_t workspace_bytes, hipStream_t st) {
+                       void* workspace, size_t workspace_bytes, bool do_head, int layer_hi, int layer_lo, bool do_embed,
+                       hipStream_t st) {
     const qst_config& c = e->cfg;
     const X3TrainPlan p = plan_x3_train(c, nseq, L);
     const X3BwdPlan w = plan_x3_bwd(c, nseq, L);
@@ -850,13 +865,13 @@ static int backward_x3(qst_encoder* e, const int64_t* ids, const int64_t* mask, 
     if (c.arch == QST_ARCH_MPNET) {
         rel = F(p.rel);
         drel = Wk(w.drel);
-        QST_HIP_CHECK(hipMemsetAsync(drel, 0, (size_t)A * L * L * 4, st));
+        if (do_head) QST_HIP_CHECK(hipMemsetAsync(drel, 0, (size_t)A * L * L * 4, st));
     }
     // dropout: the masks of the forward that filled `saved` (its thresholds from the handle's record, its (seed, step) from the
     // snapshot in the arena). ds = d(loss)/d(LayerNorm input) continues down the residual path as it is; the projection
     // that was dropped sees ds * mask (dsm, in a buffer that is free at that point).
     FwdRec fr;
-    if (!rec_get(saved, ARENA_X3, &fr)) return QST_ERR_BAD_ARG;      // not an arena a bf16x3 training forward has filled
+    if (!rec_get(saved, ARENA_X3, nseq, L, &fr)) return QST_ERR_NO_FORWARD;      // not an arena a bf16x3 training forward of this shape has filled
     const DropThr thr = {fr.hidden, fr.attn};
     const void* dst8 = sv + p.dropst;
     const bool hdrop = thr.hidden != 0, adrop = thr.attn != 0;
@@ -867,8 +882,8 @@ static int backward_x3(qst_encoder* e, const int64_t* ids, const int64_t* mask, 
         *out = tmp;
         return qst_dropout_apply_f32(&dd, g, nullptr, (int64_t)M * H, tmp, st);
     };
-    QST_TRY(qst_pool_norm_bwd(grad_emb, F(p.pooled), mask, nseq, L, H, c.normalize, dx, st));
-    for (int l = c.num_layers - 1; l >= 0; --l) {
+    if (do_head) QST_TRY(qst_pool_norm_bwd(grad_emb, F(p.pooled), mask, nseq, L, H, c.normalize, dx, st));
+    for (int l = layer_hi - 1; l >= layer_lo; --l) {
         const int b = lay.layer0[l];
         const X3Layer& a = p.layers[l];
         const float* xin = l == 0 ? F(p.x0) : F(p.layers[l - 1].x);
@@ -896,6 +911,7 @@ static int backward_x3(qst_encoder* e, const int64_t* ids, const int64_t* mask, 
         QST_TRY(dgrad(dqkv, 3 * H, b + W_QKV, H, dx, ds));                           // dx_in = dqkv . Wqkv + ds1
         QST_TRY(wgrad(dqkv, 3 * H, xin, H, b + W_QKV, b + B_QKV));
     }
+    if (!do_embed) return QST_OK;
     if (hdrop) {                                       // the embedding dropout sits AFTER its LayerNorm
         const QstDrop de = drop_of(thr, dst8, false, QST_DROP_SITE_EMBED);
         QST_TRY(qst_dropout_apply_f32(&de, dx, nullptr, (int64_t)M * H, dx, st));
@@ -946,7 +962,7 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     QST_TRY(qst_forward_prologue(ids, nseq, L, c.arch, c.pad_token_id, pos_ids, dropping ? e->drop_state : nullptr,
                                  dropping ? (uint32_t*)(sv + p.dropst) : nullptr, st));
     if (training) {                                   // remember what this forward did, for the backward over the same arena
-        rec_put(saved, thr.hidden, thr.attn, K.arena_kind);
+        rec_put(saved, thr.hidden, thr.attn, K.arena_kind, nseq, L);
     }
     {
         const QstDrop de = drop_of(thr, dst8, false, QST_DROP_SITE_EMBED);
@@ -1039,11 +1055,13 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
     if ((skip_wgrad || wgrad_only) && (layer_lo != 0 || layer_hi != 1)) return QST_ERR_BAD_ARG;
     if (!e || !ids || !mask || !params || !grads || !saved || !workspace) return QST_ERR_BAD_ARG;
     if (e->cfg.precision == QST_PREC_BF16X3) {
-        // the parity path: the whole backward in one call only (no staged exchange, no shadow)
-        if (!do_head || !do_embed || skip_wgrad || layer_lo != 0 || layer_hi != e->cfg.num_layers || !grad_emb) return QST_ERR_UNSUPPORTED;
+        // the parity path (no shadow): staged like the bf16 one, without the postponed weight-gradient launch of layer 0
+        if (skip_wgrad || wgrad_only) return QST_ERR_UNSUPPORTED;
+        if (do_head && !grad_emb) return QST_ERR_BAD_ARG;
+        if (layer_lo < 0 || layer_hi > e->cfg.num_layers || layer_lo > layer_hi) return QST_ERR_BAD_ARG;
         if (int rc = shape_ok(e, nseq, L)) return rc;
         return backward_x3(e, ids, mask, type_ids, nseq, L, params, grad_emb, grads, saved, saved_bytes, workspace, workspace_bytes,
-                           (hipStream_t)stream);
+                           do_head != 0, layer_hi, layer_lo, do_embed != 0, (hipStream_t)stream);
     }
     if (!shadow) return QST_ERR_BAD_ARG;
     // (a QST_PREC_FP8 handle: the bf16 backward over the arena its training forward filled; `shadow` = the bf16 shadows)
@@ -1084,7 +1102,7 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
     // dropout: the masks of the forward that filled `saved` are recomputed from its (seed, step) snapshot in the arena and
     // ITS thresholds (recorded by that forward, process-wide: any handle of the same model may run the backward)
     FwdRec fr;
-    if (!rec_get(saved, K.arena_kind, &fr)) return QST_ERR_BAD_ARG;  // not an arena a training forward of this operand type has filled
+    if (!rec_get(saved, K.arena_kind, nseq, L, &fr)) return QST_ERR_NO_FORWARD;  // not an arena a training forward of this operand type and shape has filled
     const DropThr thr = {fr.hidden, fr.attn};
     const bool dropping = thr.hidden != 0 || thr.attn != 0;
     const void* dst8 = sv + p.dropst;

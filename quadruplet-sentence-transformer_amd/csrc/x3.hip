@@ -710,6 +710,9 @@ extern "C" int qst_gemm_tn_x3(const QstGemmArgs* a, void* stream) {
     const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
     const int nkt = g.K / XBK;
     const int per = x3_share(nkt, tiles, a->splits > 0 ? a->splits : 256);   // tools/x3_wgrad_sweep.py: 128 - 512 workgroups are the fastest
+    // a share's row offsets are 32-bit and its buffer range is clamped to 0x7FFFFF00: a share spanning 2 GiB would read zeros
+    // past the clamp and return silently wrong gradients -- step-sized shapes are two orders below it
+    if ((int64_t)per * XBK * (int64_t)(a->lda > a->ldb ? a->lda : a->ldb) * 4 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
     g.splits = per;
     gemm_nt_x3_kernel<3, true><<<((nkt + per - 1) / per + 7) / 8 * 8 * tiles, 256, 65536, (hipStream_t)stream>>>(g);
     QST_LAUNCH_CHECK();

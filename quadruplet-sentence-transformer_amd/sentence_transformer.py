@@ -162,15 +162,8 @@ class _EncodeFn(torch.autograd.Function):
             # data-parallel fit(): the LAST outstanding encoder pass of the step (the only one on the fused [4B, L]
             # path) runs in stages with each finished layer's gradients handed to the all-reduce; gradients of earlier
             # passes of the same step are already in the arena and travel with them
-            if ctx.prec == "bf16x3":
-                # the parity path's backward is one call: the same buckets, in the staged backward's order, after it
-                model._enc.backward(ids, mask, types, grad_emb, ctx.saved, precision=ctx.prec)
-                model._dp_works += allreduce_ranges(model._enc.grads,
-                                                    staged_reduce_order(dp["buckets"], model._enc.total, dp["overlap"]),
-                                                    dp["group"], async_op=dp["overlap"])
-            else:
-                model._dp_works += staged_backward(model._enc, ids, mask, types, grad_emb, ctx.saved, None, dp["buckets"],
-                                                   dp["group"], dp["overlap"], precision=ctx.prec)
+            model._dp_works += staged_backward(model._enc, ids, mask, types, grad_emb, ctx.saved, None, dp["buckets"],
+                                               dp["group"], dp["overlap"], precision=ctx.prec)
             model._dp_reduced = True
         else:
             model._enc.backward(ids, mask, types, grad_emb, ctx.saved, precision=ctx.prec)

@@ -89,11 +89,12 @@ def staged_backward(enc: HipEncoder, ids, mask, types, grad_emb, saved, ws=None,
     handle rebuilds the masks of the forward that filled `saved` (an arena no training forward has filled is refused)."""
     lib, st = enc.lib, _lib.current_stream_ptr()
     n, L = ids.shape
-    if precision not in ("bf16", "fp8", "f16", "f16w"):
-        raise ValueError("the staged backward runs the 16-bit stages (precision 'bf16', 'f16', 'f16w' or 'fp8')")
+    if precision not in ("bf16", "fp8", "f16", "f16w", "bf16x3"):
+        raise ValueError(f"unknown precision {precision!r}")
     handle = enc._handle_for(precision)
+    x3 = precision == "bf16x3"
     if ws is None:
-        ws = enc._arena("_ws", lib.qst_encoder_bwd_workspace_bytes(handle, n, L))
+        ws = enc._arena("_ws_x3" if x3 else "_ws", lib.qst_encoder_bwd_workspace_bytes(handle, n, L))
     grad_emb = grad_emb.contiguous()
     N = enc.cfg.num_layers
 
@@ -115,6 +116,13 @@ def staged_backward(enc: HipEncoder, ids, mask, types, grad_emb, saved, ws=None,
     for k, l in enumerate(range(N - 1, 0, -1)):                        # layers N-1 ... 1
         stage(BWD_HEAD if k == 0 else 0, l + 1, l)
         works += allreduce_ranges(enc.grads, [order[k]], group, async_op=True)
+    if x3:
+        # the parity path has no postponed weight-gradient launch: layer 0 and the embeddings in one stage, then the same two
+        # buckets in the same order (round 5: rounds 3-4 reduced everything after a one-call backward)
+        stage((BWD_HEAD if N == 1 else 0) | BWD_EMBED, 1, 0)
+        works += allreduce_ranges(enc.grads, [order[N - 1]], group, async_op=True)
+        works += allreduce_ranges(enc.grads, [order[N]], group, async_op=True)
+        return works
     stage((BWD_HEAD if N == 1 else 0) | BWD_SKIP_WGRAD | BWD_EMBED, 1, 0)      # layer 0 dgrads + embeddings
     works += allreduce_ranges(enc.grads, [order[N - 1]], group, async_op=True)   # embedding bucket: the big one
     stage(BWD_WGRAD_ONLY, 1, 0)                                               # layer 0 weight gradients, under it
@@ -147,8 +155,8 @@ class QuadrupletTrainer:
         cores (MXFP8 weights and activations), dgrad / wgrad in bf16 from the fp32 master weights (H and I multiples of 128;
         dropout as on the bf16 path); or "bf16x3" -- the parity path: fp32 activations, every product as three
         split-bf16 MFMAs, gradients fp32-class (the reference trains in fp32, training/main.py:142). Several times slower;
-        data-parallel too (round 4): its backward is one call, so the buckets are all-reduced after it, in the staged
-        backward's order, without overlap.
+        data-parallel too: its backward runs in the same stages as the bf16 one (round 5), a finished layer's bucket is
+        all-reduced under the layers below.
         dropout: None / 0 = off; a float p = HF's hidden_dropout_prob = attention_probs_dropout_prob = p; a pair
         (p_hidden, p_attn). The reference's fit() trains with 0.1 (HF config defaults, train() mode). Ranks of a
         data-parallel job should pass different dropout_seed values (fit() adds the rank)."""
@@ -258,12 +266,9 @@ class QuadrupletTrainer:
         enc = self.enc
         loss, _, g, saved, (ids, mask, types) = self.forward_loss(ids4, mask4, types4, training=True, want_grads=True,
                                                                  saved=saved, precision=self.precision)
-        if self.precision == "bf16x3":
+        if self.precision == "bf16x3" and not (self.world > 1 or self.force_dp):
             enc.backward(ids, mask, types, stacked(g), saved, precision="bf16x3")
             works = []
-            if self.world > 1 or self.force_dp:     # the same buckets in the same order as the staged backward, after the call
-                works = allreduce_ranges(enc.grads, staged_reduce_order(self.buckets, enc.total, self.overlap), self.group,
-                                         async_op=True)
         elif self.precision == "fp8" and not (self.world > 1 or self.force_dp):
             enc.backward(ids, mask, types, stacked(g), saved, precision="fp8")
             works = []

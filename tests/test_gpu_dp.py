@@ -106,6 +106,33 @@ def test_parity_precision_trains_data_parallel(tmp_path):
     assert np.abs(p0 - ref).mean() < 2e-4 * moved
 
 
+@pytest.mark.parametrize("prec", ["f16", "f16w"])
+def test_f16_trains_data_parallel_under_one_loss_scale(tmp_path, prec):
+    """precision="f16" / "f16w" under two ranks (round 5): the staged backward with its overlapped all-reduces runs on the
+    SCALED gradients, every rank takes GradScaler's decision from the same reduced norm (qst_clip_adamw_step_amp after the
+    exchange), so replicas stay bit-identical -- parameters and loss scale -- and equal the single-process step on the global
+    batch up to fp32 summation order."""
+    from quadruplet_sentence_transformer_amd.synthetic import synthetic_params, synthetic_quadruplets
+    from quadruplet_sentence_transformer_amd.trainer import QuadrupletTrainer
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), True, str(tmp_path), "tiny-bert", None, prec), nprocs=world, join=True)
+    p0, p1 = np.load(tmp_path / "params_0.npy"), np.load(tmp_path / "params_1.npy")
+    np.testing.assert_array_equal(p0, p1)
+    cfg, B, L = _dp_case("tiny-bert")
+    arena = synthetic_params(cfg, seed=14, std=0.05, bias_std=0.02, ln_jitter=0.05)
+    tr = QuadrupletTrainer(cfg, arena=arena, device="cuda:0", lr=1e-3, world_size=1, precision=prec)
+    for step in range(2):
+        ids, mask, types = synthetic_quadruplets(cfg, world * B, L, seed=14, ragged=True, step=step)
+        tr.step(*[torch.from_numpy(x).cuda() for x in (ids, mask, types)])
+    assert tr.enc.amp_scaler[3].item() == 0.0
+    ref = tr.enc.params.cpu().numpy()
+    moved = np.abs(ref - arena).max()
+    assert moved > 1e-4
+    bad = np.abs(p0 - ref) > 0.05 * moved            # (zero-gradient parameters get an Adam update whose sign is rounding noise)
+    assert bad.mean() < 1e-3, f"{bad.sum()} of {bad.size} parameters differ"
+    assert np.abs(p0 - ref).mean() < 1e-3 * moved
+
+
 def test_replicas_stay_identical_with_per_rank_dropout(tmp_path):
     """With dropout every rank draws its own masks (seed + rank), so the ranks' local gradients differ by more than their
     data -- the reduced gradient, the global-norm clip and the update are still the same everywhere: replicas stay

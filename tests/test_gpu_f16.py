@@ -420,7 +420,7 @@ def test_f16_training_tracks_the_fp32_reference(name, drop, graph, prec):
 
 
 def test_f16_handles_refuse_each_others_arenas():
-    """An activation arena filled by a bf16 training forward is refused by the f16 backward and the reverse (QST_ERR_BAD_ARG):
+    """An activation arena filled by a bf16 training forward is refused by the f16 backward and the reverse (QST_ERR_NO_FORWARD):
     the 16-bit tensors in it are of the other type."""
     cfg = PRESETS["tiny-bert"]
     enc = HipEncoder(cfg)
@@ -431,6 +431,10 @@ def test_f16_handles_refuse_each_others_arenas():
     enc.ensure_train_state()
     for fwd, bwd in (("bf16", "f16"), ("f16", "bf16")):
         _, _, saved = enc.forward(idd, mdd, tdd, training=True, precision=fwd)
-        with pytest.raises(_lib.QstError):
+        with pytest.raises(_lib.QstError, match="no matching training forward"):
             enc.backward(idd, mdd, tdd, ge, saved, precision=bwd)
         enc.backward(idd, mdd, tdd, ge, saved, precision=fwd)
+    # ... and so is a backward with another shape than the forward that filled the arena (the record holds nseq and L)
+    _, _, saved = enc.forward(idd, mdd, tdd, training=True, precision="bf16")
+    with pytest.raises(_lib.QstError, match="no matching training forward"):
+        enc.backward(idd.view(4, 64), mdd.view(4, 64), tdd.view(4, 64), ge[:4], saved, precision="bf16")
