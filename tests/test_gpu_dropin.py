@@ -201,6 +201,44 @@ def test_fit_at_parity_precision(tmp_path):
     assert int(m3._enc.drop_state[2]) >= 2 and torch.isfinite(m3._enc.params).all() and not torch.equal(before, m3._enc.params)
 
 
+def test_fit_with_use_amp_trains_on_f16_operands_under_the_device_side_scaler(tmp_path):
+    """fit(use_amp=True) as the reference can call it (training/main.py:142 passes the flag; ST wraps the step in fp16 autocast +
+    GradScaler): here precision "f16" -- IEEE-half operands, the loss scaled by a device-resident GradScaler, unscale / clip /
+    step / update in qst_clip_adamw_step_amp. Same data, seed and schedule as the bf16 fit and as precision="f16w": all train
+    and end close to each other; the scaler saw no overflow; the model leaves fit() on its default precision."""
+    def run(**kw):
+        torch.manual_seed(0)
+        m = SentenceTransformer("tiny-bert", device="cuda")
+        loss = GammaQuadrupletLoss(gamma=0.6, margin_pos_neg=1.0, margin_pos_part=0.5, margin_part_neg=0.5, p=2.0)
+        lm = QuadrupletSentenceTransformerLossModel(m, loss)
+        data = [to_input_example(quad(i)) for i in range(16)]
+        dl = DataLoader(data, batch_size=8, shuffle=False, num_workers=0)
+        ev = CountingEvaluator(lm, data[:8])
+        m.fit(train_objectives=[(dl, lm)], evaluator=ev, epochs=3, scheduler="warmuplinear", warmup_steps=2,
+              optimizer_params={"lr": 2e-3}, evaluation_steps=0, output_path=str(tmp_path / "o"), show_progress_bar=False,
+              dropout=0, **kw)
+        return m, ev
+    ma, eva = run(use_amp=True)
+    mw, evw = run(precision="f16w")
+    m1, ev1 = run()
+    for ev in (eva, evw):
+        assert ev.calls[-1][2] < ev.calls[0][2], ("validation loss did not go down", ev.calls)
+    assert ma.training_precision == "bf16"
+    sc = ma._enc.amp_scaler.cpu().tolist()
+    assert sc[0] == 65536.0 and sc[3] == 0.0                       # GradScaler's init_scale, no skipped step
+    cnt = ma._enc._step2_dev.cpu().tolist()
+    assert cnt == [6, 6]                                           # six optimiser steps, six scheduler steps
+    moved = (m1._enc.params - SentenceTransformer("tiny-bert", device="cuda")._enc.params).abs().mean()
+    for m in (ma, mw):
+        d = (m._enc.params - m1._enc.params).abs()
+        assert float(d.mean()) < 0.25 * float(moved), (float(d.mean()), float(moved))
+    # encode() on the f16 precisions, against the parity path
+    texts = [sent(i, 3 + i % 7) for i in range(9)]
+    exact = ma.encode(texts, precision="bf16x3")
+    np.testing.assert_allclose(ma.encode(texts, precision="f16w"), exact, rtol=1e-3, atol=1e-4)
+    assert np.abs(ma.encode(texts, precision="f16") - exact).max() < 3e-4
+
+
 def test_fit_on_the_fp8_matrix_cores_in_train_mode(tmp_path):
     """fit(precision="fp8") exactly as the reference calls fit (training/main.py:128-148: train() mode, HF dropout 0.1 from
     the config): every forward Linear on the fp8 matrix cores, the bf16 backward, the same counter-based dropout masks as the
