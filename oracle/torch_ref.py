@@ -291,6 +291,19 @@ def mx_quant(x: torch.Tensor):
     return q8.view(torch.uint8).reshape(x.shape), (e + 127).to(torch.uint8).reshape(*x.shape[:-1], K // 32), deq
 
 
+# Accumulation of the MXFP8 oracle's products: False = fp32 through the host BLAS (what rounds 2-4 ran), True = fp64 (order-free).
+# The two differ by ~1e-7 relative before the NEXT quantisation -- enough to flip an e4m3 rounding (one step = 2^-3 relative) of a
+# value that sits on a boundary; tools/fuzz_shapes.py ... fp8train prints the HIP path's distance to either (DESIGN.md finding 37).
+MX_ACC64 = False
+
+
+def _mx_linear(a: torch.Tensor, w: torch.Tensor, b):
+    if not MX_ACC64:
+        return F.linear(a, w, b)
+    y = torch.matmul(a.double(), w.double().t()).float()
+    return y if b is None else y + b
+
+
 def _mx(x: torch.Tensor, via_bf16: bool) -> torch.Tensor:
     """Operand of an MXFP8 GEMM: optionally rounded to bf16 first (activations that reach the quantiser as bf16 tensors)."""
     if via_bf16:
@@ -306,7 +319,7 @@ class _LinearMxFwdBf16Bwd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, w, b, a_via_bf16):
         ctx.save_for_backward(a.to(torch.bfloat16).to(torch.float32), w.to(torch.bfloat16).to(torch.float32))
-        return F.linear(_mx(a, a_via_bf16), _mx(w, False), b)
+        return _mx_linear(_mx(a, a_via_bf16), _mx(w, False), b)
 
     @staticmethod
     def backward(ctx, g):
@@ -348,7 +361,7 @@ def encoder_forward_mx(P: Dict[str, torch.Tensor], cfg, ids: torch.Tensor, mask:
     def lin(a, w, b, via_bf16):
         if train:
             return _LinearMxFwdBf16Bwd.apply(a, w, b, via_bf16)
-        return F.linear(_mx(a, via_bf16), _mx(w, False), b)
+        return _mx_linear(_mx(a, via_bf16), _mx(w, False), b)
     for l in range(cfg.num_layers):
         p = f"layer.{l}."
         qkv = _r(lin(x, P[p + "w_qkv"], P[p + "b_qkv"], True), True)            # the QKV GEMM writes bf16

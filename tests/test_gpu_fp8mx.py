@@ -305,7 +305,15 @@ def test_fp8_training_step_against_the_mx_oracle(name, B, L, layers, wkw, drop):
     e_err = float((emb.cpu().view(4, B, -1) - emb_o.detach()).abs().max()) / sc
     l_err = abs(loss.item() - loss_o.item()) / max(1.0, sc)                # (bare bert-base emits un-normalised embeddings)
     print(f"[fp8-train fwd] {name} drop={drop}: embeddings {e_err:.2e}, loss {l_err:.2e}")
-    assert e_err < 4e-3 and l_err < 5e-3
+    # 4e-3 is the dropout-free bar (this suite's maximum without dropout is 3.1e-3: mpnet dims, 2 layers, 5 x 32 tokens). In train()
+    # mode every kept activation -- and with it every absolute rounding difference between two implementations of the same
+    # quantised arithmetic -- is multiplied by 1 / (1 - p_hidden) at each of the three hidden-state dropout sites, while the
+    # embedding norm the error is measured against is pinned by LayerNorm + Normalize: the bar scales by 1 / (1 - p_hidden).
+    # (tools/fp8_flip_probe.py, round 5: fuzz seed 53 case 26 -- the same shape with dropout 0.2 / 0.05 -- measures 4.37e-3
+    # against the oracle accumulating in fp32 AND in fp64: the oracle's summation order is not what separates the two sides;
+    # 3.09e-3 / 0.8 = 3.86e-3 of it is the scaling.)
+    e_bar = 4e-3 / (1.0 - (drop[0] if drop is not None else 0.0))
+    assert e_err < e_bar and l_err < 5e-3, (e_err, e_bar, l_err)
     segs, _ = build_layout(cfg)
     ga = enc.grads.cpu()
     assert torch.isfinite(ga).all()
