@@ -438,3 +438,92 @@ def test_f16_handles_refuse_each_others_arenas():
     _, _, saved = enc.forward(idd, mdd, tdd, training=True, precision="bf16")
     with pytest.raises(_lib.QstError, match="no matching training forward"):
         enc.backward(idd.view(4, 64), mdd.view(4, 64), tdd.view(4, 64), ge[:4], saved, precision="bf16")
+
+
+def check_against_fp32_autograd(name, B, L, ragged, wkw, drop, prec, layers=None, grad_bound=5e-3):
+    """forward(training=True) + backward at precision `prec` ("f16" / "f16w"), under GradScaler's initial loss scale, against fp32
+    torch autograd with the same dropout masks (oracle/dropout_ref.py): embeddings at the north-star tolerance for "f16w" and at
+    twice its atol for plain "f16" (whose weight rounding, DESIGN.md finding 34, puts single elements of trained-like models at
+    the edge), both scaled by 1 / (1 - p_hidden) in train() mode; every gradient tensor within `grad_bound` relative L2 on the
+    scale of its class. Also the body of tools/fuzz_shapes.py's f16 / f16w modes."""
+    from dataclasses import replace
+    from tests.test_gpu_encoder import cls_of
+    if name == "mpnet-2l":
+        cfg = replace(PRESETS["all-mpnet-base-v2"], num_layers=2, vocab_size=4096)
+    else:
+        cfg = PRESETS[name] if layers is None else replace(PRESETS[name], num_layers=layers, vocab_size=2048)
+    arena = synthetic_params(cfg, seed=21, **wkw)
+    ids, mask, types = synthetic_quadruplets(cfg, B, L, seed=21, ragged=ragged)
+    ids_t, mask_t, types_t = [torch.from_numpy(x) for x in (ids, mask, types)]
+    P = R.arena_to_dict(arena, cfg, requires_grad=True)
+    masks = None
+    if drop is not None:
+        from oracle.dropout_ref import Masks
+        masks = Masks(drop[2], 1, drop[0], drop[1])
+    loss32, emb32 = R.quadruplet_step(P, cfg, ids_t, mask_t, types_t if cfg.type_vocab_size else None, LOSS_KW, bf16_operands=False,
+                                      dropout=masks)
+    loss32.backward()
+    enc = HipEncoder(cfg)
+    enc.load_arena(arena)
+    enc.ensure_train_state()
+    if drop is not None:
+        enc.set_dropout(drop[0], drop[1], drop[2])
+    n = 4 * B
+    idd, mdd, tdd = ids_t.view(n, L).cuda(), mask_t.view(n, L).cuda(), types_t.view(n, L).cuda()
+    tdd = tdd if cfg.type_vocab_size else None
+    emb, _, saved = enc.forward(idd, mdd, tdd, training=True, precision=prec)
+    e4 = emb.view(4, B, -1)
+    S = 65536.0
+    loss, g = quadruplet_loss_raw(e4[0], e4[1], e4[2], e4[3], 0.6, 1.0, 0.5, 0.5, 2.0, False, 2,
+                                  grad_out=torch.tensor([S], device="cuda"), want_grads=True)
+    enc.grads.zero_()
+    enc.backward(idd, mdd, tdd, stacked(g), saved, precision=prec)
+    torch.cuda.synchronize()
+    k = 1.0 / (1.0 - (drop[0] if drop is not None else 0.0))
+    sc = max(1.0, float(emb32.detach().norm(dim=-1).mean()))                   # (bare bert-base emits un-normalised embeddings)
+    d = (emb.cpu().view(4, B, -1) - emb32.detach()).abs()
+    atol = (1e-4 if prec == "f16w" else 2e-4) * k * sc
+    bad = d > atol + 1e-3 * emb32.detach().abs()
+    print(f"[{prec} fwd] {name} B={B} L={L} drop={drop}: max|d emb| {float(d.max()):.2e} (atol {atol:.1e}), |d loss| {abs(loss.item() - loss32.item()):.1e}")
+    assert not bool(bad.any()), (float(d.max()), atol, int(bad.sum()))
+    assert abs(loss.item() - loss32.item()) < 1e-3 * k * sc
+    # a hinge within the forward tolerance of its kink is on in one implementation and off in the other (tests/test_gpu_fp8mx.py)
+    eo = emb32.detach()
+    dist = lambda x, y: (x - y + 1e-6).norm(dim=-1)                            # noqa: E731
+    args = torch.stack([1.0 + dist(eo[0], eo[1]) - dist(eo[0], eo[3]), 0.5 + dist(eo[0], eo[2]) - dist(eo[0], eo[3]),
+                        0.5 + dist(eo[0], eo[1]) - dist(eo[0], eo[2])])
+    if float(args.abs().min()) < 4 * atol:
+        print(f"[{prec}] a hinge within {float(args.abs().min()):.1e} of its kink -- gradients not compared")
+        return
+    segs, _ = build_layout(cfg)
+    ga = enc.grads.cpu() / S
+    assert torch.isfinite(ga).all()
+    gnorm = float(torch.sqrt(sum((P[s_.name].grad.double() ** 2).sum() for s_ in segs)))
+    cls_top = {}
+    for s_ in segs:
+        c = cls_of(s_.name.split(".")[-1])
+        cls_top[c] = max(cls_top.get(c, 0.0), P[s_.name].grad.norm().item())
+    worst = (0.0, "")
+    for s_ in segs:
+        ref = P[s_.name].grad
+        got = ga[s_.offset:s_.offset + s_.numel].view(*s_.shape)
+        denom = ref.norm().item()
+        if denom <= 1e-5 * gnorm:
+            assert got.norm().item() <= 1e-4 * gnorm, s_.name
+            continue
+        err = ((got - ref).norm() / max(denom, 0.05 * cls_top[cls_of(s_.name.split(".")[-1])])).item()
+        worst = max(worst, (err, s_.name))
+        lim = grad_bound * k * (2.0 if s_.name.endswith("b_qkv") else 1.0)
+        assert err < lim, f"{name} grad {s_.name}: relative L2 error {err:.3e} against {lim:.1e} (ref norm {denom:.3e})"
+    print(f"[{prec} grad-err] {name} B={B} L={L}: worst {worst[1]} {worst[0]:.2e}")
+
+
+@pytest.mark.parametrize("prec", ["f16", "f16w"])
+@pytest.mark.parametrize("name,B,L,ragged,wkw,drop", [
+    ("tiny-mpnet", 2, 64, True, dict(std=0.08, bias_std=0.05, ln_jitter=0.1), None),
+    ("minilm-2l", 2, 128, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), (0.1, 0.1, 6)),
+    ("mpnet-2l", 1, 288, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), None),          # d = 64, L > 256: one-workgroup backward
+    ("mpnet-2l", 1, 512, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), (0.2, 0.1, 7)),  # L = 512 + position bias: the dQ / dK,dV pair
+    ("minilm-2l", 33, 128, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), (0.1, 0.1, 9))])   # M = 16,896: the LayerNorm-fused kernels
+def test_f16_forward_and_backward_against_fp32_autograd(name, B, L, ragged, wkw, drop, prec):
+    check_against_fp32_autograd(name, B, L, ragged, wkw, drop, prec)

@@ -17,7 +17,10 @@ the NT GEMM epilogues at random M, N, K and tilings; with `wgrad`: the TN weight
 attention forward + backward at random (sequences, L, heads, d, position bias) (tests/test_gpu_kernels.py). With `fused`: the
 encoder check at MiniLM dims with at least 16,384 token rows (the LayerNorm-fused GEMMs and the 8-range wgrad run from there).
 
-    python tools/fuzz_shapes.py [cases] [seed] [first case to run] [fp8 | fp8train | x3 | topk | loss | gemm | wgrad | attn | fused]"""
+With `f16` / `f16w`: forward + backward on IEEE-half operands (QST_PREC_F16 / F16W) under the loss scale against fp32 autograd with
+the same dropout masks (tests/test_gpu_f16.py: check_against_fp32_autograd; gradient bound x 1.5).
+
+    python tools/fuzz_shapes.py [cases] [seed] [first case to run] [fp8 | fp8train | x3 | f16 | f16w | topk | loss | gemm | wgrad | attn | fused]"""
 import os
 import random
 import re
@@ -40,6 +43,7 @@ def main():
     fp8 = len(sys.argv) > 4 and sys.argv[4] == "fp8"
     x3 = len(sys.argv) > 4 and sys.argv[4] == "x3"
     fp8train = len(sys.argv) > 4 and sys.argv[4] == "fp8train"
+    f16 = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] in ("f16", "f16w") else None
     T8.FP8_TRAIN_GRAD_LIMITS = {k: 1.5 * v for k, v in T8.FP8_TRAIN_GRAD_LIMITS.items()}
     if len(sys.argv) > 4 and sys.argv[4] in ("loss", "gemm", "wgrad", "attn"):
         import test_gpu_kernels as TK
@@ -118,6 +122,12 @@ def main():
             continue
         print(f"case {i}: {fam} layers={layers} B={B} L={L} dropout={drop}", flush=True)
         t0 = time.time()
+        if f16:
+            import test_gpu_f16 as TH
+            TH.check_against_fp32_autograd(fam, B, L, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), drop, f16, layers=layers,
+                                           grad_bound=7.5e-3)
+            print(f"ok {i} ({f16} forward + backward vs fp32 autograd)  ({time.time() - t0:.1f} s)", flush=True)
+            continue
         if fp8train:
             T8.test_fp8_training_step_against_the_mx_oracle(fam, B, L, layers, dict(std=0.03, bias_std=0.02, ln_jitter=0.05),
                                                             None if drop is None else drop[:2])
