@@ -50,6 +50,7 @@ def main():
         from quadruplet_sentence_transformer_amd import _lib
         lib = _lib.load()
         for i in range(cases):
+            op16 = rng.choice(["bf16", "f16"])            # the operand-typed kernels exist on both 16-bit types (round 5)
             if sys.argv[4] == "loss":
                 B, D = rng.randint(1, 300), rng.choice([rng.randint(1, 64), rng.randint(65, 800), rng.randint(801, 2100)])
                 pn, swap = rng.choice([1.0, 2.0, 3.0]), rng.choice([False, True])
@@ -66,7 +67,7 @@ def main():
                 print(f"case {i}: wgrad M={M} N={N} K={K} gemm8_mode={mode}", flush=True)
                 lib.qst_gemm8_mode(mode)
                 try:
-                    TK.test_gemm_tn_wgrad(lib, mode, M, N, K)
+                    TK.test_gemm_tn_wgrad(lib, op16, mode, M, N, K)
                 finally:
                     lib.qst_gemm8_mode(-1)
                 print(f"ok {i}: wgrad M={M} N={N} K={K} gemm8_mode={mode}", flush=True)
@@ -76,7 +77,7 @@ def main():
                 if i < first:
                     continue
                 print(f"case {i}: attention n={n} L={L} A={A} d={d} rel={rel}", flush=True)
-                TK.test_attention_fwd_bwd(lib, n, L, A, d, rel)
+                TK.test_attention_fwd_bwd(lib, op16, n, L, A, d, rel)
                 print(f"ok {i}: attention n={n} L={L} A={A} d={d} rel={rel}", flush=True)
             else:
                 M, N, K = rng.randint(1, 40000), 4 * rng.randint(1, 800), 64 * rng.randint(1, 48)
@@ -84,7 +85,7 @@ def main():
                 if i < first:
                     continue
                 t0 = time.time()
-                TK.test_gemm_nt_epilogues(lib, M, N, K, form)
+                TK.test_gemm_nt_epilogues(lib, op16, M, N, K, form)
                 print(f"ok {i}: gemm M={M} N={N} K={K} form={form}  ({time.time() - t0:.1f} s)", flush=True)
         return
     if len(sys.argv) > 4 and sys.argv[4] == "topk":
