@@ -72,6 +72,8 @@ typedef struct {
     void* C4;
     const void* B2;       // qst_gemm_nt / qst_gemm_nt_ln (tiled kernels): C = A . (B + B2)^T -- a second pass over K against B2, same
                           // shape and ldb as B (QST_PREC_F16W: the low halves of split-f16 weights); NULL = none
+    int32_t b2_n0;        // with B2: only output tiles that reach columns >= b2_n0 take the second pass (the fused QKV GEMM: the V
+                          // third -- rounding of the q / k weights does not reach the pooled embedding, DESIGN.md finding 34); 0 = all
     int32_t sat16;        // f16 twins only (qst_gemm_nt_f16 / qst_gemm_nt8_f16): != 0 = 16-bit outputs saturate at +-65,504
                           // instead of overflowing to inf (forward launches); 0 = IEEE overflow (backward launches)
 } QstGemmArgs;

@@ -46,7 +46,7 @@ class QstGemmArgs(C.Structure):
     _fields_ = [("A", vp), ("B", vp), ("C", vp), ("C2", vp), ("aux", vp), ("bias", vp), ("resid", vp),
                 ("colsum", vp), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32),
                 ("ldb", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32), ("splits", C.c_int32), ("bscale", vp),
-                ("drop", QstDrop), ("drop_where", C.c_int32), ("C3", vp), ("C4", vp), ("B2", vp), ("sat16", C.c_int32)]
+                ("drop", QstDrop), ("drop_where", C.c_int32), ("C3", vp), ("C4", vp), ("B2", vp), ("b2_n0", C.c_int32), ("sat16", C.c_int32)]
 
 
 class QstLnEpi(C.Structure):

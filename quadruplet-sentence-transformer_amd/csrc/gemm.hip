@@ -94,7 +94,9 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // A_SLOTS = 3 (the LayerNorm-fused kernel: one workgroup per CU, 128 x 384 tile): the activation stages get a ring of their own,
 // three slots deep, so TWO stages of A rows -- the lines that come from HBM; the weight stages hit in L2 -- are in flight under
 // every stage of MFMAs instead of one: ring = 3 x 16 KB of A + 2 x 48 KB of B = 144 KB.
-template <int WAVES_M, int WAVES_N, typename HOOK = NoHook, bool A_ONCE = false, int A_SLOTS = 2>
+// SPLITW: the split-weight forms (QstGemmArgs.B2) are compiled in -- forward instantiations only: the LayerNorm-backward kernel
+// sits at the register limit and spilled with the extra loop in it.
+template <int WAVES_M, int WAVES_N, typename HOOK = NoHook, bool A_ONCE = false, int A_SLOTS = 2, bool SPLITW = true>
 __device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, int m0, int n0, f32x16 (&acc)[2][3],
                                             HOOK after_first_issue = HOOK()) {
     constexpr int NBM = 64 * WAVES_M, NBN = 96 * WAVES_N, NW = WAVES_M * WAVES_N;
@@ -114,7 +116,7 @@ __device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, in
     // Split weights (QstGemmArgs.B2, QST_PREC_F16W): C = A . (B + B2)^T as a second pass over K -- K-tile kt >= K / 64 takes
     // the A rows of K-tile kt - K / 64 again and the B rows from B2 (same shape and leading dimension as B): the loop below
     // simply runs twice as many stages; fragments, ring and epilogue do not know.
-    const bool split = g.B2 != nullptr;
+    const bool split = SPLITW && g.B2 != nullptr && n0 + NBN > g.b2_n0;      // (b2_n0: tiles left of it keep the single pass)
     const __amdgpu_buffer_rsrc_t rb2 = split ? make_rsrc((const op16*)g.B2 + (size_t)n0 * g.ldb, (uint32_t)rows_b * g.ldb * 2u) : rb;
     const int nk1 = g.K / NBK;
 
@@ -159,6 +161,50 @@ __device__ __forceinline__ void nt_mainloop(const QstGemmArgs& g, char* smem, in
 
     const int nk = split ? 2 * nk1 : nk1;
     const int fr = lane & 31, fh = lane >> 5;
+    if (DEEP && split) {
+        // Split weights on the kernel whose activation stages have a ring of their own: the two weight stages of a K-tile
+        // (high halves, low halves) follow one another against the SAME activation stage -- the activation rows are read once
+        // (the second pass over K above would fetch the [M, K] panel a second time: 100 MB of HBM reads at K = 1536, the rows
+        // carry the read-once hint). Step s = 2 kt + (0: high | 1: low); weight slot s & 1, activation slot kt % 3.
+        auto issue_bs = [&](int s_) {
+            char* st = slot_b(s_);
+            const uint32_t ko = (uint32_t)(s_ >> 1) * (NBK * 2);
+            const __amdgpu_buffer_rsrc_t r = (s_ & 1) ? rb2 : rb;
+#pragma unroll
+            for (int t = 0; t < B_PER_WAVE; ++t) dma16(r, st + (wave * B_PER_WAVE + t) * 1024, vb[t], ko);
+        };
+        issue_a(0);
+        issue_bs(0);
+        after_first_issue();
+        if (nk1 > 1) issue_a(1);
+        const int ns = 2 * nk1;
+        for (int s_ = 0; s_ < ns; ++s_) {
+            const int kt = s_ >> 1;
+            // queue, oldest first -- even step: [A(kt + 1)], B(s): everything must have landed (A(kt + 1) has had two steps);
+            // odd step: B(s), [A(kt + 2)]: the activation stage requested one step ago may stay in flight. Step 0 drains the hook's loads.
+            if ((s_ & 1) && kt + 2 < nk1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(A_PER_WAVE) : "memory");
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (s_ + 1 < ns) issue_bs(s_ + 1);
+            if (!(s_ & 1) && kt + 2 < nk1) issue_a(kt + 2);
+            const char* pa = slot_a(kt);
+            const char* pb = slot_b(s_);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                op16x8 fa[2], fb[3];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i] = *(const op16x8*)(pa + nt_off(wm * 64 + i * 32 + fr, ks * 2 + fh));
+#pragma unroll
+                for (int j = 0; j < 3; ++j) fb[j] = *(const op16x8*)(pb + nt_off(wn * 96 + j * 32 + fr, ks * 2 + fh));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[i][j] = mfma32_op(fb[j], fa[i], acc[i][j]);
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
     issue(0);
     after_first_issue();
     for (int kt = 0; kt < nk; ++kt) {
@@ -211,7 +257,7 @@ __device__ __forceinline__ void nt_mainloop_tall(const QstGemmArgs& g, char* sme
     const int rows_a = min(NBM, g.M - m0), rows_b = min(NBN, g.N - n0);
     const __amdgpu_buffer_rsrc_t ra = make_rsrc((const op16*)g.A + (size_t)m0 * g.lda, (uint32_t)rows_a * g.lda * 2u);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc((const op16*)g.B + (size_t)n0 * g.ldb, (uint32_t)rows_b * g.ldb * 2u);
-    const bool split = g.B2 != nullptr;                  // (see nt_mainloop)
+    const bool split = g.B2 != nullptr && n0 + NBN > g.b2_n0;                  // (see nt_mainloop)
     const __amdgpu_buffer_rsrc_t rb2 = split ? make_rsrc((const op16*)g.B2 + (size_t)n0 * g.ldb, (uint32_t)rows_b * g.ldb * 2u) : rb;
     const int nk1 = g.K / BK;
     uint32_t va[A_PER_WAVE], vb[B_PER_WAVE];
@@ -426,7 +472,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 2 ? 2 : 1) void 
     NT_STAMP(0);
     f32x16 acc[TI][3];
     if constexpr (TI == 4) nt_mainloop_tall<WAVES_M, WAVES_N>(g, smem, m0, n0, acc);
-    else nt_mainloop<WAVES_M, WAVES_N>(g, smem, m0, n0, acc);
+    else nt_mainloop<WAVES_M, WAVES_N, NoHook, false, 2, EPI != QST_EPI_GELU_BWD>(g, smem, m0, n0, acc);
     NT_STAMP(1);
 
     float* stg = (float*)smem + wave * (32 * NT_STG_LD);
@@ -768,7 +814,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(QstGemmArgs g, QstLn
         for (int q = 0; q < 3; ++q)
             if (tid + 512 * q < 3 * LN_N) vec_s[tid + 512 * q] = v3[q];
     };
-    nt_mainloop<2, 4, decltype(early_loads), true, QST_LN_ASLOTS>(g, smem, m0, 0, acc, early_loads);   // the tile spans whole rows: A is read once
+    nt_mainloop<2, 4, decltype(early_loads), true, QST_LN_ASLOTS, MODE == 0>(g, smem, m0, 0, acc, early_loads);   // the tile spans whole rows: A is read once
     LN_STAMP(2);
 
     f32x2 ag[3], ab[3];

@@ -484,9 +484,9 @@ const OpKernels& op_kernels(const qst_config& c) {
 // B2: the low halves of split weights (QST_PREC_F16W forward), or null
 int nt(const OpKernels& K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* C2, const void* aux,
        const float* bias, const float* resid, int ldr, int M, int N, int K_, int epi, bool sat, hipStream_t st,
-       const void* B2 = nullptr) {
+       const void* B2 = nullptr, int b2_n0 = 0) {
     QstGemmArgs g{};
-    g.A = A; g.B = B; g.B2 = B2; g.C = C; g.C2 = C2; g.aux = aux; g.bias = bias; g.resid = resid;
+    g.A = A; g.B = B; g.B2 = B2; g.b2_n0 = b2_n0; g.C = C; g.C2 = C2; g.aux = aux; g.bias = bias; g.resid = resid;
     g.M = M; g.N = N; g.K = K_; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
     g.sat16 = sat ? 1 : 0;
     take_drop(g);
@@ -949,8 +949,9 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     // QST_PREC_F16W: every forward Linear multiplies by hi + lo of the weight (a second pass over K: QstGemmArgs.B2)
     const bool splitw = c.precision == QST_PREC_F16W;
     auto WL = [&](int seg) -> const void* { return splitw ? sh + lay.shadow_total + lay.segs[seg].shadow_off : nullptr; };
-    auto linear = [&](const void* Ain, int Kd, int wseg, void* Cout, int N, void* C2, int bseg, const float* resid, int epi) {
-        return nt(K, Ain, Kd, W(wseg), Kd, Cout, N, C2, nullptr, P(bseg), resid, N, M, N, Kd, epi, true, st, WL(wseg));
+    auto linear = [&](const void* Ain, int Kd, int wseg, void* Cout, int N, void* C2, int bseg, const float* resid, int epi,
+                      int b2_n0 = 0) {
+        return nt(K, Ain, Kd, W(wseg), Kd, Cout, N, C2, nullptr, P(bseg), resid, N, M, N, Kd, epi, true, st, WL(wseg), b2_n0);
     };
 
     int32_t* pos_ids = (int32_t*)(sv + p.pos_ids);
@@ -988,7 +989,9 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerAct& a = p.layers[l];
         const int b = lay.layer0[l];
-        QST_TRY(linear(xb, H, b + W_QKV, sv + a.qkv, 3 * H, nullptr, b + B_QKV, nullptr, QST_EPI_BF16));
+        // (split weights: the value third of the fused QKV product only -- the rounding of the query / key weights perturbs
+        //  logits that the softmax and the pooling average out: all-split and v-only measure the same, DESIGN.md finding 34)
+        QST_TRY(linear(xb, H, b + W_QKV, sv + a.qkv, 3 * H, nullptr, b + B_QKV, nullptr, QST_EPI_BF16, 2 * H));
         {
             QstAttnDesc q{};
             q.qkv = sv + a.qkv; q.mask = mask; q.rel_pos = rel; q.nseq = nseq; q.L = L; q.A = A; q.d = d;
