@@ -527,3 +527,37 @@ def check_against_fp32_autograd(name, B, L, ragged, wkw, drop, prec, layers=None
     ("minilm-2l", 33, 128, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), (0.1, 0.1, 9))])   # M = 16,896: the LayerNorm-fused kernels
 def test_f16_forward_and_backward_against_fp32_autograd(name, B, L, ragged, wkw, drop, prec):
     check_against_fp32_autograd(name, B, L, ragged, wkw, drop, prec)
+
+
+def test_f16_training_recovers_from_an_overflowing_loss_scale():
+    """GradScaler's init_scale far too large (2^30: d(loss)/d(embedding) x 2^30 is beyond half's range, so the first f16 gradient
+    tensors of the backward are inf and everything behind them inf or nan): every such step must be SKIPPED -- parameters and
+    moments untouched, gradients zeroed, scale halved -- until the scale fits, and training must then proceed as if nothing had
+    happened (a later step whose gradients outgrow the scale is skipped the same way). The whole decision runs on the device
+    (qst_clip_adamw_step_amp); no inf / nan may reach the parameters."""
+    cfg = PRESETS["tiny-bert"]
+    arena = synthetic_params(cfg, seed=14, std=0.05, bias_std=0.02, ln_jitter=0.05)
+    tr = QuadrupletTrainer(cfg, arena=arena, device="cuda:0", lr=2e-3, weight_decay=0.01, max_grad_norm=1.0, warmup_steps=0,
+                           total_steps=0, precision="f16", amp_init_scale=2.0 ** 30, **LOSS_KW)
+    ids, mask, types = synthetic_quadruplets(cfg, 6, 32, seed=14, ragged=True, step=0)
+    batch = [torch.from_numpy(x).cuda() for x in (ids, mask, types)]
+    p0 = tr.enc.params.clone()
+    losses, scales, skipped = [], [], []
+    nsteps = 24
+    for _ in range(nsteps):
+        losses.append(tr.step(*batch).item())
+        st = tr.enc.amp_scaler.cpu().tolist()
+        scales.append(st[0])
+        skipped.append(int(st[3]))
+        assert torch.isfinite(tr.enc.params).all() and torch.isfinite(tr.enc.exp_avg).all() and torch.isfinite(tr.enc.exp_avg_sq).all()
+        assert float(tr.enc.grads.abs().max()) == 0.0                          # zero_grad, skipped or not
+        if skipped[-1] == len(losses):                       # every step so far was skipped: nothing may have moved
+            assert torch.equal(tr.enc.params, p0)
+    nskip = skipped[-1]
+    first = next(i for i in range(nsteps) if skipped[i] <= i)              # the first step that was NOT skipped
+    assert 4 <= first <= 12, (first, scales)
+    assert scales[-1] == 2.0 ** 30 / 2 ** nskip                # one halving per skipped step, no growth within 24 steps
+    cnt = tr.enc._step2_dev.cpu().tolist()
+    assert cnt[0] == nsteps - nskip                              # optimiser steps taken = steps that were not skipped
+    assert all(abs(l - losses[0]) < 1e-6 for l in losses[:first + 1])      # (same batch, unchanged parameters: the same loss)
+    assert losses[-1] < losses[first] - 0.05, losses             # ... and it trains from there
