@@ -109,7 +109,14 @@ typedef struct {
     float* partials;
 } QstLnEpi;
 int qst_gemm_nt_ln_supported(int N);
+int qst_gemm_nt_ln_block_rows(int N);    /* rows per `partials` block of mode 1: 128 at N = 384, 256 above */
 int qst_gemm_nt_ln(const QstGemmArgs* a, const QstLnEpi* ln, int mode, void* stream);
+/* The same with rows wider than one tile, N = 512 / 768 / 1024 (csrc/gemm8.hip: 256 x 256 tiles on the 8-phase loop, the
+ * N / 256 workgroups of a 256-row panel exchange the row statistics inside the launch); qst_gemm_nt_ln forwards here.
+ * partials f32 [ceil(M/256)][2][N]; no B2. qst_gemm_nt8_ln_timeouts(): 0 unless an exchange of this process ever gave up. */
+int qst_gemm_nt8_ln_supported(int N);
+int qst_gemm_nt8_ln(const QstGemmArgs* a, const QstLnEpi* ln, int mode, void* stream);
+int qst_gemm_nt8_ln_timeouts(void);
 /* The feed-forward block of a layer as one kernel (H = 384 token rows complete per tile; csrc/ffn.hip):
  *  mode 0 (forward):  u = A.B1^T + bias1 ; h = gelu(u) ; v = h.B2^T + bias2 + resid ; y = LayerNorm(v) -> C (f32),
  *                     C2 (bf16, nullable), ln->xhat / ln->rstd (nullable). save_gp / save_h (both or neither) receive
@@ -344,6 +351,9 @@ int qst_shadow_matrix(const float* src, int rows, int cols, void* dst_bf16, void
  * (fp16) + GradScaler: /root/reference/training/main.py:142, models/evaluators.py:92-94. */
 int qst_gemm_nt_f16(const QstGemmArgs* a, int epi, void* stream);
 int qst_gemm_nt_ln_f16(const QstGemmArgs* a, const QstLnEpi* ln, int mode, void* stream);
+int qst_gemm_nt8_ln_supported_f16(int N);
+int qst_gemm_nt8_ln_f16(const QstGemmArgs* a, const QstLnEpi* ln, int mode, void* stream);
+int qst_gemm_nt8_ln_timeouts_f16(void);
 int qst_ffn_chain_f16(const QstFfnArgs* a, const QstLnEpi* ln, int mode, void* stream);
 int qst_gemm_tn_f16(const QstGemmArgs* a, void* stream);
 int qst_gemm_tn_group_f16(const QstTnGroup* grp, void* stream);

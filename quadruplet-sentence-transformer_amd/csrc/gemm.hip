@@ -1335,7 +1335,10 @@ extern "C" int qst_quant_mx(const void* src, int src_is_bf16, int64_t rows, int 
     return QST_OK;
 }
 
-extern "C" int qst_gemm_nt_ln_supported(int N) { return N == LN_N ? 1 : 0; }
+extern "C" int qst_gemm_nt_ln_supported(int N) { return (N == LN_N || qst_gemm_nt8_ln_supported(N)) ? 1 : 0; }
+// rows per partial-sum block of mode 1 (the stride of `partials`): one full-row tile of 128 rows at N = 384, a 256-row panel
+// of 256-column tiles above (gemm8.hip)
+extern "C" int qst_gemm_nt_ln_block_rows(int N) { return N == LN_N ? 128 : 256; }
 #endif  // !QST_OP_F16
 
 extern "C" int QST_K(qst_gemm_nt_ln)(const QstGemmArgs* a, const QstLnEpi* ln, int mode, void* stream) {
@@ -1343,6 +1346,7 @@ extern "C" int QST_K(qst_gemm_nt_ln)(const QstGemmArgs* a, const QstLnEpi* ln, i
     if (mode != 0 && mode != 1) return QST_ERR_BAD_ARG;
     if (mode == 0 && !ln->beta) return QST_ERR_BAD_ARG;
     if (mode == 1 && (!ln->xhat || !ln->rstd)) return QST_ERR_BAD_ARG;
+    if (a->N != LN_N && qst_gemm_nt8_ln_supported(a->N)) return QST_K(qst_gemm_nt8_ln)(a, ln, mode, stream);   // several tiles per row
     if (a->N != LN_N || a->K % NBK != 0 || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->ldc % 2 != 0 || (a->resid && a->ldr % 2 != 0))
         return QST_ERR_UNSUPPORTED;
     if ((int64_t)128 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)LN_N * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;

@@ -16,6 +16,7 @@
 namespace {
 
 using g8p::f32x4_t;
+typedef qst_f32x2 f32x2;
 
 // after the swap, lane (g = lane >> 4, c = lane & 15) holds row c of the 16-row tile and the 8 consecutive columns
 // starting at pair_col(g) of the 32 columns of two adjacent 16-column tiles:  g = 0: 0, g = 1: 16, g = 2: 8, g = 3: 24
@@ -229,6 +230,360 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_f8_kernel(QstGemmArgs g) {
     nt8_epilogue<EPI>(g, o, m0, n0);
 }
 
+// ---------------------------------------------------------------- GEMM + LayerNorm over rows wider than one tile
+// C = LayerNorm(A.B^T + bias + resid) (mode 0) / the LayerNorm backward of dy = A.B^T + resid (mode 1), as gemm_nt_ln_kernel
+// (gemm.hip) computes them for N = 384 in one full-row tile -- here for N = ntn x 256 on the 256 x 256 tile of the 8-phase
+// loop: the ntn workgroups of a 256-row panel each hold a third (N = 768) of every row in their accumulators and hand the
+// row statistics to each other through global memory INSIDE the launch:
+//   pass 1   v = acc + bias (+ dropout) + resid, back into the accumulator registers; per row and wave the mean and the
+//            centred sum of squares of its 64 columns (mode 1: sum(g dy), sum(g dy xhat)) -> LDS
+//   exchange waves (wr, 0) merge the four wave-columns (Chan's update: no E[v^2] - mean^2), publish the tile's pair for
+//            each of their 128 rows as two 8-byte granules {tag = 1, value} (sc1 stores: the data is the flag,
+//            cdna_hip_programming.md Guideline 16 form R2), sweep the other tiles' granules of the same rows until every
+//            tag is set (sc1 loads, bounded: a timeout sets *tmo and the launch finishes with wrong rows instead of
+//            hanging), merge, and leave (mean, rstd) / (m1, m2) per row in LDS
+//   pass 2   normalise from the registers and store y (f32), y (bf16), xhat (bf16), rstd -- the GEMM's output never
+//            exists un-normalised in memory (the unfused pair writes it as f32 and reads it back: 1.2 GB per launch at
+//            M = 196,608).
+// Liveness needs in-order dispatch only: block b's partners are b +- 8, b +- 16 (same XCD under round-robin placement, but
+// nothing depends on placement), so the set of dispatched workgroups is a prefix of the grid and at most ntn - 1 resident
+// workgroups wait for a partner that has not started; every other one finishes and frees its CU. The granules are zeroed
+// by a memset node in front of every launch (graph-replay safe: no per-launch salt).
+// Mode 1 keeps dy in the accumulators and the tile's xhat fragment in LDS (lane-private slots in the 128 KB the K loop
+// has left) across the exchange; the gamma / beta gradient partials (column sums over the panel's rows) go to
+// partials[panel][2][N].
+struct LnXchg {
+    unsigned long long* gran;      // [ntm][ntn][256 rows][2] granules
+    unsigned* tmo;                 // sticky timeout word
+    int ntm, ntn, ppx;             // panels, tiles per panel, panels per XCD queue
+};
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+constexpr int LNX_RED = 256 * 4 * 2 * 4, LNX_STATS = 256 * 2 * 4, LNX_PR = 2 * 2 * 256 * 4;
+constexpr int LNX_LDS0 = g8p::LDS_BYTES;                                   // mode 0: the scratch aliases the K-loop buffers
+constexpr int LNX_LDS1 = g8p::LDS_BYTES + LNX_RED + LNX_STATS + LNX_PR;   // mode 1: behind the xhat stash
+
+// sum over the four lanes (lane & 15 equal) that share an accumulator row; every one of them receives the total
+__device__ __forceinline__ float xg_sum(float v) {
+    v += swap32(v);
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ void put_granule(unsigned long long* p, float v) {
+    __hip_atomic_store((gu64*)p, (1ull << 32) | (unsigned long long)__builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int MODE, int DROPW>
+__global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstLnEpi e, LnXchg x) {
+    op_saturate(MODE == 0);
+    using OPS = g8p::NtOps<8, 4>;
+    constexpr int TM = 8, NP = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bx = blockIdx.x & 7, bj = blockIdx.x >> 3;
+    const int panel = bx * x.ppx + bj / x.ntn, tile_n = bj % x.ntn;
+    if (bj / x.ntn >= x.ppx || panel >= x.ntm) return;
+    const int m0 = panel * 256, n0 = tile_n * 256;
+    OPS o;
+    o.init((const op16*)g.A + (size_t)m0 * g.lda, g.lda, min(256, g.M - m0), (const op16*)g.B + (size_t)n0 * g.ldb, g.ldb,
+           256, g.K, smem);
+    g8p::kloop8(o, o.nk);                       // returns behind a workgroup barrier, no DMA outstanding: the LDS is free
+
+    const int tid = threadIdx.x, lane = tid & 63, gq = lane >> 4, c16 = lane & 15;
+    const int rw = o.wr * 128 + c16;            // + 16 i: this lane's rows inside the panel
+    const int mw = m0 + rw;
+    const int nw = n0 + o.wc * 64 + pair_col(gq);      // + 32 jp: 8 consecutive columns
+    char* scratch = smem + (MODE == 1 ? g8p::LDS_BYTES : 0);
+    float* red = (float*)scratch;                        // [256 rows][4 wave columns][2]
+    float* stats = (float*)(scratch + LNX_RED);          // [256 rows][2]
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    DropCtx dc = DropCtx{0u, 0u, 1.f};
+    if (DROPW != 0) dc = drop_ctx(g.drop);
+
+    // ------------------------------------------------------------ pass 1
+    // per row-tile: mode 0: mean and centred squares of the wave's 64 columns; mode 1: sum(g dy), sum(g dy xhat) -> LDS
+    {
+        f32x4 ga[NP][2];                        // mode 1: gamma of this lane's columns
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) {
+            ga[jp][0] = MODE == 1 ? *(const f32x4*)(e.gamma + nw + 32 * jp) : z4;
+            ga[jp][1] = MODE == 1 ? *(const f32x4*)(e.gamma + nw + 32 * jp + 4) : z4;
+        }
+        f32x4 bv[NP][2];
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) {
+            const bool ok = MODE == 0 && g.bias != nullptr;
+            bv[jp][0] = ok ? *(const f32x4*)(g.bias + nw + 32 * jp) : z4;
+            bv[jp][1] = ok ? *(const f32x4*)(g.bias + nw + 32 * jp + 4) : z4;
+        }
+        constexpr int HT = 2;                   // row-tiles whose residual (and xhat) rows are requested in one burst
+        f32x4 rv[HT][NP][2];
+        u32x4 xv[MODE == 1 ? HT : 1][NP];
+        const u32x4 zu = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (i % HT == 0) {
+#pragma unroll
+                for (int k = 0; k < HT; ++k) {
+                    const int m = mw + 16 * (i + k);
+#pragma unroll
+                    for (int jp = 0; jp < NP; ++jp) {
+                        const int n = nw + 32 * jp;
+                        const bool ok = g.resid != nullptr && m < g.M;
+                        const float* p = g.resid + (size_t)m * g.ldr + n;
+                        rv[k][jp][0] = ok ? ld_stream((const f32x4*)p) : z4;
+                        rv[k][jp][1] = ok ? ld_stream((const f32x4*)(p + 4)) : z4;
+                        if (MODE == 1)
+                            xv[k][jp] = m < g.M ? ld_stream((const u32x4*)((const op16*)e.xhat + (size_t)m * g.N + n)) : zu;
+                    }
+                }
+            }
+            const int m = mw + 16 * i;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int jp = 0; jp < NP; ++jp) {
+                const int n = nw + 32 * jp;
+                float v[8];
+                pair8(o.acc[i][2 * jp], o.acc[i][2 * jp + 1], v);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[q] += bv[jp][0][q]; v[4 + q] += bv[jp][1][q]; }
+                if (MODE == 0 && DROPW == 1 && dc.thr) {
+                    const uint32_t e0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+#pragma unroll
+                    for (int q = 0; q < 8; q += 2) {
+                        float k0, k1;
+                        drop_pair(dc, e0 + q, k0, k1);
+                        v[q] *= k0; v[q + 1] *= k1;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[q] += rv[i % HT][jp][0][q]; v[4 + q] += rv[i % HT][jp][1][q]; }
+                if (MODE == 1 && DROPW == 3 && dc.thr) {
+                    const uint32_t e0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+#pragma unroll
+                    for (int q = 0; q < 8; q += 2) {
+                        float k0, k1;
+                        drop_pair(dc, e0 + q, k0, k1);
+                        v[q] *= k0; v[q + 1] *= k1;
+                    }
+                }
+                if (MODE == 0) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) s1 += v[q];
+                } else {
+                    const u32x4 xq = xv[i % HT][jp];
+                    *(u32x4*)(smem + ((size_t)(i * NP + jp) * 512 + tid) * 16) = xq;       // lane-private stash for pass 2
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float g0 = v[2 * q] * ga[jp][q >> 1][(2 * q) & 3], g1 = v[2 * q + 1] * ga[jp][q >> 1][(2 * q + 1) & 3];
+                        s1 += g0 + g1;
+                        s2 += g0 * op_lo(xq[q]) + g1 * op_hi(xq[q]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { o.acc[i][2 * jp][q] = v[q]; o.acc[i][2 * jp + 1][q] = v[4 + q]; }
+            }
+            s1 = xg_sum(s1);
+            if (MODE == 0) {
+                const float mu = s1 * (1.f / 64.f);
+                float q2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const float d = o.acc[i][j][q] - mu; q2 += d * d; }
+                s1 = mu;
+                s2 = xg_sum(q2);
+            } else {
+                s2 = xg_sum(s2);
+            }
+            if (gq == 0) {
+                f32x2 pr; pr[0] = s1; pr[1] = s2;
+                *(f32x2*)(red + ((rw + 16 * i) * 4 + o.wc) * 2) = pr;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------ exchange (waves (wr, 0): rows wr 128 + [0, 128), two per lane)
+    if (o.wc == 0) {
+        float ta[2], tb[2];                     // this tile's pair for the lane's two rows
+        int row[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            row[k] = o.wr * 128 + 16 * (2 * gq + k) + c16;
+            const f32x4 p0 = *(const f32x4*)(red + row[k] * 8), p1 = *(const f32x4*)(red + row[k] * 8 + 4);
+            if (MODE == 0) {
+                const float mu = (p0[0] + p0[2] + p1[0] + p1[2]) * 0.25f;
+                const float d0 = p0[0] - mu, d1 = p0[2] - mu, d2 = p1[0] - mu, d3 = p1[2] - mu;
+                ta[k] = mu;
+                tb[k] = (p0[1] + p0[3] + p1[1] + p1[3]) + 64.f * (d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+            } else {
+                ta[k] = p0[0] + p0[2] + p1[0] + p1[2];
+                tb[k] = p0[1] + p0[3] + p1[1] + p1[3];
+            }
+            unsigned long long* gp = x.gran + (((size_t)panel * x.ntn + tile_n) * 256 + row[k]) * 2;
+            put_granule(gp, ta[k]);
+            put_granule(gp + 1, tb[k]);
+        }
+        float oa[2][4], ob[2][4];               // every tile's pair (ntn <= 4)
+        bool done = false;
+#pragma unroll 1
+        for (unsigned spins = 0; !done; ++spins) {
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (t >= x.ntn) continue;
+                    if (t == tile_n) { oa[k][t] = ta[k]; ob[k][t] = tb[k]; continue; }
+                    const gu64* gp = (const gu64*)(x.gran + (((size_t)panel * x.ntn + t) * 256 + row[k]) * 2);
+                    const unsigned long long u0 = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long u1 = __hip_atomic_load(gp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ok && (u0 >> 32) == 1ull && (u1 >> 32) == 1ull;
+                    oa[k][t] = __builtin_bit_cast(float, (uint32_t)u0);
+                    ob[k][t] = __builtin_bit_cast(float, (uint32_t)u1);
+                }
+            done = __all(ok) != 0;
+            if (!done) {
+                if (spins > (1u << 18)) {       // >= 100 ms of polling: report and finish (the rows of this tile are wrong)
+                    if (lane == 0) atomicOr(x.tmo, 1u);
+                    done = true;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            f32x2 st;
+            if (MODE == 0) {
+                float mu = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) if (t < x.ntn) mu += oa[k][t];
+                mu /= (float)x.ntn;
+                float m2 = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) if (t < x.ntn) { const float d = oa[k][t] - mu; m2 += ob[k][t] + 256.f * d * d; }
+                st[0] = mu;
+                st[1] = rsqrtf(m2 / (float)g.N + e.eps);              // biased variance, as nn.LayerNorm
+            } else {
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) if (t < x.ntn) { a1 += oa[k][t]; a2 += ob[k][t]; }
+                st[0] = a1 / (float)g.N;
+                st[1] = a2 / (float)g.N;
+            }
+            *(f32x2*)(stats + row[k] * 2) = st;
+        }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------ pass 2 (column pair jp outermost: half the per-column constants live)
+    if (MODE == 0) {
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) {
+            const int n = nw + 32 * jp;
+            const f32x4 ga0 = *(const f32x4*)(e.gamma + n), ga1 = *(const f32x4*)(e.gamma + n + 4);
+            const f32x4 be0 = *(const f32x4*)(e.beta + n), be1 = *(const f32x4*)(e.beta + n + 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = mw + 16 * i;
+                const f32x2 st = *(const f32x2*)(stats + (rw + 16 * i) * 2);
+                if (m >= g.M) continue;
+                if (jp == 0 && tile_n == 0 && o.wc == 0 && gq == 0 && e.rstd) e.rstd[m] = st[1];
+                f32x4 lo, hi, hl, hh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    hl[q] = (o.acc[i][2 * jp][q] - st[0]) * st[1];
+                    hh[q] = (o.acc[i][2 * jp + 1][q] - st[0]) * st[1];
+                    lo[q] = hl[q] * ga0[q] + be0[q];
+                    hi[q] = hh[q] * ga1[q] + be1[q];
+                }
+                const size_t off = (size_t)m * g.ldc + n;
+                st_stream((f32x4*)((float*)g.C + off), lo);
+                st_stream((f32x4*)((float*)g.C + off + 4), hi);
+                if (g.C2) {
+                    u32x4 pk;
+                    pk[0] = pack_op2(lo[0], lo[1]); pk[1] = pack_op2(lo[2], lo[3]);
+                    pk[2] = pack_op2(hi[0], hi[1]); pk[3] = pack_op2(hi[2], hi[3]);
+                    st_stream((u32x4*)((op16*)g.C2 + off), pk);
+                }
+                if (e.xhat) {
+                    u32x4 pk;
+                    pk[0] = pack_op2(hl[0], hl[1]); pk[1] = pack_op2(hl[2], hl[3]);
+                    pk[2] = pack_op2(hh[0], hh[1]); pk[3] = pack_op2(hh[2], hh[3]);
+                    st_stream((u32x4*)((op16*)e.xhat + (size_t)m * g.N + n), pk);
+                }
+            }
+        }
+    } else {
+        float* pr = (float*)(scratch + LNX_RED + LNX_STATS);           // [2 wave rows][2][256 columns]
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) {
+            const int n = nw + 32 * jp;
+            const f32x4 ga0 = *(const f32x4*)(e.gamma + n), ga1 = *(const f32x4*)(e.gamma + n + 4);
+            float ag[8], ab[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { ag[q] = 0.f; ab[q] = 0.f; }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = mw + 16 * i;
+                const f32x2 st = *(const f32x2*)(stats + (rw + 16 * i) * 2);
+                const float rs = m < g.M ? e.rstd[m] : 0.f;
+                const u32x4 xq = *(const u32x4*)(smem + ((size_t)(i * NP + jp) * 512 + tid) * 16);
+                float ov[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float dy = (q < 4) ? o.acc[i][2 * jp][q & 3] : o.acc[i][2 * jp + 1][q & 3];
+                    const float xh = (q & 1) ? op_hi(xq[q >> 1]) : op_lo(xq[q >> 1]);
+                    const float gm = (q < 4) ? ga0[q & 3] : ga1[q & 3];
+                    ag[q] += dy * xh;                                // rows past M carry dy = 0
+                    ab[q] += dy;
+                    ov[q] = rs * (dy * gm - st[0] - xh * st[1]);
+                }
+                if (m >= g.M) continue;
+                const size_t off = (size_t)m * g.ldc + n;
+                f32x4 lo, hi;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { lo[q] = ov[q]; hi[q] = ov[4 + q]; }
+                st_stream((f32x4*)((float*)g.C + off), lo);
+                st_stream((f32x4*)((float*)g.C + off + 4), hi);
+                if (g.C2) {
+                    if (DROPW == 2 && dc.thr) {
+                        const uint32_t e0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+#pragma unroll
+                        for (int q = 0; q < 8; q += 2) {
+                            float k0, k1;
+                            drop_pair(dc, e0 + q, k0, k1);
+                            ov[q] *= k0; ov[q + 1] *= k1;
+                        }
+                    }
+                    u32x4 pk;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) pk[q] = pack_op2(ov[2 * q], ov[2 * q + 1]);
+                    st_stream((u32x4*)((op16*)g.C2 + off), pk);
+                }
+            }
+            if (e.partials) {
+                // column sums over the panel's 256 rows: over the 16 rows of a lane row by DPP, over the two wave rows through LDS
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float a = row16_sum(ag[q]), b = row16_sum(ab[q]);
+                    if (c16 == 0) {
+                        const int col = o.wc * 64 + pair_col(gq) + 32 * jp + q;
+                        pr[(o.wr * 2 + 0) * 256 + col] = a;
+                        pr[(o.wr * 2 + 1) * 256 + col] = b;
+                    }
+                }
+            }
+        }
+        if (e.partials) {
+            __syncthreads();
+            const int which = tid >> 8, col = tid & 255;
+            e.partials[((size_t)panel * 2 + which) * g.N + n0 + col] = pr[which * 256 + col] + pr[(2 + which) * 256 + col];
+        }
+    }
+}
+
 // ---------------------------------------------------------------- grouped weight gradients
 // Bias gradient = column sums of A (= dY) over the reduction rows: the four waves of a wave row hold the same A fragments,
 // so each sums a quarter of the row's tiles (v_dot2c_f32_bf16 against (1, 1): one VALU instruction per register).
@@ -415,6 +770,77 @@ extern "C" int QST_K(qst_gemm_nt8)(const QstGemmArgs* a, int epi, int tile, void
         default: return QST_ERR_BAD_ARG;
     }
 #undef QST_NT8_CASE
+}
+
+// The granules of the row-statistics exchange: one buffer per stream that has launched the kernel (two launches in flight on
+// different streams must not share tags), grown on demand, zeroed by a memset node in front of every launch.
+namespace {
+struct LnxBuf { hipStream_t st; unsigned long long* gran; size_t bytes; bool used; };
+LnxBuf g_lnx[8];
+unsigned* g_lnx_tmo = nullptr;
+}  // namespace
+
+static int lnx_get(hipStream_t st, size_t bytes, LnXchg& x) {
+    if (!g_lnx_tmo) {
+        QST_HIP_CHECK(hipMalloc((void**)&g_lnx_tmo, 256));
+        QST_HIP_CHECK(hipMemset(g_lnx_tmo, 0, 256));
+    }
+    LnxBuf* b = nullptr;
+    for (auto& q : g_lnx) if (q.used && q.st == st) { b = &q; break; }
+    if (!b) for (auto& q : g_lnx) if (!q.used) { b = &q; b->used = true; b->st = st; b->gran = nullptr; b->bytes = 0; break; }
+    if (!b) return QST_ERR_UNSUPPORTED;                  // more than eight streams in one process
+    if (b->bytes < bytes) {
+        if (b->gran) { QST_HIP_CHECK(hipStreamSynchronize(st)); QST_HIP_CHECK(hipFree(b->gran)); b->gran = nullptr; b->bytes = 0; }
+        QST_HIP_CHECK(hipMalloc((void**)&b->gran, bytes));
+        b->bytes = bytes;
+    }
+    x.gran = b->gran; x.tmo = g_lnx_tmo;
+    return QST_OK;
+}
+
+// 1 when qst_gemm_nt_ln can take N on this kernel (whole 256-column tiles, at most four per row panel)
+extern "C" int QST_K(qst_gemm_nt8_ln_supported)(int N) { return (N % 256 == 0 && N >= 512 && N <= 1024) ? 1 : 0; }
+// the sticky timeout word of the exchange (0 = no launch of this process has ever given up waiting); reads synchronously
+extern "C" int QST_K(qst_gemm_nt8_ln_timeouts)(void) {
+    unsigned v = 0;
+    if (g_lnx_tmo && hipMemcpy(&v, g_lnx_tmo, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)v;
+}
+
+template <int MODE, int DROPW>
+static int launch_nt8_ln(const QstGemmArgs* a, const QstLnEpi* ln, hipStream_t st) {
+    constexpr int lds = MODE == 0 ? LNX_LDS0 : LNX_LDS1;
+    static QstLdsAttr attr;
+    if (int rc = qst_ensure_lds(attr, (const void*)gemm_nt8_ln_kernel<MODE, DROPW>, lds)) return rc;
+    LnXchg x{};
+    x.ntm = (a->M + 255) / 256; x.ntn = a->N / 256; x.ppx = (x.ntm + 7) / 8;
+    const size_t bytes = (size_t)x.ntm * x.ntn * 256 * 2 * sizeof(unsigned long long);
+    if (int rc = lnx_get(st, bytes, x)) return rc;
+    QST_HIP_CHECK(hipMemsetAsync(x.gran, 0, bytes, st));
+    gemm_nt8_ln_kernel<MODE, DROPW><<<dim3(8 * x.ntn * x.ppx), dim3(512), lds, st>>>(*a, *ln, x);
+    QST_LAUNCH_CHECK();
+    return QST_OK;
+}
+
+// Arguments, modes and dropout sites as qst_gemm_nt_ln (which forwards here for N = 512 / 768 / 1024); partials are
+// f32 [ceil(M/256)][2][N].
+extern "C" int QST_K(qst_gemm_nt8_ln)(const QstGemmArgs* a, const QstLnEpi* ln, int mode, void* stream) {
+    if (!a || !ln || !a->A || !a->B || !a->C || !ln->gamma || a->M <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
+    if (mode != 0 && mode != 1) return QST_ERR_BAD_ARG;
+    if (mode == 0 && !ln->beta) return QST_ERR_BAD_ARG;
+    if (mode == 1 && (!ln->xhat || !ln->rstd)) return QST_ERR_BAD_ARG;
+    if (!QST_K(qst_gemm_nt8_ln_supported)(a->N) || a->B2) return QST_ERR_UNSUPPORTED;
+    if (a->K % 64 != 0 || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->ldc % 8 != 0 || (a->resid && a->ldr % 4 != 0)) return QST_ERR_UNSUPPORTED;
+    if ((int64_t)256 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)256 * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
+    const bool drop = a->drop.thr16 && a->drop.state;
+    if (drop) {
+        if (a->drop.thr16 > 65535u || (int64_t)a->M * a->N >= ((int64_t)1 << 32)) return QST_ERR_UNSUPPORTED;
+        if (mode == 0 ? a->drop_where != 1 : (a->drop_where != 2 && a->drop_where != 3)) return QST_ERR_BAD_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0) return drop ? launch_nt8_ln<0, 1>(a, ln, st) : launch_nt8_ln<0, 0>(a, ln, st);
+    if (!drop) return launch_nt8_ln<1, 0>(a, ln, st);
+    return a->drop_where == 2 ? launch_nt8_ln<1, 2>(a, ln, st) : launch_nt8_ln<1, 3>(a, ln, st);
 }
 
 #if !QST_OP_F16

@@ -161,6 +161,7 @@ struct qst_encoder {
     // 144 us and 157 vs 125 us): their side outputs (gelu'(u), h / du: 100-200 MB per call) are stored by the same waves
     // that wait on the LDS-DMA stream, and stores and DMAs retire through one in-order counter.
     int ffn_chain = 1;
+    int ln_fusion = 0;      // qst_encoder_set_ln_fusion: 0 = by size, 1 = wherever a fused kernel exists, 2 = never
 };
 
 extern "C" int64_t qst_arena_elems(const qst_config* cfg) { return cfg_ok(cfg) ? build_layout(cfg).total : QST_ERR_BAD_ARG; }
@@ -446,6 +447,11 @@ extern "C" int qst_encoder_set_ffn_chain(qst_encoder* e, int mask) {
     e->ffn_chain = mask;
     return QST_OK;
 }
+extern "C" int qst_encoder_set_ln_fusion(qst_encoder* e, int mode) {
+    if (!e || mode < 0 || mode > 2) return QST_ERR_BAD_ARG;
+    e->ln_fusion = mode;
+    return QST_OK;
+}
 extern "C" int qst_encoder_set_dropout(qst_encoder* e, float p_hidden, float p_attn, uint32_t* state_dev) {
     if (!e || !(p_hidden >= 0.f && p_hidden < 1.f) || !(p_attn >= 0.f && p_attn < 1.f)) return QST_ERR_BAD_ARG;
     if ((p_hidden > 0.f || p_attn > 0.f) && !state_dev) return QST_ERR_BAD_ARG;
@@ -518,6 +524,15 @@ int ffn_chain(const OpKernels& K, const void* A, const void* B1, const void* B2,
 }
 
 constexpr int kFuseLnMinRows = 16384;      // token rows from which the fused GEMM+LayerNorm kernels win (see forward)
+// ... and for H = 512 / 768 / 1024, where a row spans several 256-column tiles whose workgroups exchange the row statistics
+// (gemm8.hip): from two tiles per CU on. Measured at H = 768 (tools/ln8_bench.py, fused against the GEMM + row-kernel pair):
+// M = 49,152: forward -6 ... -10%, backward -8 ... -9%; M = 196,608: forward -6 ... -10%, backward -13 ... -19%.
+static bool fuse_ln_rows(int H, int M, int mode) {
+    if (!qst_gemm_nt_ln_supported(H) || mode == 2) return false;
+    if (mode == 1) return true;
+    if (qst_gemm_nt_ln_block_rows(H) == 128) return M >= kFuseLnMinRows;
+    return (int64_t)((M + 255) / 256) * (H / 256) >= 512;
+}
 
 #define QST_TRY(expr) do { int _rc = (expr); if (_rc != QST_OK) return _rc; } while (0)
 
@@ -982,7 +997,7 @@ extern "C" int qst_encoder_forward(qst_encoder* e, const int64_t* ids, const int
     // H = 384: the LayerNorm after each projection runs inside that GEMM's epilogue (full-row tiles) -- from M = 16384
     // token rows on: one 128-row tile per workgroup gives a small batch too few workgroups (measured: the unfused pair
     // is 5-25% faster up to M = 8192, equal at 16384, 25% slower at 32768)
-    const bool fuse_ln = qst_gemm_nt_ln_supported(H) != 0 && M >= kFuseLnMinRows;
+    const bool fuse_ln = fuse_ln_rows(H, M, e->ln_fusion) && !(splitw && qst_gemm_nt_ln_block_rows(H) != 128);   // (no split weights on the 8-phase loop)
     // ... and the whole feed-forward block (FFN-1, GELU, FFN-2, LayerNorm) is ONE kernel: h never returns from HBM, and
     // an inference forward does not write it at all
     const bool fuse_ffn = fuse_ln && !dropping && !splitw && (e->ffn_chain & (training ? 2 : 1)) && qst_ffn_chain_supported(H, I) != 0;
@@ -1101,7 +1116,7 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
     lnb.nblocks = (int)(qst_ln_bwd_scratch_bytes(M, H) / ((size_t)2 * H * sizeof(float)));
     // H = 384: every LayerNorm backward except the top one (whose input comes from the pooling head, not from a GEMM)
     // runs inside the epilogue of the dgrad GEMM that produces its input; those write one partial row per 128-row tile
-    const bool fuse_ln = qst_gemm_nt_ln_supported(H) != 0 && M >= kFuseLnMinRows;
+    const bool fuse_ln = fuse_ln_rows(H, M, e->ln_fusion);
     // dropout: the masks of the forward that filled `saved` are recomputed from its (seed, step) snapshot in the arena and
     // ITS thresholds (recorded by that forward, process-wide: any handle of the same model may run the backward)
     FwdRec fr;
@@ -1110,7 +1125,7 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
     const bool dropping = thr.hidden != 0 || thr.attn != 0;
     const void* dst8 = sv + p.dropst;
     const bool fuse_ffn = fuse_ln && !dropping && (e->ffn_chain & 4) && qst_ffn_chain_supported(H, I) != 0;
-    const int fused_rows = (M + 127) / 128;
+    const int fused_rows = (M + qst_gemm_nt_ln_block_rows(H) - 1) / qst_gemm_nt_ln_block_rows(H);
     auto hdrop = [&](uint32_t site, QstDrop& d) -> const QstDrop* {          // hidden-state mask of `site`, or none
         if (!dropping || !thr.hidden) return nullptr;
         d = drop_of(thr, dst8, false, site);

@@ -139,6 +139,14 @@ class HipEncoder:
         forward (default), bit 1 training forward, bit 2 backward."""
         _lib.check(self.lib.qst_encoder_set_ffn_chain(self.handle, int(mask)), "qst_encoder_set_ffn_chain")
 
+    def set_ln_fusion(self, mode: int) -> None:
+        """Where a projection + LayerNorm (and a dgrad + LayerNorm backward) run as one kernel (include/qst.h
+        qst_encoder_set_ln_fusion): 0 by size (default), 1 wherever such a kernel exists, 2 never. Every precision's handle."""
+        for h in (self.handle, self.handle_mx, self.handle_x3, self.handle_f16, self.handle_f16w):
+            if h is not None:
+                _lib.check(self.lib.qst_encoder_set_ln_fusion(h, int(mode)), "qst_encoder_set_ln_fusion")
+        self.ln_fusion = int(mode)
+
     def set_dropout_step(self, step: int) -> None:
         """Continue the mask stream at `step` training forwards (checkpoint resume)."""
         if self.dropout is not None:
@@ -191,6 +199,16 @@ class HipEncoder:
 
     # ------------------------------------------------------------------ forward / backward
     def _handle_for(self, precision: str):
+        h = self._handle_for_raw(precision)
+        if getattr(self, "ln_fusion", 0) and not getattr(h, "_ln_fusion_set", None) == self.ln_fusion:
+            _lib.check(self.lib.qst_encoder_set_ln_fusion(h, self.ln_fusion), "qst_encoder_set_ln_fusion")
+            try:
+                h._ln_fusion_set = self.ln_fusion
+            except AttributeError:
+                pass
+        return h
+
+    def _handle_for_raw(self, precision: str):
         if precision in ("bf16", 0, None):
             return self.handle
         if precision in ("fp8", 3):

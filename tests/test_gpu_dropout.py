@@ -108,11 +108,11 @@ def test_row_kernels_apply_the_mask(lib, M, H):
     assert torch.equal(masked_out[0], plain[0]) and torch.equal(masked_out[1], (plain[0] * mk).to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("M,K", [(300, 384), (1000, 1536)])
-def test_projection_epilogues_apply_the_mask(lib, M, K):
-    """C = (A.B^T + bias) * mask + resid: the plain fp32 epilogue and the LayerNorm-fused one (forward); the fused LayerNorm
-    backward with the mask on its bf16 result (where 2) or on the incoming gradient (where 3)."""
-    N = 384
+@pytest.mark.parametrize("M,K,N", [(300, 384, 384), (1000, 1536, 384), (700, 768, 768), (1300, 3072, 768)])
+def test_projection_epilogues_apply_the_mask(lib, M, K, N):
+    """C = (A.B^T + bias) * mask + resid: the plain fp32 epilogue and the LayerNorm-fused one (forward; N = 768: the
+    several-tiles-per-row form); the fused LayerNorm backward with the mask on its bf16 result (where 2) or on the incoming
+    gradient (where 3)."""
     g = torch.Generator().manual_seed(M + K)
     seed, step, p, site = 5, 1, 0.1, D.site_ffn_out(3)
     st = make_state(lib, seed, step)
@@ -147,7 +147,8 @@ def test_projection_epilogues_apply_the_mask(lib, M, K):
     xhat = bfr(torch.randn(M, N, generator=g)); rstd = torch.rand(M, generator=g) + 0.5
     xhd, rsd = xhat.to(torch.bfloat16).cuda(), rstd.cuda()
     ln2 = _lib.QstLnEpi()
-    part = torch.zeros((M + 127) // 128, 2, N, device="cuda")
+    br = lib.qst_gemm_nt_ln_block_rows(N)
+    part = torch.zeros((M + br - 1) // br, 2, N, device="cuda")
     ln2.gamma, ln2.xhat, ln2.rstd, ln2.partials = gd.data_ptr(), xhd.data_ptr(), rsd.data_ptr(), part.data_ptr()
 
     def ln_bwd_ref(dy):

@@ -45,7 +45,7 @@ def cls_of(leaf):
 
 
 def run_case(name, B, L, ragged, weights_kw, check_grads=True, emb_atol_vs_bf16_oracle=1e-4, scale_by_emb=False,
-             mask_edges=False, dropout=None, ffn_chain=None):
+             mask_edges=False, dropout=None, ffn_chain=None, ln_fusion=None):
     """dropout = (p_hidden, p_attn, seed): the HIP encoder runs its training forward / backward with dropout on, the
     oracle with the SAME masks (oracle/dropout_ref.py regenerates them from seed, step 1) -- same comparisons, same
     bounds."""
@@ -77,6 +77,8 @@ def run_case(name, B, L, ragged, weights_kw, check_grads=True, emb_atol_vs_bf16_
         enc.set_dropout(dropout[0], dropout[1], dropout[2])
     if ffn_chain is not None:
         enc.set_ffn_chain(ffn_chain)
+    if ln_fusion is not None:
+        enc.set_ln_fusion(ln_fusion)
     n = 4 * B
     idd, mdd, tdd = ids_t.view(n, L).cuda(), mask_t.view(n, L).cuda(), types_t.view(n, L).cuda()
     emb, tok, saved = enc.forward(idd, mdd, tdd if cfg.type_vocab_size else None, training=True, want_tokens=True)
@@ -225,6 +227,49 @@ def test_bert_base_two_layers_l384_with_gradients(drop):
                  scale_by_emb=True)
     finally:
         del PRESETS["bert-2l"]
+
+
+@pytest.mark.parametrize("base,L,drop", [("bert-base-uncased", 384, None), ("bert-base-uncased", 384, (0.1, 0.1, 9)),
+                                         ("all-mpnet-base-v2", 288, (0.2, 0.1, 7))], ids=["bert", "bert_dropout", "mpnet_dropout"])
+def test_layernorm_fused_across_the_tiles_of_a_row_h768(base, L, drop):
+    """H = 768: every projection + LayerNorm and dgrad + LayerNorm backward as ONE launch whose three workgroups per 256-row
+    panel exchange the row statistics (csrc/gemm8.hip gemm_nt8_ln_kernel; taken by size from two tiles per CU, forced here
+    with set_ln_fusion(1) on 1,536 / 1,152 token rows -- the second not a multiple of the panel height): (a) the whole
+    oracle comparison of run_case, every gradient tensor included; (b) against the unfused pair (set_ln_fusion(2)) on the
+    same inputs, bf16 and f16 operands: same arithmetic up to fp32 summation order."""
+    from dataclasses import replace
+    PRESETS["h768-2l"] = replace(PRESETS[base], num_layers=2, vocab_size=4096)
+    try:
+        cfg = PRESETS["h768-2l"]
+        run_case("h768-2l", 1, L, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), emb_atol_vs_bf16_oracle=1.5e-3, dropout=drop,
+                 scale_by_emb=(base == "bert-base-uncased"), ln_fusion=1)
+        arena = synthetic_params(cfg, seed=15, std=0.03, bias_std=0.02, ln_jitter=0.05)
+        ids, mask, types = [torch.from_numpy(x).view(4, L).cuda() for x in synthetic_quadruplets(cfg, 1, L, seed=15, ragged=True)]
+        tt = types if cfg.type_vocab_size else None
+        for prec in ("bf16", "f16"):
+            out = {}
+            for mode in (2, 1):
+                enc = HipEncoder(cfg)
+                enc.load_arena(arena)
+                if drop is not None:
+                    enc.set_dropout(*drop)
+                enc.set_ln_fusion(mode)
+                enc.ensure_train_state()
+                emb, _, saved = enc.forward(ids, mask, tt, training=True, precision=prec)
+                gen = torch.Generator().manual_seed(3)
+                ge = torch.randn(emb.shape, generator=gen).cuda()
+                enc.grads.zero_()
+                enc.backward(ids, mask, tt, ge, saved, precision=prec)
+                torch.cuda.synchronize()
+                out[mode] = (emb.clone(), enc.grads.clone())
+            sc = out[2][0].abs().max().item()
+            torch.testing.assert_close(out[1][0], out[2][0], rtol=0, atol=3e-5 * sc)
+            gs = out[2][1].abs().max().item()
+            d = (out[1][1] - out[2][1]).abs().max().item()
+            assert d <= 2e-3 * gs, f"{prec}: gradients of the fused and the unfused path differ by {d:.3e} (largest gradient {gs:.3e})"
+        assert enc.lib.qst_gemm_nt8_ln_timeouts() == 0 and enc.lib.qst_gemm_nt8_ln_timeouts_f16() == 0
+    finally:
+        del PRESETS["h768-2l"]
 
 
 @pytest.mark.parametrize("name,B,L,ragged,wkw,drop", [

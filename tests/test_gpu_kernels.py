@@ -258,12 +258,14 @@ def test_layernorm_fwd_bwd(lib, op, M, H):
     torch.testing.assert_close(dg.cpu(), gr.grad, rtol=1e-2, atol=1e-2 * math.sqrt(M))
 
 
-@pytest.mark.parametrize("M,K", [(128, 64), (300, 384), (1000, 1536), (4096, 1152)])
-def test_gemm_nt_fused_layernorm(lib, op, M, K):
-    """qst_gemm_nt_ln (N = 384 full-row tiles) against the unfused pair it replaces: qst_gemm_nt(F32_RESID) followed
+@pytest.mark.parametrize("M,K,N", [(128, 64, 384), (300, 384, 384), (1000, 1536, 384), (4096, 1152, 384),
+                                   (300, 768, 768), (1000, 3072, 768), (4096, 2304, 768), (8200, 768, 768), (600, 128, 512),
+                                   (257, 64, 1024)])
+def test_gemm_nt_fused_layernorm(lib, op, M, K, N):
+    """qst_gemm_nt_ln (N = 384: full-row tiles; N = 512 / 768 / 1024: the workgroups of a row panel exchange the row
+    statistics inside the launch, gemm8.hip) against the unfused pair it replaces: qst_gemm_nt(F32_RESID) followed
     by qst_ln_fwd / qst_ln_bwd -- same arithmetic, so fp32 outputs agree to accumulation-order noise."""
-    N = 384
-    assert lib.qst_gemm_nt_ln_supported(N) == 1 and lib.qst_gemm_nt_ln_supported(768) == 0
+    assert lib.qst_gemm_nt_ln_supported(N) == 1 and lib.qst_gemm_nt_ln_supported(192) == 0
     g = torch.Generator().manual_seed(M + K)
     Ad = dev(opr(op, torch.randn(M, K, generator=g)).to(OPDT[op]))
     Bd = dev(opr(op, torch.randn(N, K, generator=g) * 0.05).to(OPDT[op]))
@@ -317,7 +319,8 @@ def test_gemm_nt_fused_layernorm(lib, op, M, K):
     _lib.check(kf(lib, "qst_ln_bwd", op)(dy.data_ptr(), xh0.data_ptr(), rs0.data_ptr(), gamma.data_ptr(), M, N, ds0.data_ptr(),
                               dsb0.data_ptr(), dg0.data_ptr(), db0.data_ptr(), scratch.data_ptr(), stream()))
     ds1, dsb1 = f32(M, N), b16(M, N)
-    ntile = (M + 127) // 128
+    br = lib.qst_gemm_nt_ln_block_rows(N)
+    ntile = (M + br - 1) // br
     part = torch.full((ntile, 2, N), float("nan"), device="cuda")
     _lib.check(kf(lib, "qst_gemm_nt_ln", op)(gemm_args(A=Ad, B=Bd, C=ds1, C2=dsb1, resid=resid, M=M, N=N, K=K, lda=K, ldb=K, ldc=N,
                                             ldr=N),
@@ -330,6 +333,7 @@ def test_gemm_nt_fused_layernorm(lib, op, M, K):
     # bad shapes are refused, not mis-computed
     assert kf(lib, "qst_gemm_nt_ln", op)(gemm_args(A=Ad, B=Bd, C=ds1, M=M, N=192, K=K, lda=K, ldb=K, ldc=192),
                               ln_epi(gamma=gamma, xhat=xh0, rstd=rs0), 1, stream()) == -2
+    assert kf(lib, "qst_gemm_nt8_ln_timeouts", op)() == 0        # no exchange of row statistics ever gave up waiting
 
 
 @pytest.mark.parametrize("M,I", [(128, 192), (416, 768), (1000, 1536), (4096, 1536)])
