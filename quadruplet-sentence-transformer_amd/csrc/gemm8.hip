@@ -238,7 +238,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_f8_kernel(QstGemmArgs g) {
 //   pass 1   v = acc + bias (+ dropout) + resid, back into the accumulator registers; per row and wave the mean and the
 //            centred sum of squares of its 64 columns (mode 1: sum(g dy), sum(g dy xhat)) -> LDS
 //   exchange waves (wr, 0) merge the four wave-columns (Chan's update: no E[v^2] - mean^2), publish the tile's pair for
-//            each of their 128 rows as two 8-byte granules {tag = 1, value} (sc1 stores: the data is the flag,
+//            each of their 128 rows as two 8-byte granules {tag, value} (sc1 stores: the data is the flag,
 //            cdna_hip_programming.md Guideline 16 form R2), sweep the other tiles' granules of the same rows until every
 //            tag is set (sc1 loads, bounded: a timeout sets *tmo and the launch finishes with wrong rows instead of
 //            hanging), merge, and leave (mean, rstd) / (m1, m2) per row in LDS
@@ -247,13 +247,18 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_f8_kernel(QstGemmArgs g) {
 //            M = 196,608).
 // Liveness needs in-order dispatch only: block b's partners are b +- 8, b +- 16 (same XCD under round-robin placement, but
 // nothing depends on placement), so the set of dispatched workgroups is a prefix of the grid and at most ntn - 1 resident
-// workgroups wait for a partner that has not started; every other one finishes and frees its CU. The granules are zeroed
-// by a memset node in front of every launch (graph-replay safe: no per-launch salt).
+// workgroups wait for a partner that has not started; every other one finishes and frees its CU. A granule's tag is the
+// epoch of its buffer + 1; the last workgroup of a launch to finish advances the epoch (device-resident: a replayed graph
+// counts on like an eager launch, nothing is zeroed between launches, no per-launch salt in the arguments).
 // Mode 1 keeps dy in the accumulators and the tile's xhat fragment in LDS (lane-private slots in the 128 KB the K loop
 // has left) across the exchange; the gamma / beta gradient partials (column sums over the panel's rows) go to
 // partials[panel][2][N].
+#ifndef QST_LN8_HT1
+#define QST_LN8_HT1 2      // mode 1: 4 spills one to four registers per lane (A/B: tools/ln8_bench.py)
+#endif
 struct LnXchg {
     unsigned long long* gran;      // [ntm][ntn][256 rows][2] granules
+    unsigned* ctl;                 // {epoch, workgroups done} of the buffer `gran` belongs to
     unsigned* tmo;                 // sticky timeout word
     int ntm, ntn, ppx;             // panels, tiles per panel, panels per XCD queue
 };
@@ -269,9 +274,21 @@ __device__ __forceinline__ float xg_sum(float v) {
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return a + b;
 }
-__device__ __forceinline__ void put_granule(unsigned long long* p, float v) {
-    __hip_atomic_store((gu64*)p, (1ull << 32) | (unsigned long long)__builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+typedef __attribute__((address_space(1))) unsigned gu32;
+__device__ __forceinline__ void put_granule(unsigned long long* p, unsigned tag, float v) {
+    __hip_atomic_store((gu64*)p, ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(uint32_t, v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Every workgroup of a launch passes here once (thread 0): the last one advances the buffer's epoch for the next launch.
+// The epoch cannot move while a workgroup of this launch has not arrived, so every workgroup reads the same value.
+__device__ __forceinline__ void lnx_finish(unsigned* ctl) {
+    if (threadIdx.x != 0) return;
+    const unsigned ep = __hip_atomic_load((gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned old = __hip_atomic_fetch_add((gu32*)(ctl + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == gridDim.x - 1) {
+        __hip_atomic_store((gu32*)(ctl + 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((gu32*)ctl, ep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 template <int MODE, int DROPW>
@@ -282,7 +299,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstL
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bx = blockIdx.x & 7, bj = blockIdx.x >> 3;
     const int panel = bx * x.ppx + bj / x.ntn, tile_n = bj % x.ntn;
-    if (bj / x.ntn >= x.ppx || panel >= x.ntm) return;
+    if (bj / x.ntn >= x.ppx || panel >= x.ntm) { lnx_finish(x.ctl); return; }
     const int m0 = panel * 256, n0 = tile_n * 256;
     OPS o;
     o.init((const op16*)g.A + (size_t)m0 * g.lda, g.lda, min(256, g.M - m0), (const op16*)g.B + (size_t)n0 * g.ldb, g.ldb,
@@ -290,6 +307,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstL
     g8p::kloop8(o, o.nk);                       // returns behind a workgroup barrier, no DMA outstanding: the LDS is free
 
     const int tid = threadIdx.x, lane = tid & 63, gq = lane >> 4, c16 = lane & 15;
+    // the tag of this launch's granules = the buffer's epoch + 1 (0 = never written); requested now, used after pass 1
+    unsigned tag = 0;
+    if (o.wc == 0) tag = __hip_atomic_load((gu32*)x.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     const int rw = o.wr * 128 + c16;            // + 16 i: this lane's rows inside the panel
     const int mw = m0 + rw;
     const int nw = n0 + o.wc * 64 + pair_col(gq);      // + 32 jp: 8 consecutive columns
@@ -316,7 +336,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstL
             bv[jp][0] = ok ? *(const f32x4*)(g.bias + nw + 32 * jp) : z4;
             bv[jp][1] = ok ? *(const f32x4*)(g.bias + nw + 32 * jp + 4) : z4;
         }
-        constexpr int HT = 2;                   // row-tiles whose residual (and xhat) rows are requested in one burst
+        constexpr int HT = MODE == 0 ? 4 : QST_LN8_HT1;   // row-tiles whose residual (and xhat) rows are requested in one burst
         f32x4 rv[HT][NP][2];
         u32x4 xv[MODE == 1 ? HT : 1][NP];
         const u32x4 zu = {0u, 0u, 0u, 0u};
@@ -422,8 +442,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstL
                 tb[k] = p0[1] + p0[3] + p1[1] + p1[3];
             }
             unsigned long long* gp = x.gran + (((size_t)panel * x.ntn + tile_n) * 256 + row[k]) * 2;
-            put_granule(gp, ta[k]);
-            put_granule(gp + 1, tb[k]);
+            put_granule(gp, tag, ta[k]);
+            put_granule(gp + 1, tag, tb[k]);
         }
         float oa[2][4], ob[2][4];               // every tile's pair (ntn <= 4)
         bool done = false;
@@ -439,7 +459,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstL
                     const gu64* gp = (const gu64*)(x.gran + (((size_t)panel * x.ntn + t) * 256 + row[k]) * 2);
                     const unsigned long long u0 = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const unsigned long long u1 = __hip_atomic_load(gp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = ok && (u0 >> 32) == 1ull && (u1 >> 32) == 1ull;
+                    ok = ok && (unsigned)(u0 >> 32) == tag && (unsigned)(u1 >> 32) == tag;
                     oa[k][t] = __builtin_bit_cast(float, (uint32_t)u0);
                     ob[k][t] = __builtin_bit_cast(float, (uint32_t)u1);
                 }
@@ -582,6 +602,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstL
             e.partials[((size_t)panel * 2 + which) * g.N + n0 + col] = pr[which * 256 + col] + pr[(2 + which) * 256 + col];
         }
     }
+    lnx_finish(x.ctl);
 }
 
 // ---------------------------------------------------------------- grouped weight gradients
@@ -772,10 +793,10 @@ extern "C" int QST_K(qst_gemm_nt8)(const QstGemmArgs* a, int epi, int tile, void
 #undef QST_NT8_CASE
 }
 
-// The granules of the row-statistics exchange: one buffer per stream that has launched the kernel (two launches in flight on
-// different streams must not share tags), grown on demand, zeroed by a memset node in front of every launch.
+// The granules of the row-statistics exchange: one buffer (with its epoch) per stream that has launched the kernel -- two
+// launches in flight on different streams must not share one -- grown on demand.
 namespace {
-struct LnxBuf { hipStream_t st; unsigned long long* gran; size_t bytes; bool used; };
+struct LnxBuf { hipStream_t st; unsigned long long* gran; size_t bytes; bool used; };     // gran[0 .. 31] = control block
 LnxBuf g_lnx[8];
 unsigned* g_lnx_tmo = nullptr;
 }  // namespace
@@ -787,14 +808,26 @@ static int lnx_get(hipStream_t st, size_t bytes, LnXchg& x) {
     }
     LnxBuf* b = nullptr;
     for (auto& q : g_lnx) if (q.used && q.st == st) { b = &q; break; }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    QST_HIP_CHECK(hipStreamIsCapturing(st, &cap));
+    if (cap != hipStreamCaptureStatusNone && (!b || b->bytes < bytes)) {
+        // a capturing stream cannot allocate: the launch being recorded takes the buffer an eager launch of this size has
+        // left (the warm-up step every capture follows); a graph and eager launches must then not run side by side
+        b = nullptr;
+        for (auto& q : g_lnx) if (q.used && q.bytes >= bytes && (!b || q.bytes < b->bytes)) b = &q;
+        if (!b) return QST_ERR_UNSUPPORTED;              // no eager launch of this size before the capture
+        x.gran = b->gran + 32; x.ctl = (unsigned*)b->gran; x.tmo = g_lnx_tmo;
+        return QST_OK;
+    }
     if (!b) for (auto& q : g_lnx) if (!q.used) { b = &q; b->used = true; b->st = st; b->gran = nullptr; b->bytes = 0; break; }
     if (!b) return QST_ERR_UNSUPPORTED;                  // more than eight streams in one process
     if (b->bytes < bytes) {
         if (b->gran) { QST_HIP_CHECK(hipStreamSynchronize(st)); QST_HIP_CHECK(hipFree(b->gran)); b->gran = nullptr; b->bytes = 0; }
-        QST_HIP_CHECK(hipMalloc((void**)&b->gran, bytes));
+        QST_HIP_CHECK(hipMalloc((void**)&b->gran, bytes + 256));
+        QST_HIP_CHECK(hipMemset(b->gran, 0, bytes + 256));       // epoch 0, no tag set; never zeroed again (tags carry the epoch)
         b->bytes = bytes;
     }
-    x.gran = b->gran; x.tmo = g_lnx_tmo;
+    x.gran = b->gran + 32; x.ctl = (unsigned*)b->gran; x.tmo = g_lnx_tmo;
     return QST_OK;
 }
 
@@ -816,7 +849,6 @@ static int launch_nt8_ln(const QstGemmArgs* a, const QstLnEpi* ln, hipStream_t s
     x.ntm = (a->M + 255) / 256; x.ntn = a->N / 256; x.ppx = (x.ntm + 7) / 8;
     const size_t bytes = (size_t)x.ntm * x.ntn * 256 * 2 * sizeof(unsigned long long);
     if (int rc = lnx_get(st, bytes, x)) return rc;
-    QST_HIP_CHECK(hipMemsetAsync(x.gran, 0, bytes, st));
     gemm_nt8_ln_kernel<MODE, DROPW><<<dim3(8 * x.ntn * x.ppx), dim3(512), lds, st>>>(*a, *ln, x);
     QST_LAUNCH_CHECK();
     return QST_OK;

@@ -336,6 +336,39 @@ def test_gemm_nt_fused_layernorm(lib, op, M, K, N):
     assert kf(lib, "qst_gemm_nt8_ln_timeouts", op)() == 0        # no exchange of row statistics ever gave up waiting
 
 
+def test_gemm_nt_fused_layernorm_n768_under_graph_capture(lib):
+    """The several-tiles-per-row form tags its exchange granules with an epoch that lives on the device (the last workgroup
+    of a launch advances it) and takes, while a stream is capturing, the buffer an eager launch has left: a captured launch
+    replays to the eager result, three times, with eager launches in between."""
+    M, K, N = 1300, 768, 768
+    g = torch.Generator().manual_seed(5)
+    A = dev(torch.randn(M, K, generator=g).to(torch.bfloat16)); B = dev((torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16))
+    bias, resid = dev(torch.randn(N, generator=g)), dev(torch.randn(M, N, generator=g))
+    gamma, beta = dev(1 + 0.1 * torch.randn(N, generator=g)), dev(0.1 * torch.randn(N, generator=g))
+    y0, y1 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    e = _lib.QstLnEpi()
+    e.gamma, e.beta, e.eps = gamma.data_ptr(), beta.data_ptr(), 1e-12
+
+    def launch(out):
+        _lib.check(lib.qst_gemm_nt_ln(gemm_args(A=A, B=B, C=out, bias=bias, resid=resid, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, ldr=N),
+                                      e, 0, stream()))
+    launch(y0)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        launch(y1)
+    y2 = torch.empty(M, N, device="cuda")
+    for _ in range(3):
+        y1.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y1, y0)
+        launch(y2)
+        torch.cuda.synchronize()
+        assert torch.equal(y2, y0)
+    assert lib.qst_gemm_nt8_ln_timeouts() == 0
+
+
 @pytest.mark.parametrize("M,I", [(128, 192), (416, 768), (1000, 1536), (4096, 1536)])
 def test_ffn_chain_matches_the_two_kernel_path(lib, op, M, I):
     """qst_ffn_chain (csrc/ffn.hip: the feed-forward block as one kernel) against the launches it replaces --

@@ -38,7 +38,9 @@ def main():
     L = int(sys.argv[6]) if len(sys.argv) > 6 else 128
     rounds = int(sys.argv[7]) if len(sys.argv) > 7 else 4
     cfg = PRESETS[model]
-    tr = QuadrupletTrainer(cfg, arena=synthetic_params(cfg, seed=14), device="cuda:0", lr=2e-5, weight_decay=0.01, max_grad_norm=1.0)
+    drop = float(os.environ.get("AB_DROPOUT", "0"))          # AB_DROPOUT=0.1: the reference's train()-mode step, as bench.py times it
+    tr = QuadrupletTrainer(cfg, arena=synthetic_params(cfg, seed=14), device="cuda:0", lr=2e-5, weight_decay=0.01, max_grad_norm=1.0,
+                           dropout=(drop, drop) if drop > 0 else None, dropout_seed=14)
     batch = [torch.from_numpy(x).cuda() for x in synthetic_quadruplets(cfg, B, L, seed=14)]
     sw = getattr(tr.enc, name)
     res = {v0: [[], []], v1: [[], []]}
