@@ -164,6 +164,11 @@ int qst_gemm_tn_group(const QstTnGroup* grp, void* stream);
  * N % 8 == 0, lda / ldb / ldc % 8 == 0 (qst_gemm_nt8_supported tells). Epilogues and dropout as qst_gemm_nt.
  * qst_gemm8_mode(mode): -1 = the library chooses per call (default); otherwise bit 0 = every supported NT GEMM, bit 1 =
  * every weight-gradient launch on this path, 0 = none. Returns the previous mode; mode < -1 only reads it. Process-wide. */
+/* qst_gemm8_stagger(cycles): the first round of workgroups of an 8-phase NT launch (more than two tiles per CU) starts spread
+ * over `cycles` clock cycles, so that the CUs do not all store at the same time; 0 = together; -1 (default) = the library's
+ * choice (together for the plain GEMMs, 40,000 cycles for the GEMM + LayerNorm launches). Returns the previous value; an
+ * argument below -1 only reads. Process-wide. */
+int qst_gemm8_stagger(int cycles);
 int qst_gemm_nt8_supported(const QstGemmArgs* a, int epi);
 int qst_gemm_nt8(const QstGemmArgs* a, int epi, int tile, void* stream);
 int qst_gemm_tn8_group(const QstTnGroup* grp, void* stream);

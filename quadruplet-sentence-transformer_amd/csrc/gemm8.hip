@@ -195,9 +195,22 @@ __device__ __forceinline__ void nt8_epilogue(const QstGemmArgs& g, OPS& o, int m
 }
 
 
+// Staggered start (qst_gemm8_stagger): one workgroup per CU runs { K loop ; epilogue } with nothing else resident, every CU
+// of the chip starts together and does the same work, so all of them store at the same time and HBM's write side idles during
+// the K loops. The workgroups of the FIRST round sleep for a fraction `key / 256` of `cycles` before they start; later rounds
+// inherit the phase of the CU they land on.
+__device__ __forceinline__ void stagger_start(int cycles, unsigned key) {
+    if (cycles <= 0) return;
+    const unsigned r = __brev(key & 255u) >> 24;                  // 0 .. 255, neighbours far apart
+    const int n = (int)(((long long)cycles * r) >> 8) >> 10;      // s_sleep 16 = 1,024 cycles
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+}
+
 template <int EPI, int TM, int TN>
-__global__ __launch_bounds__(512, 1) void gemm_nt8_kernel(QstGemmArgs g) {
+__global__ __launch_bounds__(512, 1) void gemm_nt8_kernel(QstGemmArgs g, int stagger) {
     op_saturate(g.sat16 != 0);
+    if (blockIdx.x < 256) stagger_start(stagger, blockIdx.x);
     using OPS = g8p::NtOps<TM, TN>;
     constexpr int BM = OPS::BM, BN = OPS::BN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -292,8 +305,9 @@ __device__ __forceinline__ void lnx_finish(unsigned* ctl) {
 }
 
 template <int MODE, int DROPW>
-__global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstLnEpi e, LnXchg x) {
+__global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstLnEpi e, LnXchg x, int stagger) {
     op_saturate(MODE == 0);
+    if (blockIdx.x < 256) stagger_start(stagger, (blockIdx.x & 7) * 32 + (blockIdx.x >> 3) / x.ntn);   // one phase per row panel
     using OPS = g8p::NtOps<8, 4>;
     constexpr int TM = 8, NP = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -735,6 +749,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn8_group_kernel(QstTnGroup grp) 
 
 #if !QST_OP_F16
 std::atomic<int> g_mode{-1};       // qst_gemm8_mode
+std::atomic<int> g_stagger{-1};    // qst_gemm8_stagger (-1: the library's defaults)
 #endif
 
 }  // namespace
@@ -748,8 +763,22 @@ extern "C" int qst_gemm8_mode(int mode) {
     return old;
 }
 int qst_gemm8_mode_get() { return g_mode.load(); }
+// cycles over which the first round of an 8-phase NT launch spreads its start (0 = all together; -1 = the library's defaults:
+// 0 for the plain GEMMs, whose workgroups share operand rows through L2 while they run in step, kLnStagger for the GEMM +
+// LayerNorm launches); returns the previous value, an argument below -1 only reads. Process-wide.
+// Measured at M = 196,608 (tools/stagger_bench.py, us, spread 0 / 20k / 40k / 80k / 160k cycles): QKV 709 / 722 / 737 / 742 /
+// 769, FFN-1 + GELU 1,246 / 1,315 / 1,345 / 1,365 / 1,381, GELU' dgrad 1,151 / 1,155 / 1,153 / 1,173 / 1,186; FFN-2 +
+// LayerNorm 1,097 / 1,068 / 1,071 / 1,099 / 1,116, out-projection + LayerNorm 615 / 601 / 583 / 580 / 597, FFN-1 dgrad +
+// LayerNorm' 1,104 / 1,077 / 1,084 / 1,087 / 1,109.
+extern "C" int qst_gemm8_stagger(int cycles) {
+    const int old = g_stagger.load();
+    if (cycles >= -1) g_stagger.store(cycles);
+    return old;
+}
+int qst_gemm8_stagger_get() { return g_stagger.load(); }
 #else
 int qst_gemm8_mode_get();
+int qst_gemm8_stagger_get();
 #endif
 
 template <int EPI, int TM, int TN>
@@ -758,7 +787,7 @@ static int launch_nt8(const QstGemmArgs* a, hipStream_t st) {
     static QstLdsAttr attr;
     if (int rc = qst_ensure_lds(attr, (const void*)gemm_nt8_kernel<EPI, TM, TN>, g8p::LDS_BYTES)) return rc;
     const int ntm = (a->M + OPS::BM - 1) / OPS::BM, ntn = (a->N + OPS::BN - 1) / OPS::BN;
-    gemm_nt8_kernel<EPI, TM, TN><<<dim3(ntm * ntn), dim3(512), g8p::LDS_BYTES, st>>>(*a);
+    gemm_nt8_kernel<EPI, TM, TN><<<dim3(ntm * ntn), dim3(512), g8p::LDS_BYTES, st>>>(*a, ntm * ntn > 512 && qst_gemm8_stagger_get() > 0 ? qst_gemm8_stagger_get() : 0);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
@@ -840,6 +869,7 @@ extern "C" int QST_K(qst_gemm_nt8_ln_timeouts)(void) {
     return (int)v;
 }
 
+constexpr int kLnStagger = 40000;     // cycles; see qst_gemm8_stagger
 template <int MODE, int DROPW>
 static int launch_nt8_ln(const QstGemmArgs* a, const QstLnEpi* ln, hipStream_t st) {
     constexpr int lds = MODE == 0 ? LNX_LDS0 : LNX_LDS1;
@@ -849,7 +879,7 @@ static int launch_nt8_ln(const QstGemmArgs* a, const QstLnEpi* ln, hipStream_t s
     x.ntm = (a->M + 255) / 256; x.ntn = a->N / 256; x.ppx = (x.ntm + 7) / 8;
     const size_t bytes = (size_t)x.ntm * x.ntn * 256 * 2 * sizeof(unsigned long long);
     if (int rc = lnx_get(st, bytes, x)) return rc;
-    gemm_nt8_ln_kernel<MODE, DROPW><<<dim3(8 * x.ntn * x.ppx), dim3(512), lds, st>>>(*a, *ln, x);
+    gemm_nt8_ln_kernel<MODE, DROPW><<<dim3(8 * x.ntn * x.ppx), dim3(512), lds, st>>>(*a, *ln, x, x.ntm * x.ntn > 512 ? (qst_gemm8_stagger_get() < 0 ? kLnStagger : qst_gemm8_stagger_get()) : 0);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }

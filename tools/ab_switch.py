@@ -42,7 +42,7 @@ def main():
     tr = QuadrupletTrainer(cfg, arena=synthetic_params(cfg, seed=14), device="cuda:0", lr=2e-5, weight_decay=0.01, max_grad_norm=1.0,
                            dropout=(drop, drop) if drop > 0 else None, dropout_seed=14)
     batch = [torch.from_numpy(x).cuda() for x in synthetic_quadruplets(cfg, B, L, seed=14)]
-    sw = getattr(tr.enc, name)
+    sw = getattr(tr.enc.lib, name[4:]) if name.startswith("lib:") else getattr(tr.enc, name)     # lib:qst_gemm8_stagger = a process-wide knob
     res = {v0: [[], []], v1: [[], []]}
     for _ in range(rounds):
         for v in (v0, v1):
