@@ -825,47 +825,57 @@ extern "C" int QST_K(qst_gemm_nt8)(const QstGemmArgs* a, int epi, int tile, void
 // The granules of the row-statistics exchange: one buffer (with its epoch) per stream that has launched the kernel -- two
 // launches in flight on different streams must not share one -- grown on demand.
 namespace {
-struct LnxBuf { hipStream_t st; unsigned long long* gran; size_t bytes; bool used; };     // gran[0 .. 31] = control block
-LnxBuf g_lnx[8];
-unsigned* g_lnx_tmo = nullptr;
+struct LnxBuf { int dev; hipStream_t st; unsigned long long* gran; size_t bytes; bool used; };     // gran[0 .. 31] = control block
+LnxBuf g_lnx[16];
+unsigned* g_lnx_tmo[16] = {};        // per device
+constexpr size_t kLnxMinBytes = (size_t)16 << 20;      // covers 262,144 token rows at H = 1024: regrowth is the exception
 }  // namespace
 
 static int lnx_get(hipStream_t st, size_t bytes, LnXchg& x) {
-    if (!g_lnx_tmo) {
-        QST_HIP_CHECK(hipMalloc((void**)&g_lnx_tmo, 256));
-        QST_HIP_CHECK(hipMemset(g_lnx_tmo, 0, 256));
-    }
-    LnxBuf* b = nullptr;
-    for (auto& q : g_lnx) if (q.used && q.st == st) { b = &q; break; }
+    int dev = 0;
+    QST_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return QST_ERR_UNSUPPORTED;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     QST_HIP_CHECK(hipStreamIsCapturing(st, &cap));
-    if (cap != hipStreamCaptureStatusNone && (!b || b->bytes < bytes)) {
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (!g_lnx_tmo[dev]) {
+        if (capturing) return QST_ERR_UNSUPPORTED;       // no eager launch on this device before the capture
+        QST_HIP_CHECK(hipMalloc((void**)&g_lnx_tmo[dev], 256));
+        QST_HIP_CHECK(hipMemset(g_lnx_tmo[dev], 0, 256));
+    }
+    LnxBuf* b = nullptr;
+    for (auto& q : g_lnx) if (q.used && q.dev == dev && q.st == st) { b = &q; break; }
+    if (capturing && (!b || b->bytes < bytes)) {
         // a capturing stream cannot allocate: the launch being recorded takes the buffer an eager launch of this size has
         // left (the warm-up step every capture follows); a graph and eager launches must then not run side by side
         b = nullptr;
-        for (auto& q : g_lnx) if (q.used && q.bytes >= bytes && (!b || q.bytes < b->bytes)) b = &q;
+        for (auto& q : g_lnx) if (q.used && q.dev == dev && q.bytes >= bytes && (!b || q.bytes < b->bytes)) b = &q;
         if (!b) return QST_ERR_UNSUPPORTED;              // no eager launch of this size before the capture
-        x.gran = b->gran + 32; x.ctl = (unsigned*)b->gran; x.tmo = g_lnx_tmo;
-        return QST_OK;
+    } else {
+        if (!b) for (auto& q : g_lnx) if (!q.used) { b = &q; *b = LnxBuf{dev, st, nullptr, 0, true}; break; }
+        if (!b) return QST_ERR_UNSUPPORTED;              // more than sixteen (device, stream) pairs in one process
+        if (b->bytes < bytes) {
+            // (a buffer that is outgrown is NOT freed: a captured graph may hold its address; it is 16 MB or a few times that)
+            const size_t want = bytes > kLnxMinBytes ? bytes : kLnxMinBytes;
+            unsigned long long* p = nullptr;
+            QST_HIP_CHECK(hipMalloc((void**)&p, want + 256));
+            QST_HIP_CHECK(hipMemset(p, 0, want + 256));  // epoch 0, no tag set; never zeroed again (tags carry the epoch)
+            b->gran = p; b->bytes = want;
+        }
     }
-    if (!b) for (auto& q : g_lnx) if (!q.used) { b = &q; b->used = true; b->st = st; b->gran = nullptr; b->bytes = 0; break; }
-    if (!b) return QST_ERR_UNSUPPORTED;                  // more than eight streams in one process
-    if (b->bytes < bytes) {
-        if (b->gran) { QST_HIP_CHECK(hipStreamSynchronize(st)); QST_HIP_CHECK(hipFree(b->gran)); b->gran = nullptr; b->bytes = 0; }
-        QST_HIP_CHECK(hipMalloc((void**)&b->gran, bytes + 256));
-        QST_HIP_CHECK(hipMemset(b->gran, 0, bytes + 256));       // epoch 0, no tag set; never zeroed again (tags carry the epoch)
-        b->bytes = bytes;
-    }
-    x.gran = b->gran + 32; x.ctl = (unsigned*)b->gran; x.tmo = g_lnx_tmo;
+    x.gran = b->gran + 32; x.ctl = (unsigned*)b->gran; x.tmo = g_lnx_tmo[dev];
     return QST_OK;
 }
 
 // 1 when qst_gemm_nt_ln can take N on this kernel (whole 256-column tiles, at most four per row panel)
 extern "C" int QST_K(qst_gemm_nt8_ln_supported)(int N) { return (N % 256 == 0 && N >= 512 && N <= 1024) ? 1 : 0; }
-// the sticky timeout word of the exchange (0 = no launch of this process has ever given up waiting); reads synchronously
+// the sticky timeout word of the exchange on the current device (0 = no launch of this process has ever given up waiting);
+// reads synchronously
 extern "C" int QST_K(qst_gemm_nt8_ln_timeouts)(void) {
     unsigned v = 0;
-    if (g_lnx_tmo && hipMemcpy(&v, g_lnx_tmo, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -1;
+    if (g_lnx_tmo[dev] && hipMemcpy(&v, g_lnx_tmo[dev], 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (int)v;
 }
 

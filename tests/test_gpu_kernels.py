@@ -260,7 +260,7 @@ def test_layernorm_fwd_bwd(lib, op, M, H):
 
 @pytest.mark.parametrize("M,K,N", [(128, 64, 384), (300, 384, 384), (1000, 1536, 384), (4096, 1152, 384),
                                    (300, 768, 768), (1000, 3072, 768), (4096, 2304, 768), (8200, 768, 768), (600, 128, 512),
-                                   (257, 64, 1024)])
+                                   (257, 64, 1024), (100, 128, 768), (1, 64, 512)])
 def test_gemm_nt_fused_layernorm(lib, op, M, K, N):
     """qst_gemm_nt_ln (N = 384: full-row tiles; N = 512 / 768 / 1024: the workgroups of a row panel exchange the row
     statistics inside the launch, gemm8.hip) against the unfused pair it replaces: qst_gemm_nt(F32_RESID) followed
