@@ -117,6 +117,10 @@ int qst_gemm_nt_ln(const QstGemmArgs* a, const QstLnEpi* ln, int mode, void* str
 int qst_gemm_nt8_ln_supported(int N);
 int qst_gemm_nt8_ln(const QstGemmArgs* a, const QstLnEpi* ln, int mode, void* stream);
 int qst_gemm_nt8_ln_timeouts(void);
+/* Mode 0 of the same on the fp8 matrix cores: operands as qst_gemm_nt_f8 (A, B e4m3; a->aux / a->bscale their E8M0 scales;
+ * K % 128 == 0, ldc == N); outputs as above plus, when a->C3 / a->C4 are given, the normalised rows as MXFP8 (e4m3 [M, N] +
+ * scales in qst_quant_mx's layout, quantised from the 16-bit-rounded values as qst_ln_fwd_mx_train does). QST_PREC_FP8 forward. */
+int qst_gemm_nt8_f8_ln(const QstGemmArgs* a, const QstLnEpi* ln, void* stream);
 /* The feed-forward block of a layer as one kernel (H = 384 token rows complete per tile; csrc/ffn.hip):
  *  mode 0 (forward):  u = A.B1^T + bias1 ; h = gelu(u) ; v = h.B2^T + bias2 + resid ; y = LayerNorm(v) -> C (f32),
  *                     C2 (bf16, nullable), ln->xhat / ln->rstd (nullable). save_gp / save_h (both or neither) receive

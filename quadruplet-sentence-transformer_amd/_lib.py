@@ -115,6 +115,7 @@ SIGNATURES = {
     "qst_gemm_nt8_ln_supported": (C.c_int, [C.c_int]),
     "qst_gemm_nt8_ln": (C.c_int, [C.POINTER(QstGemmArgs), C.POINTER(QstLnEpi), C.c_int, vp]),
     "qst_gemm_nt8_ln_timeouts": (C.c_int, []),
+    "qst_gemm_nt8_f8_ln": (C.c_int, [C.POINTER(QstGemmArgs), C.POINTER(QstLnEpi), vp]),
     "qst_ffn_chain_supported": (C.c_int, [C.c_int, C.c_int]),
     "qst_ffn_chain": (C.c_int, [C.POINTER(QstFfnArgs), C.POINTER(QstLnEpi), C.c_int, vp]),
     "qst_gemm_tn": (C.c_int, [C.POINTER(QstGemmArgs), vp]),

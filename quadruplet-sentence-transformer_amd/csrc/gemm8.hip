@@ -304,11 +304,18 @@ __device__ __forceinline__ void lnx_finish(unsigned* ctl) {
     }
 }
 
-template <int MODE, int DROPW>
+// F8: both operands MXFP8 (operands as gemm_nt8_f8_kernel: g.aux / g.bscale = their E8M0 scales), mode 0 only, and the
+// normalised output leaves a fourth time, as MXFP8 (g.C3 = e4m3 [M, N], g.C4 = scales, stage-major), quantised from the
+// 16-bit-rounded values exactly as qst_ln_fwd_mx_train does it -- the A operand of the next fp8 GEMM (QST_PREC_FP8 forward).
+template <bool F8> struct LnOpsOf { using type = g8p::NtOps<8, 4>; };
+template <> struct LnOpsOf<true> { using type = g8p::NtOpsF8<8, 4>; };
+
+template <int MODE, int DROPW, bool F8 = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstLnEpi e, LnXchg x, int stagger) {
+    static_assert(!F8 || MODE == 0, "the fp8 form is a forward kernel");
     op_saturate(MODE == 0);
     if (blockIdx.x < 256) stagger_start(stagger, (blockIdx.x & 7) * 32 + (blockIdx.x >> 3) / x.ntn);   // one phase per row panel
-    using OPS = g8p::NtOps<8, 4>;
+    using OPS = typename LnOpsOf<F8>::type;
     constexpr int TM = 8, NP = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bx = blockIdx.x & 7, bj = blockIdx.x >> 3;
@@ -316,8 +323,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstL
     if (bj / x.ntn >= x.ppx || panel >= x.ntm) { lnx_finish(x.ctl); return; }
     const int m0 = panel * 256, n0 = tile_n * 256;
     OPS o;
-    o.init((const op16*)g.A + (size_t)m0 * g.lda, g.lda, min(256, g.M - m0), (const op16*)g.B + (size_t)n0 * g.ldb, g.ldb,
-           256, g.K, smem);
+    if constexpr (F8)
+        o.init((const uint8_t*)g.A + (size_t)m0 * g.lda, g.lda, min(256, g.M - m0), (const uint8_t*)g.aux, g.M, m0,
+               (const uint8_t*)g.B + (size_t)n0 * g.ldb, g.ldb, 256, (const uint8_t*)g.bscale, g.N, n0, g.K, smem);
+    else
+        o.init((const op16*)g.A + (size_t)m0 * g.lda, g.lda, min(256, g.M - m0), (const op16*)g.B + (size_t)n0 * g.ldb, g.ldb,
+               256, g.K, smem);
     g8p::kloop8(o, o.nk);                       // returns behind a workgroup barrier, no DMA outstanding: the LDS is free
 
     const int tid = threadIdx.x, lane = tid & 63, gq = lane >> 4, c16 = lane & 15;
@@ -546,6 +557,35 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstL
                     pk[0] = pack_op2(hl[0], hl[1]); pk[1] = pack_op2(hl[2], hl[3]);
                     pk[2] = pack_op2(hh[0], hh[1]); pk[3] = pack_op2(hh[2], hh[3]);
                     st_stream((u32x4*)((op16*)e.xhat + (size_t)m * g.N + n), pk);
+                }
+                if (F8 && g.C3) {
+                    // the 16-bit-rounded y as MXFP8: the four lanes of a row (one per 16-lane row of the wave) hold the 32
+                    // columns of one MX block (all four take this branch together: same m, same block)
+                    float hv[8], amax = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const uint32_t p0 = pack_op2(lo[2 * q], lo[2 * q + 1]), p1 = pack_op2(hi[2 * q], hi[2 * q + 1]);
+                        hv[2 * q] = op_lo(p0); hv[2 * q + 1] = op_hi(p0);
+                        hv[4 + 2 * q] = op_lo(p1); hv[4 + 2 * q + 1] = op_hi(p1);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) amax = fmaxf(amax, fabsf(hv[q]));
+                    amax = fmaxf(amax, swap32(amax));
+                    {
+                        float a2 = amax, b2 = amax;
+                        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a2), "+v"(b2));
+                        amax = fmaxf(a2, b2);
+                    }
+                    const int ex = mx_exponent(amax);
+                    const float inv = pow2f(-ex);
+                    uint32_t p0 = 0, p1 = 0;
+                    p0 = __builtin_amdgcn_cvt_pk_fp8_f32(hv[0] * inv, hv[1] * inv, p0, false);
+                    p0 = __builtin_amdgcn_cvt_pk_fp8_f32(hv[2] * inv, hv[3] * inv, p0, true);
+                    p1 = __builtin_amdgcn_cvt_pk_fp8_f32(hv[4] * inv, hv[5] * inv, p1, false);
+                    p1 = __builtin_amdgcn_cvt_pk_fp8_f32(hv[6] * inv, hv[7] * inv, p1, true);
+                    u32x2 q2; q2[0] = p0; q2[1] = p1;
+                    st_stream((u32x2*)((uint8_t*)g.C3 + (size_t)m * g.N + n), q2);
+                    if (gq == 0) ((uint8_t*)g.C4)[((size_t)(n >> 7) * g.M + m) * 4 + ((n >> 5) & 3)] = (uint8_t)(ex + 127);
                 }
             }
         }
@@ -880,16 +920,16 @@ extern "C" int QST_K(qst_gemm_nt8_ln_timeouts)(void) {
 }
 
 constexpr int kLnStagger = 40000;     // cycles; see qst_gemm8_stagger
-template <int MODE, int DROPW>
+template <int MODE, int DROPW, bool F8 = false>
 static int launch_nt8_ln(const QstGemmArgs* a, const QstLnEpi* ln, hipStream_t st) {
-    constexpr int lds = MODE == 0 ? LNX_LDS0 : LNX_LDS1;
+    constexpr int lds = F8 ? (int)g8p::NtOpsF8<8, 4>::LDS_TOTAL : (MODE == 0 ? LNX_LDS0 : LNX_LDS1);
     static QstLdsAttr attr;
-    if (int rc = qst_ensure_lds(attr, (const void*)gemm_nt8_ln_kernel<MODE, DROPW>, lds)) return rc;
+    if (int rc = qst_ensure_lds(attr, (const void*)gemm_nt8_ln_kernel<MODE, DROPW, F8>, lds)) return rc;
     LnXchg x{};
     x.ntm = (a->M + 255) / 256; x.ntn = a->N / 256; x.ppx = (x.ntm + 7) / 8;
     const size_t bytes = (size_t)x.ntm * x.ntn * 256 * 2 * sizeof(unsigned long long);
     if (int rc = lnx_get(st, bytes, x)) return rc;
-    gemm_nt8_ln_kernel<MODE, DROPW><<<dim3(8 * x.ntn * x.ppx), dim3(512), lds, st>>>(*a, *ln, x, x.ntm * x.ntn > 512 ? (qst_gemm8_stagger_get() < 0 ? kLnStagger : qst_gemm8_stagger_get()) : 0);
+    gemm_nt8_ln_kernel<MODE, DROPW, F8><<<dim3(8 * x.ntn * x.ppx), dim3(512), lds, st>>>(*a, *ln, x, x.ntm * x.ntn > 512 ? (qst_gemm8_stagger_get() < 0 ? kLnStagger : qst_gemm8_stagger_get()) : 0);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
@@ -916,6 +956,26 @@ extern "C" int QST_K(qst_gemm_nt8_ln)(const QstGemmArgs* a, const QstLnEpi* ln, 
 }
 
 #if !QST_OP_F16
+// The forward of the same fusion on the fp8 matrix cores: operands as qst_gemm_nt_f8 (A, B = e4m3, a->aux / a->bscale their
+// E8M0 scales, K % 128 == 0); outputs as mode 0 of qst_gemm_nt8_ln plus, when a->C3 / a->C4 are given, the normalised rows
+// as MXFP8 (e4m3 [M, N] + scales in qst_quant_mx's layout, quantised from the 16-bit-rounded values as qst_ln_fwd_mx_train
+// does) -- the A operand of the next fp8 GEMM. Dropout of the projection output as mode 0 (drop_where 1).
+extern "C" int qst_gemm_nt8_f8_ln(const QstGemmArgs* a, const QstLnEpi* ln, void* stream) {
+    if (!a || !ln || !a->A || !a->B || !a->C || !a->aux || !a->bscale || !ln->gamma || !ln->beta || a->M <= 0 || a->K <= 0) return QST_ERR_BAD_ARG;
+    if ((a->C3 == nullptr) != (a->C4 == nullptr)) return QST_ERR_BAD_ARG;
+    if (!qst_gemm_nt8_ln_supported(a->N) || a->B2) return QST_ERR_UNSUPPORTED;
+    if (a->K % 128 != 0 || a->lda % 16 != 0 || a->ldb % 16 != 0 || a->ldc != a->N || (a->resid && a->ldr % 4 != 0)) return QST_ERR_UNSUPPORTED;
+    if ((int64_t)256 * a->lda >= 0x7FFFFF00LL || (int64_t)256 * a->ldb >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
+    if ((int64_t)(a->K / 128) * (a->M > a->N ? a->M : a->N) * 4 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
+    const bool drop = a->drop.thr16 && a->drop.state;
+    if (drop) {
+        if (a->drop.thr16 > 65535u || (int64_t)a->M * a->N >= ((int64_t)1 << 32)) return QST_ERR_UNSUPPORTED;
+        if (a->drop_where != 1) return QST_ERR_BAD_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    return drop ? launch_nt8_ln<0, 1, true>(a, ln, st) : launch_nt8_ln<0, 0, true>(a, ln, st);
+}
+
 template <int EPI, int TM, int TN>
 static int launch_nt8_f8(const QstGemmArgs* a, hipStream_t st) {
     using OPS = g8p::NtOpsF8<TM, TN>;

@@ -593,6 +593,20 @@ extern "C" int qst_refresh_shadow_mx(const qst_encoder* e, const float* params, 
 // Linear on MXFP8 operands (qst_gemm_nt_f8). Activations are quantised where they are produced when the producer is a
 // GEMM (gelu(u) never exists in another format) or a LayerNorm (qst_ln_fwd_mx), and by qst_quant_mx from the bf16 tensor
 // the attention kernel writes.
+// fp8 GEMM + LayerNorm in one launch (csrc/gemm8.hip gemm_nt8_ln_kernel<0, *, true>): y fp32, y 16-bit / xhat / rstd (nullable)
+// and y as MXFP8 for the next fp8 GEMM
+static int f8_ln(const void* Aq, const void* As, int K, const void* Bq, const void* Bs, const float* bias, const float* resid,
+                 const float* gamma, const float* beta, float eps, int M, int N, float* y, void* yb, void* xh, float* rs,
+                 void* yq, void* ys, const QstDrop* drop, hipStream_t st) {
+    QstGemmArgs g{};
+    g.A = Aq; g.aux = As; g.B = Bq; g.bscale = (const float*)Bs; g.C = y; g.C2 = yb; g.C3 = yq; g.C4 = ys; g.bias = bias; g.resid = resid;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.ldr = N;
+    if (drop) { g.drop = *drop; g.drop_where = 1; }
+    QstLnEpi e{};
+    e.gamma = gamma; e.beta = beta; e.eps = eps; e.xhat = xh; e.rstd = rs;
+    return qst_gemm_nt8_f8_ln(&g, &e, st);
+}
+
 static int forward_mx(qst_encoder* e, const int64_t* ids, const int64_t* mask, const int64_t* type_ids, int nseq, int L,
                       const float* params, const void* shadow, float* out_emb, float* out_tok, void* saved, size_t saved_bytes,
                       hipStream_t st) {
@@ -624,6 +638,8 @@ static int forward_mx(qst_encoder* e, const int64_t* ids, const int64_t* mask, c
     }
     float* s = (float*)(sv + p.s);
     float* y1 = (float*)(sv + p.y1);
+    // H = 512 / 768 / 1024, two tiles per CU or more: projection + LayerNorm (+ MX emission) as one launch (gemm8.hip)
+    const bool fuse_ln = qst_gemm_nt8_ln_supported(H) != 0 && fuse_ln_rows(H, M, e->ln_fusion) && H % 128 == 0 && I % 128 == 0;
     for (int l = 0; l < c.num_layers; ++l) {
         const int b = lay.layer0[l];
         float* xn = (float*)(sv + p.x[(l + 1) & 1]);
@@ -635,11 +651,21 @@ static int forward_mx(qst_encoder* e, const int64_t* ids, const int64_t* mask, c
             QST_TRY(qst_attention_fwd_ex(&q, st));
         }
         QST_TRY(qst_quant_mx(sv + p.ctx, 1, M, H, sv + p.cq, sv + p.cs, st));
-        QST_TRY(gemm(sv + p.cq, sv + p.cs, H, b + W_O, s, nullptr, H, b + B_O, x, QST_EPI_F32_RESID));
-        QST_TRY(qst_ln_fwd_mx(s, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, y1, nullptr, sv + p.yq, sv + p.ys, st));
+        if (fuse_ln) {
+            QST_TRY(f8_ln(sv + p.cq, sv + p.cs, H, WQ(b + W_O), WS(b + W_O), P(b + B_O), x, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps,
+                          M, H, y1, nullptr, nullptr, nullptr, sv + p.yq, sv + p.ys, nullptr, st));
+        } else {
+            QST_TRY(gemm(sv + p.cq, sv + p.cs, H, b + W_O, s, nullptr, H, b + B_O, x, QST_EPI_F32_RESID));
+            QST_TRY(qst_ln_fwd_mx(s, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, y1, nullptr, sv + p.yq, sv + p.ys, st));
+        }
         QST_TRY(gemm(sv + p.yq, sv + p.ys, H, b + W_1, sv + p.hq, sv + p.hs, I, b + B_1, nullptr, QST_EPI_GELU_MX));
-        QST_TRY(gemm(sv + p.hq, sv + p.hs, I, b + W_2, s, nullptr, H, b + B_2, y1, QST_EPI_F32_RESID));
-        QST_TRY(qst_ln_fwd_mx(s, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, M, H, xn, nullptr, sv + p.xq, sv + p.xs, st));
+        if (fuse_ln) {
+            QST_TRY(f8_ln(sv + p.hq, sv + p.hs, I, WQ(b + W_2), WS(b + W_2), P(b + B_2), y1, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps,
+                          M, H, xn, nullptr, nullptr, nullptr, sv + p.xq, sv + p.xs, nullptr, st));
+        } else {
+            QST_TRY(gemm(sv + p.hq, sv + p.hs, I, b + W_2, s, nullptr, H, b + B_2, y1, QST_EPI_F32_RESID));
+            QST_TRY(qst_ln_fwd_mx(s, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, M, H, xn, nullptr, sv + p.xq, sv + p.xs, st));
+        }
         x = xn;
     }
     QST_TRY(qst_pool_norm_fwd(x, mask, nseq, L, H, c.normalize, out_emb, (float*)(sv + p.pooled), st));
@@ -697,6 +723,7 @@ static int forward_mx_train(qst_encoder* e, const int64_t* ids, const int64_t* m
     }
     const float* x = (const float*)(sv + p.x0);
     float* s = (float*)(sv + p.s_scratch);
+    const bool fuse_ln = qst_gemm_nt8_ln_supported(H) != 0 && fuse_ln_rows(H, M, e->ln_fusion) && H % 128 == 0 && I % 128 == 0;
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerAct& a = p.layers[l];
         const int b = lay.layer0[l];
@@ -709,9 +736,21 @@ static int forward_mx_train(qst_encoder* e, const int64_t* ids, const int64_t* m
             QST_TRY(qst_attention_fwd_ex(&q, st));
         }
         QST_TRY(qst_quant_mx(sv + a.ctx, 1, M, H, sv + t.cq, sv + t.cs, st));
-        QST_TRY(gemm(sv + t.cq, sv + t.cs, H, b + W_O, s, nullptr, H, b + B_O, x, QST_EPI_F32_RESID, QST_DROP_SITE_ATTN_OUT(l)));
-        QST_TRY(qst_ln_fwd_mx_train(s, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, (float*)(sv + a.y1), sv + a.y1b,
-                                    sv + a.xh1, (float*)(sv + a.rs1), sv + t.yq, sv + t.ys, st));
+        QstDrop dd{};
+        auto hd = [&](uint32_t site) -> const QstDrop* {
+            if (!dropping || !thr.hidden) return nullptr;
+            dd = drop_of(thr, dst8, false, site);
+            return &dd;
+        };
+        if (fuse_ln) {
+            QST_TRY(f8_ln(sv + t.cq, sv + t.cs, H, WQ(b + W_O), WS(b + W_O), P(b + B_O), x, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps,
+                          M, H, (float*)(sv + a.y1), sv + a.y1b, sv + a.xh1, (float*)(sv + a.rs1), sv + t.yq, sv + t.ys,
+                          hd(QST_DROP_SITE_ATTN_OUT(l)), st));
+        } else {
+            QST_TRY(gemm(sv + t.cq, sv + t.cs, H, b + W_O, s, nullptr, H, b + B_O, x, QST_EPI_F32_RESID, QST_DROP_SITE_ATTN_OUT(l)));
+            QST_TRY(qst_ln_fwd_mx_train(s, P(b + LN1_G), P(b + LN1_B), c.layer_norm_eps, M, H, (float*)(sv + a.y1), sv + a.y1b,
+                                        sv + a.xh1, (float*)(sv + a.rs1), sv + t.yq, sv + t.ys, st));
+        }
         // FFN-1: gelu'(u) and h leave as bf16 (the backward's operands) and, from the same epilogue, the bf16-rounded h as
         // MXFP8 for FFN-2
         {
@@ -721,10 +760,16 @@ static int forward_mx_train(qst_encoder* e, const int64_t* ids, const int64_t* m
             g.M = M; g.N = I; g.K = H; g.lda = H; g.ldb = H; g.ldc = I; g.ldr = I;
             QST_TRY(qst_gemm_nt_f8(&g, QST_EPI_GELU_MX_TRAIN, st));
         }
-        QST_TRY(gemm(sv + t.hq, sv + t.hs, I, b + W_2, s, nullptr, H, b + B_2, (const float*)(sv + a.y1), QST_EPI_F32_RESID,
-                     QST_DROP_SITE_FFN_OUT(l)));
-        QST_TRY(qst_ln_fwd_mx_train(s, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, M, H, (float*)(sv + a.x), sv + a.xb,
-                                    sv + a.xh2, (float*)(sv + a.rs2), sv + t.xq, sv + t.xs, st));
+        if (fuse_ln) {
+            QST_TRY(f8_ln(sv + t.hq, sv + t.hs, I, WQ(b + W_2), WS(b + W_2), P(b + B_2), (const float*)(sv + a.y1), P(b + LN2_G),
+                          P(b + LN2_B), c.layer_norm_eps, M, H, (float*)(sv + a.x), sv + a.xb, sv + a.xh2, (float*)(sv + a.rs2),
+                          sv + t.xq, sv + t.xs, hd(QST_DROP_SITE_FFN_OUT(l)), st));
+        } else {
+            QST_TRY(gemm(sv + t.hq, sv + t.hs, I, b + W_2, s, nullptr, H, b + B_2, (const float*)(sv + a.y1), QST_EPI_F32_RESID,
+                         QST_DROP_SITE_FFN_OUT(l)));
+            QST_TRY(qst_ln_fwd_mx_train(s, P(b + LN2_G), P(b + LN2_B), c.layer_norm_eps, M, H, (float*)(sv + a.x), sv + a.xb,
+                                        sv + a.xh2, (float*)(sv + a.rs2), sv + t.xq, sv + t.xs, st));
+        }
         x = (const float*)(sv + a.x);
     }
     QST_TRY(qst_pool_norm_fwd(x, mask, nseq, L, H, c.normalize, out_emb, (float*)(sv + p.pooled), st));

@@ -209,6 +209,49 @@ def test_encoder_fp8_trained_like_weights_and_mpnet():
     run_encoder_mx("all-mpnet-base-v2", 1, 256, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), layers=2, emb_atol=4e-3)
 
 
+@pytest.mark.parametrize("M,K,N", [(300, 768, 768), (1000, 3072, 768), (4100, 2304, 768), (257, 128, 512)])
+def test_gemm_f8_with_fused_layernorm(lib, M, K, N):
+    """qst_gemm_nt8_f8_ln (fp8 GEMM + LayerNorm + MX emission in one launch, the workgroups of a row panel exchanging row
+    statistics: csrc/gemm8.hip) against the pair it replaces in the QST_PREC_FP8 forward -- qst_gemm_nt_f8 with the residual
+    epilogue, then qst_ln_fwd_mx_train; its MXFP8 output must be bit for bit what mx_quant makes of its own bf16 output."""
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g) * 2)
+    B = torch.randn(N, K, generator=g) * 0.05
+    bias, resid = (torch.randn(N, generator=g) * 0.3).cuda(), torch.randn(M, N, generator=g).cuda()
+    gamma, beta = (1 + 0.2 * torch.randn(N, generator=g)).cuda(), (0.3 * torch.randn(N, generator=g)).cuda()
+    (Aq, As), (Bq, Bs) = quant_dev(lib, A), quant_dev(lib, B)
+
+    def outs():
+        return (torch.empty(M, N, device="cuda"), torch.empty(M, N, dtype=torch.bfloat16, device="cuda"),
+                torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), torch.empty(M, device="cuda"),
+                torch.empty(M, N, dtype=torch.uint8, device="cuda"), torch.zeros(N // 128 * M * 4, dtype=torch.uint8, device="cuda"))
+    s = torch.empty(M, N, device="cuda")
+    _lib.check(lib.qst_gemm_nt_f8(gemm_args(A=Aq, B=Bq, aux=As, bscale=Bs, C=s, bias=bias, resid=resid, M=M, N=N, K=K, lda=K, ldb=K,
+                                            ldc=N, ldr=N), 1, st()))
+    y0, yb0, xh0, rs0, yq0, ys0 = outs()
+    _lib.check(lib.qst_ln_fwd_mx_train(s.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-12, M, N, y0.data_ptr(), yb0.data_ptr(),
+                                       xh0.data_ptr(), rs0.data_ptr(), yq0.data_ptr(), ys0.data_ptr(), st()))
+    y1, yb1, xh1, rs1, yq1, ys1 = outs()
+    e = _lib.QstLnEpi()
+    e.gamma, e.beta, e.eps, e.xhat, e.rstd = gamma.data_ptr(), beta.data_ptr(), 1e-12, xh1.data_ptr(), rs1.data_ptr()
+    _lib.check(lib.qst_gemm_nt8_f8_ln(gemm_args(A=Aq, B=Bq, aux=As, bscale=Bs, C=y1, C2=yb1, C3=yq1, C4=ys1, bias=bias, resid=resid,
+                                                M=M, N=N, K=K, lda=K, ldb=K, ldc=N, ldr=N), e, st()))
+    torch.testing.assert_close(y1, y0, rtol=1e-4, atol=2e-4)
+    torch.testing.assert_close(rs1, rs0, rtol=1e-4, atol=0)
+    torch.testing.assert_close(yb1.float(), yb0.float(), rtol=8e-3, atol=1e-2)
+    torch.testing.assert_close(xh1.float(), xh0.float(), rtol=8e-3, atol=1e-2)
+    qr, sr, _ = R.mx_quant(yb1.float().cpu())
+    assert torch.equal(yq1.cpu(), qr) and torch.equal(ys1.cpu(), stage_major(sr))
+    # inference: only y (f32) and its MXFP8 copy
+    y2, _, _, _, yq2, ys2 = outs()
+    e2 = _lib.QstLnEpi()
+    e2.gamma, e2.beta, e2.eps = gamma.data_ptr(), beta.data_ptr(), 1e-12
+    _lib.check(lib.qst_gemm_nt8_f8_ln(gemm_args(A=Aq, B=Bq, aux=As, bscale=Bs, C=y2, C3=yq2, C4=ys2, bias=bias, resid=resid, M=M, N=N,
+                                                K=K, lda=K, ldb=K, ldc=N, ldr=N), e2, st()))
+    assert torch.equal(y2, y1) and torch.equal(yq2, yq1) and torch.equal(ys2, ys1)
+    assert lib.qst_gemm_nt8_ln_timeouts() == 0
+
+
 @pytest.mark.parametrize("M,H", [(37, 768), (128, 384), (5, 1024)])
 def test_layernorm_mx_output_equals_quantising_its_bf16_output(lib, M, H):
     """qst_ln_fwd_mx / qst_embed_ln_fwd_mx: the MXFP8 copy must be bit for bit what qst_quant_mx (= the oracle's mx_quant)
@@ -237,6 +280,22 @@ def test_layernorm_mx_output_equals_quantising_its_bf16_output(lib, M, H):
     torch.testing.assert_close(y, ref, rtol=1e-5, atol=1e-5)
     qr, sr, _ = R.mx_quant(yb.float().cpu())
     assert torch.equal(yq.cpu(), qr) and torch.equal(ys.cpu(), stage_major(sr))
+
+
+_LN_FUSION = None        # HipEncoder.set_ln_fusion of the encoder the test below builds (None = by size: unfused at test sizes)
+
+
+@pytest.mark.parametrize("drop", [None, (0.1, 0.1)], ids=["eval", "train_mode_dropout"])
+def test_fp8_training_step_with_the_fused_layernorm_launches(drop):
+    """The same comparison with every projection + LayerNorm of the fp8 forward (qst_gemm_nt8_f8_ln: GEMM, LayerNorm and MX
+    emission in one launch) and every dgrad + LayerNorm backward (qst_gemm_nt8_ln mode 1) forced onto the fused launches that
+    configs[4] takes by size -- same oracle, same bounds."""
+    global _LN_FUSION
+    _LN_FUSION = 1
+    try:
+        test_fp8_training_step_against_the_mx_oracle("bert-base-uncased", 1, 384, 2, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), drop)
+    finally:
+        _LN_FUSION = None
 
 
 @pytest.mark.parametrize("name,B,L,layers,wkw,drop", [
@@ -283,6 +342,8 @@ def test_fp8_training_step_against_the_mx_oracle(name, B, L, layers, wkw, drop):
     enc = HipEncoder(cfg)
     enc.load_arena(arena)
     enc.ensure_train_state()
+    if _LN_FUSION is not None:
+        enc.set_ln_fusion(_LN_FUSION)
     if drop is not None:
         enc.set_dropout(drop[0], drop[1], seed)
     dev = [t.cuda() for t in (ids_t, mask_t, types_t)]

@@ -39,8 +39,13 @@ def main():
     rounds = int(sys.argv[7]) if len(sys.argv) > 7 else 4
     cfg = PRESETS[model]
     drop = float(os.environ.get("AB_DROPOUT", "0"))          # AB_DROPOUT=0.1: the reference's train()-mode step, as bench.py times it
+    # (the LR schedule of bench.py: 10,000 warm-up steps. Without it the trainer overfits its one batch within tens of steps,
+    #  the hinges go inactive, every gradient is exactly zero -- and a power-limited chip multiplies zeros 4-5% faster:
+    #  tools/step_timing_probe.py)
     tr = QuadrupletTrainer(cfg, arena=synthetic_params(cfg, seed=14), device="cuda:0", lr=2e-5, weight_decay=0.01, max_grad_norm=1.0,
-                           dropout=(drop, drop) if drop > 0 else None, dropout_seed=14)
+                           warmup_steps=10000, total_steps=1000000,
+                           dropout=(drop, drop) if drop > 0 else None, dropout_seed=14,
+                           precision=os.environ.get("AB_PRECISION", "bf16"))      # AB_PRECISION=fp8 | f16 | f16w | bf16x3
     batch = [torch.from_numpy(x).cuda() for x in synthetic_quadruplets(cfg, B, L, seed=14)]
     sw = getattr(tr.enc.lib, name[4:]) if name.startswith("lib:") else getattr(tr.enc, name)     # lib:qst_gemm8_stagger = a process-wide knob
     res = {v0: [[], []], v1: [[], []]}
