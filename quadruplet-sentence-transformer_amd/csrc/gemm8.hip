@@ -3,9 +3,13 @@
 //   gemm_nt8_kernel<EPI, TM, TN>     C[M,N] = A[M,K] . B[N,K]^T + the epilogues of qst_gemm_nt (QST_EPI_*); forward Linear and
 //                                    dgrad of the K >= 768 models (nn.Linear inside BertLayer / MPNetLayer, transformers
 //                                    modeling_bert.py:154-156, 282-293, 325-351)
+//   gemm_nt8_ln_kernel<MODE, DROPW, F8>   the same GEMM with the LayerNorm that follows it (mode 0: BertSelfOutput / BertOutput,
+//                                    modeling_bert.py:296-306, 340-351) or the LayerNorm backward that follows the dgrad (mode 1)
+//                                    in the epilogue, for rows of 2-4 tiles (H = 512 / 768 / 1024): the workgroups of a row
+//                                    panel exchange row statistics inside the launch; F8: on the fp8 matrix cores, + MX emission
 //   gemm_tn8_group_kernel<TM, TN>    all weight gradients of a layer in one launch: C_p[N_p, K_p] += A_p[M, N_p]^T . B_p[M, K_p]
 //                                    with fp32 atomics over per-XCD ranges of M, bias gradients as column sums of A
-// Both are one 512-thread workgroup per CU (128 KB of LDS, <= 256 registers). The epilogues work on registers only: a
+// All are one 512-thread workgroup per CU (128 KB of LDS, <= 256 registers). The epilogues work on registers only: a
 // v_permlane16_swap per accumulator register turns the 16x16 MFMA layout (4 consecutive columns per lane) into 8
 // consecutive columns per lane, so every global access is a 16-byte, row-contiguous piece (64 to 128 bytes per row and
 // instruction) -- no LDS staging, no workgroup barrier after the K loop.

@@ -32,6 +32,8 @@ def _dp_case(name):
     from quadruplet_sentence_transformer_amd.config import PRESETS
     if name == "minilm-c4":
         return replace(PRESETS["all-MiniLM-L6-v2"], num_layers=2, vocab_size=4096), 32, 128
+    if name == "h768-fused":      # bert-base layer dims, the GEMM + LayerNorm launches of configs[4] forced (set_ln_fusion(1)) on 1,536 rows
+        return replace(PRESETS["bert-base-uncased"], num_layers=2, vocab_size=4096), 1, 384
     return PRESETS[name], 4, 32
 
 
@@ -155,6 +157,8 @@ def _grads_after(cfg, arena, batch, mode, group=None):
     from quadruplet_sentence_transformer_amd.trainer import QuadrupletTrainer, gradient_buckets, staged_backward
     tr = QuadrupletTrainer(cfg, arena=arena, device="cuda:0")
     enc = tr.enc
+    if cfg.hidden_size == 768:
+        enc.set_ln_fusion(1)
     enc.grads.zero_()
     loss, _, g, saved, (ids, mask, types) = tr.forward_loss(*batch, training=True, want_grads=True)
     if mode == "oneshot":
@@ -166,7 +170,7 @@ def _grads_after(cfg, arena, batch, mode, group=None):
     return enc.grads.clone(), float(loss.item())
 
 
-def _one_rank_group_worker(rank, world, port, out_dir, backend="gloo"):
+def _one_rank_group_worker(rank, world, port, out_dir, backend="gloo", case="minilm-c4"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -180,7 +184,7 @@ def _one_rank_group_worker(rank, world, port, out_dir, backend="gloo"):
         dist.init_process_group(backend, rank=rank, world_size=world)
     from quadruplet_sentence_transformer_amd.synthetic import synthetic_params, synthetic_quadruplets
     torch.cuda.set_device(0)
-    cfg, B, L = _dp_case("minilm-c4")
+    cfg, B, L = _dp_case(case)
     arena = synthetic_params(cfg, seed=14, std=0.05, bias_std=0.02, ln_jitter=0.05)
     batch = [torch.from_numpy(x).cuda() for x in synthetic_quadruplets(cfg, B, L, seed=14, ragged=True)]
     g1, l1 = _grads_after(cfg, arena, batch, "oneshot")
@@ -191,8 +195,8 @@ def _one_rank_group_worker(rank, world, port, out_dir, backend="gloo"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("backend", ["gloo", "nccl"])
-def test_staged_backward_matches_one_call_on_the_fused_path(tmp_path, backend):
+@pytest.mark.parametrize("backend,case", [("gloo", "minilm-c4"), ("nccl", "minilm-c4"), ("nccl", "h768-fused")])
+def test_staged_backward_matches_one_call_on_the_fused_path(tmp_path, backend, case):
     """backend "nccl": the same through REAL RCCL works on the one GPU a test box has (world_size 1): dist.all_reduce(
     async_op=True) on RCCL's own stream, ordered against the kernels the C-ABI enqueues on torch's current stream, waited
     before the comparison -- the mechanism of configs[3], which gloo (a blocking host-staged reduce) never exercises.
@@ -201,11 +205,11 @@ def test_staged_backward_matches_one_call_on_the_fused_path(tmp_path, backend):
     grouped wgrad comes last -- must produce the gradients of the single call. fp32 atomics make the weight gradients
     order-dependent in the last bits, so equality is per-tensor relative L2 < 1e-5 (two one-call runs differ as much)."""
     from quadruplet_sentence_transformer_amd.config import build_layout
-    mp.spawn(_one_rank_group_worker, args=(1, _free_port(), str(tmp_path), backend), nprocs=1, join=True)
+    mp.spawn(_one_rank_group_worker, args=(1, _free_port(), str(tmp_path), backend, case), nprocs=1, join=True)
     g1, g2 = np.load(tmp_path / "g_oneshot.npy"), np.load(tmp_path / "g_staged.npy")
     l = np.load(tmp_path / "loss.npy")
     assert l[0] == l[1] and np.isfinite(g1).all() and np.isfinite(g2).all()
-    cfg, _, _ = _dp_case("minilm-c4")
+    cfg, _, _ = _dp_case(case)
     segs, _ = build_layout(cfg)
     for s in segs:
         a, b = g1[s.offset:s.offset + s.numel], g2[s.offset:s.offset + s.numel]
