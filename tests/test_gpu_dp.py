@@ -211,10 +211,14 @@ def test_staged_backward_matches_one_call_on_the_fused_path(tmp_path, backend, c
     assert l[0] == l[1] and np.isfinite(g1).all() and np.isfinite(g2).all()
     cfg, _, _ = _dp_case(case)
     segs, _ = build_layout(cfg)
+    gnorm = float(np.linalg.norm(g1))
     for s in segs:
         a, b = g1[s.offset:s.offset + s.numel], g2[s.offset:s.offset + s.numel]
         na = float(np.linalg.norm(a))
         assert na > 0 or "b_qkv" in s.name, s.name
+        if na <= 1e-6 * gnorm:          # zero by symmetry (bare bert-base: the last LayerNorm's beta shifts every embedding alike): rounding noise
+            assert float(np.linalg.norm(b)) <= 1e-5 * gnorm, s.name
+            continue
         assert float(np.linalg.norm(a - b)) <= 1e-5 * max(na, 1e-12) + 1e-9, s.name
 
 
