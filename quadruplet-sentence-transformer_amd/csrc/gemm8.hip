@@ -270,9 +270,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_f8_kernel(QstGemmArgs g) {
 // Mode 1 keeps dy in the accumulators and the tile's xhat fragment in LDS (lane-private slots in the 128 KB the K loop
 // has left) across the exchange; the gamma / beta gradient partials (column sums over the panel's rows) go to
 // partials[panel][2][N].
-#ifndef QST_LN8_HT1
-#define QST_LN8_HT1 2      // mode 1: 4 spills one to four registers per lane (A/B: tools/ln8_bench.py)
-#endif
 struct LnXchg {
     unsigned long long* gran;      // [ntm][ntn][256 rows][2] granules
     unsigned* ctl;                 // {epoch, workgroups done} of the buffer `gran` belongs to
@@ -365,10 +362,22 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstL
             bv[jp][0] = ok ? *(const f32x4*)(g.bias + nw + 32 * jp) : z4;
             bv[jp][1] = ok ? *(const f32x4*)(g.bias + nw + 32 * jp + 4) : z4;
         }
-        constexpr int HT = MODE == 0 ? 4 : QST_LN8_HT1;   // row-tiles whose residual (and xhat) rows are requested in one burst
+        constexpr int HT = 4;                   // row-tiles whose residual rows are requested in one burst
         f32x4 rv[HT][NP][2];
-        u32x4 xv[MODE == 1 ? HT : 1][NP];
-        const u32x4 zu = {0u, 0u, 0u, 0u};
+        if (MODE == 1) {
+            // the tile's xhat fragment goes straight into its lane-private LDS slots (the 128 KB the K loop has left), all 16
+            // LDS-DMAs of the wave at once, ahead of the residual bursts: no registers, one round trip for the whole tile
+            // (rows past M lie beyond the descriptor: zero fill)
+            const int rows_here = min(256, g.M - m0);
+            const __amdgpu_buffer_rsrc_t rx = g8p::rsrc((const op16*)e.xhat + (size_t)m0 * g.N, (uint32_t)rows_here * (uint32_t)g.N * 2u);
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jp = 0; jp < NP; ++jp)
+                    g8p::dma16(rx, smem + ((size_t)(i * NP + jp) * 512 + wave * 64) * 16,
+                               (uint32_t)(((rw + 16 * i) * g.N + (nw + 32 * jp)) * 2), 0u);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             if (i % HT == 0) {
@@ -382,10 +391,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstL
                         const float* p = g.resid + (size_t)m * g.ldr + n;
                         rv[k][jp][0] = ok ? ld_stream((const f32x4*)p) : z4;
                         rv[k][jp][1] = ok ? ld_stream((const f32x4*)(p + 4)) : z4;
-                        if (MODE == 1)
-                            xv[k][jp] = m < g.M ? ld_stream((const u32x4*)((const op16*)e.xhat + (size_t)m * g.N + n)) : zu;
                     }
                 }
+                if (MODE == 1 && i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the xhat DMAs (and this first burst) have landed
             }
             const int m = mw + 16 * i;
             float s1 = 0.f, s2 = 0.f;
@@ -420,8 +428,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstL
 #pragma unroll
                     for (int q = 0; q < 8; ++q) s1 += v[q];
                 } else {
-                    const u32x4 xq = xv[i % HT][jp];
-                    *(u32x4*)(smem + ((size_t)(i * NP + jp) * 512 + tid) * 16) = xq;       // lane-private stash for pass 2
+                    const u32x4 xq = *(const u32x4*)(smem + ((size_t)(i * NP + jp) * 512 + tid) * 16);   // this lane's slot (stays for pass 2)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float g0 = v[2 * q] * ga[jp][q >> 1][(2 * q) & 3], g1 = v[2 * q + 1] * ga[jp][q >> 1][(2 * q + 1) & 3];
