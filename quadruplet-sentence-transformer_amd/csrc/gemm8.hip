@@ -301,7 +301,7 @@ __device__ __forceinline__ void lnx_finish(unsigned* ctl) {
     const unsigned old = __hip_atomic_fetch_add((gu32*)(ctl + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == gridDim.x - 1) {
         __hip_atomic_store((gu32*)(ctl + 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store((gu32*)ctl, ep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((gu32*)ctl, ep + 1u == 0xFFFFFFFFu ? 0u : ep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tag = epoch + 1 is never 0
     }
 }
 
