@@ -16,11 +16,12 @@ quadruplet-loss kernel at random B, D, p, swap (all three reductions, values and
 the NT GEMM epilogues at random M, N, K and tilings; with `wgrad`: the TN weight-gradient GEMM; with `attn`: the bf16
 attention forward + backward at random (sequences, L, heads, d, position bias) (tests/test_gpu_kernels.py). With `fused`: the
 encoder check at MiniLM dims with at least 16,384 token rows (the LayerNorm-fused GEMMs and the 8-range wgrad run from there).
+With `ln768` / `ln768fp8`: mpnet-base / bert-base dims with the several-tiles-per-row GEMM + LayerNorm launches forced (bf16 check / fp8 training step).
 
 With `f16` / `f16w`: forward + backward on IEEE-half operands (QST_PREC_F16 / F16W) under the loss scale against fp32 autograd with
 the same dropout masks (tests/test_gpu_f16.py: check_against_fp32_autograd; gradient bound x 1.5).
 
-    python tools/fuzz_shapes.py [cases] [seed] [first case to run] [fp8 | fp8train | x3 | f16 | f16w | topk | loss | gemm | wgrad | attn | fused]"""
+    python tools/fuzz_shapes.py [cases] [seed] [first case to run] [fp8 | fp8train | x3 | f16 | f16w | topk | loss | gemm | wgrad | attn | fused | ln768 | ln768fp8]"""
 import os
 import random
 import re
@@ -105,9 +106,17 @@ def main():
             print(f"ok {i}: topk {mode} nq={nq} nc={nc} dim={dim} k={k}  ({time.time() - t0:.1f} s)", flush=True)
         return
     T.GRAD_LIMITS = {k: 1.5 * v for k, v in T.GRAD_LIMITS.items()}
+    # "ln768" / "ln768fp8": the H = 768 families with the GEMM + LayerNorm launches forced (set_ln_fusion(1): csrc/gemm8.hip,
+    # the workgroups of a row panel exchanging row statistics), bf16 training check / fp8 training step
+    ln768 = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] in ("ln768", "ln768fp8") else None
+    if ln768 == "ln768fp8":
+        fp8train = True
+        T8._LN_FUSION = 1
     big = len(sys.argv) > 4 and sys.argv[4] == "fused"      # M >= 16,384 token rows at H = 384: the LayerNorm-fused GEMMs, the
     for i in range(cases):                                  # 8-range wgrad and (L <= 128) the single-workgroup attention backward
         fam = rng.choice(["all-MiniLM-L6-v2", "all-mpnet-base-v2", "bert-base-uncased"])
+        if ln768:
+            fam = rng.choice(["all-mpnet-base-v2", "bert-base-uncased"])
         layers = rng.choice([1, 2])
         L = 32 * rng.randint(1, 16)
         B = rng.randint(1, 6 if L <= 256 else 2)
@@ -152,7 +161,7 @@ def main():
             print(f"ok {i} (x3 forward + backward)  ({time.time() - t0:.1f} s){note}", flush=True)
             continue
         T.run_case("fuzz", B, L, True, dict(std=0.03, bias_std=0.02, ln_jitter=0.05), emb_atol_vs_bf16_oracle=1.5e-3,
-                   scale_by_emb=not cfg.normalize, dropout=drop)
+                   scale_by_emb=not cfg.normalize, dropout=drop, ln_fusion=1 if ln768 else None)
         print(f"ok {i}: {fam} layers={layers} B={B} L={L} dropout={drop}  ({time.time() - t0:.1f} s)", flush=True)
 
 
