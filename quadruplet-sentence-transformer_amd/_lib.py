@@ -211,6 +211,10 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise QstError(f"HIP extension not built: {LIB_PATH} is missing (no CPU fallback exists). "
                        f"Run `make -C {os.path.join(_HERE, 'csrc')}` or __graft_entry__.build().")
+    # torch first: its wheel bundles a HIP runtime, and libqst.so must bind to THAT copy (device pointers and streams come
+    # from torch). Loaded the other way round -- libqst.so pulling /opt/rocm's runtime in before torch is imported -- the
+    # process holds two runtimes and the second one to initialise sees no device (`python __graft_entry__.py smoke`, round 5).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
