@@ -109,12 +109,14 @@ typedef struct {
     float* partials;
 } QstLnEpi;
 int qst_gemm_nt_ln_supported(int N);
-int qst_gemm_nt_ln_block_rows(int N);    /* rows per `partials` block of mode 1: 128 at N = 384, 256 above */
+int qst_gemm_nt_ln_block_rows(int N);    /* rows per `partials` block of mode 1: 128 at N = 384; above, see the _m form */
+int qst_gemm_nt_ln_block_rows_m(int N, int M);   /* ... exactly: above N = 384 the tile (256 x 256 or 128 x 384) depends on M */
 int qst_gemm_nt_ln(const QstGemmArgs* a, const QstLnEpi* ln, int mode, void* stream);
 /* The same with rows wider than one tile, N = 512 / 768 / 1024 (csrc/gemm8.hip: 256 x 256 tiles on the 8-phase loop, the
  * N / 256 workgroups of a 256-row panel exchange the row statistics inside the launch); qst_gemm_nt_ln forwards here.
- * partials f32 [ceil(M/256)][2][N]; no B2. qst_gemm_nt8_ln_timeouts(): 0 unless an exchange of this process ever gave up. */
+ * partials f32 [ceil(M / qst_gemm_nt8_ln_block_rows(M, N))][2][N]; no B2. qst_gemm_nt8_ln_timeouts(): 0 unless an exchange of this process ever gave up. */
 int qst_gemm_nt8_ln_supported(int N);
+int qst_gemm_nt8_ln_block_rows(int M, int N);   /* 256, or 128 where the 128 x 384 tile is taken (N = 768, 32,768 <= M < 43,691) */
 int qst_gemm_nt8_ln(const QstGemmArgs* a, const QstLnEpi* ln, int mode, void* stream);
 int qst_gemm_nt8_ln_timeouts(void);
 /* Mode 0 of the same on the fp8 matrix cores: operands as qst_gemm_nt_f8 (A, B e4m3; a->aux / a->bscale their E8M0 scales;
@@ -361,6 +363,7 @@ int qst_shadow_matrix(const float* src, int rows, int cols, void* dst_bf16, void
 int qst_gemm_nt_f16(const QstGemmArgs* a, int epi, void* stream);
 int qst_gemm_nt_ln_f16(const QstGemmArgs* a, const QstLnEpi* ln, int mode, void* stream);
 int qst_gemm_nt8_ln_supported_f16(int N);
+int qst_gemm_nt8_ln_block_rows_f16(int M, int N);
 int qst_gemm_nt8_ln_f16(const QstGemmArgs* a, const QstLnEpi* ln, int mode, void* stream);
 int qst_gemm_nt8_ln_timeouts_f16(void);
 int qst_ffn_chain_f16(const QstFfnArgs* a, const QstLnEpi* ln, int mode, void* stream);

@@ -111,6 +111,8 @@ SIGNATURES = {
     "qst_gemm_nt_ln_supported": (C.c_int, [C.c_int]),
     "qst_gemm_nt_ln": (C.c_int, [C.POINTER(QstGemmArgs), C.POINTER(QstLnEpi), C.c_int, vp]),
     "qst_gemm_nt_ln_block_rows": (C.c_int, [C.c_int]),
+    "qst_gemm_nt_ln_block_rows_m": (C.c_int, [C.c_int, C.c_int]),
+    "qst_gemm_nt8_ln_block_rows": (C.c_int, [C.c_int, C.c_int]),
     "qst_gemm8_stagger": (C.c_int, [C.c_int]),
     "qst_gemm_nt8_ln_supported": (C.c_int, [C.c_int]),
     "qst_gemm_nt8_ln": (C.c_int, [C.POINTER(QstGemmArgs), C.POINTER(QstLnEpi), C.c_int, vp]),
@@ -188,7 +190,7 @@ SIGNATURES = {
 }
 
 # f16-operand twins (include/qst_kernels.h, "f16-operand twins"): same signatures, IEEE half where the original has bf16
-F16_TWINS = ["qst_gemm_nt", "qst_gemm_nt_ln", "qst_gemm_nt8_ln_supported", "qst_gemm_nt8_ln", "qst_gemm_nt8_ln_timeouts", "qst_ffn_chain", "qst_gemm_tn", "qst_gemm_tn_group", "qst_gemm_nt8_supported",
+F16_TWINS = ["qst_gemm_nt", "qst_gemm_nt_ln", "qst_gemm_nt8_ln_supported", "qst_gemm_nt8_ln_block_rows", "qst_gemm_nt8_ln", "qst_gemm_nt8_ln_timeouts", "qst_ffn_chain", "qst_gemm_tn", "qst_gemm_tn_group", "qst_gemm_nt8_supported",
              "qst_gemm_nt8", "qst_gemm_tn8_group", "qst_embed_ln_fwd", "qst_embed_ln_fwd_drop", "qst_ln_fwd", "qst_ln_bwd",
              "qst_ln_bwd_drop", "qst_attention_fwd", "qst_attention_bwd", "qst_attention_fwd_ex", "qst_attention_bwd_ex",
              "qst_shadow_all", "qst_shadow_matrix"]

@@ -1339,6 +1339,8 @@ extern "C" int qst_gemm_nt_ln_supported(int N) { return (N == LN_N || qst_gemm_n
 // rows per partial-sum block of mode 1 (the stride of `partials`): one full-row tile of 128 rows at N = 384, a 256-row panel
 // of 256-column tiles above (gemm8.hip)
 extern "C" int qst_gemm_nt_ln_block_rows(int N) { return N == LN_N ? 128 : 256; }
+// ... exactly: above N = 384 the tile -- and with it the block height -- depends on M too (gemm8.hip: 256 x 256 or 128 x 384)
+extern "C" int qst_gemm_nt_ln_block_rows_m(int N, int M) { return N == LN_N ? 128 : qst_gemm_nt8_ln_block_rows(M, N); }
 #endif  // !QST_OP_F16
 
 extern "C" int QST_K(qst_gemm_nt_ln)(const QstGemmArgs* a, const QstLnEpi* ln, int mode, void* stream) {

@@ -308,40 +308,44 @@ __device__ __forceinline__ void lnx_finish(unsigned* ctl) {
 // F8: both operands MXFP8 (operands as gemm_nt8_f8_kernel: g.aux / g.bscale = their E8M0 scales), mode 0 only, and the
 // normalised output leaves a fourth time, as MXFP8 (g.C3 = e4m3 [M, N], g.C4 = scales, stage-major), quantised from the
 // 16-bit-rounded values exactly as qst_ln_fwd_mx_train does it -- the A operand of the next fp8 GEMM (QST_PREC_FP8 forward).
-template <bool F8> struct LnOpsOf { using type = g8p::NtOps<8, 4>; };
-template <> struct LnOpsOf<true> { using type = g8p::NtOpsF8<8, 4>; };
+// TM, TN: 8, 4 = the 256 x 256 tile (two tiles per CU from M = 43,691 at H = 768); 4, 6 = 128 x 384, which gives M = 32,768
+// token rows at H = 768 (configs[2]) 512 whole tiles -- two per CU -- where 256 x 256 leaves 384, a round and a half.
+template <bool F8, int TM, int TN> struct LnOpsOf { using type = g8p::NtOps<TM, TN>; };
+template <int TM, int TN> struct LnOpsOf<true, TM, TN> { using type = g8p::NtOpsF8<TM, TN>; };
 
-template <int MODE, int DROPW, bool F8 = false>
+template <int MODE, int DROPW, bool F8 = false, int TM = 8, int TN = 4>
 __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstLnEpi e, LnXchg x, int stagger) {
     static_assert(!F8 || MODE == 0, "the fp8 form is a forward kernel");
+    static_assert(TM % 4 == 0 && TN % 2 == 0, "tile geometry");
+    constexpr int BM = 32 * TM, BN = 64 * TN, NP = TN / 2, WC = BN / 4, KR = TM / 4;   // WC: columns per wave; KR: rows per polling lane
+    constexpr int RED_B = BM * 4 * 2 * 4, STATS_B = BM * 2 * 4;
     op_saturate(MODE == 0);
     if (blockIdx.x < 256) stagger_start(stagger, (blockIdx.x & 7) * 32 + (blockIdx.x >> 3) / x.ntn);   // one phase per row panel
-    using OPS = typename LnOpsOf<F8>::type;
-    constexpr int TM = 8, NP = 2;
+    using OPS = typename LnOpsOf<F8, TM, TN>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bx = blockIdx.x & 7, bj = blockIdx.x >> 3;
     const int panel = bx * x.ppx + bj / x.ntn, tile_n = bj % x.ntn;
     if (bj / x.ntn >= x.ppx || panel >= x.ntm) { lnx_finish(x.ctl); return; }
-    const int m0 = panel * 256, n0 = tile_n * 256;
+    const int m0 = panel * BM, n0 = tile_n * BN;
     OPS o;
     if constexpr (F8)
-        o.init((const uint8_t*)g.A + (size_t)m0 * g.lda, g.lda, min(256, g.M - m0), (const uint8_t*)g.aux, g.M, m0,
-               (const uint8_t*)g.B + (size_t)n0 * g.ldb, g.ldb, 256, (const uint8_t*)g.bscale, g.N, n0, g.K, smem);
+        o.init((const uint8_t*)g.A + (size_t)m0 * g.lda, g.lda, min(BM, g.M - m0), (const uint8_t*)g.aux, g.M, m0,
+               (const uint8_t*)g.B + (size_t)n0 * g.ldb, g.ldb, BN, (const uint8_t*)g.bscale, g.N, n0, g.K, smem);
     else
-        o.init((const op16*)g.A + (size_t)m0 * g.lda, g.lda, min(256, g.M - m0), (const op16*)g.B + (size_t)n0 * g.ldb, g.ldb,
-               256, g.K, smem);
+        o.init((const op16*)g.A + (size_t)m0 * g.lda, g.lda, min(BM, g.M - m0), (const op16*)g.B + (size_t)n0 * g.ldb, g.ldb,
+               BN, g.K, smem);
     g8p::kloop8(o, o.nk);                       // returns behind a workgroup barrier, no DMA outstanding: the LDS is free
 
     const int tid = threadIdx.x, lane = tid & 63, gq = lane >> 4, c16 = lane & 15;
     // the tag of this launch's granules = the buffer's epoch + 1 (0 = never written); requested now, used after pass 1
     unsigned tag = 0;
     if (o.wc == 0) tag = __hip_atomic_load((gu32*)x.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    const int rw = o.wr * 128 + c16;            // + 16 i: this lane's rows inside the panel
+    const int rw = o.wr * (BM / 2) + c16;       // + 16 i: this lane's rows inside the panel
     const int mw = m0 + rw;
-    const int nw = n0 + o.wc * 64 + pair_col(gq);      // + 32 jp: 8 consecutive columns
+    const int nw = n0 + o.wc * WC + pair_col(gq);      // + 32 jp: 8 consecutive columns
     char* scratch = smem + (MODE == 1 ? g8p::LDS_BYTES : 0);
-    float* red = (float*)scratch;                        // [256 rows][4 wave columns][2]
-    float* stats = (float*)(scratch + LNX_RED);          // [256 rows][2]
+    float* red = (float*)scratch;                        // [BM rows][4 wave columns][2]
+    float* stats = (float*)(scratch + RED_B);            // [BM rows][2]
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     DropCtx dc = DropCtx{0u, 0u, 1.f};
     if (DROPW != 0) dc = drop_ctx(g.drop);
@@ -362,13 +366,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstL
             bv[jp][0] = ok ? *(const f32x4*)(g.bias + nw + 32 * jp) : z4;
             bv[jp][1] = ok ? *(const f32x4*)(g.bias + nw + 32 * jp + 4) : z4;
         }
-        constexpr int HT = 4;                   // row-tiles whose residual rows are requested in one burst
+        constexpr int HT = NP == 2 ? 4 : 2;     // row-tiles whose residual rows are requested in one burst (HT NP 8 registers)
         f32x4 rv[HT][NP][2];
         if (MODE == 1) {
             // the tile's xhat fragment goes straight into its lane-private LDS slots (the 128 KB the K loop has left), all 16
             // LDS-DMAs of the wave at once, ahead of the residual bursts: no registers, one round trip for the whole tile
             // (rows past M lie beyond the descriptor: zero fill)
-            const int rows_here = min(256, g.M - m0);
+            const int rows_here = min(BM, g.M - m0);
             const __amdgpu_buffer_rsrc_t rx = g8p::rsrc((const op16*)e.xhat + (size_t)m0 * g.N, (uint32_t)rows_here * (uint32_t)g.N * 2u);
             const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
@@ -441,10 +445,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstL
             }
             s1 = xg_sum(s1);
             if (MODE == 0) {
-                const float mu = s1 * (1.f / 64.f);
+                const float mu = s1 * (1.f / (float)WC);
                 float q2 = 0.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { const float d = o.acc[i][j][q] - mu; q2 += d * d; }
                 s1 = mu;
@@ -460,39 +464,39 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstL
     }
     __syncthreads();
 
-    // ------------------------------------------------------------ exchange (waves (wr, 0): rows wr 128 + [0, 128), two per lane)
+    // ------------------------------------------------------------ exchange (waves (wr, 0): rows wr BM/2 + [0, BM/2), KR per lane)
     if (o.wc == 0) {
-        float ta[2], tb[2];                     // this tile's pair for the lane's two rows
-        int row[2];
+        float ta[KR], tb[KR];                   // this tile's pair for the lane's rows
+        int row[KR];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            row[k] = o.wr * 128 + 16 * (2 * gq + k) + c16;
+        for (int k = 0; k < KR; ++k) {
+            row[k] = o.wr * (BM / 2) + 16 * (KR * gq + k) + c16;
             const f32x4 p0 = *(const f32x4*)(red + row[k] * 8), p1 = *(const f32x4*)(red + row[k] * 8 + 4);
             if (MODE == 0) {
                 const float mu = (p0[0] + p0[2] + p1[0] + p1[2]) * 0.25f;
                 const float d0 = p0[0] - mu, d1 = p0[2] - mu, d2 = p1[0] - mu, d3 = p1[2] - mu;
                 ta[k] = mu;
-                tb[k] = (p0[1] + p0[3] + p1[1] + p1[3]) + 64.f * (d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+                tb[k] = (p0[1] + p0[3] + p1[1] + p1[3]) + (float)WC * (d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
             } else {
                 ta[k] = p0[0] + p0[2] + p1[0] + p1[2];
                 tb[k] = p0[1] + p0[3] + p1[1] + p1[3];
             }
-            unsigned long long* gp = x.gran + (((size_t)panel * x.ntn + tile_n) * 256 + row[k]) * 2;
+            unsigned long long* gp = x.gran + (((size_t)panel * x.ntn + tile_n) * BM + row[k]) * 2;
             put_granule(gp, tag, ta[k]);
             put_granule(gp + 1, tag, tb[k]);
         }
-        float oa[2][4], ob[2][4];               // every tile's pair (ntn <= 4)
+        float oa[KR][4], ob[KR][4];             // every tile's pair (ntn <= 4)
         bool done = false;
 #pragma unroll 1
         for (unsigned spins = 0; !done; ++spins) {
             bool ok = true;
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
+            for (int k = 0; k < KR; ++k)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     if (t >= x.ntn) continue;
                     if (t == tile_n) { oa[k][t] = ta[k]; ob[k][t] = tb[k]; continue; }
-                    const gu64* gp = (const gu64*)(x.gran + (((size_t)panel * x.ntn + t) * 256 + row[k]) * 2);
+                    const gu64* gp = (const gu64*)(x.gran + (((size_t)panel * x.ntn + t) * BM + row[k]) * 2);
                     const unsigned long long u0 = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const unsigned long long u1 = __hip_atomic_load(gp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ok = ok && (unsigned)(u0 >> 32) == tag && (unsigned)(u1 >> 32) == tag;
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstL
             }
         }
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < KR; ++k) {
             f32x2 st;
             if (MODE == 0) {
                 float mu = 0.f;
@@ -518,7 +522,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstL
                 mu /= (float)x.ntn;
                 float m2 = 0.f;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) if (t < x.ntn) { const float d = oa[k][t] - mu; m2 += ob[k][t] + 256.f * d * d; }
+                for (int t = 0; t < 4; ++t) if (t < x.ntn) { const float d = oa[k][t] - mu; m2 += ob[k][t] + (float)BN * d * d; }
                 st[0] = mu;
                 st[1] = rsqrtf(m2 / (float)g.N + e.eps);              // biased variance, as nn.LayerNorm
             } else {
@@ -601,7 +605,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstL
             }
         }
     } else {
-        float* pr = (float*)(scratch + LNX_RED + LNX_STATS);           // [2 wave rows][2][256 columns]
+        float* pr = (float*)(scratch + RED_B + STATS_B);               // [2 wave rows][2][BN columns]
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp) {
             const int n = nw + 32 * jp;
@@ -654,17 +658,19 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstL
                 for (int q = 0; q < 8; ++q) {
                     const float a = row16_sum(ag[q]), b = row16_sum(ab[q]);
                     if (c16 == 0) {
-                        const int col = o.wc * 64 + pair_col(gq) + 32 * jp + q;
-                        pr[(o.wr * 2 + 0) * 256 + col] = a;
-                        pr[(o.wr * 2 + 1) * 256 + col] = b;
+                        const int col = o.wc * WC + pair_col(gq) + 32 * jp + q;
+                        pr[(o.wr * 2 + 0) * BN + col] = a;
+                        pr[(o.wr * 2 + 1) * BN + col] = b;
                     }
                 }
             }
         }
         if (e.partials) {
             __syncthreads();
-            const int which = tid >> 8, col = tid & 255;
-            e.partials[((size_t)panel * 2 + which) * g.N + n0 + col] = pr[which * 256 + col] + pr[(2 + which) * 256 + col];
+            for (int idx = tid; idx < 2 * BN; idx += 512) {
+                const int which = idx / BN, col = idx - which * BN;
+                e.partials[((size_t)panel * 2 + which) * g.N + n0 + col] = pr[which * BN + col] + pr[(2 + which) * BN + col];
+            }
         }
     }
     lnx_finish(x.ctl);
@@ -931,16 +937,27 @@ extern "C" int QST_K(qst_gemm_nt8_ln_timeouts)(void) {
 }
 
 constexpr int kLnStagger = 40000;     // cycles; see qst_gemm8_stagger
-template <int MODE, int DROPW, bool F8 = false>
+// Which tile a (M, N) problem takes: 0 = 256 x 256, 1 = 128 x 384. The first from two tiles per CU on (and wherever 384 does not
+// divide N); the second where it -- and not the first -- gives two tiles per CU (N = 768: 32,768 <= M < 43,691).
+static int ln8_tile(int M, int N) {
+    const int64_t t256 = (int64_t)((M + 255) / 256) * (N / 256);
+    if (N % 256 == 0 && (t256 >= 512 || N % 384 != 0)) return 0;
+    const int64_t t384 = (int64_t)((M + 127) / 128) * (N / 384);
+    return (N % 384 == 0 && (t384 >= 512 || N % 256 != 0)) ? 1 : 0;
+}
+extern "C" int QST_K(qst_gemm_nt8_ln_block_rows)(int M, int N) { return ln8_tile(M, N) ? 128 : 256; }
+
+template <int MODE, int DROPW, bool F8 = false, int TM = 8, int TN = 4>
 static int launch_nt8_ln(const QstGemmArgs* a, const QstLnEpi* ln, hipStream_t st) {
+    constexpr int BM = 32 * TM, BN = 64 * TN;
     constexpr int lds = F8 ? (int)g8p::NtOpsF8<8, 4>::LDS_TOTAL : (MODE == 0 ? LNX_LDS0 : LNX_LDS1);
     static QstLdsAttr attr;
-    if (int rc = qst_ensure_lds(attr, (const void*)gemm_nt8_ln_kernel<MODE, DROPW, F8>, lds)) return rc;
+    if (int rc = qst_ensure_lds(attr, (const void*)gemm_nt8_ln_kernel<MODE, DROPW, F8, TM, TN>, lds)) return rc;
     LnXchg x{};
-    x.ntm = (a->M + 255) / 256; x.ntn = a->N / 256; x.ppx = (x.ntm + 7) / 8;
-    const size_t bytes = (size_t)x.ntm * x.ntn * 256 * 2 * sizeof(unsigned long long);
+    x.ntm = (a->M + BM - 1) / BM; x.ntn = a->N / BN; x.ppx = (x.ntm + 7) / 8;
+    const size_t bytes = (size_t)x.ntm * x.ntn * BM * 2 * sizeof(unsigned long long);
     if (int rc = lnx_get(st, bytes, x)) return rc;
-    gemm_nt8_ln_kernel<MODE, DROPW, F8><<<dim3(8 * x.ntn * x.ppx), dim3(512), lds, st>>>(*a, *ln, x, x.ntm * x.ntn > 512 ? (qst_gemm8_stagger_get() < 0 ? kLnStagger : qst_gemm8_stagger_get()) : 0);
+    gemm_nt8_ln_kernel<MODE, DROPW, F8, TM, TN><<<dim3(8 * x.ntn * x.ppx), dim3(512), lds, st>>>(*a, *ln, x, x.ntm * x.ntn > 512 ? (qst_gemm8_stagger_get() < 0 ? kLnStagger : qst_gemm8_stagger_get()) : 0);
     QST_LAUNCH_CHECK();
     return QST_OK;
 }
@@ -954,13 +971,18 @@ extern "C" int QST_K(qst_gemm_nt8_ln)(const QstGemmArgs* a, const QstLnEpi* ln, 
     if (mode == 1 && (!ln->xhat || !ln->rstd)) return QST_ERR_BAD_ARG;
     if (!QST_K(qst_gemm_nt8_ln_supported)(a->N) || a->B2) return QST_ERR_UNSUPPORTED;
     if (a->K % 64 != 0 || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->ldc % 8 != 0 || (a->resid && a->ldr % 4 != 0)) return QST_ERR_UNSUPPORTED;
-    if ((int64_t)256 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)256 * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
+    if ((int64_t)256 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)384 * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
     const bool drop = a->drop.thr16 && a->drop.state;
     if (drop) {
         if (a->drop.thr16 > 65535u || (int64_t)a->M * a->N >= ((int64_t)1 << 32)) return QST_ERR_UNSUPPORTED;
         if (mode == 0 ? a->drop_where != 1 : (a->drop_where != 2 && a->drop_where != 3)) return QST_ERR_BAD_ARG;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (ln8_tile(a->M, a->N)) {
+        if (mode == 0) return drop ? launch_nt8_ln<0, 1, false, 4, 6>(a, ln, st) : launch_nt8_ln<0, 0, false, 4, 6>(a, ln, st);
+        if (!drop) return launch_nt8_ln<1, 0, false, 4, 6>(a, ln, st);
+        return a->drop_where == 2 ? launch_nt8_ln<1, 2, false, 4, 6>(a, ln, st) : launch_nt8_ln<1, 3, false, 4, 6>(a, ln, st);
+    }
     if (mode == 0) return drop ? launch_nt8_ln<0, 1>(a, ln, st) : launch_nt8_ln<0, 0>(a, ln, st);
     if (!drop) return launch_nt8_ln<1, 0>(a, ln, st);
     return a->drop_where == 2 ? launch_nt8_ln<1, 2>(a, ln, st) : launch_nt8_ln<1, 3>(a, ln, st);

@@ -525,13 +525,13 @@ int ffn_chain(const OpKernels& K, const void* A, const void* B1, const void* B2,
 
 constexpr int kFuseLnMinRows = 16384;      // token rows from which the fused GEMM+LayerNorm kernels win (see forward)
 // ... and for H = 512 / 768 / 1024, where a row spans several 256-column tiles whose workgroups exchange the row statistics
-// (gemm8.hip): from two tiles per CU on. Measured at H = 768 (tools/ln8_bench.py, fused against the GEMM + row-kernel pair):
+// (gemm8.hip): from two tiles per CU on (256 x 256, or 128 x 384 where only that gives two). Measured at H = 768 (tools/ln8_bench.py, fused against the GEMM + row-kernel pair):
 // M = 49,152: forward -6 ... -10%, backward -8 ... -9%; M = 196,608: forward -6 ... -10%, backward -13 ... -19%.
 static bool fuse_ln_rows(int H, int M, int mode) {
     if (!qst_gemm_nt_ln_supported(H) || mode == 2) return false;
     if (mode == 1) return true;
     if (qst_gemm_nt_ln_block_rows(H) == 128) return M >= kFuseLnMinRows;
-    return (int64_t)((M + 255) / 256) * (H / 256) >= 512;
+    return (int64_t)((M + 255) / 256) * (H / 256) >= 512 || (H % 384 == 0 && (int64_t)((M + 127) / 128) * (H / 384) >= 512);
 }
 
 #define QST_TRY(expr) do { int _rc = (expr); if (_rc != QST_OK) return _rc; } while (0)
@@ -1170,7 +1170,7 @@ extern "C" int qst_encoder_backward_stage(qst_encoder* e, const int64_t* ids, co
     const bool dropping = thr.hidden != 0 || thr.attn != 0;
     const void* dst8 = sv + p.dropst;
     const bool fuse_ffn = fuse_ln && !dropping && (e->ffn_chain & 4) && qst_ffn_chain_supported(H, I) != 0;
-    const int fused_rows = (M + qst_gemm_nt_ln_block_rows(H) - 1) / qst_gemm_nt_ln_block_rows(H);
+    const int fused_rows = (M + qst_gemm_nt_ln_block_rows_m(H, M) - 1) / qst_gemm_nt_ln_block_rows_m(H, M);
     auto hdrop = [&](uint32_t site, QstDrop& d) -> const QstDrop* {          // hidden-state mask of `site`, or none
         if (!dropping || !thr.hidden) return nullptr;
         d = drop_of(thr, dst8, false, site);

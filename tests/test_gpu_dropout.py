@@ -108,7 +108,7 @@ def test_row_kernels_apply_the_mask(lib, M, H):
     assert torch.equal(masked_out[0], plain[0]) and torch.equal(masked_out[1], (plain[0] * mk).to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("M,K,N", [(300, 384, 384), (1000, 1536, 384), (700, 768, 768), (1300, 3072, 768)])
+@pytest.mark.parametrize("M,K,N", [(300, 384, 384), (1000, 1536, 384), (700, 768, 768), (1300, 3072, 768), (33100, 128, 768)])
 def test_projection_epilogues_apply_the_mask(lib, M, K, N):
     """C = (A.B^T + bias) * mask + resid: the plain fp32 epilogue and the LayerNorm-fused one (forward; N = 768: the
     several-tiles-per-row form); the fused LayerNorm backward with the mask on its bf16 result (where 2) or on the incoming
@@ -147,7 +147,7 @@ def test_projection_epilogues_apply_the_mask(lib, M, K, N):
     xhat = bfr(torch.randn(M, N, generator=g)); rstd = torch.rand(M, generator=g) + 0.5
     xhd, rsd = xhat.to(torch.bfloat16).cuda(), rstd.cuda()
     ln2 = _lib.QstLnEpi()
-    br = lib.qst_gemm_nt_ln_block_rows(N)
+    br = lib.qst_gemm_nt_ln_block_rows_m(N, M)
     part = torch.zeros((M + br - 1) // br, 2, N, device="cuda")
     ln2.gamma, ln2.xhat, ln2.rstd, ln2.partials = gd.data_ptr(), xhd.data_ptr(), rsd.data_ptr(), part.data_ptr()
 

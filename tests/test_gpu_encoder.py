@@ -277,6 +277,39 @@ def test_layernorm_fused_across_the_tiles_of_a_row_h768(base, L, drop):
         del PRESETS["h768-2l"]
 
 
+def test_layernorm_fused_on_the_128x384_tile_in_the_encoder():
+    """M = 32,768 token rows at H = 768 (configs[2]'s row count): the size rule takes the GEMM + LayerNorm launches on their
+    128 x 384 tile (two tiles per CU; 256 x 256 would leave a round and a half). One bert-base layer, 256 sequences x 128
+    tokens, dropout on: embeddings and every gradient of the fused path (set_ln_fusion(0): by size) against the GEMM +
+    row-kernel pair (set_ln_fusion(2)) on the same inputs and masks."""
+    from dataclasses import replace
+    cfg = replace(PRESETS["bert-base-uncased"], num_layers=1, vocab_size=4096)
+    L, nseq = 128, 256
+    arena = synthetic_params(cfg, seed=16, std=0.03, bias_std=0.02, ln_jitter=0.05)
+    ids, mask, types = [torch.from_numpy(x).view(nseq, L).cuda() for x in synthetic_quadruplets(cfg, nseq // 4, L, seed=16, ragged=True)]
+    lib = _lib.load()
+    assert lib.qst_gemm_nt_ln_block_rows_m(768, nseq * L) == 128 and lib.qst_gemm_nt_ln_block_rows_m(768, 196608) == 256
+    out = {}
+    for mode in (2, 0):
+        enc = HipEncoder(cfg)
+        enc.load_arena(arena)
+        enc.set_dropout(0.1, 0.1, 21)
+        enc.set_ln_fusion(mode)
+        enc.ensure_train_state()
+        emb, _, saved = enc.forward(ids, mask, types, training=True)
+        ge = torch.randn(emb.shape, generator=torch.Generator().manual_seed(3)).cuda()
+        enc.grads.zero_()
+        enc.backward(ids, mask, types, ge, saved)
+        torch.cuda.synchronize()
+        out[mode] = (emb.clone(), enc.grads.clone())
+        del enc
+    sc, gs = out[2][0].abs().max().item(), out[2][1].abs().max().item()
+    de, dg = (out[0][0] - out[2][0]).abs().max().item(), (out[0][1] - out[2][1]).abs().max().item()
+    print(f"[ln-fusion 128x384] max|d emb| {de:.2e} of {sc:.2e}, max|d grad| {dg:.2e} of {gs:.2e}")
+    assert de <= 4e-4 * sc and dg <= 1e-2 * gs
+    assert lib.qst_gemm_nt8_ln_timeouts() == 0
+
+
 @pytest.mark.parametrize("name,B,L,ragged,wkw,drop", [
     ("tiny-bert", 3, 64, True, dict(std=0.08, bias_std=0.05, ln_jitter=0.1), None),
     ("tiny-mpnet", 2, 64, True, dict(std=0.08, bias_std=0.05, ln_jitter=0.1), None),

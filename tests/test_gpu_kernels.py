@@ -260,7 +260,8 @@ def test_layernorm_fwd_bwd(lib, op, M, H):
 
 @pytest.mark.parametrize("M,K,N", [(128, 64, 384), (300, 384, 384), (1000, 1536, 384), (4096, 1152, 384),
                                    (300, 768, 768), (1000, 3072, 768), (4096, 2304, 768), (8200, 768, 768), (600, 128, 512),
-                                   (257, 64, 1024), (100, 128, 768), (1, 64, 512)])
+                                   (257, 64, 1024), (100, 128, 768), (1, 64, 512),
+                                   (33000, 768, 768), (40001, 128, 768)])          # the 128 x 384 tile (N = 768, 32,768 <= M < 43,691)
 def test_gemm_nt_fused_layernorm(lib, op, M, K, N):
     """qst_gemm_nt_ln (N = 384: full-row tiles; N = 512 / 768 / 1024: the workgroups of a row panel exchange the row
     statistics inside the launch, gemm8.hip) against the unfused pair it replaces: qst_gemm_nt(F32_RESID) followed
@@ -319,7 +320,7 @@ def test_gemm_nt_fused_layernorm(lib, op, M, K, N):
     _lib.check(kf(lib, "qst_ln_bwd", op)(dy.data_ptr(), xh0.data_ptr(), rs0.data_ptr(), gamma.data_ptr(), M, N, ds0.data_ptr(),
                               dsb0.data_ptr(), dg0.data_ptr(), db0.data_ptr(), scratch.data_ptr(), stream()))
     ds1, dsb1 = f32(M, N), b16(M, N)
-    br = lib.qst_gemm_nt_ln_block_rows(N)
+    br = lib.qst_gemm_nt_ln_block_rows_m(N, M)
     ntile = (M + br - 1) // br
     part = torch.full((ntile, 2, N), float("nan"), device="cuda")
     _lib.check(kf(lib, "qst_gemm_nt_ln", op)(gemm_args(A=Ad, B=Bd, C=ds1, C2=dsb1, resid=resid, M=M, N=N, K=K, lda=K, ldb=K, ldc=N,

@@ -36,7 +36,7 @@ def main():
         xh2 = torch.empty(M, N, device="cuda", dtype=bf); rs2 = torch.empty(M, device="cuda")
         dgam = torch.zeros(N, device="cuda"); dbet = torch.zeros(N, device="cuda")
         scratch = torch.empty(lib.qst_ln_bwd_scratch_bytes(M, N) // 4, device="cuda")
-        part = torch.zeros((M + 255) // 256, 2, N, device="cuda")
+        part = torch.zeros((M + 127) // 128, 2, N, device="cuda")
         for K in (768, 2304, 3072):
             A = torch.randn(M, K, device="cuda").to(bf); B = (torch.randn(N, K, device="cuda") * 0.02).to(bf)
             e = _lib.QstLnEpi()

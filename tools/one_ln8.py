@@ -26,7 +26,7 @@ gamma = torch.ones(N, device="cuda"); beta = torch.zeros(N, device="cuda"); bias
 resid = torch.randn(M, N, device="cuda"); s = torch.empty(M, N, device="cuda")
 y = torch.empty(M, N, device="cuda"); yb = torch.empty(M, N, device="cuda", dtype=bf)
 xh = torch.empty(M, N, device="cuda", dtype=bf); rs = torch.empty(M, device="cuda")
-part = torch.zeros((M + 255) // 256, 2, N, device="cuda")
+part = torch.zeros((M + 127) // 128, 2, N, device="cuda")
 dg = torch.zeros(N, device="cuda"); db = torch.zeros(N, device="cuda")
 scratch = torch.empty(lib.qst_ln_bwd_scratch_bytes(M, N) // 4, device="cuda")
 e0 = _lib.QstLnEpi(); e0.gamma, e0.beta, e0.eps, e0.xhat, e0.rstd = gamma.data_ptr(), beta.data_ptr(), 1e-12, xh.data_ptr(), rs.data_ptr()

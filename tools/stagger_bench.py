@@ -36,7 +36,7 @@ def main():
     resid = torch.randn(M, H, device="cuda"); y = torch.empty(M, H, device="cuda"); yb = torch.empty(M, H, device="cuda", dtype=bf)
     xh = torch.empty(M, H, device="cuda", dtype=bf); rs = torch.empty(M, device="cuda")
     gamma = torch.ones(H, device="cuda"); beta = torch.zeros(H, device="cuda")
-    part = torch.zeros((M + 255) // 256, 2, H, device="cuda")
+    part = torch.zeros((M + 127) // 128, 2, H, device="cuda")
     e0 = _lib.QstLnEpi(); e0.gamma, e0.beta, e0.eps, e0.xhat, e0.rstd = gamma.data_ptr(), beta.data_ptr(), 1e-12, xh.data_ptr(), rs.data_ptr()
     e1 = _lib.QstLnEpi(); e1.gamma, e1.xhat, e1.rstd, e1.partials = gamma.data_ptr(), xh.data_ptr(), rs.data_ptr(), part.data_ptr()
     cases = [
