@@ -13,6 +13,7 @@
 // v_permlane16_swap per accumulator register turns the 16x16 MFMA layout (4 consecutive columns per lane) into 8
 // consecutive columns per lane, so every global access is a 16-byte, row-contiguous piece (64 to 128 bytes per row and
 // instruction) -- no LDS staging, no workgroup barrier after the K loop.
+#include <cstdlib>
 #include "qst_common.h"
 #include "qst_kernels.h"
 #include "gemm8p.h"
@@ -940,6 +941,8 @@ constexpr int kLnStagger = 40000;     // cycles; see qst_gemm8_stagger
 // Which tile a (M, N) problem takes: 0 = 256 x 256, 1 = 128 x 384. The first from two tiles per CU on (and wherever 384 does not
 // divide N); the second where it -- and not the first -- gives two tiles per CU (N = 768: 32,768 <= M < 43,691).
 static int ln8_tile(int M, int N) {
+    static const int forced = [] { const char* e = getenv("QST_LN8_TILE"); return e ? atoi(e) : -1; }();   // tools only: 0 / 1 where both divide N
+    if (forced >= 0 && N % 256 == 0 && N % 384 == 0) return forced ? 1 : 0;
     const int64_t t256 = (int64_t)((M + 255) / 256) * (N / 256);
     if (N % 256 == 0 && (t256 >= 512 || N % 384 != 0)) return 0;
     const int64_t t384 = (int64_t)((M + 127) / 128) * (N / 384);
