@@ -175,6 +175,9 @@ int qst_gemm_tn_group(const QstTnGroup* grp, void* stream);
  * choice (together for the plain GEMMs, 40,000 cycles for the GEMM + LayerNorm launches). Returns the previous value; an
  * argument below -1 only reads. Process-wide. */
 int qst_gemm8_stagger(int cycles);
+/* fp32 row stores of the GEMM + LayerNorm launches: 0 = 64 contiguous bytes per row and instruction, 1 = 16-byte fragments,
+ * -1 (default) = by tile (fragments on the 256 x 256 tile, whose shapes stream from HBM; contiguous on 128 x 384). */
+int qst_gemm8_ln_store(int mode);
 int qst_gemm_nt8_supported(const QstGemmArgs* a, int epi);
 int qst_gemm_nt8(const QstGemmArgs* a, int epi, int tile, void* stream);
 int qst_gemm_tn8_group(const QstTnGroup* grp, void* stream);

@@ -114,6 +114,7 @@ SIGNATURES = {
     "qst_gemm_nt_ln_block_rows_m": (C.c_int, [C.c_int, C.c_int]),
     "qst_gemm_nt8_ln_block_rows": (C.c_int, [C.c_int, C.c_int]),
     "qst_gemm8_stagger": (C.c_int, [C.c_int]),
+    "qst_gemm8_ln_store": (C.c_int, [C.c_int]),
     "qst_gemm_nt8_ln_supported": (C.c_int, [C.c_int]),
     "qst_gemm_nt8_ln": (C.c_int, [C.POINTER(QstGemmArgs), C.POINTER(QstLnEpi), C.c_int, vp]),
     "qst_gemm_nt8_ln_timeouts": (C.c_int, []),

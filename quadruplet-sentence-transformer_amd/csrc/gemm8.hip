@@ -276,11 +276,34 @@ struct LnXchg {
     unsigned* ctl;                 // {epoch, workgroups done} of the buffer `gran` belongs to
     unsigned* tmo;                 // sticky timeout word
     int ntm, ntn, ppx;             // panels, tiles per panel, panels per XCD queue
+    int frag;                      // fp32 rows stored as each lane's own 16-byte halves (qst_gemm8_ln_store)
 };
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 constexpr int LNX_RED = 256 * 4 * 2 * 4, LNX_STATS = 256 * 2 * 4, LNX_PR = 2 * 2 * 256 * 4;
 constexpr int LNX_LDS0 = g8p::LDS_BYTES;                                   // mode 0: the scratch aliases the K-loop buffers
 constexpr int LNX_LDS1 = g8p::LDS_BYTES + LNX_RED + LNX_STATS + LNX_PR;   // mode 1: behind the xhat stash
+
+// fp32 rows leave in 16-byte pieces, one per lane and instruction. A lane holds 8 consecutive columns = 32 bytes, its row's
+// four lanes the columns 0-7 / 16-23 / 8-15 / 24-31 of a 32-column group: storing each lane's two halves as they are makes
+// every instruction write four 16-byte pieces with 16-byte holes between them -- half sectors. After trading halves between
+// the lanes 16 apart (v_permlane16_swap: even g keeps its low half and receives g + 1's low half, odd g receives g - 1's high
+// half and keeps its own) lane g's first piece is columns 4 r .. 4 r + 3 and its second 16 + 4 r .. with r = 0, 1, 2, 3 for
+// g = 0, 1, 2, 3: each instruction covers 64 contiguous bytes of a row -- two whole sectors.
+__device__ __forceinline__ void store_f32_row8(float* row_base /* the 32-column group */, int gq, f32x4 lo, f32x4 hi, bool frag = false) {
+    if (frag) {                                 // each lane's own two halves, as the plain epilogue stores them (qst_gemm8_ln_store)
+        st_stream((f32x4*)(row_base + pair_col(gq)), lo);
+        st_stream((f32x4*)(row_base + pair_col(gq) + 4), hi);
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float a = lo[r], b = hi[r];
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        lo[r] = a; hi[r] = b;
+    }
+    st_stream((f32x4*)(row_base + 4 * gq), lo);
+    st_stream((f32x4*)(row_base + 16 + 4 * gq), hi);
+}
 
 // sum over the four lanes (lane & 15 equal) that share an accumulator row; every one of them receives the total
 __device__ __forceinline__ float xg_sum(float v) {
@@ -560,8 +583,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstL
                     hi[q] = hh[q] * ga1[q] + be1[q];
                 }
                 const size_t off = (size_t)m * g.ldc + n;
-                st_stream((f32x4*)((float*)g.C + off), lo);
-                st_stream((f32x4*)((float*)g.C + off + 4), hi);
+                store_f32_row8((float*)g.C + (off - pair_col(gq)), gq, lo, hi, x.frag != 0);
                 if (g.C2) {
                     u32x4 pk;
                     pk[0] = pack_op2(lo[0], lo[1]); pk[1] = pack_op2(lo[2], lo[3]);
@@ -635,8 +657,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstL
                 f32x4 lo, hi;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { lo[q] = ov[q]; hi[q] = ov[4 + q]; }
-                st_stream((f32x4*)((float*)g.C + off), lo);
-                st_stream((f32x4*)((float*)g.C + off + 4), hi);
+                store_f32_row8((float*)g.C + (off - pair_col(gq)), gq, lo, hi, x.frag != 0);
                 if (g.C2) {
                     if (DROPW == 2 && dc.thr) {
                         const uint32_t e0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
@@ -808,6 +829,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn8_group_kernel(QstTnGroup grp) 
 #if !QST_OP_F16
 std::atomic<int> g_mode{-1};       // qst_gemm8_mode
 std::atomic<int> g_stagger{-1};    // qst_gemm8_stagger (-1: the library's defaults)
+std::atomic<int> g_ln_store{-1};   // qst_gemm8_ln_store (-1: by tile)
 #endif
 
 }  // namespace
@@ -834,9 +856,19 @@ extern "C" int qst_gemm8_stagger(int cycles) {
     return old;
 }
 int qst_gemm8_stagger_get() { return g_stagger.load(); }
+// How the GEMM + LayerNorm launches store their fp32 rows: 0 = 64 contiguous bytes per row and instruction (halves traded
+// between lanes first), 1 = each lane's own two 16-byte halves (fragments with 16-byte holes, filled by the second
+// instruction), -1 (default) = by tile. Returns the previous value; an argument below -1 only reads. Process-wide.
+extern "C" int qst_gemm8_ln_store(int mode) {
+    const int old = g_ln_store.load();
+    if (mode >= -1 && mode <= 1) g_ln_store.store(mode);
+    return old;
+}
+int qst_gemm8_ln_store_get() { return g_ln_store.load(); }
 #else
 int qst_gemm8_mode_get();
 int qst_gemm8_stagger_get();
+int qst_gemm8_ln_store_get();
 #endif
 
 template <int EPI, int TM, int TN>
@@ -960,6 +992,7 @@ static int launch_nt8_ln(const QstGemmArgs* a, const QstLnEpi* ln, hipStream_t s
     x.ntm = (a->M + BM - 1) / BM; x.ntn = a->N / BN; x.ppx = (x.ntm + 7) / 8;
     const size_t bytes = (size_t)x.ntm * x.ntn * BM * 2 * sizeof(unsigned long long);
     if (int rc = lnx_get(st, bytes, x)) return rc;
+    x.frag = qst_gemm8_ln_store_get() < 0 ? (TM == 8 ? 1 : 0) : qst_gemm8_ln_store_get();      // by tile: see qst_gemm8_ln_store
     gemm_nt8_ln_kernel<MODE, DROPW, F8, TM, TN><<<dim3(8 * x.ntn * x.ppx), dim3(512), lds, st>>>(*a, *ln, x, x.ntm * x.ntn > 512 ? (qst_gemm8_stagger_get() < 0 ? kLnStagger : qst_gemm8_stagger_get()) : 0);
     QST_LAUNCH_CHECK();
     return QST_OK;
@@ -972,7 +1005,9 @@ extern "C" int QST_K(qst_gemm_nt8_ln)(const QstGemmArgs* a, const QstLnEpi* ln, 
     if (mode != 0 && mode != 1) return QST_ERR_BAD_ARG;
     if (mode == 0 && !ln->beta) return QST_ERR_BAD_ARG;
     if (mode == 1 && (!ln->xhat || !ln->rstd)) return QST_ERR_BAD_ARG;
-    if (!QST_K(qst_gemm_nt8_ln_supported)(a->N) || a->B2) return QST_ERR_UNSUPPORTED;
+    // (N = 384 -- one 128 x 384 tile per row panel, no partner -- is accepted here for tools/ln8_n384_bench.py; the library takes
+    //  gemm_nt_ln_kernel there)
+    if ((!QST_K(qst_gemm_nt8_ln_supported)(a->N) && a->N != 384) || a->B2) return QST_ERR_UNSUPPORTED;
     if (a->K % 64 != 0 || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->ldc % 8 != 0 || (a->resid && a->ldr % 4 != 0)) return QST_ERR_UNSUPPORTED;
     if ((int64_t)256 * a->lda * 2 >= 0x7FFFFF00LL || (int64_t)384 * a->ldb * 2 >= 0x7FFFFF00LL) return QST_ERR_UNSUPPORTED;
     const bool drop = a->drop.thr16 && a->drop.state;
