@@ -417,8 +417,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstL
                         const int n = nw + 32 * jp;
                         const bool ok = g.resid != nullptr && m < g.M;
                         const float* p = g.resid + (size_t)m * g.ldr + n;
-                        rv[k][jp][0] = ok ? ld_stream((const f32x4*)p) : z4;
-                        rv[k][jp][1] = ok ? ld_stream((const f32x4*)(p + 4)) : z4;
+                        // (contiguous form: the lane fetches columns 4 r .. and 16 + 4 r .. of the 32-column group -- 64 contiguous
+                        //  bytes per row and instruction -- and trades halves back where the rows are used; see store_f32_row8)
+                        const float* p0 = x.frag ? p : p - pair_col(gq) + 4 * gq;
+                        const float* p1 = x.frag ? p + 4 : p - pair_col(gq) + 16 + 4 * gq;
+                        rv[k][jp][0] = ok ? ld_stream((const f32x4*)p0) : z4;
+                        rv[k][jp][1] = ok ? ld_stream((const f32x4*)p1) : z4;
                     }
                 }
                 if (MODE == 1 && i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the xhat DMAs (and this first burst) have landed
@@ -442,7 +446,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_ln_kernel(QstGemmArgs g, QstL
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { v[q] += rv[i % HT][jp][0][q]; v[4 + q] += rv[i % HT][jp][1][q]; }
+                for (int q = 0; q < 4; ++q) {
+                    float r0 = rv[i % HT][jp][0][q], r1 = rv[i % HT][jp][1][q];
+                    if (!x.frag) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(r0), "+v"(r1));     // uniform over the launch
+                    v[q] += r0; v[4 + q] += r1;
+                }
                 if (MODE == 1 && DROPW == 3 && dc.thr) {
                     const uint32_t e0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
 #pragma unroll
