@@ -146,7 +146,8 @@ int qst_dropout_init(uint32_t* state_dev, uint64_t seed, void* stream);
 int qst_encoder_set_ffn_chain(qst_encoder* enc, int mask);
 /* Where this handle runs a projection and the LayerNorm behind it (forward), or a dgrad and the LayerNorm backward behind
  * it, as ONE kernel (H = 384: full-row tiles; H = 512 / 768 / 1024: the workgroups of a row panel exchange row statistics
- * inside the launch): 0 = by size (default: from 16,384 token rows at H = 384, from two 256 x 256 tiles per CU above),
+ * inside the launch): 0 = by size (default: from 16,384 token rows at H = 384; above, from two tiles per CU -- 256 x 256, or
+ * 128 x 384 where only that gives two: H = 768 from 32,768 token rows),
  * 1 = wherever such a kernel exists, 2 = never. Same results to fp32 summation order. */
 int qst_encoder_set_ln_fusion(qst_encoder* enc, int mode);
 int qst_dropout_advance(uint32_t* state_dev, void* stream);
