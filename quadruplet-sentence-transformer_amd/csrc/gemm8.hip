@@ -250,7 +250,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_f8_kernel(QstGemmArgs g) {
 
 // ---------------------------------------------------------------- GEMM + LayerNorm over rows wider than one tile
 // C = LayerNorm(A.B^T + bias + resid) (mode 0) / the LayerNorm backward of dy = A.B^T + resid (mode 1), as gemm_nt_ln_kernel
-// (gemm.hip) computes them for N = 384 in one full-row tile -- here for N = ntn x 256 on the 256 x 256 tile of the 8-phase
+// (gemm.hip) computes them for N = 384 in one full-row tile -- here for N = ntn x 256 on the 256 x 256 tile (or ntn x 384 on the 128 x 384 tile) of the 8-phase
 // loop: the ntn workgroups of a 256-row panel each hold a third (N = 768) of every row in their accumulators and hand the
 // row statistics to each other through global memory INSIDE the launch:
 //   pass 1   v = acc + bias (+ dropout) + resid, back into the accumulator registers; per row and wave the mean and the
@@ -272,14 +272,14 @@ __global__ __launch_bounds__(512, 1) void gemm_nt8_f8_kernel(QstGemmArgs g) {
 // has left) across the exchange; the gamma / beta gradient partials (column sums over the panel's rows) go to
 // partials[panel][2][N].
 struct LnXchg {
-    unsigned long long* gran;      // [ntm][ntn][256 rows][2] granules
+    unsigned long long* gran;      // [ntm][ntn][BM rows][2] granules
     unsigned* ctl;                 // {epoch, workgroups done} of the buffer `gran` belongs to
     unsigned* tmo;                 // sticky timeout word
     int ntm, ntn, ppx;             // panels, tiles per panel, panels per XCD queue
     int frag;                      // fp32 rows stored as each lane's own 16-byte halves (qst_gemm8_ln_store)
 };
 typedef __attribute__((address_space(1))) unsigned long long gu64;
-constexpr int LNX_RED = 256 * 4 * 2 * 4, LNX_STATS = 256 * 2 * 4, LNX_PR = 2 * 2 * 256 * 4;
+constexpr int LNX_RED = 256 * 4 * 2 * 4, LNX_STATS = 256 * 2 * 4, LNX_PR = 2 * 2 * 256 * 4;   // 256 x 256 tile; 128 x 384 needs 3 KB less in all
 constexpr int LNX_LDS0 = g8p::LDS_BYTES;                                   // mode 0: the scratch aliases the K-loop buffers
 constexpr int LNX_LDS1 = g8p::LDS_BYTES + LNX_RED + LNX_STATS + LNX_PR;   // mode 1: behind the xhat stash
 
