@@ -93,12 +93,13 @@ int qst_gemm_nt_f8(const QstGemmArgs* a, int epi, void* stream);
  * ((kb / 4) * rows + r) * 4 + kb % 4, ceil(K / 128) * rows * 4 bytes in all -- the four scales a GEMM stage (128 K) needs
  * from a row are one aligned dword, and 32 consecutive rows one 128-byte line. K % 32 == 0. */
 int qst_quant_mx(const void* src, int src_is_bf16, int64_t rows, int K, void* q, void* scales, void* stream);
-/* NT GEMM with a LayerNorm fused into the epilogue (one 128 x 384 tile spans whole rows: N must be 384;
- * qst_gemm_nt_ln_supported(N) tells). xhat is bf16 [M, 384] contiguous, rstd f32 [M].
+/* NT GEMM with a LayerNorm fused into the epilogue (N = 384: one 128 x 384 tile spans whole rows; N = 512 / 768 / 1024:
+ * qst_gemm_nt8_ln below, which this entry point forwards to; qst_gemm_nt_ln_supported(N) tells). xhat is bf16 [M, N]
+ * contiguous, rstd f32 [M].
  *  mode 0 (forward):  v = A.B^T + bias + resid ; y = LayerNorm(v) -> C (f32), C2 (bf16, nullable);
  *                     xhat, rstd (nullable) are written for the backward pass.
  *  mode 1 (backward): dy = A.B^T + resid ; ds = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)) -> C (f32),
- *                     C2 (bf16, nullable); partials (nullable) f32 [ceil(M/128)][2][384] receives each tile's
+ *                     C2 (bf16, nullable); partials (nullable) f32 [ceil(M / qst_gemm_nt_ln_block_rows_m(N, M))][2][N] receives each tile's
  *                     sum(dy*xhat) and sum(dy) rows (reduce with qst_ln_bwd_reduce_batch). */
 typedef struct {
     const float* gamma;
