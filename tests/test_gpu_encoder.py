@@ -33,6 +33,10 @@ from oracle import torch_ref as R  # noqa: E402
 #          implementations, largest on the smallest batch (M = 256 rows);
 #   b_qkv  its key third has a mathematically zero gradient (softmax shift invariance), so a third of the vector is pure
 #          rounding noise in both implementations.
+# For scale: the arithmetic tests/test_gpu_f16.py derives its bound from -- 12 roundings per layer x 6 layers of independent relative
+# errors of one unit roundoff, 12 x 6 x u / sqrt(12 x 6) -- gives 1.66e-2 for bf16 (u = 2^-9): the calibrated "w" bound is that figure,
+# i.e. against the same-rounding oracle the kernels are allowed what ONE more set of bf16 roundings would cost (values on a rounding
+# boundary that flip between the two implementations), no more.
 GRAD_LIMITS = {"w": 1.65e-2, "emb": 1.55e-2, "vec": 2.2e-2, "b_qkv": 3.55e-2}     # [1.31e-2, 1.22e-2, 1.74e-2, 2.83e-2]
 
 LOSS_KW = dict(gamma=0.6, margin_pos_neg=1.0, margin_pos_part=0.5, margin_part_neg=0.5, p=2.0, swap=False)

@@ -38,7 +38,7 @@ def main():
     cfg = PRESETS["all-MiniLM-L6-v2"]
     batches = [tuple(torch.from_numpy(x).cuda() for x in synthetic_quadruplets(cfg, 64, 128, seed=14, step=i)) for i in range(4)]
     out = {p: run(cfg, p, batches, steps) for p in precs}
-    marks = [0, 1, 2, 3] + list(range(24, steps, 25)) + [steps - 1]
+    marks = sorted(set([0, 1, 2, 3] + list(range(24, steps, 25)) + [steps - 1]))
     print(f"all-MiniLM-L6-v2 dims, 64 quadruplets x 128 tokens, four fixed batches in turn, {steps} steps, lr 5e-5 (20 warm-up steps), "
           "dropout off, same initial parameters")
     print("step   " + "".join(f"{p:>10s}" for p in precs))
